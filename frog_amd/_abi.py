@@ -1,0 +1,188 @@
+"""ctypes view of include/frog_types.h, include/frog_hip.h and include/frog_host.h.
+
+The shared libraries are built in-tree by ``__graft_entry__.build()`` (or
+``make -C frog_amd/csrc``).  Loading fails loudly when they are missing: there is
+no Python or CPU stand-in for the HIP path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+
+
+class FrogModel(C.Structure):
+    """frog_model (include/frog_types.h)."""
+    _fields_ = [("n_images", C.c_uint32),
+                ("point_offset", C.c_void_p),
+                ("xyz", C.c_void_p),
+                ("row_ptr", C.c_void_p),
+                ("link_image", C.c_void_p),
+                ("link_point", C.c_void_p)]
+
+
+class FrogOptions(C.Structure):
+    """frog_options; defaults = imageGroup.h:52-82, stats.cxx:10-12."""
+    _fields_ = [("linear_alpha", C.c_float),
+                ("use_scale", C.c_int32),
+                ("initial_grid_size", C.c_float),
+                ("bounding_box_margin", C.c_float),
+                ("inlier_threshold", C.c_float),
+                ("guarantee_diffeomorphism", C.c_int32),
+                ("max_displacement_ratio", C.c_float),
+                ("stats_max_size", C.c_int32),
+                ("stats_max_iterations", C.c_int32),
+                ("stats_epsilon", C.c_float),
+                ("reserved", C.c_int32 * 6)]
+
+    @classmethod
+    def default(cls, **kw):
+        o = cls(0.5, 1, 100.0, 0.1, 0.5, 1, 0.4, 10000, 10000, 1e-6)
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        return o
+
+
+class FrogGridInfo(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 3),
+                ("n_grid", C.c_int32),
+                ("origin", C.c_double * 3),
+                ("spacing", C.c_double * 3),
+                ("bbox", C.c_double * 6)]
+
+
+class FrogCounts(C.Structure):
+    _fields_ = [("points", C.c_int64), ("pairs", C.c_int64),
+                ("inliers", C.c_int64), ("outliers", C.c_int64),
+                ("c1", C.c_float), ("c2", C.c_float), ("ratio", C.c_float), ("pad_", C.c_float)]
+
+
+class FrogSynthParams(C.Structure):
+    _fields_ = [("n_images", C.c_uint32),
+                ("points_per_image", C.c_uint32),
+                ("n_landmarks", C.c_uint32),
+                ("pairs_per_block", C.c_double),
+                ("partners_per_image", C.c_uint32),
+                ("outlier_fraction", C.c_float),
+                ("noise_sigma", C.c_float),
+                ("bump_amplitude", C.c_float),
+                ("scale_min", C.c_float),
+                ("scale_max", C.c_float),
+                ("translation_range", C.c_float),
+                ("seed", C.c_uint64)]
+
+
+FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM = range(6)
+FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
+
+# name -> (restype, argtypes): every symbol include/frog_hip.h declares
+HIP_SYMBOLS = {
+    "frog_device_count": (C.c_int, []),
+    "frog_last_error": (C.c_char_p, []),
+    "frog_create": (C.c_int, [C.POINTER(FrogModel), C.POINTER(FrogOptions), C.c_int, C.c_uint32, C.c_uint32,
+                              C.POINTER(C.c_void_p)]),
+    "frog_destroy": (None, [C.c_void_p]),
+    "frog_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "frog_synchronize": (C.c_int, [C.c_void_p]),
+    "frog_linear_init": (C.c_int, [C.c_void_p, c_float_p]),
+    "frog_transform_points": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_update_stats": (C.c_int, [C.c_void_p]),
+    "frog_linear_step": (C.c_int, [C.c_void_p, c_double_p]),
+    "frog_deformable_setup": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(FrogGridInfo)]),
+    "frog_deformable_step": (C.c_int, [C.c_void_p, C.c_float, c_double_p]),
+    "frog_count_inliers": (C.c_int, [C.c_void_p, C.POINTER(FrogCounts)]),
+    "frog_num_points": (C.c_uint64, [C.c_void_p]),
+    "frog_num_images": (C.c_uint32, [C.c_void_p]),
+    "frog_get_points": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "frog_set_points2": (C.c_int, [C.c_void_p, c_float_p]),
+    "frog_get_linear": (C.c_int, [C.c_void_p, C.c_uint32, c_double_p]),
+    "frog_get_em": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
+    "frog_set_em": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
+    "frog_get_samples": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, c_u32_p, C.c_int, C.POINTER(C.c_int)]),
+    "frog_get_histogram": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_int, C.POINTER(C.c_int)]),
+    "frog_num_grids": (C.c_int, [C.c_void_p]),
+    "frog_get_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
+    "frog_get_point_sums": (C.c_int, [C.c_void_p, c_float_p]),
+    "frog_get_gradient": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_size_t]),
+    "frog_comm_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "frog_update_stats_local": (C.c_int, [C.c_void_p]),
+    "frog_stats_publish": (C.c_int, [C.c_void_p]),
+    "frog_transform_points_local": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_linear_step_local": (C.c_int, [C.c_void_p]),
+    "frog_energy_read": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "frog_bounds_local": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "frog_deformable_setup_bounds": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, C.POINTER(FrogGridInfo)]),
+    "frog_deformable_phase_a": (C.c_int, [C.c_void_p, C.c_float]),
+    "frog_deformable_phase_b": (C.c_int, [C.c_void_p]),
+    "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
+}
+
+HOST_SYMBOLS = {
+    "frog_pairs_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "frog_pairs_write": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "frog_pairs_free": (None, [C.c_void_p]),
+    "frog_pairs_model": (None, [C.c_void_p, C.POINTER(FrogModel)]),
+    "frog_pairs_num_pairs": (C.c_uint64, [C.c_void_p]),
+    "frog_pairs_num_points": (C.c_uint64, [C.c_void_p]),
+    "frog_pairs_num_images": (C.c_uint32, [C.c_void_p]),
+    "frog_pairs_num_blocks": (C.c_uint32, [C.c_void_p]),
+    "frog_pairs_block": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                   C.POINTER(C.c_uint32), C.POINTER(c_u32_p), C.POINTER(c_u32_p)]),
+    "frog_pairs_from_arrays": (C.c_void_p, [C.c_uint32, c_u32_p, c_float_p, c_float_p, C.c_uint32,
+                                            C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                            C.POINTER(C.c_uint64), c_u32_p, c_u32_p]),
+    "frog_synth_defaults": (None, [C.POINTER(FrogSynthParams)]),
+    "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
+}
+
+
+def _load(name, symbols):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C frog_amd/csrc`). frog_amd has no fallback for its native libraries.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for sym, (res, args) in symbols.items():
+        fn = getattr(lib, sym)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        _hip = _load("libfrog_hip.so", HIP_SYMBOLS)
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()                       # libfrog_host.so links against it
+        _host = _load("libfrog_host.so", HOST_SYMBOLS)
+    return _host
+
+
+class FrogError(RuntimeError):
+    def __init__(self, code, where):
+        msg = hip_lib().frog_last_error()
+        super().__init__(f"{where}: status {code}: {msg.decode() if msg else ''}")
+        self.code = code
+
+
+def check(code, where):
+    if code != FROG_OK:
+        raise FrogError(code, where)

@@ -1,0 +1,173 @@
+// ctx.h -- device context of libfrog_hip.so: buffers, layout tables, error plumbing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/frog_hip.h"
+
+namespace frog {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define FROG_HIP_CHECK(expr)                                                            \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return ::frog::fail(FROG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Owning device allocation.
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v, hipStream_t s)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- link layout (built on the host in prep.h) --------------------------------
+
+constexpr int TILE_POINTS = 256;     // points per sweep tile (one wavefront each)
+
+// One sweep tile: a run of consecutive points of ONE image and all their
+// half-links, sorted by partner image (then by point).
+struct Tile {
+    uint32_t pt_begin;      // global point index
+    uint32_t pt_count;
+    uint32_t rec_begin;     // index into LinkRec array
+    uint32_t rec_count;
+    uint32_t image;
+    uint32_t pad_[3];
+};
+
+// One half-link: global indices of its own point and of the partner point.
+// 8 bytes, the size of the reference's Link (point.h:11-16).
+struct LinkRec {
+    uint32_t a;
+    uint32_t b;
+};
+
+// Per-image constants derived from (c1, c2, ratio) for getInlierProbability
+// (stats.h:84-92): inv1 = 1/(c1+eps), inv2 = 1/(c2+eps),
+// k1 = ratio*c*inv1, k2 = (1-ratio)*c*inv2 with c = 0.797884560802865f.
+struct EmDerived {
+    float inv1, inv2, k1, k2;
+};
+
+struct GridGeom {
+    int dims[3];
+    int n_cp;               // dims[0]*dims[1]*dims[2]
+    double origin[3];
+    double spacing[3];
+    int cells[3];           // dims - 3
+    int brick;              // cells per brick edge (8 or 4)
+    int nbricks[3];
+    int n_bricks;           // per image
+};
+
+struct GridRecord {         // a finished or current lattice of the chain
+    frog_grid_info info;
+    std::vector<float> host_coeffs;     // [owned images][G][3], filled when the lattice is retired
+    bool retired = false;
+};
+
+} // namespace frog
+
+struct frog_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    frog_options opt{};
+
+    uint32_t nI = 0, ib = 0, ie = 0;          // images, owned range
+    uint64_t P = 0;                           // all points
+    uint32_t own_pt_begin = 0, own_pt_end = 0;
+    uint64_t L_own = 0;                       // half-links of owned images
+    std::vector<uint32_t> poff;               // host copy
+    std::vector<uint64_t> img_link_begin;     // per image: first half-link ordinal base (ref-order CSR, owned rows only)
+
+    // points
+    frog::DevBuf<float4> pos, pos2;           // xyz|image, xyz2|image
+    frog::DevBuf<uint32_t> d_poff;            // [nI+1]
+    // reference-order CSR of the owned rows (for the reservoir ordinals)
+    frog::DevBuf<uint64_t> ref_rowptr;        // [ownP + 1], relative to the first owned link
+    frog::DevBuf<uint32_t> ref_link;          // [L_own] partner global index
+    // sweep layout
+    frog::DevBuf<frog::Tile> tiles;
+    frog::DevBuf<frog::LinkRec> recs;
+    uint32_t n_tiles = 0;
+    frog::DevBuf<uint32_t> img_tile_ptr;      // [nI+1] tiles of image (owned only non-empty)
+    std::vector<uint32_t> h_img_tile_ptr;
+    frog::DevBuf<double> tile_partial;        // [n_tiles][18]
+    frog::DevBuf<long long> tile_counts;      // [n_tiles][2]
+    frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
+
+    // statistics
+    frog::DevBuf<float4> em;                  // [nI] c1,c2,ratio,0
+    frog::DevBuf<frog::EmDerived> emd;        // [nI]
+    frog::DevBuf<float> samples;              // [nOwned][cap]
+    frog::DevBuf<uint32_t> sample_ord;        // [nOwned][cap]
+    frog::DevBuf<uint32_t> sample_count;      // [nOwned]
+    frog::DevBuf<uint32_t> mt_state;          // [nOwned][625] (624 words + index)
+    std::vector<uint32_t> h_virtual;          // per owned image: virtualSize (clamped to 2^32-1)
+    frog::DevBuf<uint32_t> d_virtual;         // [nOwned]
+    int sample_cap = 0;
+
+    // linear
+    frog::DevBuf<double> mat;                 // [nI][16]; owned rows live
+    // energy / counters
+    frog::DevBuf<double> energy;              // [4]
+    double *h_energy = nullptr;               // pinned [4]
+
+    // deformable
+    bool deformable = false;
+    frog::GridGeom geom{};
+    frog::DevBuf<float4> coeff;               // [nOwned][G]
+    frog::DevBuf<float4> grad;                // [nOwned][G]
+    frog::DevBuf<double> gridsum;             // [3G]
+    frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)
+    frog::DevBuf<uint32_t> brick_ptr;         // [nOwned*n_bricks + 1]
+    frog::DevBuf<uint32_t> brick_cursor;
+    uint32_t max_brick_count = 0;
+    frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
+    frog::DevBuf<unsigned long long> n_big;   // oversize-coefficient counter
+    frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
+    std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
+    std::vector<frog::GridRecord> grids;
+    float pending_alpha = 0;
+    int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
+
+    uint32_t n_owned() const { return ie - ib; }
+};

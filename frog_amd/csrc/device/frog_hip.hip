@@ -1,0 +1,722 @@
+// frog_hip.hip -- C ABI of libfrog_hip.so (include/frog_hip.h): context life cycle,
+// launch sequences of the kernels in k_*.hip.h, read-back.  gfx950 only; there is
+// no CPU path in this library.
+
+#include "ctx.h"
+#include "prep.h"
+#include "k_links.hip.h"
+#include "k_stats.hip.h"
+#include "k_grid.hip.h"
+
+#include <cmath>
+#include <limits>
+#include <new>
+
+namespace frog {
+thread_local std::string g_last_error;
+constexpr int BOUNDS_BLOCKS = 256;
+}
+
+using namespace frog;
+
+#define CTX_GUARD(ctx)                                                   \
+    do {                                                                 \
+        if (!(ctx)) return fail(FROG_E_INVALID, "null context");         \
+        FROG_HIP_CHECK(hipSetDevice((ctx)->device));                      \
+    } while (0)
+
+static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+extern "C" {
+
+int frog_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *frog_last_error(void) { return g_last_error.c_str(); }
+
+void frog_destroy(frog_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->h_energy) (void)hipHostFree(ctx->h_energy);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int frog_create(const frog_model *m, const frog_options *o, int device,
+                uint32_t image_begin, uint32_t image_end, frog_ctx **out)
+{
+    if (!m || !o || !out) return fail(FROG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (m->n_images < 1 || image_begin >= image_end || image_end > m->n_images)
+        return fail(FROG_E_INVALID, "bad image range");
+    for (size_t i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++)
+        if (o->reserved[i]) return fail(FROG_E_INVALID, "reserved option fields must be 0");
+    if (o->stats_max_size < 1) return fail(FROG_E_INVALID, "stats_max_size < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FROG_E_NODEVICE, "no HIP device: libfrog_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
+    FROG_HIP_CHECK(hipSetDevice(device));
+
+    frog_ctx *c = new (std::nothrow) frog_ctx;
+    if (!c) return fail(FROG_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->opt = *o;
+    c->nI = m->n_images; c->ib = image_begin; c->ie = image_end;
+    c->poff.assign(m->point_offset, m->point_offset + c->nI + 1);
+    c->P = c->poff[c->nI];
+    c->own_pt_begin = c->poff[c->ib]; c->own_pt_end = c->poff[c->ie];
+    if (c->P >= 0x7FFFFFFFull) { delete c; return fail(FROG_E_INVALID, "more than 2^31-1 points"); }
+
+    Layout lay;
+    std::string err;
+    int rc = build_layout(*m, c->ib, c->ie, lay, err);
+    if (rc) { delete c; return fail(rc, err); }
+    c->L_own = lay.recs.size();
+    c->n_tiles = (uint32_t)lay.tiles.size();
+    c->h_img_tile_ptr = lay.img_tile_ptr;
+    c->img_link_begin = lay.img_link_begin;
+
+#define CREATE_CHECK(expr)                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            std::string msg_ = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            frog_destroy(c);                                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? FROG_E_NOMEM : FROG_E_HIP, msg_);                \
+        }                                                                                            \
+    } while (0)
+
+    CREATE_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 4 * sizeof(double)));
+    hipStream_t s = c->stream;
+
+    // points: xyz | image id
+    std::vector<float4> hp(c->P);
+    c->h_img_bbox.assign((size_t)c->nI * 6, 0.0);
+    for (uint32_t i = 0; i < c->nI; i++) {
+        double mn[3] = { std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max() };
+        double mx[3] = { -mn[0], -mn[1], -mn[2] };
+        for (uint32_t p = c->poff[i]; p < c->poff[i + 1]; p++) {
+            float4 v;
+            v.x = m->xyz[3 * (size_t)p]; v.y = m->xyz[3 * (size_t)p + 1]; v.z = m->xyz[3 * (size_t)p + 2];
+            int id = (int)i;
+            std::memcpy(&v.w, &id, 4);
+            hp[p] = v;
+            const double q[3] = { v.x, v.y, v.z };
+            for (int k = 0; k < 3; k++) { if (q[k] < mn[k]) mn[k] = q[k]; if (q[k] > mx[k]) mx[k] = q[k]; }
+        }
+        for (int k = 0; k < 3; k++) { c->h_img_bbox[(size_t)i * 6 + k] = mn[k]; c->h_img_bbox[(size_t)i * 6 + 3 + k] = mx[k]; }
+    }
+    CREATE_CHECK(c->pos.upload(hp, s));
+    CREATE_CHECK(c->pos2.upload(hp, s));
+    CREATE_CHECK(c->d_poff.upload(c->poff, s));
+    CREATE_CHECK(c->point_sums.alloc(c->P));
+    CREATE_CHECK(hipMemsetAsync(c->point_sums.p, 0, c->point_sums.bytes(), s));
+
+    CREATE_CHECK(c->ref_rowptr.upload(lay.ref_rowptr, s));
+    CREATE_CHECK(c->ref_link.upload(lay.ref_link, s));
+    CREATE_CHECK(c->tiles.upload(lay.tiles, s));
+    CREATE_CHECK(c->recs.upload(lay.recs, s));
+    CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
+    CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * LINEAR_SUMS));
+    CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * 2));
+    CREATE_CHECK(c->img_counts.alloc((size_t)c->n_owned() * 2));
+
+    // statistics: Stats ctor (stats.h:94-99) + setupStats (imageGroup.cxx:1151-1159)
+    std::vector<float4> hem(c->nI, make_float4(10.f, 300.f, 0.5f, 0.f));
+    CREATE_CHECK(c->em.upload(hem, s));
+    CREATE_CHECK(c->emd.alloc(c->nI));
+    c->h_virtual.resize(c->n_owned());
+    uint32_t cap = 1;
+    for (uint32_t i = c->ib; i < c->ie; i++) {
+        uint64_t v = lay.img_link_begin[i + 1] - lay.img_link_begin[i];
+        c->h_virtual[i - c->ib] = (uint32_t)v;
+        cap = std::max<uint32_t>(cap, (uint32_t)std::min<uint64_t>(v, (uint64_t)o->stats_max_size));
+    }
+    c->sample_cap = (int)cap;
+    CREATE_CHECK(c->d_virtual.upload(c->h_virtual, s));
+    CREATE_CHECK(c->samples.alloc((size_t)c->n_owned() * cap));
+    CREATE_CHECK(c->sample_ord.alloc((size_t)c->n_owned() * cap));
+    CREATE_CHECK(c->sample_count.alloc(c->n_owned()));
+    CREATE_CHECK(hipMemsetAsync(c->sample_count.p, 0, c->sample_count.bytes(), s));
+    {
+        // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
+        std::vector<uint32_t> st((size_t)c->n_owned() * MT_WORDS);
+        uint32_t x[MT_WORDS];
+        x[0] = 0u;
+        for (int k = 1; k < MT_N; k++) x[k] = 1812433253u * (x[k - 1] ^ (x[k - 1] >> 30)) + (uint32_t)k;
+        x[MT_N] = MT_N;
+        for (uint32_t i = 0; i < c->n_owned(); i++) std::memcpy(&st[(size_t)i * MT_WORDS], x, sizeof x);
+        CREATE_CHECK(c->mt_state.upload(st, s));
+    }
+
+    std::vector<double> hm((size_t)c->nI * 16, 0.0);
+    for (uint32_t i = 0; i < c->nI; i++) for (int k = 0; k < 4; k++) hm[(size_t)i * 16 + 5 * k] = 1.0;
+    CREATE_CHECK(c->mat.upload(hm, s));
+    CREATE_CHECK(c->energy.alloc(4));
+    CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
+    CREATE_CHECK(c->n_big.alloc(1));
+    CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
+    CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6));
+    em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
+    CREATE_CHECK(hipGetLastError());
+    CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
+#undef CREATE_CHECK
+    *out = c;
+    return FROG_OK;
+}
+
+int frog_set_stream(frog_ctx *ctx, void *hip_stream)
+{
+    CTX_GUARD(ctx);
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) FROG_HIP_CHECK(hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return FROG_OK;
+}
+
+int frog_synchronize(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+uint64_t frog_num_points(const frog_ctx *ctx) { return ctx ? ctx->P : 0; }
+uint32_t frog_num_images(const frog_ctx *ctx) { return ctx ? ctx->nI : 0; }
+
+// ---- setupLinearTransforms (imageGroup.cxx:806-848) ------------------------------
+int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
+{
+    CTX_GUARD(ctx);
+    if (!anchor_pos) return fail(FROG_E_INVALID, "null anchor");
+    const uint32_t nI = ctx->nI;
+    std::vector<float> anchors((size_t)nI * 3);
+    float average[3] = { 0, 0, 0 };
+    for (uint32_t i = 0; i < nI; i++)
+        for (int j = 0; j < 3; j++) {
+            const float cpos = anchor_pos[j];
+            const double lo = ctx->h_img_bbox[(size_t)i * 6 + j], hi = ctx->h_img_bbox[(size_t)i * 6 + 3 + j];
+            const float a = (float)((double)(1 - cpos) * lo + (double)cpos * hi);
+            anchors[3 * (size_t)i + j] = a;
+            average[j] += a / (float)nI;
+        }
+    std::vector<double> hm((size_t)nI * 16, 0.0);
+    for (uint32_t i = 0; i < nI; i++) {
+        for (int k = 0; k < 4; k++) hm[(size_t)i * 16 + 5 * k] = 1.0;
+        for (int j = 0; j < 3; j++) hm[(size_t)i * 16 + 4 * j + 3] = (double)(average[j] - anchors[3 * (size_t)i + j]);
+    }
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->mat.p, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->deformable = false;
+    return FROG_OK;
+}
+
+// ---- transformPoints (imageGroup.cxx:910-916, image.cxx:3-13) -----------------------
+int frog_transform_points_local(frog_ctx *ctx, int apply)
+{
+    CTX_GUARD(ctx);
+    const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    if (!n) return FROG_OK;
+    if (!ctx->deformable) {
+        transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->mat.p,
+                                                                        ctx->own_pt_begin, ctx->own_pt_end, apply);
+    } else {
+        transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->coeff.p,
+                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply);
+    }
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+int frog_transform_points(frog_ctx *ctx, int apply) { return frog_transform_points_local(ctx, apply); }
+
+// ---- updateStats (imageGroup.cxx:569-598) --------------------------------------------
+int frog_update_stats_local(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    const uint32_t nO = ctx->n_owned();
+    const uint32_t cap = (uint32_t)ctx->sample_cap;
+    hipStream_t s = ctx->stream;
+    select_kernel<<<nO, 64, 0, s>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord.p, ctx->sample_count.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
+        ctx->sample_ord.p, ctx->sample_count.p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
+        ctx->ref_rowptr.p, ctx->ref_link.p, ctx->pos2.p, ctx->samples.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    em_kernel<<<nO, 256, 0, s>>>(ctx->samples.p, ctx->sample_count.p, cap, ctx->ib, ctx->em.p,
+                                 ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+    FROG_HIP_CHECK(hipGetLastError());
+    // rows of other ranks' images: zero, so that an all-reduce(sum) completes the table
+    if (ctx->ib > 0) FROG_HIP_CHECK(hipMemsetAsync(ctx->em.p, 0, (size_t)ctx->ib * sizeof(float4), s));
+    if (ctx->ie < ctx->nI)
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->em.p + ctx->ie, 0, (size_t)(ctx->nI - ctx->ie) * sizeof(float4), s));
+    return FROG_OK;
+}
+
+int frog_stats_publish(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    em_derive_kernel<<<div_up(ctx->nI, 256), 256, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+int frog_update_stats(frog_ctx *ctx)
+{
+    if (ctx && ctx->n_owned() != ctx->nI)
+        return fail(FROG_E_STATE, "context owns a sub-range of images: use frog_update_stats_local + all-reduce + frog_stats_publish");
+    int rc = frog_update_stats_local(ctx);
+    if (rc) return rc;
+    return frog_stats_publish(ctx);
+}
+
+// ---- updateLinearTransforms (imageGroup.cxx:1063-1149) ----------------------------------
+static SweepArgs sweep_args(frog_ctx *ctx)
+{
+    SweepArgs a;
+    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
+    a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.point_sums = ctx->point_sums.p;
+    return a;
+}
+
+int frog_linear_step_local(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
+    hipStream_t s = ctx->stream;
+    sweep_kernel<SWEEP_LINEAR><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    FROG_HIP_CHECK(hipGetLastError());
+    linear_update_kernel<<<ctx->n_owned(), 64, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
+                                                      ctx->opt.linear_alpha, ctx->opt.use_scale);
+    FROG_HIP_CHECK(hipGetLastError());
+    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, LINEAR_SUMS, 16, ctx->energy.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+int frog_energy_read(frog_ctx *ctx, double *E, double *n_oversize)
+{
+    CTX_GUARD(ctx);
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (E) *E = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]);
+    if (n_oversize) *n_oversize = ctx->h_energy[2];
+    return FROG_OK;
+}
+
+int frog_linear_step(frog_ctx *ctx, double *E)
+{
+    int rc = frog_linear_step_local(ctx);
+    if (rc) return rc;
+    return frog_energy_read(ctx, E, nullptr);
+}
+
+// ---- setupDeformableTransforms (imageGroup.cxx:159-218) ----------------------------------
+int frog_bounds_local(frog_ctx *ctx, double mins[3], double maxs[3])
+{
+    CTX_GUARD(ctx);
+    bounds_kernel<<<BOUNDS_BLOCKS, 256, 0, ctx->stream>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->bounds_scratch.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    std::vector<float> h((size_t)BOUNDS_BLOCKS * 6);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->bounds_scratch.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; k++) { mins[k] = std::numeric_limits<double>::max(); maxs[k] = -std::numeric_limits<double>::max(); }
+    for (int b = 0; b < BOUNDS_BLOCKS; b++)
+        for (int k = 0; k < 3; k++) {
+            mins[k] = std::min(mins[k], (double)h[(size_t)b * 6 + k]);
+            maxs[k] = std::max(maxs[k], (double)h[(size_t)b * 6 + 3 + k]);
+        }
+    return FROG_OK;
+}
+
+static int retire_current_grid(frog_ctx *ctx)
+{
+    if (ctx->grids.empty() || ctx->grids.back().retired) return FROG_OK;
+    GridRecord &gr = ctx->grids.back();
+    const size_t G = (size_t)ctx->geom.n_cp;
+    const size_t n = (size_t)ctx->n_owned() * G;
+    std::vector<float4> h(n);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    gr.host_coeffs.resize(n * 3);
+    for (size_t i = 0; i < n; i++) { gr.host_coeffs[3 * i] = h[i].x; gr.host_coeffs[3 * i + 1] = h[i].y; gr.host_coeffs[3 * i + 2] = h[i].z; }
+    gr.retired = true;
+    return FROG_OK;
+}
+
+int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3], const double maxs[3], frog_grid_info *out)
+{
+    CTX_GUARD(ctx);
+    if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
+    int rc = retire_current_grid(ctx);
+    if (rc) return rc;
+
+    // box.ScaleAboutCenter(1 + 2*margin) then the lattice (imageGroup.cxx:161-179)
+    GridGeom g{};
+    frog_grid_info info{};
+    const double size = (double)ctx->opt.initial_grid_size / std::pow(2, level);
+    const float sc = 1 + 2 * ctx->opt.bounding_box_margin;
+    for (int k = 0; k < 3; k++) {
+        const double cen = 0.5 * (mins[k] + maxs[k]);
+        const double lo = cen + (double)sc * (mins[k] - cen);
+        const double hi = cen + (double)sc * (maxs[k] - cen);
+        const double length = hi - lo;
+        int d = (int)std::round(length / size);
+        if (d < 1) d = 1;
+        g.spacing[k] = length / d;
+        g.origin[k] = lo - g.spacing[k];
+        g.cells[k] = d;
+        g.dims[k] = d + 3;
+        info.bbox[2 * k] = lo; info.bbox[2 * k + 1] = hi;
+        info.dims[k] = g.dims[k]; info.origin[k] = g.origin[k]; info.spacing[k] = g.spacing[k];
+    }
+    const size_t G = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
+    if (G > 0x7FFFFFFFull) return fail(FROG_E_INVALID, "lattice too large");
+    g.n_cp = (int)G;
+    const uint32_t nO = ctx->n_owned();
+    const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
+    // brick edge: 8 cells while bricks keep enough points to amortise their flush
+    auto bricks_for = [&](int B) { size_t n = 1; for (int k = 0; k < 3; k++) n *= (size_t)((g.cells[k] + B - 1) / B); return n; };
+    g.brick = ((double)nPts / ((double)nO * (double)bricks_for(8)) >= 96.0) ? 8 : 4;
+    for (int k = 0; k < 3; k++) g.nbricks[k] = (g.cells[k] + g.brick - 1) / g.brick;
+    const size_t nb = bricks_for(g.brick);
+    if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
+    g.n_bricks = (int)nb;
+    ctx->geom = g;
+    info.n_grid = (int)ctx->grids.size();
+
+    hipStream_t s = ctx->stream;
+    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G));
+    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G));
+    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
+
+    // bin the owned points into bricks
+    const uint32_t n_keys = nO * (uint32_t)nb;
+    frog::DevBuf<uint32_t> counts;
+    FROG_HIP_CHECK(counts.alloc(n_keys));
+    FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
+    FROG_HIP_CHECK(ctx->brick_ptr.alloc((size_t)n_keys + 1));
+    FROG_HIP_CHECK(ctx->brick_cursor.alloc((size_t)n_keys + 1));
+    if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
+    const GeomDev gd = to_dev(g);
+    if (nPts) {
+        brick_count_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->ib, gd, counts.p);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
+    brick_scan_kernel<<<1, 1024, 0, s>>>(counts.p, n_keys, ctx->brick_ptr.p, ctx->brick_cursor.p, ctx->brick_cursor.p + n_keys);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpyAsync(&ctx->max_brick_count, ctx->brick_cursor.p + n_keys, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (nPts) {
+        brick_place_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->ib, gd,
+                                                           ctx->brick_cursor.p, ctx->perm.p);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
+    FROG_HIP_CHECK(hipStreamSynchronize(s));      // max_brick_count is on the host; `counts` may go
+
+    GridRecord rec;
+    rec.info = info;
+    ctx->grids.push_back(std::move(rec));
+    ctx->deformable = true;
+    ctx->phase = 0;
+    if (out) *out = info;
+    return FROG_OK;
+}
+
+int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out)
+{
+    if (ctx && ctx->n_owned() != ctx->nI)
+        return fail(FROG_E_STATE, "context owns a sub-range of images: use frog_bounds_local + all-reduce + frog_deformable_setup_bounds");
+    double mn[3], mx[3];
+    int rc = frog_bounds_local(ctx, mn, mx);
+    if (rc) return rc;
+    return frog_deformable_setup_bounds(ctx, level, mn, mx, out);
+}
+
+// ---- updateDeformableTransforms (imageGroup.cxx:234-472) -----------------------------------
+int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
+{
+    CTX_GUARD(ctx);
+    if (!ctx->deformable) return fail(FROG_E_STATE, "deformable step before frog_deformable_setup");
+    hipStream_t s = ctx->stream;
+    const GeomDev gd = to_dev(ctx->geom);
+    const uint32_t nO = ctx->n_owned();
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));         // Fill(0), :249
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->n_big.p, 0, sizeof(unsigned long long), s));
+    sweep_kernel<SWEEP_DEFORMABLE><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    FROG_HIP_CHECK(hipGetLastError());
+    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, 2, 0, ctx->energy.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    const uint32_t n_keys = nO * (uint32_t)ctx->geom.n_bricks;
+    const uint32_t chunks = std::max(1u, div_up(ctx->max_brick_count, SCATTER_CHUNK));
+    if (ctx->max_brick_count) {
+        scatter_kernel<<<dim3(n_keys, chunks), 256, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p, ctx->brick_ptr.p,
+                                                          ctx->grad.p, gd);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
+    cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    ctx->pending_alpha = alpha;
+    ctx->phase = 1;
+    return FROG_OK;
+}
+
+int frog_deformable_phase_b(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    if (ctx->phase != 1) return fail(FROG_E_STATE, "phase_b without phase_a");
+    hipStream_t s = ctx->stream;
+    const GridGeom &g = ctx->geom;
+    const float maxD = ctx->opt.max_displacement_ratio;
+    cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nI, ctx->gridsum.p,
+                                                        (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
+                                                        (double)maxD * g.spacing[2], ctx->n_big.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    nbig_publish_kernel<<<1, 1, 0, s>>>(ctx->n_big.p, ctx->energy.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    ctx->phase = 2;
+    return FROG_OK;
+}
+
+int frog_deformable_phase_c(frog_ctx *ctx, double *E)
+{
+    CTX_GUARD(ctx);
+    if (ctx->phase != 2) return fail(FROG_E_STATE, "phase_c without phase_b");
+    double e = 0, nbig = 0;
+    int rc = frog_energy_read(ctx, &e, &nbig);
+    if (rc) return rc;
+    ctx->phase = 0;
+    if (ctx->opt.guarantee_diffeomorphism && nbig > 0) {        // :434-439, nothing committed
+        if (E) *E = -1.0;
+        return FROG_OK;
+    }
+    const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
+    cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n);
+    FROG_HIP_CHECK(hipGetLastError());
+    if (E) *E = e;
+    return FROG_OK;
+}
+
+int frog_deformable_step(frog_ctx *ctx, float alpha, double *E)
+{
+    if (ctx && ctx->n_owned() != ctx->nI)
+        return fail(FROG_E_STATE, "context owns a sub-range of images: use the phase_a/b/c entry points");
+    int rc = frog_deformable_phase_a(ctx, alpha);
+    if (rc) return rc;
+    rc = frog_deformable_phase_b(ctx);
+    if (rc) return rc;
+    return frog_deformable_phase_c(ctx, E);
+}
+
+// ---- countInliers (imageGroup.cxx:988-1060) --------------------------------------------------
+int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
+{
+    CTX_GUARD(ctx);
+    if (!per_image) return fail(FROG_E_INVALID, "null output");
+    hipStream_t s = ctx->stream;
+    const uint32_t nO = ctx->n_owned();
+    sweep_kernel<SWEEP_COUNT><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    FROG_HIP_CHECK(hipGetLastError());
+    count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    std::vector<long long> h((size_t)nO * 2);
+    std::vector<float4> hem(ctx->nI);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->img_counts.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipMemcpyAsync(hem.data(), ctx->em.p, hem.size() * sizeof(float4), hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < nO; i++) {
+        frog_counts &c = per_image[ctx->ib + i];
+        c.points = ctx->poff[ctx->ib + i + 1] - ctx->poff[ctx->ib + i];
+        c.inliers = h[(size_t)i * 2]; c.outliers = h[(size_t)i * 2 + 1];
+        c.pairs = c.inliers + c.outliers;
+        c.c1 = hem[ctx->ib + i].x; c.c2 = hem[ctx->ib + i].y; c.ratio = hem[ctx->ib + i].z; c.pad_ = 0;
+    }
+    return FROG_OK;
+}
+
+// ---- read-back ---------------------------------------------------------------------------------
+static int download_points(frog_ctx *ctx, const float4 *src, float *dst)
+{
+    std::vector<float4> h(ctx->P);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t p = 0; p < ctx->P; p++) { dst[3 * p] = h[p].x; dst[3 * p + 1] = h[p].y; dst[3 * p + 2] = h[p].z; }
+    return FROG_OK;
+}
+
+int frog_get_points(frog_ctx *ctx, float *xyz, float *xyz2)
+{
+    CTX_GUARD(ctx);
+    int rc = FROG_OK;
+    if (xyz) rc = download_points(ctx, ctx->pos.p, xyz);
+    if (!rc && xyz2) rc = download_points(ctx, ctx->pos2.p, xyz2);
+    return rc;
+}
+
+int frog_set_points2(frog_ctx *ctx, const float *xyz2)
+{
+    CTX_GUARD(ctx);
+    if (!xyz2) return fail(FROG_E_INVALID, "null input");
+    std::vector<float4> h(ctx->P);
+    for (uint32_t i = 0; i < ctx->nI; i++)
+        for (uint32_t p = ctx->poff[i]; p < ctx->poff[i + 1]; p++) {
+            float4 v; v.x = xyz2[3 * (size_t)p]; v.y = xyz2[3 * (size_t)p + 1]; v.z = xyz2[3 * (size_t)p + 2];
+            int id = (int)i; std::memcpy(&v.w, &id, 4);
+            h[p] = v;
+        }
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_get_linear(frog_ctx *ctx, uint32_t image, double m16[16])
+{
+    CTX_GUARD(ctx);
+    if (image >= ctx->nI || !m16) return fail(FROG_E_INVALID, "bad image");
+    FROG_HIP_CHECK(hipMemcpyAsync(m16, ctx->mat.p + (size_t)image * 16, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_get_em(frog_ctx *ctx, uint32_t image, float out[3])
+{
+    CTX_GUARD(ctx);
+    if (image >= ctx->nI || !out) return fail(FROG_E_INVALID, "bad image");
+    float4 v;
+    FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->em.p + image, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+    return FROG_OK;
+}
+
+int frog_set_em(frog_ctx *ctx, uint32_t image, const float in[3])
+{
+    CTX_GUARD(ctx);
+    if (image >= ctx->nI || !in) return fail(FROG_E_INVALID, "bad image");
+    float4 v = make_float4(in[0], in[1], in[2], 0.f);
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->em.p + image, &v, sizeof v, hipMemcpyHostToDevice, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return frog_stats_publish(ctx);
+}
+
+int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *ordinals, int cap, int *n)
+{
+    CTX_GUARD(ctx);
+    if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
+    const uint32_t li = image - ctx->ib;
+    uint32_t cnt = 0;
+    FROG_HIP_CHECK(hipMemcpyAsync(&cnt, ctx->sample_count.p + li, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n) *n = (int)cnt;
+    const size_t m = std::min<size_t>(cnt, cap > 0 ? (size_t)cap : 0);
+    if (m && samples)
+        FROG_HIP_CHECK(hipMemcpyAsync(samples, ctx->samples.p + (size_t)li * ctx->sample_cap, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (m && ordinals)
+        FROG_HIP_CHECK(hipMemcpyAsync(ordinals, ctx->sample_ord.p + (size_t)li * ctx->sample_cap, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+// Stats::getHistogram (stats.cxx:121-131) over the retained samples; integer
+// binning of values computed on the device, done on the host at output time.
+int frog_get_histogram(frog_ctx *ctx, uint32_t image, float *bins, int cap, int *n)
+{
+    if (!ctx) return fail(FROG_E_INVALID, "null context");
+    int cnt = 0;
+    int rc = frog_get_samples(ctx, image, nullptr, nullptr, 0, &cnt);
+    if (rc) return rc;
+    std::vector<float> smp((size_t)std::max(cnt, 1));
+    rc = frog_get_samples(ctx, image, smp.data(), nullptr, cnt, &cnt);
+    if (rc) return rc;
+    if (cnt == 0) { if (n) *n = 0; return FROG_OK; }
+    float mx = smp[0];
+    for (int i = 1; i < cnt; i++) mx = std::max(mx, smp[i]);
+    const int size = (int)std::round(mx / 1.0f) + 1;
+    std::vector<float> h((size_t)size, 0.f);
+    for (int i = 0; i < cnt; i++) h[(size_t)std::round(smp[i] / 1.0f)]++;
+    if (n) *n = size;
+    if (bins) std::memcpy(bins, h.data(), (size_t)std::min(size, cap) * sizeof(float));
+    return FROG_OK;
+}
+
+int frog_num_grids(const frog_ctx *ctx) { return ctx ? (int)ctx->grids.size() : 0; }
+
+int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, float *coeffs, size_t cap)
+{
+    CTX_GUARD(ctx);
+    if (k < 0 || k >= (int)ctx->grids.size()) return fail(FROG_E_INVALID, "bad lattice index");
+    GridRecord &gr = ctx->grids[k];
+    if (info) *info = gr.info;
+    if (!coeffs) return FROG_OK;
+    if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
+    const size_t G = (size_t)gr.info.dims[0] * gr.info.dims[1] * gr.info.dims[2];
+    const size_t li = image - ctx->ib;
+    const size_t nfl = std::min(cap, 3 * G);
+    if (gr.retired) {
+        std::memcpy(coeffs, gr.host_coeffs.data() + li * 3 * G, nfl * sizeof(float));
+        return FROG_OK;
+    }
+    std::vector<float4> h(G);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->coeff.p + li * G, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nfl; i++) { const float4 &v = h[i / 3]; coeffs[i] = (i % 3 == 0) ? v.x : (i % 3 == 1) ? v.y : v.z; }
+    return FROG_OK;
+}
+
+int frog_get_point_sums(frog_ctx *ctx, float *out)
+{
+    CTX_GUARD(ctx);
+    std::vector<float4> h(ctx->P);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->point_sums.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, h.data(), h.size() * sizeof(float4));
+    return FROG_OK;
+}
+
+int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
+{
+    CTX_GUARD(ctx);
+    if (!ctx->deformable) return fail(FROG_E_STATE, "no lattice");
+    if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
+    const size_t G = (size_t)ctx->geom.n_cp;
+    const size_t n = std::min(cap, 4 * G);
+    FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->grad.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t *row_begin, size_t *row_end)
+{
+    CTX_GUARD(ctx);
+    size_t b = 0, rb = 0, re = 0;
+    void *p = nullptr;
+    switch (which) {
+    case FROG_BUF_XYZ2: p = ctx->pos2.p; b = ctx->pos2.bytes(); rb = ctx->own_pt_begin; re = ctx->own_pt_end; break;
+    case FROG_BUF_EM: p = ctx->em.p; b = ctx->em.bytes(); rb = ctx->ib; re = ctx->ie; break;
+    case FROG_BUF_ENERGY: p = ctx->energy.p; b = ctx->energy.bytes(); rb = 0; re = 4; break;
+    case FROG_BUF_GRIDSUM:
+        if (!ctx->deformable) return fail(FROG_E_STATE, "no lattice");
+        p = ctx->gridsum.p; b = ctx->gridsum.bytes(); rb = 0; re = ctx->gridsum.n; break;
+    default: return fail(FROG_E_INVALID, "unknown buffer");
+    }
+    if (ptr) *ptr = p;
+    if (bytes) *bytes = b;
+    if (row_begin) *row_begin = rb;
+    if (row_end) *row_end = re;
+    return FROG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,222 @@
+// k_links.hip.h -- the half-link sweep (K3 / K6 / K14 of SURVEY.md section 2.2) and
+// the per-image linear update (K4).
+//
+// One wavefront per tile (ctx.h): 64 half-links per step, records streamed from
+// HBM as coalesced 8-byte loads, both end points gathered as one 16-byte load
+// each from the xyz2 table (L2 resident thanks to the partner-synchronous order
+// of prep.h).  Nothing here is GEMM shaped: it is a gather + weighted reduction,
+// bound by the record stream and the gathers, so no MFMA.
+//
+// Arithmetic contract (reference lines in the comments):
+//   dist2, dist  -- f32, no FMA contraction, correctly rounded sqrt: bit-exact
+//                   with the reference, so `d < 0.1` and the sample values agree.
+//   inlier weight -- f32 with reciprocals and expf: within a few f32 ulps of the
+//                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92);
+//                   the reference rounds d/c to f32 before squaring, which already
+//                   perturbs the exponent by more than this.
+//   linear sums  -- f32 products, f64 accumulation (imageGroup.cxx:1102-1117);
+//                   per-tile partials reduced in a fixed order (deterministic).
+//   deformable   -- f32 products, f32 per-point sums in partner order
+//                   (imageGroup.cxx:270-278), accumulated in LDS.
+#pragma once
+
+#include "ctx.h"
+
+namespace frog {
+
+enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
+constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
+
+struct SweepArgs {
+    const Tile *tiles;
+    const LinkRec *recs;
+    const float4 *pos2;
+    const EmDerived *emd;
+    uint32_t n_tiles;
+    float threshold;
+    double *tile_partial;       // [n_tiles][18] (linear) or [n_tiles][2] (deformable)
+    long long *tile_counts;     // [n_tiles][2]  (count)
+    float4 *point_sums;         // deformable
+};
+
+// getInlierProbability (stats.h:84-92) from precomputed per-image constants.
+__device__ __forceinline__ float inlier_probability(float d, const EmDerived e)
+{
+    // `d < 0.1` compares (double)d with 0.1; no float lies in [0.1, 0.1f), so
+    // the f32 comparison with 0.1f selects the same values.
+    if (d < 0.1f) return 1.0f;
+    float u1 = d * e.inv1; u1 *= u1;
+    float u2 = d * e.inv2; u2 *= u2;
+    float x1 = e.k1 * u1 * expf(-0.5f * u1);
+    float x2 = e.k2 * u2 * expf(-0.5f * u2);
+    return x1 / (x1 + x2 + 1e-10f);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
+{
+    __shared__ float acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS * 4 : 4];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + wave;
+    const bool live = t < a.n_tiles;
+
+    Tile tl;
+    tl.pt_begin = 0; tl.pt_count = 0; tl.rec_begin = 0; tl.rec_count = 0; tl.image = 0;
+    if (live) tl = a.tiles[t];
+    float *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS * 4 : 0);
+
+    if (MODE == SWEEP_DEFORMABLE) {
+        for (int k = lane; k < TILE_POINTS * 4; k += 64) my[k] = 0.f;
+        __syncthreads();
+    }
+
+    const EmDerived eA = a.emd[tl.image];
+
+    double s[(MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2];
+    #pragma unroll
+    for (int k = 0; k < ((MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2); k++) s[k] = 0.0;
+    long long n_in = 0, n_out = 0;
+
+    const LinkRec *rec = a.recs + tl.rec_begin;
+    for (uint32_t r = lane; r < tl.rec_count; r += 64) {
+        const LinkRec lr = rec[r];
+        const float4 pa = a.pos2[lr.a];
+        const float4 pb = a.pos2[lr.b];
+        const EmDerived eB = a.emd[__float_as_int(pb.w)];
+
+        const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float d = sqrtf(d2);
+        const float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
+
+        if (MODE == SWEEP_LINEAR) {
+            // imageGroup.cxx:1102-1117
+            s[16] += (double)(w * w * d * d);
+            s[17] += (double)(w * w);
+            s[0] += (double)(w * dx); s[1] += (double)(w * dy); s[2] += (double)(w * dz);
+            s[3] += (double)(w * pa.x); s[4] += (double)(w * pa.y); s[5] += (double)(w * pa.z);
+            s[6] += (double)(w * pb.x); s[7] += (double)(w * pb.y); s[8] += (double)(w * pb.z);
+            s[9] += (double)(w * pa.x * pa.x); s[10] += (double)(w * pa.y * pa.y); s[11] += (double)(w * pa.z * pa.z);
+            s[12] += (double)(w * pb.x * pb.x); s[13] += (double)(w * pb.y * pb.y); s[14] += (double)(w * pb.z * pb.z);
+            s[15] += (double)w;
+        } else if (MODE == SWEEP_DEFORMABLE) {
+            // imageGroup.cxx:270-278
+            if (w >= a.threshold) {
+                const float w2 = w * w;
+                s[1] += (double)w2;
+                s[0] += (double)(w2 * d2);
+                float *dst = my + (lr.a - tl.pt_begin) * 4;
+                atomicAdd(dst + 0, w2 * dx);
+                atomicAdd(dst + 1, w2 * dy);
+                atomicAdd(dst + 2, w2 * dz);
+                atomicAdd(dst + 3, w2);
+            }
+        } else {
+            // imageGroup.cxx:1022-1027
+            if (w < a.threshold) n_out++; else n_in++;
+        }
+    }
+
+    if (MODE == SWEEP_LINEAR) {
+        #pragma unroll
+        for (int k = 0; k < LINEAR_SUMS; k++) {
+            double v = wave_sum(s[k]);
+            if (lane == 0 && live) a.tile_partial[(size_t)t * LINEAR_SUMS + k] = v;
+        }
+    } else if (MODE == SWEEP_DEFORMABLE) {
+        double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);
+        if (lane == 0 && live) { a.tile_partial[(size_t)t * 2] = v0; a.tile_partial[(size_t)t * 2 + 1] = v1; }
+        __syncthreads();
+        const float4 *src = reinterpret_cast<const float4 *>(my);
+        for (uint32_t k = lane; k < tl.pt_count; k += 64) a.point_sums[tl.pt_begin + k] = src[k];
+    } else {
+        long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
+        if (lane == 0 && live) { a.tile_counts[(size_t)t * 2] = v0; a.tile_counts[(size_t)t * 2 + 1] = v1; }
+    }
+}
+
+// Sum of the (sDistances, sWeights) tile partials in a fixed order -> energy[0..1].
+// One block; the tree is the same on every run.
+__global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partial, uint32_t n_tiles,
+                                                            int stride, int off, double *energy)
+{
+    __shared__ double sh[2][256];
+    double a0 = 0, a1 = 0;
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 256) {
+        a0 += partial[(size_t)t * stride + off];
+        a1 += partial[(size_t)t * stride + off + 1];
+    }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) { sh[0][threadIdx.x] += sh[0][threadIdx.x + h]; sh[1][threadIdx.x] += sh[1][threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { energy[0] = sh[0][0]; energy[1] = sh[1][0]; energy[2] = 0.0; energy[3] = 0.0; }
+}
+
+// K4: per-image scale / translation update (imageGroup.cxx:1123-1143).
+// One 64-thread block per owned image: lanes 0..17 add the image's tile partials
+// in tile order, lanes 0..2 then update one axis each.
+__global__ __launch_bounds__(64) void linear_update_kernel(const double *partial, const uint32_t *img_tile_ptr,
+                                                           uint32_t image_begin, double *mat,
+                                                           float linear_alpha, int use_scale)
+{
+    __shared__ double sums[LINEAR_SUMS];
+    const uint32_t image = image_begin + blockIdx.x;
+    const uint32_t t0 = img_tile_ptr[image], t1 = img_tile_ptr[image + 1];
+    if (threadIdx.x < LINEAR_SUMS) {
+        double v = 0;
+        for (uint32_t t = t0; t < t1; t++) v += partial[(size_t)t * LINEAR_SUMS + threadIdx.x];
+        sums[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        double *M = mat + (size_t)image * 16;
+        const double sDisp = sums[k], sPosA = sums[3 + k], sPosB = sums[6 + k];
+        const double sPosA2 = sums[9 + k], sPosB2 = sums[12 + k], sWeight = sums[15];
+        const float scale = (float)M[5 * k];
+        float newScale = 1.0f;
+        if (use_scale)
+            newScale = (float)pow((sWeight * sPosB2 - sPosB * sPosB) / (sWeight * sPosA2 - sPosA * sPosA),
+                                  0.5 * (double)linear_alpha);
+        if (!isnan(newScale)) {
+            M[5 * k] = (double)(scale * newScale);
+            const float translation = (float)M[4 * k + 3];
+            if (!isnan(translation))
+                M[4 * k + 3] = (double)translation + (double)linear_alpha * sDisp / sWeight
+                             + sPosA * (double)(1 - newScale) / sWeight;
+        }
+    }
+}
+
+// per-image census from the tile counters (imageGroup.cxx:1033-1046)
+__global__ void count_reduce_kernel(const long long *tile_counts, const uint32_t *img_tile_ptr,
+                                    uint32_t image_begin, uint32_t n_owned, long long *out /*[n_owned][2]*/)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_owned) return;
+    const uint32_t image = image_begin + i;
+    long long a = 0, b = 0;
+    for (uint32_t t = img_tile_ptr[image]; t < img_tile_ptr[image + 1]; t++) { a += tile_counts[(size_t)t * 2]; b += tile_counts[(size_t)t * 2 + 1]; }
+    out[(size_t)i * 2] = a; out[(size_t)i * 2 + 1] = b;
+}
+
+} // namespace frog

@@ -1,0 +1,251 @@
+// k_stats.hip.h -- updateStats on the device (K1, K2 and the reservoir S1 of
+// SURVEY.md): which half-links feed the EM fit, their distances, and the fit.
+//
+// Reservoir (stats.h:58-76, setupStats imageGroup.cxx:1151-1159): an image with
+// more half-links than Stats::maxSize keeps a sample when
+//     (float) rng() / rng.max()  <=  (float) capacity / virtualSize
+// and stops drawing once the buffer is full; the mt19937 is seeded with 0 once
+// and never reseeded, so the state carries over from refresh to refresh.  Which
+// ordinals are kept therefore depends only on (virtualSize, capacity, number of
+// earlier refreshes), not on the data: select_kernel replays the generator, one
+// wavefront per image, and emits the kept ordinals bit-exactly.
+#pragma once
+
+#include "ctx.h"
+
+namespace frog {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+constexpr int MT_WORDS = MT_N + 1;      // state + index of the next unread word
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far)
+{
+    uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Regenerates all 624 state words in place (std::mt19937's _M_gen_rand), one
+// wavefront, state in LDS.  Four dependency phases: [0,227) [227,454) [454,623) {623}.
+__device__ __forceinline__ void mt_regenerate(uint32_t *x, int lane)
+{
+    const int starts[5] = { 0, 227, 454, 623, 624 };
+    #pragma unroll
+    for (int ph = 0; ph < 4; ph++) {
+        uint32_t v[4];
+        #pragma unroll
+        for (int m = 0; m < 4; m++) {
+            int k = starts[ph] + lane + 64 * m;
+            if (k < starts[ph + 1]) {
+                int k1 = (k + 1 == MT_N) ? 0 : k + 1;
+                int km = (k + MT_M >= MT_N) ? k + MT_M - MT_N : k + MT_M;
+                v[m] = mt_twist(x[k], x[k1], x[km]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int m = 0; m < 4; m++) {
+            int k = starts[ph] + lane + 64 * m;
+            if (k < starts[ph + 1]) x[k] = v[m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// One wavefront (block of 64) per owned image.
+//   virtual_size[i] <= cap : every ordinal is kept, no draw (needsRandom false).
+//   else                   : replay draws until the buffer is full or the
+//                            image's half-links are exhausted.
+__global__ __launch_bounds__(64) void select_kernel(uint32_t *mt_state, const uint32_t *virtual_size,
+                                                    uint32_t cap, uint32_t *sample_ord, uint32_t *sample_count)
+{
+    __shared__ uint32_t x[MT_N];
+    const int lane = threadIdx.x;
+    const uint32_t img = blockIdx.x;
+    const uint32_t vs = virtual_size[img];
+    uint32_t *ord = sample_ord + (size_t)img * cap;
+
+    if (vs <= cap) {
+        for (uint32_t k = lane; k < vs; k += 64) ord[k] = k;
+        if (lane == 0) sample_count[img] = vs;
+        return;
+    }
+
+    uint32_t *st = mt_state + (size_t)img * MT_WORDS;
+    for (int k = lane; k < MT_N; k += 64) x[k] = st[k];
+    uint32_t idx = st[MT_N];                       // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const float thresh = (float)cap / (float)vs;   // (float) samples.size() / virtualSize
+    uint32_t count = 0;                            // kept so far
+    uint32_t ordinal = 0;                          // draws consumed this refresh
+    bool done = false;
+    while (!done && ordinal < vs) {
+        if (idx >= (uint32_t)MT_N) { mt_regenerate(x, lane); idx = 0; }
+        // consume up to 64 words [idx, idx+64) of the current block
+        const uint32_t avail = min((uint32_t)MT_N - idx, vs - ordinal);
+        const uint32_t n = min(avail, 64u);
+        bool keep = false;
+        if ((uint32_t)lane < n) {
+            const uint32_t y = mt_temper(x[idx + lane]);
+            const float r = (float)y / 4294967296.0f;   // (float) rng() / rng.max(); (float)0xFFFFFFFF == 2^32
+            keep = !(r > thresh);
+        }
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t kept = (uint32_t)__popcll(mask);
+        const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (count + kept >= cap) {
+            // the buffer fills inside this group: keep the first (cap - count)
+            const uint32_t need = cap - count;
+            if (keep && before < need) ord[count + before] = ordinal + lane;
+            // lane holding the need-th kept draw = last draw consumed
+            const bool last = keep && (before == need - 1);
+            const unsigned long long lm = __ballot(last);
+            const uint32_t jstar = (uint32_t)__ffsll((long long)lm) - 1u;
+            idx += jstar + 1;
+            ordinal += jstar + 1;
+            count = cap;
+            done = true;
+        } else {
+            if (keep) ord[count + before] = ordinal + lane;
+            count += kept;
+            idx += n;
+            ordinal += n;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < MT_N; k += 64) st[k] = x[k];
+    if (lane == 0) { st[MT_N] = idx; sample_count[img] = count; }
+}
+
+// K1: distance of every kept half-link (imageGroup.cxx:579-590), thread per slot.
+// ordinal -> owning point by binary search in the reference-order row pointers.
+__global__ __launch_bounds__(256) void sample_distance_kernel(
+    const uint32_t *sample_ord, const uint32_t *sample_count, uint32_t cap,
+    const uint32_t *poff, uint32_t image_begin, uint32_t own_pt_begin,
+    const uint64_t *ref_rowptr, const uint32_t *ref_link, const float4 *pos2, float *samples)
+{
+    const uint32_t img = blockIdx.y;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= sample_count[img]) return;
+    const uint32_t image = image_begin + img;
+    const uint32_t pb = poff[image] - own_pt_begin, pe = poff[image + 1] - own_pt_begin;
+    const uint64_t l = ref_rowptr[pb] + sample_ord[(size_t)img * cap + slot];
+    // largest p in [pb, pe) with rowptr[p] <= l
+    uint32_t lo = pb, hi = pe;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ref_rowptr[mid] <= l) lo = mid; else hi = mid;
+    }
+    const float4 a = pos2[own_pt_begin + lo];
+    const float4 b = pos2[ref_link[l]];
+    // vtkMath::Distance2BetweenPoints(pA, pB), f32
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    samples[(size_t)img * cap + slot] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// chipdf (stats.h:10-16) with the reference's promotions: f32 c*x2, f64 exp.
+__device__ __forceinline__ float chi_pdf_ref(float x)
+{
+    const float c = 0.797884560802865f;
+    const float x2 = x * x;
+    const float cx2 = c * x2;
+    return (float)((double)cx2 * exp(-0.5 * (double)x2));
+}
+
+// K2: Stats::estimateDistribution (stats.cxx:14-70), one block per owned image.
+// Per-sample terms follow the reference's promotions exactly; the five sums are
+// accumulated as f64 partials and tree-reduced (the reference adds 10^4 terms
+// sequentially in f32; its own rounding noise is ~1e-6).
+__global__ __launch_bounds__(256) void em_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
+                                                 uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
+{
+    __shared__ double red[4][256];
+    __shared__ float params[3];
+    __shared__ int stop;
+    const uint32_t img = blockIdx.x;
+    const uint32_t n = sample_count[img];
+    const float *smp = samples + (size_t)img * cap;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        float4 e = em[image_begin + img];
+        params[0] = e.x; params[1] = e.y; params[2] = e.z; stop = 0;
+    }
+    __syncthreads();
+    const float esp = 1.59576912160573f;
+    int iteration = 0;
+    while (iteration++ < max_iterations) {
+        const float c1 = params[0], c2 = params[1], ratio = params[2];
+        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const float x = smp[i];
+            const float f1 = ratio * chi_pdf_ref(x / c1) / c1;
+            const float f2 = (float)((1.0 - (double)ratio) * (double)chi_pdf_ref(x / c2) / (double)c2);
+            const float t = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
+            const float p = x * 1.0f;                  // weights are all 1 (addSample default)
+            s1 += (double)(t * p);
+            s2 += (double)(t * 1.0f);
+            s3 += (1.0 - (double)t) * (double)p;
+            s4 += (1.0 - (double)t) * 1.0;
+        }
+        red[0][tid] = s1; red[1][tid] = s2; red[2][tid] = s3; red[3][tid] = s4;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if (tid < h) {
+                red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h];
+                red[2][tid] += red[2][tid + h]; red[3][tid] += red[3][tid + h];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float sum1 = (float)red[0][0], sum2 = (float)red[1][0], sum3 = (float)red[2][0], sum4 = (float)red[3][0];
+            float sum5 = (float)n;
+            sum2 = fmaxf(sum2, epsilon);
+            sum3 = fmaxf(sum3, epsilon);
+            sum5 = fmaxf(sum5, epsilon);
+            const float nc1 = fmaxf(epsilon, sum1 / sum2 / esp);
+            const float nc2 = fmaxf(epsilon, sum3 / sum4 / esp);
+            const float nr = fmaxf(epsilon, sum2 / sum5);
+            const bool done = (double)fabsf((c1 - nc1) / nc1) < 0.001
+                           && (double)fabsf((c2 - nc2) / nc2) < 0.001
+                           && (double)fabsf((nr - ratio) / nr) < 0.001;
+            params[0] = nc1; params[1] = nc2; params[2] = nr;
+            stop = done ? 1 : 0;
+        }
+        __syncthreads();
+        if (stop) break;
+    }
+    if (tid == 0) em[image_begin + img] = make_float4(params[0], params[1], params[2], 0.f);
+}
+
+// (c1,c2,ratio) -> constants of inlier_probability for ALL images (after the
+// EM table has been made whole by the all-reduce in multi-rank runs).
+__global__ void em_derive_kernel(const float4 *em, EmDerived *emd, uint32_t n_images)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const float eps = 1e-10f;
+    const float c = 0.797884560802865f;
+    float4 e = em[i];
+    EmDerived d;
+    d.inv1 = 1.0f / (e.x + eps);
+    d.inv2 = 1.0f / (e.y + eps);
+    d.k1 = e.z * c * d.inv1;
+    d.k2 = (1.0f - e.z) * c * d.inv2;
+    emd[i] = d;
+}
+
+} // namespace frog

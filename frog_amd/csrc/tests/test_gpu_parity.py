@@ -1,0 +1,194 @@
+"""HIP path vs CPU oracle, through the C ABI (include/frog_hip.h).
+
+Bars (BASELINE.json north_star): sampled-link ordinals, sample values and
+histogram bins bit-exact on identical inputs; transform parameters (matrix
+entries, B-spline coefficients) within 1e-4 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from frog_amd import _abi
+from frog_amd.image_group import ImageGroup
+from oracle.oracle_api import OracleGroup
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4          # north-star tolerance for transform parameters
+
+
+def make(pairs, **opt):
+    o = _abi.FrogOptions.default(**opt)
+    g = ImageGroup(pairs, **opt)
+    ref = OracleGroup(pairs.model, o)
+    ref.setup_stats()
+    return g, ref
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)
+
+
+def start(g, ref):
+    g.setupLinearTransforms(); ref.linear_init()
+    g.transformPoints(); ref.transform_points()
+
+
+def test_linear_init_and_transform_bit_exact(small_pairs):
+    g, ref = make(small_pairs)
+    start(g, ref)
+    for i in range(small_pairs.n_images):
+        assert np.array_equal(g.matrix(i), ref.matrix(i))
+    xyz, xyz2 = g.points()
+    assert np.array_equal(xyz, ref.xyz())
+    assert np.array_equal(xyz2, ref.xyz2())
+
+
+@pytest.mark.parametrize("max_size", [10000, 2000])
+def test_update_stats_samples_bit_exact(small_pairs, max_size):
+    # 3000 points x ~5 partners x 1500 pairs -> 15000 half-links per image:
+    # max_size 10000 and 2000 both exercise the mt19937 reservoir
+    g, ref = make(small_pairs, stats_max_size=max_size)
+    start(g, ref)
+    for refresh in range(3):            # generator state carries over between refreshes
+        g.updateStats(); ref.update_stats()
+        for i in range(small_pairs.n_images):
+            s, o = g.samples(i)
+            rs, ro = ref.samples(i)
+            assert np.array_equal(o, ro), f"ordinals differ, image {i}, refresh {refresh}"
+            assert np.array_equal(s, rs), f"sample distances differ, image {i}, refresh {refresh}"
+            assert np.array_equal(g.histogram(i), ref.histogram(i))
+            np.testing.assert_allclose(g.em(i), ref.em(i), rtol=2e-5)
+
+
+def test_update_stats_without_reservoir(tiny_pairs):
+    # 600 points x 3 partners x 300 pairs = 1800 half-links < maxSize: every link is a sample
+    g, ref = make(tiny_pairs)
+    start(g, ref)
+    g.updateStats(); ref.update_stats()
+    for i in range(tiny_pairs.n_images):
+        s, o = g.samples(i)
+        rs, ro = ref.samples(i)
+        assert len(s) == len(rs) and np.array_equal(o, ro) and np.array_equal(s, rs)
+
+
+def test_linear_step_matches(small_pairs):
+    g, ref = make(small_pairs)
+    start(g, ref)
+    ref.update_stats()
+    for i in range(small_pairs.n_images):
+        g.set_em(i, ref.em(i))          # identical EM parameters on both sides
+    e = g.updateLinearTransforms(); er = ref.linear_step()
+    assert abs(e - er) / er < 1e-6
+    for i in range(small_pairs.n_images):
+        m, mr = g.matrix(i), ref.matrix(i)
+        assert relerr(np.diag(m)[:3], np.diag(mr)[:3]) < 1e-6
+        assert relerr(m[:3, 3], mr[:3, 3]) < 1e-6
+
+
+def test_linear_stage_50_iterations(small_pairs):
+    g, ref = make(small_pairs)
+    start(g, ref)
+    for it in range(50):
+        if it % 10 == 0:
+            g.updateStats(); ref.update_stats()
+        e = g.updateLinearTransforms(); er = ref.linear_step()
+        g.transformPoints(); ref.transform_points()
+        assert abs(e - er) / er < REL
+    for i in range(small_pairs.n_images):
+        m, mr = g.matrix(i), ref.matrix(i)
+        assert relerr(np.diag(m)[:3], np.diag(mr)[:3]) < REL
+        assert relerr(m[:3, 3], mr[:3, 3]) < REL
+    assert relerr(g.points()[1], ref.xyz2()) < REL
+
+
+def _to_deformable(g, ref, iters=20):
+    start(g, ref)
+    for it in range(iters):
+        if it % 10 == 0:
+            ref.update_stats()
+            for i in range(ref.n_images):
+                g.set_em(i, ref.em(i))
+        g.updateLinearTransforms(); ref.linear_step()
+        g.transformPoints(); ref.transform_points()
+    g.transformPoints(True); ref.transform_points(True)
+    # continue from identical coordinates so that the deformable kernels are compared in isolation
+    g_xyz, _ = g.points()
+    return g_xyz
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_deformable_step_pieces(small_pairs, level):
+    g, ref = make(small_pairs)
+    _to_deformable(g, ref)
+    info = g.setupDeformableTransforms(level)
+    rinfo = ref.deformable_setup(level, _abi.FrogGridInfo())
+    assert list(info.dims) == list(rinfo.dims)
+    np.testing.assert_allclose(list(info.origin), list(rinfo.origin), rtol=1e-6)
+    np.testing.assert_allclose(list(info.spacing), list(rinfo.spacing), rtol=1e-6)
+    g.transformPoints(); ref.transform_points()
+    assert relerr(g.points()[1], ref.xyz2()) < 1e-6
+    ref.update_stats()
+    for i in range(ref.n_images):
+        g.set_em(i, ref.em(i))
+    n_cp = info.dims[0] * info.dims[1] * info.dims[2]
+    e = g.updateDeformableTransforms(0.02); er = ref.deformable_step(0.02)
+    assert er > 0 and abs(e - er) / er < 1e-5
+    ps, rps = g.point_sums(), ref.point_sums()
+    assert relerr(ps, rps) < 1e-5
+    for i in range(ref.n_images):
+        _, c = g.grid(i, 0)
+        _, rc = ref.grid(i, 0, _abi.FrogGridInfo())
+        assert relerr(c, rc) < REL
+    g.transformPoints(); ref.transform_points()
+    assert relerr(g.points()[1], ref.xyz2()) < 1e-6
+
+
+def test_diffeomorphism_guard_rejects_without_state_change(small_pairs):
+    g, ref = make(small_pairs, max_displacement_ratio=1e-4)
+    _to_deformable(g, ref)
+    g.setupDeformableTransforms(1); ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    before = g.points()[1].copy()
+    e = g.updateDeformableTransforms(0.02); er = ref.deformable_step(0.02)
+    assert e == -1.0 and er == -1.0
+    _, c = g.grid(0, 0)
+    assert not c.any()
+    g.transformPoints()
+    assert np.array_equal(g.points()[1], before)
+
+
+def test_count_inliers(small_pairs):
+    g, ref = make(small_pairs)
+    _to_deformable(g, ref)
+    c = g.countInliers()
+    rc = ref.count_inliers((_abi.FrogCounts * ref.n_images)())
+    for i in range(ref.n_images):
+        assert c[i].points == rc[i].points and c[i].pairs == rc[i].pairs
+        # weights agree to a few f32 ulps, so only links within ~1e-6 of the threshold may flip
+        assert abs(c[i].inliers - rc[i].inliers) <= 2
+
+
+def test_full_run_parity(small_pairs):
+    """Whole schedule of run() (imageGroup.cxx:31-157) at reduced iteration counts."""
+    g, ref = make(small_pairs)
+    g.linearIterations, g.deformableLevels, g.deformableIterations = 30, 3, 40
+    E = np.array(g.run())
+    Er, grids_r = ref.run(li=30, dl=3, di=40)
+    assert g.gridsPerLevel == grids_r
+    assert len(E) == len(Er)
+    assert np.max(np.abs(E - Er) / Er) < REL
+    for i in range(ref.n_images):
+        m, mr = g.matrix(i), ref.matrix(i)
+        assert relerr(np.diag(m)[:3], np.diag(mr)[:3]) < REL
+        assert relerr(m[:3, 3], mr[:3, 3]) < REL
+    assert g.num_grids() == ref.num_grids()
+    for k in range(ref.num_grids()):
+        for i in range(ref.n_images):
+            info, c = g.grid(i, k)
+            rinfo, rc = ref.grid(i, k, _abi.FrogGridInfo())
+            assert list(info.dims) == list(rinfo.dims)
+            assert relerr(c, rc) < REL, f"lattice {k} image {i}"
+    assert relerr(g.points()[0], ref.xyz()) < REL

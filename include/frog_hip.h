@@ -1,0 +1,147 @@
+/*
+ * frog_hip.h -- C ABI of the MI355X (gfx950) device library libfrog_hip.so.
+ *
+ * The drop-in seam of valette/FROG's groupwise solver: the reference has no
+ * plugin/FFI interface (frog is one statically linked TU set,
+ * registration/CMakeLists.txt:17), so the boundary is the set of ImageGroup
+ * methods that ImageGroup::run (registration/imageGroup.cxx:31-157) invokes in
+ * its loops.  Each entry point below replaces one of them; a host that keeps
+ * the reference's control flow (this repo's libfrog_host.so, or the reference's
+ * own run() with the stub shown in INTEGRATION.md) calls them in the same
+ * order.  Plain pointers and sizes only; the library owns all device memory.
+ *
+ * Conventions carried over from the reference: single caller thread, calls
+ * strictly sequential (the reference's phases are barriers); every function
+ * returns an int status (FROG_OK = 0; the reference's only error channels are
+ * exit(1) and the -1 energy, which is kept: *E = -1 when a deformable step is
+ * rejected by the diffeomorphism guard).  There is NO CPU fallback: without a
+ * HIP device frog_create fails with FROG_E_NODEVICE.
+ *
+ * Multi-GPU: one process per GPU, each context owns a contiguous range of
+ * images [image_begin, image_end) (the unit of every omp-for in the reference)
+ * and keeps read-only replicas of what the link loops read from other images
+ * (transformed coordinates, EM parameters).  The *_local / phase_* entry points
+ * stop where the reference reads another image's state; the host runs the
+ * collective (RCCL all-gather / all-reduce) on the buffers exposed by
+ * frog_comm_buffer and calls the next phase.  With one rank the plain entry
+ * points run all phases back to back.
+ */
+#ifndef FROG_HIP_H
+#define FROG_HIP_H
+
+#include "frog_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct frog_ctx frog_ctx;
+
+/* ---- life cycle ----------------------------------------------------------- */
+
+int frog_device_count(void);
+/* Message for the last non-OK status returned on this thread. */
+const char *frog_last_error(void);
+
+/* ImageGroup ctor + readPairs' in-memory result + setupStats
+ * (imageGroup.h:52-82, imageGroup.cxx:1353-1417, :1151-1159).
+ * Copies the model to `device`, builds the device-side link layout and one
+ * reservoir per image.  image_begin/image_end select the images this context
+ * updates (0, n_images for a single GPU). */
+int frog_create(const frog_model *model, const frog_options *options, int device,
+                uint32_t image_begin, uint32_t image_end, frog_ctx **out);
+void frog_destroy(frog_ctx *ctx);
+
+/* Run all work of this context on an existing HIP stream (hipStream_t), e.g.
+ * the stream a host framework issues its collectives against.  Default: a
+ * stream created by frog_create. */
+int frog_set_stream(frog_ctx *ctx, void *hip_stream);
+int frog_synchronize(frog_ctx *ctx);
+
+/* ---- the six methods run() calls ------------------------------------------- */
+
+/* setupLinearTransforms (imageGroup.cxx:806-848). */
+int frog_linear_init(frog_ctx *ctx, const float anchor[3]);
+/* transformPoints(apply) (imageGroup.cxx:910-916 -> image.cxx:3-13). */
+int frog_transform_points(frog_ctx *ctx, int apply);
+/* updateStats (imageGroup.cxx:569-598): reservoir refresh + EM fit per image. */
+int frog_update_stats(frog_ctx *ctx);
+/* updateLinearTransforms (imageGroup.cxx:1063-1149); *E = sqrt(sum w2 d2 / sum w2). */
+int frog_linear_step(frog_ctx *ctx, double *E);
+/* setupDeformableTransforms(level) (imageGroup.cxx:159-218). */
+int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out);
+/* updateDeformableTransforms(alpha) (imageGroup.cxx:234-472); *E = -1 and no
+ * state change when guarantee_diffeomorphism is set and a coefficient exceeds
+ * max_displacement_ratio * spacing. */
+int frog_deformable_step(frog_ctx *ctx, float alpha, double *E);
+/* countInliers (imageGroup.cxx:988-1060); per_image has n_images entries, only
+ * the owned range is filled. */
+int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image);
+
+/* ---- read-back for the writers (saveTransforms, histograms, bbox) ---------- */
+
+uint64_t frog_num_points(const frog_ctx *ctx);
+uint32_t frog_num_images(const frog_ctx *ctx);
+/* xyz / xyz2 as 3*P floats (either may be NULL). */
+int frog_get_points(frog_ctx *ctx, float *xyz, float *xyz2);
+/* Overwrite xyz2 (3*P floats) -- test hook to start two implementations from
+ * identical coordinates. */
+int frog_set_points2(frog_ctx *ctx, const float *xyz2);
+int frog_get_linear(frog_ctx *ctx, uint32_t image, double matrix16[16]);
+int frog_get_em(frog_ctx *ctx, uint32_t image, float c1_c2_ratio[3]);
+int frog_set_em(frog_ctx *ctx, uint32_t image, const float c1_c2_ratio[3]);
+/* Retained samples of the last refresh, and the ordinal (position in the
+ * image's half-link traversal) each one was drawn from. */
+int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *ordinals,
+                     int cap, int *n);
+/* Stats::getHistogram(1.0) over the retained samples (stats.cxx:121-131). */
+int frog_get_histogram(frog_ctx *ctx, uint32_t image, float *bins, int cap, int *n);
+int frog_num_grids(const frog_ctx *ctx);
+/* Lattice k of the chain: geometry + 3*G coefficients of `image`. */
+int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info,
+                  float *coeffs, size_t cap_floats);
+/* Per-point (sDisp xyz, sWeight) of the last deformable step (4*P floats) and the
+ * gradient lattice (4*G floats) as left by the scatter -- diagnostics / tests. */
+int frog_get_point_sums(frog_ctx *ctx, float *out4P);
+int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out4G, size_t cap_floats);
+
+/* ---- split phases for one-process-per-GPU runs ----------------------------- */
+
+enum {
+    FROG_BUF_XYZ2    = 0,  /* float4[P]   x,y,z,image-id; owned rows written by transform */
+    FROG_BUF_EM      = 1,  /* float4[n_images]  c1,c2,ratio,0; owned rows written by stats  */
+    FROG_BUF_ENERGY  = 2,  /* double[4]   sum w2 d2, sum w2, #oversize coefficients, 0      */
+    FROG_BUF_GRIDSUM = 3   /* double[3*G] sum over owned images of the proposed coefficients */
+};
+/* Device pointer + size of a collective buffer; `row_begin`/`row_end` (in
+ * elements of the buffer's row type) delimit what this context owns (NULL ok). */
+int frog_comm_buffer(frog_ctx *ctx, int which, void **device_ptr, size_t *bytes,
+                     size_t *row_begin, size_t *row_end);
+
+/* updateStats, owned images only; afterwards all-reduce(sum) FROG_BUF_EM
+ * (non-owned rows are zero) and call frog_stats_publish. */
+int frog_update_stats_local(frog_ctx *ctx);
+int frog_stats_publish(frog_ctx *ctx);
+/* transformPoints, owned images; afterwards all-gather FROG_BUF_XYZ2. */
+int frog_transform_points_local(frog_ctx *ctx, int apply);
+/* updateLinearTransforms, owned images; afterwards all-reduce(sum) the first
+ * two doubles of FROG_BUF_ENERGY and read E with frog_energy_read. */
+int frog_linear_step_local(frog_ctx *ctx);
+int frog_energy_read(frog_ctx *ctx, double *E, double *n_oversize);
+/* Bounding box of the owned images' xyz; all-reduce min/max on the host side,
+ * then frog_deformable_setup_bounds with the group-wide box. */
+int frog_bounds_local(frog_ctx *ctx, double mins[3], double maxs[3]);
+int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
+                                 const double maxs[3], frog_grid_info *out);
+/* phase A: link pass, scatter, control-point step, sum of proposals over owned
+ * images -> all-reduce(sum) FROG_BUF_GRIDSUM and FROG_BUF_ENERGY[0..1];
+ * phase B: subtract the group mean, count oversize coefficients ->
+ * all-reduce(sum) FROG_BUF_ENERGY[2]; phase C: commit or reject, *E as above. */
+int frog_deformable_phase_a(frog_ctx *ctx, float alpha);
+int frog_deformable_phase_b(frog_ctx *ctx);
+int frog_deformable_phase_c(frog_ctx *ctx, double *E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FROG_HIP_H */

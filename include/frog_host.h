@@ -1,0 +1,82 @@
+/*
+ * frog_host.h -- C ABI of the host-side library (libfrog_host.so).
+ *
+ * File formats and host control flow of the FROG groupwise solver, i.e. the
+ * parts of registration/imageGroup.cxx + registration/frog.cxx that stay on the
+ * CPU: parsing pairs.bin, driving the iteration schedule of ImageGroup::run and
+ * writing the result files.  All numeric work is delegated to libfrog_hip.so
+ * (frog_hip.h); this library contains no solver arithmetic and no CPU fallback.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   ImageGroup::readPairs            registration/imageGroup.cxx:1353-1417
+ *   pairs.bin writer                 match/match.cpp:675-744
+ *   ImageGroup::run                  registration/imageGroup.cxx:31-157
+ *   main / flag parsing              registration/frog.cxx:8-221
+ *   writeFrogJSON (-j form)          tools/transformIO.h:163-258
+ *   saveDistanceHistograms           registration/imageGroup.cxx:850-885
+ *   saveMeasures                     registration/imageGroup.cxx:1475-1491
+ */
+#ifndef FROG_HOST_H
+#define FROG_HOST_H
+
+#include "frog_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- pairs.bin ------------------------------------------------------------ */
+
+/* An in-memory pairs.bin: per-image point tables, the pair blocks in file
+ * order, and the half-link CSR in reference order (built on load). */
+typedef struct frog_pairs frog_pairs;
+
+/* readPairs (imageGroup.cxx:1353-1417).  pointIdType is u32 (INT_PTIDS=ON, the
+ * reference default, CMakeLists.txt:8-12).  Returns NULL on I/O error; a block
+ * with size 0 is the reference's "Error : number of pairs is 0" (exit(1)):
+ * reported as *status = FROG_E_INVALID. */
+frog_pairs *frog_pairs_read(const char *path, int *status);
+/* Writes the format of match.cpp:684-742. */
+int  frog_pairs_write(const frog_pairs *p, const char *path);
+void frog_pairs_free(frog_pairs *p);
+
+/* SoA/CSR view (pointers stay valid until frog_pairs_free). */
+void frog_pairs_model(const frog_pairs *p, frog_model *out);
+uint64_t frog_pairs_num_pairs(const frog_pairs *p);
+uint64_t frog_pairs_num_points(const frog_pairs *p);
+uint32_t frog_pairs_num_images(const frog_pairs *p);
+uint32_t frog_pairs_num_blocks(const frog_pairs *p);
+/* block b: images, size, and pointers to its (p1,p2) index arrays */
+int frog_pairs_block(const frog_pairs *p, uint32_t b, uint16_t *image1, uint16_t *image2,
+                     uint32_t *size, const uint32_t **p1, const uint32_t **p2);
+
+/* Builds a frog_pairs from caller arrays (copies).  blocks are given as
+ * block_image1/2[nb], block_ptr[nb+1] into p1/p2. */
+frog_pairs *frog_pairs_from_arrays(uint32_t n_images, const uint32_t *point_offset,
+                                   const float *xyz, const float *other /* may be NULL */,
+                                   uint32_t n_blocks, const uint16_t *block_image1,
+                                   const uint16_t *block_image2, const uint64_t *block_ptr,
+                                   const uint32_t *p1, const uint32_t *p2);
+
+/* ---- synthetic groups (the reference ships no data) -- */
+typedef struct frog_synth_params {
+    uint32_t n_images;
+    uint32_t points_per_image;      /* exact                                    */
+    uint32_t n_landmarks;           /* common-space landmarks, 0 => points_per_image */
+    double   pairs_per_block;       /* mean pairs per linked image pair         */
+    uint32_t partners_per_image;    /* 0 => all image pairs; else ~k random partners */
+    float    outlier_fraction;      /* fraction of false (random) pairs, 0.3    */
+    float    noise_sigma;           /* keypoint localisation noise, mm (2.0)    */
+    float    bump_amplitude;        /* smooth deformation amplitude, mm (15)    */
+    float    scale_min, scale_max;  /* per-axis scale range (0.8, 1.25)         */
+    float    translation_range;     /* +- mm (100)                              */
+    uint64_t seed;
+} frog_synth_params;
+
+void frog_synth_defaults(frog_synth_params *p);
+frog_pairs *frog_synth_generate(const frog_synth_params *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,275 @@
+"""ctypes binding of the CPU oracle (oracle/libfrog_oracle.so) and of the
+reference-Stats build (oracle/_ref/libfrog_refstats.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under frog_amd/ imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+u32p = C.POINTER(C.c_uint32)
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libfrog_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        L = C.CDLL(path)
+        L.frogo_create.restype = C.c_void_p
+        L.frogo_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.frogo_destroy.argtypes = [C.c_void_p]
+        L.frogo_set_threads.argtypes = [C.c_int]
+        L.frogo_get_max_threads.restype = C.c_int
+        for n in ("frogo_setup_stats", "frogo_update_stats"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.frogo_linear_init.argtypes = [C.c_void_p, fp]
+        L.frogo_transform_points.argtypes = [C.c_void_p, C.c_int]
+        L.frogo_linear_step.restype = C.c_double
+        L.frogo_linear_step.argtypes = [C.c_void_p]
+        L.frogo_deformable_setup.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.frogo_deformable_step.restype = C.c_double
+        L.frogo_deformable_step.argtypes = [C.c_void_p, C.c_float]
+        L.frogo_count_inliers.argtypes = [C.c_void_p, C.c_void_p]
+        L.frogo_run.restype = C.c_int
+        L.frogo_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, dp, C.c_int,
+                                C.POINTER(C.c_int)]
+        L.frogo_num_points.restype = C.c_uint64
+        L.frogo_num_points.argtypes = [C.c_void_p]
+        for n in ("frogo_get_xyz", "frogo_get_xyz2", "frogo_set_xyz2", "frogo_get_point_sums"):
+            getattr(L, n).argtypes = [C.c_void_p, fp]
+        L.frogo_get_matrix.argtypes = [C.c_void_p, C.c_uint32, dp]
+        L.frogo_get_em.argtypes = [C.c_void_p, C.c_uint32, fp]
+        L.frogo_set_em.argtypes = [C.c_void_p, C.c_uint32, fp]
+        L.frogo_get_samples.restype = C.c_int
+        L.frogo_get_samples.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_int]
+        L.frogo_get_sample_ordinals.restype = C.c_int
+        L.frogo_get_sample_ordinals.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_int]
+        L.frogo_get_histogram.restype = C.c_int
+        L.frogo_get_histogram.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_int]
+        L.frogo_num_grids.restype = C.c_int
+        L.frogo_num_grids.argtypes = [C.c_void_p]
+        L.frogo_get_grid.restype = C.c_int
+        L.frogo_get_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, fp, C.c_size_t]
+        L.frogo_get_gradient.restype = C.c_int
+        L.frogo_get_gradient.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_size_t]
+        _bind_stats(L, "frogo_stats_")
+        L.frogo_chipdf.restype = C.c_float
+        L.frogo_chipdf.argtypes = [C.c_float]
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The reference's own stats.cxx (oracle/_ref); None when it was not built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libfrog_refstats.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        _bind_stats(L, "refstats_")
+        L.refstats_chipdf.restype = C.c_float
+        L.refstats_chipdf.argtypes = [C.c_float]
+        _ref = L
+    return _ref
+
+
+def _bind_stats(L, pre):
+    g = lambda n: getattr(L, pre + n)
+    g("new").restype = C.c_void_p
+    g("new").argtypes = [C.c_int, C.c_int, C.c_float]
+    g("free").argtypes = [C.c_void_p]
+    g("add_slots").argtypes = [C.c_void_p, C.c_int]
+    g("reset").argtypes = [C.c_void_p]
+    g("add_samples").argtypes = [C.c_void_p, fp, C.c_int]
+    g("estimate").argtypes = [C.c_void_p]
+    g("inlier_probability").restype = C.c_float
+    g("inlier_probability").argtypes = [C.c_void_p, C.c_float]
+    g("get_params").argtypes = [C.c_void_p, fp]
+    g("set_params").argtypes = [C.c_void_p, fp]
+    g("size").restype = C.c_int
+    g("size").argtypes = [C.c_void_p]
+    g("get_samples").restype = C.c_int
+    g("get_samples").argtypes = [C.c_void_p, fp, C.c_int]
+    g("histogram").restype = C.c_int
+    g("histogram").argtypes = [C.c_void_p, C.c_float, fp, C.c_int]
+
+
+class Stats:
+    """Stats object of either the restatement (which='oracle') or the reference build (which='ref')."""
+
+    def __init__(self, which="oracle", max_size=10000, max_iterations=10000, epsilon=1e-6):
+        self.L = lib() if which == "oracle" else ref_lib()
+        if self.L is None:
+            raise RuntimeError("oracle/_ref not built")
+        self.pre = "frogo_stats_" if which == "oracle" else "refstats_"
+        self.h = C.c_void_p(self._f("new")(max_size, max_iterations, epsilon))
+
+    def _f(self, n):
+        return getattr(self.L, self.pre + n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._f("free")(self.h)
+            self.h = None
+
+    def add_slots(self, n):
+        self._f("add_slots")(self.h, n)
+
+    def reset(self):
+        self._f("reset")(self.h)
+
+    def add_samples(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        self._f("add_samples")(self.h, v.ctypes.data_as(fp), len(v))
+
+    def estimate(self):
+        self._f("estimate")(self.h)
+
+    def params(self):
+        o = np.empty(3, np.float32)
+        self._f("get_params")(self.h, o.ctypes.data_as(fp))
+        return o
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        self._f("set_params")(self.h, p.ctypes.data_as(fp))
+
+    def prob(self, d):
+        return self._f("inlier_probability")(self.h, float(d))
+
+    def size(self):
+        return self._f("size")(self.h)
+
+    def samples(self):
+        n = self.size()
+        o = np.empty(n, np.float32)
+        self._f("get_samples")(self.h, o.ctypes.data_as(fp), n)
+        return o
+
+    def histogram(self, bin=1.0):
+        n = self._f("histogram")(self.h, bin, None, 0)
+        o = np.empty(n, np.float32)
+        self._f("histogram")(self.h, bin, o.ctypes.data_as(fp), n)
+        return o
+
+
+class OracleGroup:
+    """frogo_group: the CPU restatement of ImageGroup over a frog_model."""
+
+    def __init__(self, model, options):
+        self.L = lib()
+        self._model, self._opt = model, options       # keep alive
+        self.h = C.c_void_p(self.L.frogo_create(C.byref(model), C.byref(options)))
+        self.n_images = model.n_images
+        self.P = self.L.frogo_num_points(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.frogo_destroy(self.h)
+            self.h = None
+
+    def setup_stats(self):
+        self.L.frogo_setup_stats(self.h)
+
+    def linear_init(self, anchor=(0.5, 0.5, 0.5)):
+        self.L.frogo_linear_init(self.h, (C.c_float * 3)(*anchor))
+
+    def transform_points(self, apply=False):
+        self.L.frogo_transform_points(self.h, int(apply))
+
+    def update_stats(self):
+        self.L.frogo_update_stats(self.h)
+
+    def linear_step(self):
+        return self.L.frogo_linear_step(self.h)
+
+    def deformable_setup(self, level, info):
+        self.L.frogo_deformable_setup(self.h, level, C.byref(info))
+        return info
+
+    def deformable_step(self, alpha):
+        return self.L.frogo_deformable_step(self.h, alpha)
+
+    def count_inliers(self, counts_array):
+        self.L.frogo_count_inliers(self.h, counts_array)
+        return counts_array
+
+    def run(self, li=50, dl=3, di=200, da=0.02, si=10, anchor=(0.5, 0.5, 0.5)):
+        cap = li + dl * di + 8
+        E = (C.c_double * cap)()
+        ng = (C.c_int * max(dl, 1))()
+        n = self.L.frogo_run(self.h, li, dl, di, da, si, (C.c_float * 3)(*anchor), E, cap, ng)
+        return np.array(E[:n]), list(ng[:dl])
+
+    def xyz(self):
+        o = np.empty((self.P, 3), np.float32)
+        self.L.frogo_get_xyz(self.h, o.ctypes.data_as(fp))
+        return o
+
+    def xyz2(self):
+        o = np.empty((self.P, 3), np.float32)
+        self.L.frogo_get_xyz2(self.h, o.ctypes.data_as(fp))
+        return o
+
+    def set_xyz2(self, a):
+        a = np.ascontiguousarray(a, np.float32)
+        self.L.frogo_set_xyz2(self.h, a.ctypes.data_as(fp))
+
+    def matrix(self, image):
+        o = np.empty(16, np.float64)
+        self.L.frogo_get_matrix(self.h, image, o.ctypes.data_as(dp))
+        return o.reshape(4, 4)
+
+    def em(self, image):
+        o = np.empty(3, np.float32)
+        self.L.frogo_get_em(self.h, image, o.ctypes.data_as(fp))
+        return o
+
+    def set_em(self, image, v):
+        v = np.ascontiguousarray(v, np.float32)
+        self.L.frogo_set_em(self.h, image, v.ctypes.data_as(fp))
+
+    def samples(self, image):
+        n = self.L.frogo_get_samples(self.h, image, None, 0)
+        s = np.empty(n, np.float32)
+        o = np.empty(n, np.uint32)
+        self.L.frogo_get_samples(self.h, image, s.ctypes.data_as(fp), n)
+        self.L.frogo_get_sample_ordinals(self.h, image, o.ctypes.data_as(u32p), n)
+        return s, o
+
+    def histogram(self, image):
+        n = self.L.frogo_get_histogram(self.h, image, None, 0)
+        o = np.empty(n, np.float32)
+        self.L.frogo_get_histogram(self.h, image, o.ctypes.data_as(fp), n)
+        return o
+
+    def num_grids(self):
+        return self.L.frogo_num_grids(self.h)
+
+    def grid(self, image, k, info):
+        self.L.frogo_get_grid(self.h, image, k, C.byref(info), None, 0)
+        g = info.dims[0] * info.dims[1] * info.dims[2]
+        c = np.empty((g, 3), np.float32)
+        self.L.frogo_get_grid(self.h, image, k, C.byref(info), c.ctypes.data_as(fp), 3 * g)
+        return info, c
+
+    def point_sums(self):
+        o = np.empty((self.P, 4), np.float32)
+        self.L.frogo_get_point_sums(self.h, o.ctypes.data_as(fp))
+        return o
+
+    def gradient(self, image, n_cp):
+        o = np.empty((n_cp, 4), np.float32)
+        self.L.frogo_get_gradient(self.h, image, o.ctypes.data_as(fp), 4 * n_cp)
+        return o
