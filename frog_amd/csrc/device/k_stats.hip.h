@@ -166,70 +166,86 @@ __device__ __forceinline__ float chi_pdf_ref(float x)
     return (float)((double)cx2 * exp(-0.5 * (double)x2));
 }
 
-// K2: Stats::estimateDistribution (stats.cxx:14-70), one block per owned image.
-// Per-sample terms follow the reference's promotions exactly; the five sums are
-// accumulated as f64 partials and tree-reduced (the reference adds 10^4 terms
-// sequentially in f32; its own rounding noise is ~1e-6).
-__global__ __launch_bounds__(256) void em_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
-                                                 uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
+// K2: Stats::estimateDistribution (stats.cxx:14-70), one wavefront per owned image.
+// The reference adds the per-sample terms SEQUENTIALLY into f32 accumulators
+// (sum3/sum4 through an f64 add that is rounded back to f32 each step); the fit's
+// stop test makes the result sensitive to that order at the 1e-5 level, which is
+// amplified in the fine lattices.  So the order is kept: the 64 lanes compute the
+// terms of 64 consecutive samples in parallel (the two f64 exps per sample are the
+// expensive part), then every lane runs the same four dependent chains over them
+// in sample order, reading term k with v_readlane.  After the first refresh the
+// fit converges in 1-3 iterations (it is warm-started), so the chain is cheap.
+__device__ __forceinline__ float lane_f32(float v, int k)
 {
-    __shared__ double red[4][256];
-    __shared__ float params[3];
-    __shared__ int stop;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+__device__ __forceinline__ double lane_f64(double v, int k)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), k);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), k);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+#define FROG_EM_STEP(k)                                                   \
+    do {                                                                  \
+        sum1 += lane_f32(a, (k));                                         \
+        sum2 += lane_f32(t, (k));                                         \
+        sum3 = (float)((double)sum3 + lane_f64(b, (k)));                  \
+        sum4 = (float)((double)sum4 + lane_f64(c, (k)));                  \
+    } while (0)
+
+__global__ __launch_bounds__(64) void em_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
+                                                uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
+{
     const uint32_t img = blockIdx.x;
     const uint32_t n = sample_count[img];
     const float *smp = samples + (size_t)img * cap;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        float4 e = em[image_begin + img];
-        params[0] = e.x; params[1] = e.y; params[2] = e.z; stop = 0;
-    }
-    __syncthreads();
+    const int lane = threadIdx.x;
+    const float4 e0 = em[image_begin + img];
+    float c1 = e0.x, c2 = e0.y, ratio = e0.z;
     const float esp = 1.59576912160573f;
     int iteration = 0;
     while (iteration++ < max_iterations) {
-        const float c1 = params[0], c2 = params[1], ratio = params[2];
-        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-        for (uint32_t i = tid; i < n; i += 256) {
-            const float x = smp[i];
-            const float f1 = ratio * chi_pdf_ref(x / c1) / c1;
-            const float f2 = (float)((1.0 - (double)ratio) * (double)chi_pdf_ref(x / c2) / (double)c2);
-            const float t = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
-            const float p = x * 1.0f;                  // weights are all 1 (addSample default)
-            s1 += (double)(t * p);
-            s2 += (double)(t * 1.0f);
-            s3 += (1.0 - (double)t) * (double)p;
-            s4 += (1.0 - (double)t) * 1.0;
-        }
-        red[0][tid] = s1; red[1][tid] = s2; red[2][tid] = s3; red[3][tid] = s4;
-        __syncthreads();
-        for (int h = 128; h > 0; h >>= 1) {
-            if (tid < h) {
-                red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h];
-                red[2][tid] += red[2][tid + h]; red[3][tid] += red[3][tid + h];
+        float sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            float t = 0, a = 0;
+            double b = 0, c = 0;
+            if (i < n) {
+                const float x = smp[i];
+                const float f1 = ratio * chi_pdf_ref(x / c1) / c1;
+                const float f2 = (float)((1.0 - (double)ratio) * (double)chi_pdf_ref(x / c2) / (double)c2);
+                t = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
+                const float p = x * 1.0f;               // weights are all 1 (addSample's default)
+                a = t * p;
+                b = (1.0 - (double)t) * (double)p;
+                c = (1.0 - (double)t) * 1.0;
             }
-            __syncthreads();
+            const uint32_t cnt = min(64u, n - base);
+            if (cnt == 64u) {
+                #pragma unroll
+                for (int k = 0; k < 64; k++) FROG_EM_STEP(k);
+            } else {
+                for (uint32_t k = 0; k < cnt; k++) FROG_EM_STEP((int)k);
+            }
         }
-        if (tid == 0) {
-            float sum1 = (float)red[0][0], sum2 = (float)red[1][0], sum3 = (float)red[2][0], sum4 = (float)red[3][0];
-            float sum5 = (float)n;
-            sum2 = fmaxf(sum2, epsilon);
-            sum3 = fmaxf(sum3, epsilon);
-            sum5 = fmaxf(sum5, epsilon);
-            const float nc1 = fmaxf(epsilon, sum1 / sum2 / esp);
-            const float nc2 = fmaxf(epsilon, sum3 / sum4 / esp);
-            const float nr = fmaxf(epsilon, sum2 / sum5);
-            const bool done = (double)fabsf((c1 - nc1) / nc1) < 0.001
-                           && (double)fabsf((c2 - nc2) / nc2) < 0.001
-                           && (double)fabsf((nr - ratio) / nr) < 0.001;
-            params[0] = nc1; params[1] = nc2; params[2] = nr;
-            stop = done ? 1 : 0;
-        }
-        __syncthreads();
-        if (stop) break;
+        float sum5 = (float)n;                          // n additions of 1.0f, exact below 2^24
+        sum2 = fmaxf(sum2, epsilon);
+        sum3 = fmaxf(sum3, epsilon);
+        sum5 = fmaxf(sum5, epsilon);
+        const float nc1 = fmaxf(epsilon, sum1 / sum2 / esp);
+        const float nc2 = fmaxf(epsilon, sum3 / sum4 / esp);
+        const float nr = fmaxf(epsilon, sum2 / sum5);
+        const bool done = (double)fabsf((c1 - nc1) / nc1) < 0.001
+                       && (double)fabsf((c2 - nc2) / nc2) < 0.001
+                       && (double)fabsf((nr - ratio) / nr) < 0.001;
+        c1 = nc1; c2 = nc2; ratio = nr;
+        if (done) break;
     }
-    if (tid == 0) em[image_begin + img] = make_float4(params[0], params[1], params[2], 0.f);
+    if (lane == 0) em[image_begin + img] = make_float4(c1, c2, ratio, 0.f);
 }
+#undef FROG_EM_STEP
 
 // (c1,c2,ratio) -> constants of inlier_probability for ALL images (after the
 // EM table has been made whole by the all-reduce in multi-rank runs).
