@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- registration iterations/s of the FROG groupwise hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): 100 synthetic images x 20 000 keypoints,
+~50 M pairs (10^8 half-links), default solver flags (-g 100, -gd 1, -si 10).
+One "step" = one registration iteration of ImageGroup::run's loops
+(registration/imageGroup.cxx:54-66 and :88-121): updateStats every 10th
+iteration, update{Linear,Deformable}Transforms, transformPoints.  The K timed
+steps keep the reference's default mix 50 : 200 : 200 : 200 (linear : level 0 :
+level 1 : level 2), i.e. n_lin = round(K*50/650) linear iterations followed by
+three deformable levels sharing the rest; lattice set-up, re-basing and any
+regrid the diffeomorphism guard triggers are inside the timed region.  Warm-up =
+linear set-up + W linear iterations.  Inputs are resident in HBM before the
+timed region starts.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def schedule(k):
+    """Split K timed iterations into (linear, [level0, level1, level2])."""
+    n_lin = max(1, int(round(k * 50.0 / 650.0))) if k > 1 else k
+    rest = k - n_lin
+    per = [rest // 3] * 3
+    per[2] += rest - 3 * (rest // 3)
+    return n_lin, per
+
+
+def cpu_baseline(pairs, n_lin, per_level, stat_interval):
+    """Oracle (CPU restatement, OpenMP over images like the reference) on a bounded
+    sample of the same workload: one stats refresh, one linear iteration, one
+    deformable iteration per level; extrapolated to the timed schedule."""
+    from frog_amd import _abi
+    from oracle.oracle_api import OracleGroup, lib
+    cores = lib().frogo_get_max_threads()
+    ref = OracleGroup(pairs.model, _abi.FrogOptions.default())
+    ref.setup_stats()
+    ref.linear_init()
+    ref.transform_points()
+    t = time.perf_counter(); ref.update_stats(); t_stats = time.perf_counter() - t
+    t = time.perf_counter(); ref.linear_step(); ref.transform_points(); t_lin = time.perf_counter() - t
+    ref.transform_points(True)
+    t_def = []
+    for level in range(3):
+        if per_level[level] == 0:
+            t_def.append(0.0)
+            continue
+        ref.deformable_setup(level, _abi.FrogGridInfo())
+        ref.transform_points()
+        t = time.perf_counter(); ref.deformable_step(0.02); ref.transform_points(); t_def.append(time.perf_counter() - t)
+        ref.transform_points(True)
+    refreshes = -(-n_lin // stat_interval) + sum(-(-n // stat_interval) for n in per_level)
+    total = n_lin * t_lin + sum(n * t for n, t in zip(per_level, t_def)) + refreshes * t_stats
+    k = n_lin + sum(per_level)
+    return {"value": k / total, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "1 updateStats + 1 linear iteration + 1 deformable iteration per level on the same "
+                      "pairs, timed with the oracle (oracle/frog_oracle.cpp, OpenMP over images) and "
+                      "extrapolated to the timed schedule",
+            "seconds": {"stats_refresh": t_stats, "linear_iteration": t_lin, "deformable_iteration": t_def}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=65)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--images", type=int, default=100)
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--pairs-per-block", type=float, default=10101.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from frog_amd import _abi
+    from frog_amd.pairs import Pairs
+    from frog_amd.distributed import HipEngine, ShardedImageGroup, plan_shards
+
+    if _abi.hip_lib().frog_device_count() < 1:
+        raise SystemExit("no HIP device: bench.py measures the HIP path only")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    t0 = time.perf_counter()
+    pairs = Pairs.synthetic(args.images, args.points, args.pairs_per_block, seed=1)
+    t_gen = time.perf_counter() - t0
+    shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
+    opts = _abi.FrogOptions.default()
+    t0 = time.perf_counter()
+    engine = HipEngine(pairs, opts, local_rank, shards[rank])
+    t_create = time.perf_counter() - t0
+    grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world)
+
+    n_lin, per_level = schedule(args.steps)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up: linear set-up + W linear iterations --------------------------------
+    grp.setupLinearTransforms()
+    grp.transformPoints()
+    it = 0
+    for _ in range(args.warmup):
+        if it % grp.statIntervalUpdate == 0:
+            grp.updateStats()
+        grp.updateLinearTransforms()
+        grp.transformPoints()
+        it += 1
+
+    # ---- timed region: exactly K iterations --------------------------------------------
+    engine.profile_enable(True)
+    phase_s = {}
+    sync()
+    t_start = time.perf_counter()
+    tp = t_start
+    for _ in range(n_lin):
+        if it % grp.statIntervalUpdate == 0:
+            grp.updateStats()
+        e = grp.updateLinearTransforms()
+        grp.transformPoints()
+        it += 1
+    grp.transformPoints(True)
+    torch.cuda.synchronize()
+    phase_s["linear"] = time.perf_counter() - tp
+    grids = []
+    for level in range(3):
+        if per_level[level] == 0:
+            continue
+        tp = time.perf_counter()
+        grids.append(grp.run_level(level, per_level[level]))
+        torch.cuda.synchronize()
+        phase_s[f"level{level}"] = time.perf_counter() - tp
+    sync()
+    elapsed = time.perf_counter() - t_start
+    engine.profile_enable(False)
+    if grp.measures:
+        e = grp.measures[-1]
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = engine.profile_read()
+    k = n_lin + sum(per_level)
+    own_b, own_e = shards[rank]
+    po, rp = pairs.point_offset, pairs.row_ptr
+    p_own = int(po[own_e]) - int(po[own_b])
+    l_own = int(rp[int(po[own_e])]) - int(rp[int(po[own_b])])
+    # dominant kernel: the half-link sweep of the deformable step
+    dom = "sweep_deformable" if prof["sweep_deformable"][1] else "sweep_linear"
+    ms, launches = prof[dom]
+    alg_bytes = 20.0 * l_own + 12.0 * p_own      # 8 B link + 12 B gathered xyz2 per half-link, 12 B own xyz2 per point
+    achieved = alg_bytes / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None,
+                "avg_launch_ms": ms / launches if launches else None, "launches": int(launches),
+                "algorithmic_bytes_per_launch": alg_bytes}
+
+    if rank == 0:
+        out = {
+            "metric": "registration iterations/sec (linear+deformable)",
+            "value": k / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": k,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / k,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.images} images x {args.points} keypoints, {pairs.n_pairs} pairs "
+                                   f"({pairs.n_half_links} half-links), linear + 3 deformable levels, -g 100 -gd 1 -si 10",
+                       "schedule": {"linear": n_lin, "deformable_per_level": per_level},
+                       "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
+                       "final_E": e},
+            "roofline": roofline,
+            "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items()},
+            "phase_iterations_per_s": {
+                "linear": n_lin / phase_s["linear"],
+                **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(3) if per_level[l]}},
+            "setup_seconds": {"generate": t_gen, "create": t_create},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,11 @@ class FrogSynthParams(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+class FrogKernelTime(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
+
+
+FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM = range(6)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 
@@ -122,6 +127,8 @@ HIP_SYMBOLS = {
     "frog_deformable_phase_a": (C.c_int, [C.c_void_p, C.c_float]),
     "frog_deformable_phase_b": (C.c_int, [C.c_void_p]),
     "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
+    "frog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(FrogKernelTime), C.c_int]),
 }
 
 HOST_SYMBOLS = {

@@ -27,6 +27,24 @@ using namespace frog;
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// RAII bracket: records a HIP event pair around the launches issued in its scope.
+struct Span {
+    frog_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Span(frog_ctx *ctx, int s) : c(ctx), slot(s)
+    {
+        if (!c->profiling) return;
+        if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
+        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Span()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({ a, b, slot });
+    }
+};
+
 extern "C" {
 
 int frog_device_count(void)
@@ -43,6 +61,8 @@ void frog_destroy(frog_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->h_energy) (void)hipHostFree(ctx->h_energy);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -227,6 +247,7 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
     CTX_GUARD(ctx);
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     if (!n) return FROG_OK;
+    Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->mat.p,
                                                                         ctx->own_pt_begin, ctx->own_pt_end, apply);
@@ -247,6 +268,7 @@ int frog_update_stats_local(frog_ctx *ctx)
     const uint32_t nO = ctx->n_owned();
     const uint32_t cap = (uint32_t)ctx->sample_cap;
     hipStream_t s = ctx->stream;
+    Span span(ctx, FROG_K_STATS);
     select_kernel<<<nO, 64, 0, s>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord.p, ctx->sample_count.p);
     FROG_HIP_CHECK(hipGetLastError());
     sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
@@ -295,7 +317,10 @@ int frog_linear_step_local(frog_ctx *ctx)
     CTX_GUARD(ctx);
     if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
     hipStream_t s = ctx->stream;
-    sweep_kernel<SWEEP_LINEAR><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    {
+        Span span(ctx, FROG_K_SWEEP_LINEAR);
+        sweep_kernel<SWEEP_LINEAR><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 64, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
@@ -399,6 +424,8 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     hipStream_t s = ctx->stream;
     FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G));
     FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G));
+    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));
     FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
@@ -454,20 +481,27 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     hipStream_t s = ctx->stream;
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));         // Fill(0), :249
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));       // Fill(0), :249
     FROG_HIP_CHECK(hipMemsetAsync(ctx->n_big.p, 0, sizeof(unsigned long long), s));
-    sweep_kernel<SWEEP_DEFORMABLE><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    {
+        Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
+        sweep_kernel<SWEEP_DEFORMABLE><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    }
     FROG_HIP_CHECK(hipGetLastError());
     energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, 2, 0, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     const uint32_t n_keys = nO * (uint32_t)ctx->geom.n_bricks;
     const uint32_t chunks = std::max(1u, div_up(ctx->max_brick_count, SCATTER_CHUNK));
     if (ctx->max_brick_count) {
-        scatter_kernel<<<dim3(n_keys, chunks), 256, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p, ctx->brick_ptr.p,
-                                                          ctx->grad.p, gd);
+        Span span(ctx, FROG_K_SCATTER);
+        scatter_kernel<<<dim3(n_keys, chunks), 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p, ctx->brick_ptr.p,
+                                                          ctx->gradf.p, gd);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    {
+        Span span(ctx, FROG_K_LATTICE);
+        cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->gradf.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     ctx->pending_alpha = alpha;
     ctx->phase = 1;
@@ -481,6 +515,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     const GridGeom &g = ctx->geom;
     const float maxD = ctx->opt.max_displacement_ratio;
+    Span span(ctx, FROG_K_LATTICE);
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
                                                         (double)maxD * g.spacing[2], ctx->n_big.p);
@@ -504,7 +539,10 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
         return FROG_OK;
     }
     const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
-    cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n);
+    {
+        Span span(ctx, FROG_K_LATTICE);
+        cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     if (E) *E = e;
     return FROG_OK;
@@ -693,8 +731,33 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
     const size_t G = (size_t)ctx->geom.n_cp;
     const size_t n = std::min(cap, 4 * G);
-    FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->grad.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->gradf.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_profile_enable(frog_ctx *ctx, int on)
+{
+    CTX_GUARD(ctx);
+    ctx->profiling = on != 0;
+    return FROG_OK;
+}
+
+int frog_profile_read(frog_ctx *ctx, frog_kernel_time *out, int reset)
+{
+    CTX_GUARD(ctx);
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &sp : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            ctx->ktime[sp.slot].ms_total += (double)ms;
+            ctx->ktime[sp.slot].launches += 1;
+        }
+        ctx->free_events.emplace_back(sp.a, sp.b);
+    }
+    ctx->spans.clear();
+    if (out) std::memcpy(out, ctx->ktime, sizeof ctx->ktime);
+    if (reset) std::memset(ctx->ktime, 0, sizeof ctx->ktime);
     return FROG_OK;
 }
 

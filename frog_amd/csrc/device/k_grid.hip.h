@@ -5,8 +5,9 @@
 // (sum w*sDisp xyz, sum w*sWeight), control point (i,j,k) at i + dx*(j + dy*k) as
 // in vtkImageData.  Points are binned once per lattice into bricks of B^3 cells
 // (B = 8 or 4); a brick touches (B+3)^3 control points, which fit in LDS, so the
-// 64-tap scatter of a point runs on LDS float atomics (one lane per tap) and only
-// the brick's sums go to HBM, as float atomics in rows of (B+3)*16 bytes.
+// 64-tap scatter of a point runs in LDS (one lane per tap, wave-private tile,
+// plain read-add-write) and only the brick's sums go to HBM, as float atomics
+// onto the gradient lattice gradf[image][cp] (float4: sum w*sDisp xyz, sum w*sWeight).
 #pragma once
 
 #include "ctx.h"
@@ -229,12 +230,19 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, uin
 }
 
 // ---- K7: scatter of the per-point sums onto the gradient lattice ----------------
-// grid = (n_keys, max chunks per key); block = 256 threads = 4 wavefronts.  Each
-// wavefront takes batches of 64 points of the chunk.  Phase 1, lane = point: cell
-// and the 12 cubic weights (f64, imageGroup.cxx:303-310) go to a per-wave LDS
-// scratch.  Phase 2, lane = tap (i + 4j + 16k): w = wx[i]*wy[j]*wz[k] in f64
-// (imageGroup.cxx:322) and four LDS float atomics per point into the brick tile.
-constexpr int SCATTER_CHUNK = 1024;
+// grid = (n_keys, max chunks per key); block = ONE wavefront with a private LDS
+// tile of the brick's (B+3)^3 control points, float, component-major.
+// Batches of 64 points.  Phase 1, lane = point: cell and the 12 cubic weights
+// (f64, imageGroup.cxx:303-310) go to an LDS scratch.  Phase 2, lane = tap
+// (i + 4j + 16k): w = wx[i]*wy[j]*wz[k] in f64 (imageGroup.cxx:322), then a plain
+// LDS read-add-write per component: the 64 taps of a point are 64 distinct
+// control points and the tile belongs to this wavefront alone, so no atomic is
+// needed.  (ds_add_f32 runs ~25x slower than read+add+write on gfx950 and integer
+// fixed point cannot hold the dynamic range of the tensor weights: control points
+// on the shell of the cloud have gw ~ 1e-10 and still need g/gw to f32 relative
+// precision -- scripts/microbench/lds_atomic.hip)
+// The tile is flushed to HBM with float atomics (memory-side, ~1.3 TB/s).
+constexpr int SCATTER_CHUNK = 512;
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 
 struct ScatterScratch {
@@ -243,22 +251,22 @@ struct ScatterScratch {
     int4 cell[64];          // ic xyz, w = 1 if the point contributes
 };
 
-__global__ __launch_bounds__(256) void scatter_kernel(const float4 *pos, const float4 *point_sums,
-                                                      const uint32_t *perm, const uint32_t *brick_ptr,
-                                                      float4 *grad, const GeomDev g)
+__global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
+                                                     const uint32_t *perm, const uint32_t *brick_ptr,
+                                                     float4 *gradf, const GeomDev g)
 {
-    __shared__ float tile[BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX * 4];
-    __shared__ ScatterScratch scratch[4];
+    __shared__ float tile[4 * BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX];
+    __shared__ ScatterScratch sc;
     const uint32_t key = blockIdx.x;
     const uint32_t begin = brick_ptr[key] + blockIdx.y * SCATTER_CHUNK;
     const uint32_t end_all = brick_ptr[key + 1];
     if (begin >= end_all) return;
     const uint32_t end = min(begin + (uint32_t)SCATTER_CHUNK, end_all);
 
+    const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
     const int n_tile = E * E * E;
-    for (int k = threadIdx.x; k < n_tile * 4; k += 256) tile[k] = 0.f;
-    __syncthreads();
+    for (int k = lane; k < n_tile * 4; k += 64) tile[k] = 0.f;
 
     const uint32_t img = key / g.n_bricks;
     uint32_t bidx = key - img * g.n_bricks;
@@ -267,12 +275,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4 *pos, const f
     const int bz = bidx / g.nbricks[1];
     // first control point of the brick: cell c (1-based) uses control points c-1..c+2
     const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
-    float *gimg = reinterpret_cast<float *>(grad + (size_t)img * g.n_cp);
+    float *gimg = reinterpret_cast<float *>(gradf + (size_t)img * g.n_cp);
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ti = lane & 3, tj = (lane >> 2) & 3, tk = lane >> 4;
-    ScatterScratch &sc = scratch[wave];
-    for (uint32_t batch = begin + wave * 64; batch < end; batch += 4 * 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t batch = begin; batch < end; batch += 64) {
         // phase 1: lane = point
         const uint32_t s = batch + lane;
         int4 cell = make_int4(0, 0, 0, 0);
@@ -310,8 +318,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4 *pos, const f
             const float a2 = (float)(w * (double)sm.z), a3 = (float)(w * (double)sm.w);
             const int lx = c.x - 1 - cp0[0] + ti, ly = c.y - 1 - cp0[1] + tj, lz = c.z - 1 - cp0[2] + tk;
             if (lx >= 0 && ly >= 0 && lz >= 0 && lx < E && ly < E && lz < E) {
-                float *dst = tile + 4 * (lx + E * (ly + E * lz));
-                atomicAdd(dst + 0, a0); atomicAdd(dst + 1, a1); atomicAdd(dst + 2, a2); atomicAdd(dst + 3, a3);
+                float *dst = tile + (lx + E * (ly + E * lz));
+                dst[0] += a0; dst[n_tile] += a1; dst[2 * n_tile] += a2; dst[3 * n_tile] += a3;
             } else {
                 // stray point clamped into this brick (outside the scaled box): straight to HBM
                 const int gx = c.x - 1 + ti, gy = c.y - 1 + tj, gz = c.z - 1 + tk;
@@ -324,14 +332,13 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4 *pos, const f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
 
-    // flush: consecutive threads walk components, then x -> contiguous 16-byte control points
-    for (int k = threadIdx.x; k < n_tile * 4; k += 256) {
-        const float val = tile[k];
-        if (val == 0.f) continue;
+    // flush: consecutive lanes walk components, then x -> contiguous 16-byte control points
+    for (int k = lane; k < n_tile * 4; k += 64) {
         const int c = k & 3;
         int q = k >> 2;
+        const float val = tile[c * n_tile + q];
+        if (val == 0.f) continue;
         const int lx = q % E; q /= E;
         const int ly = q % E;
         const int lz = q / E;
@@ -343,7 +350,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4 *pos, const f
 
 // ---- K8 + first half of K9: control-point step and sum over owned images --------
 // thread per control point; images in ascending order (imageGroup.cxx:346-375, :411-415)
-__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, float4 *grad, uint32_t n_owned,
+__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, const float4 *gradf,
+                                                         float4 *grad, uint32_t n_owned,
                                                          int n_cp, float alpha, double *gridsum)
 {
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, fl
     double sx = 0, sy = 0, sz = 0;
     for (uint32_t i = 0; i < n_owned; i++) {
         const size_t o = (size_t)i * n_cp + cp;
-        const float4 g4 = grad[o];
+        const float4 g4 = gradf[o];
         const float4 c4 = coeff[o];
         float4 n4;
         if (g4.w > 0) {

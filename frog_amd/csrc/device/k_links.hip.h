@@ -16,8 +16,10 @@
 //                   perturbs the exponent by more than this.
 //   linear sums  -- f32 products, f64 accumulation (imageGroup.cxx:1102-1117);
 //                   per-tile partials reduced in a fixed order (deterministic).
-//   deformable   -- f32 products, f32 per-point sums in partner order
-//                   (imageGroup.cxx:270-278), accumulated in LDS.
+//   deformable   -- f32 products as in imageGroup.cxx:270-278, per-point sums
+//                   accumulated in LDS in 32.32 fixed point with integer atomics
+//                   (exact in the addends, order independent; the reference's
+//                   running f32 sum differs from this by its own rounding).
 #pragma once
 
 #include "ctx.h"
@@ -69,7 +71,8 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 template <int MODE>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
-    __shared__ float acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS * 4 : 4];
+    // per-wave accumulators [component][point], 32.32 fixed point (ctx.h)
+    __shared__ unsigned long long acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS * 4 : 1];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -79,10 +82,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     Tile tl;
     tl.pt_begin = 0; tl.pt_count = 0; tl.rec_begin = 0; tl.rec_count = 0; tl.image = 0;
     if (live) tl = a.tiles[t];
-    float *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS * 4 : 0);
+    unsigned long long *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS * 4 : 0);
 
     if (MODE == SWEEP_DEFORMABLE) {
-        for (int k = lane; k < TILE_POINTS * 4; k += 64) my[k] = 0.f;
+        for (int k = lane; k < TILE_POINTS * 4; k += 64) my[k] = 0ull;
         __syncthreads();
     }
 
@@ -121,11 +124,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
                 const float w2 = w * w;
                 s[1] += (double)w2;
                 s[0] += (double)(w2 * d2);
-                float *dst = my + (lr.a - tl.pt_begin) * 4;
-                atomicAdd(dst + 0, w2 * dx);
-                atomicAdd(dst + 1, w2 * dy);
-                atomicAdd(dst + 2, w2 * dz);
-                atomicAdd(dst + 3, w2);
+                unsigned long long *dst = my + (lr.a - tl.pt_begin);
+                atomicAdd(dst, to_fixed32(w2 * dx));
+                atomicAdd(dst + TILE_POINTS, to_fixed32(w2 * dy));
+                atomicAdd(dst + 2 * TILE_POINTS, to_fixed32(w2 * dz));
+                atomicAdd(dst + 3 * TILE_POINTS, to_fixed32(w2));
             }
         } else {
             // imageGroup.cxx:1022-1027
@@ -143,8 +146,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);
         if (lane == 0 && live) { a.tile_partial[(size_t)t * 2] = v0; a.tile_partial[(size_t)t * 2 + 1] = v1; }
         __syncthreads();
-        const float4 *src = reinterpret_cast<const float4 *>(my);
-        for (uint32_t k = lane; k < tl.pt_count; k += 64) a.point_sums[tl.pt_begin + k] = src[k];
+        for (uint32_t k = lane; k < tl.pt_count; k += 64)
+            a.point_sums[tl.pt_begin + k] = make_float4(from_fixed32(my[k]), from_fixed32(my[k + TILE_POINTS]),
+                                                        from_fixed32(my[k + 2 * TILE_POINTS]), from_fixed32(my[k + 3 * TILE_POINTS]));
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
         if (lane == 0 && live) { a.tile_counts[(size_t)t * 2] = v0; a.tile_counts[(size_t)t * 2 + 1] = v1; }

@@ -1,0 +1,310 @@
+"""One process per GPU: images sharded across ranks, collectives over RCCL.
+
+The reference parallelises every loop over images (omp parallel-for,
+registration/imageGroup.cxx:239,572,912,1067).  Here each rank owns a contiguous
+range of images, balanced by half-link count, and the places where the
+reference's loops read ANOTHER image's state become collectives
+(``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in tests):
+
+  transformPoints      -> all-gather of the xyz2 rows            (12 B x P)
+  updateStats          -> all-reduce(sum) of the EM table, rows of other ranks zero
+  updateLinear...      -> all-reduce(sum) of (sum w2 d2, sum w2)
+  setupDeformable...   -> all-reduce(max) of the bounding box (as [max, -min])
+  updateDeformable...  -> all-reduce(sum) of the proposed-coefficient sums (3 G f64:
+                          the cross-image mean of imageGroup.cxx:400-432), then one
+                          all-reduce(sum) of (energy sums, oversize count)
+
+The numeric work is behind an *engine* with the split-phase entry points of
+include/frog_hip.h; ``HipEngine`` is the only engine this package provides
+(no CPU engine: the product path needs the HIP library).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import check
+
+
+def plan_shards(row_ptr, point_offset, world_size):
+    """Contiguous image ranges, one per rank, balanced by half-link count.
+
+    Every rank gets at least one image; requires n_images >= world_size.
+    """
+    po = np.asarray(point_offset, dtype=np.int64)
+    n_images = len(po) - 1
+    if world_size < 1 or n_images < world_size:
+        raise ValueError(f"cannot shard {n_images} images over {world_size} ranks")
+    links = np.asarray(row_ptr, dtype=np.int64)[po]            # cumulative half-links at image boundaries
+    total = int(links[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        i = int(np.searchsorted(links, target, side="left"))
+        # nearest boundary, but leave room for the ranks on both sides
+        if i > 0 and abs(links[i - 1] - target) <= abs(links[min(i, n_images)] - target):
+            i -= 1
+        i = max(i, bounds[-1] + 1)
+        i = min(i, n_images - (world_size - r))
+        bounds.append(i)
+    bounds.append(n_images)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+class _DeviceArray:
+    """__cuda_array_interface__ view of a raw device pointer owned by libfrog_hip."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class HipEngine:
+    """Split-phase entry points of libfrog_hip.so for one context (one GPU)."""
+
+    def __init__(self, pairs, options, device, image_range):
+        import torch
+        self._torch = torch
+        self._lib = _abi.hip_lib()
+        self.pairs = pairs
+        self.device = device
+        ctx = C.c_void_p()
+        b, e = image_range
+        check(self._lib.frog_create(C.byref(pairs.model), C.byref(options), device, b, e, C.byref(ctx)), "frog_create")
+        self._ctx = ctx
+        self.image_begin, self.image_end = b, e
+        self.n_images = pairs.n_images
+        # run on torch's current stream so that torch.distributed orders against our kernels
+        torch.cuda.set_device(device)
+        check(self._lib.frog_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "frog_set_stream")
+        self.xyz2, (self.pt_begin, self.pt_end) = self._buffer(_abi.FROG_BUF_XYZ2, "<f4", 4)
+        self.em, _ = self._buffer(_abi.FROG_BUF_EM, "<f4", 4)
+        self.energy, _ = self._buffer(_abi.FROG_BUF_ENERGY, "<f8", 1)
+        self.gridsum = None
+
+    def close(self):
+        if self._ctx:
+            self._lib.frog_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _buffer(self, which, typestr, width):
+        ptr, nbytes, rb, re = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(self._lib.frog_comm_buffer(self._ctx, which, C.byref(ptr), C.byref(nbytes), C.byref(rb), C.byref(re)),
+              "frog_comm_buffer")
+        item = int(typestr[2:])
+        n = nbytes.value // (item * width)
+        shape = (n, width) if width > 1 else (n,)
+        t = self._torch.as_tensor(_DeviceArray(ptr.value, shape, typestr), device=f"cuda:{self.device}")
+        return t, (rb.value, re.value)
+
+    # split-phase calls ------------------------------------------------------------
+    def linear_init(self, anchor):
+        check(self._lib.frog_linear_init(self._ctx, (C.c_float * 3)(*anchor)), "frog_linear_init")
+
+    def transform_points_local(self, apply):
+        check(self._lib.frog_transform_points_local(self._ctx, int(apply)), "frog_transform_points_local")
+
+    def update_stats_local(self):
+        check(self._lib.frog_update_stats_local(self._ctx), "frog_update_stats_local")
+
+    def stats_publish(self):
+        check(self._lib.frog_stats_publish(self._ctx), "frog_stats_publish")
+
+    def linear_step_local(self):
+        check(self._lib.frog_linear_step_local(self._ctx), "frog_linear_step_local")
+
+    def energy_read(self):
+        e, nb = C.c_double(), C.c_double()
+        check(self._lib.frog_energy_read(self._ctx, C.byref(e), C.byref(nb)), "frog_energy_read")
+        return e.value, nb.value
+
+    def bounds_local(self):
+        mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+        check(self._lib.frog_bounds_local(self._ctx, mn, mx), "frog_bounds_local")
+        return list(mn), list(mx)
+
+    def deformable_setup_bounds(self, level, mins, maxs):
+        info = _abi.FrogGridInfo()
+        check(self._lib.frog_deformable_setup_bounds(self._ctx, level, (C.c_double * 3)(*mins),
+                                                     (C.c_double * 3)(*maxs), C.byref(info)),
+              "frog_deformable_setup_bounds")
+        self.gridsum, _ = self._buffer(_abi.FROG_BUF_GRIDSUM, "<f8", 1)
+        return info
+
+    def phase_a(self, alpha):
+        check(self._lib.frog_deformable_phase_a(self._ctx, alpha), "frog_deformable_phase_a")
+
+    def phase_b(self):
+        check(self._lib.frog_deformable_phase_b(self._ctx), "frog_deformable_phase_b")
+
+    def phase_c(self):
+        e = C.c_double()
+        check(self._lib.frog_deformable_phase_c(self._ctx, C.byref(e)), "frog_deformable_phase_c")
+        return e.value
+
+    def count_inliers(self):
+        arr = (_abi.FrogCounts * self.n_images)()
+        check(self._lib.frog_count_inliers(self._ctx, arr), "frog_count_inliers")
+        return arr
+
+    def make_tensor(self, values, dtype):
+        return self._torch.tensor(values, dtype=dtype, device=f"cuda:{self.device}")
+
+    # read-back used by tests / writers
+    def matrix(self, image):
+        m = np.empty(16, np.float64)
+        check(self._lib.frog_get_linear(self._ctx, image, m.ctypes.data_as(_abi.c_double_p)), "frog_get_linear")
+        return m.reshape(4, 4)
+
+    def grid(self, image, k):
+        info = _abi.FrogGridInfo()
+        check(self._lib.frog_get_grid(self._ctx, image, k, C.byref(info), None, 0), "frog_get_grid")
+        g = info.dims[0] * info.dims[1] * info.dims[2]
+        c = np.empty((g, 3), np.float32)
+        check(self._lib.frog_get_grid(self._ctx, image, k, C.byref(info), c.ctypes.data_as(_abi.c_float_p), 3 * g),
+              "frog_get_grid")
+        return info, c
+
+    def num_grids(self):
+        return self._lib.frog_num_grids(self._ctx)
+
+    def profile_enable(self, on=True):
+        check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")
+
+    def profile_read(self, reset=True):
+        arr = (_abi.FrogKernelTime * len(_abi.FROG_K_NAMES))()
+        check(self._lib.frog_profile_read(self._ctx, arr, int(reset)), "frog_profile_read")
+        return {n: (arr[i].ms_total, arr[i].launches) for i, n in enumerate(_abi.FROG_K_NAMES)}
+
+
+class ShardedImageGroup:
+    """ImageGroup's methods (imageGroup.cxx) over image shards, one rank per GPU.
+
+    ``engine`` implements the split-phase calls for this rank's images and exposes
+    the collective buffers as torch tensors (``xyz2`` [P,4] f32, ``em`` [nI,4] f32,
+    ``energy`` [4] f64, ``gridsum`` [3G] f64 after a lattice exists).  ``shards`` is
+    the list of (image_begin, image_end) per rank and ``point_offset`` the model's
+    point offsets.  With world_size 1 no collective is issued.
+    """
+
+    def __init__(self, engine, shards, point_offset, rank, world_size, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.engine = engine
+        self.shards = list(shards)
+        self.po = np.asarray(point_offset, dtype=np.int64)
+        self.rank, self.world_size, self.group = rank, world_size, group
+        self.linearIterations = 50
+        self.deformableLevels = 3
+        self.deformableIterations = 200
+        self.deformableAlpha = 0.02
+        self.linearInitializationAnchor = (0.5, 0.5, 0.5)
+        self.statIntervalUpdate = 10
+        self.measures = []
+        self.gridsPerLevel = []
+
+    @property
+    def multi(self):
+        return self.world_size > 1
+
+    # -- the six methods -----------------------------------------------------------
+    def setupLinearTransforms(self):
+        self.engine.linear_init(self.linearInitializationAnchor)
+
+    def transformPoints(self, apply=False):
+        self.engine.transform_points_local(apply)
+        if self.multi:
+            # ragged all-gather of the owned xyz2 rows: one broadcast per owner
+            works = []
+            for r, (ib, ie) in enumerate(self.shards):
+                rows = self.engine.xyz2[int(self.po[ib]):int(self.po[ie])]
+                works.append(self._dist.broadcast(rows, src=self._global_rank(r), group=self.group, async_op=True))
+            for w in works:
+                w.wait()
+
+    def updateStats(self):
+        self.engine.update_stats_local()
+        if self.multi:
+            self._dist.all_reduce(self.engine.em, op=self._dist.ReduceOp.SUM, group=self.group)
+        self.engine.stats_publish()
+
+    def updateLinearTransforms(self):
+        self.engine.linear_step_local()
+        if self.multi:
+            self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group)
+        return self.engine.energy_read()[0]
+
+    def setupDeformableTransforms(self, level):
+        mn, mx = self.engine.bounds_local()
+        if self.multi:
+            t = self.engine.make_tensor(list(mx) + [-v for v in mn], self._torch.float64)
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+            v = t.cpu().tolist()
+            mx, mn = v[:3], [-x for x in v[3:]]
+        return self.engine.deformable_setup_bounds(level, mn, mx)
+
+    def updateDeformableTransforms(self, alpha):
+        self.engine.phase_a(alpha)
+        if self.multi:
+            self._dist.all_reduce(self.engine.gridsum, op=self._dist.ReduceOp.SUM, group=self.group)
+        self.engine.phase_b()
+        if self.multi:
+            self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group)
+        return self.engine.phase_c()
+
+    def countInliers(self):
+        return self.engine.count_inliers()
+
+    def _global_rank(self, r):
+        if self.group is None:
+            return r
+        return self._dist.get_global_rank(self.group, r)
+
+    # -- run(), imageGroup.cxx:31-157 ------------------------------------------------
+    def run(self):
+        self.measures, self.gridsPerLevel = [], []
+        self.setupLinearTransforms()
+        self.transformPoints()
+        for it in range(self.linearIterations):
+            if it % self.statIntervalUpdate == 0:
+                self.updateStats()
+            e = self.updateLinearTransforms()
+            self.transformPoints()
+            self.measures.append(float(np.float32(e)))
+        self.transformPoints(True)
+        for level in range(self.deformableLevels):
+            self.gridsPerLevel.append(self.run_level(level, self.deformableIterations))
+        return self.measures
+
+    def run_level(self, level, iterations):
+        """One deformable level with the regrid / alpha-halving state machine (:78-128)."""
+        self.setupDeformableTransforms(level)
+        self.transformPoints()
+        n_grids, alpha, n_diffeo, it = 1, np.float32(self.deformableAlpha), 0, 0
+        while it < iterations:
+            if it % self.statIntervalUpdate == 0:
+                self.updateStats()
+            e = self.updateDeformableTransforms(float(alpha))
+            if e < 0:
+                if n_diffeo == 0:
+                    alpha = np.float32(alpha / np.float32(2))
+                n_grids += 1
+                self.transformPoints(True)
+                self.setupDeformableTransforms(level)
+                self.transformPoints()
+                n_diffeo = 0
+                continue
+            n_diffeo += 1
+            self.transformPoints()
+            self.measures.append(float(np.float32(e)))
+            it += 1
+        self.transformPoints(True)
+        return n_grids

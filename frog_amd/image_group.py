@@ -110,6 +110,15 @@ class ImageGroup:
     def synchronize(self):
         check(self._lib.frog_synchronize(self._ctx), "frog_synchronize")
 
+    def profile_enable(self, on=True):
+        check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")
+
+    def profile_read(self, reset=True):
+        """{kernel name: (total ms, launches)} measured with HIP events on the context's stream."""
+        arr = (_abi.FrogKernelTime * len(_abi.FROG_K_NAMES))()
+        check(self._lib.frog_profile_read(self._ctx, arr, int(reset)), "frog_profile_read")
+        return {n: (arr[i].ms_total, arr[i].launches) for i, n in enumerate(_abi.FROG_K_NAMES)}
+
     # -- run(), imageGroup.cxx:31-157 (no fixed images, no landmarks) ------------------
     def run(self, log=None):
         say = log if log else (lambda *_: None)

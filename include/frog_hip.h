@@ -141,6 +141,27 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha);
 int frog_deformable_phase_b(frog_ctx *ctx);
 int frog_deformable_phase_c(frog_ctx *ctx, double *E);
 
+/* ---- live kernel timing (HIP events on the context's stream) ------------------ */
+enum {
+    FROG_K_SWEEP_LINEAR = 0,   /* half-link sweep of updateLinearTransforms     */
+    FROG_K_SWEEP_DEFORMABLE,   /* half-link sweep of updateDeformableTransforms */
+    FROG_K_SCATTER,            /* B-spline gradient scatter                     */
+    FROG_K_LATTICE,            /* control-point step, mean removal, commit      */
+    FROG_K_TRANSFORM,          /* transformPoints                               */
+    FROG_K_STATS,              /* reservoir + distances + EM fit                */
+    FROG_K_COUNT_
+};
+typedef struct frog_kernel_time {
+    double   ms_total;      /* sum of hipEventElapsedTime over the launches */
+    uint64_t launches;
+} frog_kernel_time;
+/* While enabled every launch of the kernels above is bracketed by a pair of
+ * hipEvents recorded on the context's stream. */
+int frog_profile_enable(frog_ctx *ctx, int on);
+/* Waits for the stream, adds up the recorded pairs into out[FROG_K_COUNT_];
+ * reset != 0 clears the accumulators afterwards. */
+int frog_profile_read(frog_ctx *ctx, frog_kernel_time *out, int reset);
+
 #ifdef __cplusplus
 }
 #endif
