@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (kernel stats + PMC passes) into one text summary.
+
+usage: summarize_profile.py OUT.txt TRACE_DIR [PMC_DIR ...]
+"""
+import collections
+import csv
+import glob
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("frog::", "")
+
+
+def main():
+    out, trace, pmcs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    lines = []
+    for f in glob.glob(f"{trace}/**/*_kernel_stats.csv", recursive=True):
+        lines.append(f"# rocprofv3 --kernel-trace --stats  ({f})")
+        lines.append(f"{'kernel':38s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
+        for r in csv.DictReader(open(f)):
+            lines.append(f"{short(r['Name'])[:38]:38s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.3f} "
+                         f"{float(r['AverageNs'])/1e3:10.1f} {float(r['MinNs'])/1e3:9.1f} {float(r['MaxNs'])/1e3:9.1f} "
+                         f"{float(r['Percentage']):6.2f}")
+    for d in pmcs:
+        for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(f)):
+                k = (short(r["Kernel_Name"]), r["Counter_Name"])
+                acc[k][0] += float(r["Counter_Value"])
+                acc[k][1] += 1
+            lines.append("")
+            lines.append(f"# rocprofv3 --pmc  ({f}) -- average counter value per launch")
+            for (k, c), (v, n) in sorted(acc.items()):
+                lines.append(f"{k[:38]:38s} {c:14s} {v / n:16.1f}  launches {n}")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
