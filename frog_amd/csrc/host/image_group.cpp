@@ -1,0 +1,422 @@
+// image_group.cpp -- control flow and file output of the groupwise solver on the
+// host; all arithmetic is in libfrog_hip.so.  Follows ImageGroup::run
+// (registration/imageGroup.cxx:31-157) step for step; stdout wording follows the
+// reference because the DESK UI greps it (js/groupwiseDeformableRegistration.js:522-545).
+
+#include "image_group.h"
+#include "json_out.h"
+#include "pairs_store.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+
+using std::cout;
+using std::endl;
+
+#define print(v, size) { for (int i_ = 0; i_ < size; i_++) { cout << v[i_]; if (i_ < (size - 1)) cout << " "; } cout << endl; }
+
+ImageGroup::ImageGroup()
+{
+    // imageGroup.h:52-82
+    boundingBoxMargin = 0.1f;
+    deformableAlpha = 0.02f;
+    deformableIterations = 200;
+    fixedTransformsDirectory = 0;
+    guaranteeDiffeomorphism = true;
+    invertLandmarksCoordinates = true;
+    landmarksConstraintsWeight = 50;
+    initialGridSize = 100;
+    inlierThreshold = 0.5f;
+    linearAlpha = 0.5f;
+    linearInitializationAnchor[0] = linearInitializationAnchor[1] = linearInitializationAnchor[2] = 0.5f;
+    linearIterations = 50;
+    maxDisplacementRatio = 0.4f;
+    deformableLevels = 3;
+    numberOfFixedImages = 0;
+    numberOfRANSACIterations = 5000;
+    printLinear = false;
+    printStats = false;
+    RANSACInlierDistance = 50;
+    RANSACMaxScale = 10;
+    statIntervalUpdate = 10;
+    useRANSAC = true;
+    useScale = true;
+    writePairs = false;
+    writeSingleFileTransforms = false;
+    transformSubdirectory = "transforms";
+    errorMapsSubdirectory = "errorMaps";
+    statsMaxSize = 10000;       // stats.cxx:10-12
+    statsMaxIterations = 10000;
+    statsEpsilon = 1e-6f;
+}
+
+ImageGroup::~ImageGroup()
+{
+    if (ctx) frog_destroy(ctx);
+    if (pairs && ownPairs) frog_pairs_free(pairs);
+}
+
+void ImageGroup::check(int rc, const char *what)
+{
+    if (rc == FROG_OK) return;
+    cout << "Error : " << what << " failed (" << rc << "): " << frog_last_error() << endl;
+    exit(1);
+}
+
+// readPairs, imageGroup.cxx:1353-1417
+void ImageGroup::readPairs(const char *fileName)
+{
+    int status = 0;
+    frog_pairs *p = frog_pairs_read(fileName, &status);
+    if (!p) {
+        // a block of size 0 is the reference's "Error : number of pairs is 0", exit(1)
+        cout << "Error : number of pairs is 0 or unreadable file " << fileName << endl;
+        exit(1);
+    }
+    usePairs(p);
+    ownPairs = true;
+    const uint64_t n = frog_pairs_num_pairs(pairs);
+    cout << n << " pairs read : " << n * 2 << " half pairs " << endl;
+}
+
+void ImageGroup::usePairs(frog_pairs *p)
+{
+    if (pairs && ownPairs) frog_pairs_free(pairs);
+    pairs = p;
+    ownPairs = false;
+}
+
+// ImageGroup ctor state + setupStats (:1151): the reservoirs are sized in frog_create.
+// Called from run() so that -ss/-emi/-se given after the file name take effect, as in
+// the reference where setupStats runs inside run().
+void ImageGroup::createContext()
+{
+    if (numberOfFixedImages != 0 || fixedTransformsDirectory) {
+        cout << "Error : fixed images (-fi/-fd/-r) are not supported by this build" << endl;
+        exit(1);
+    }
+    frog_options o;
+    frog_options_default(&o);
+    o.linear_alpha = linearAlpha;
+    o.use_scale = useScale;
+    o.initial_grid_size = initialGridSize;
+    o.bounding_box_margin = boundingBoxMargin;
+    o.inlier_threshold = inlierThreshold;
+    o.guarantee_diffeomorphism = guaranteeDiffeomorphism;
+    o.max_displacement_ratio = maxDisplacementRatio;
+    o.stats_max_size = statsMaxSize;
+    o.stats_max_iterations = statsMaxIterations;
+    o.stats_epsilon = statsEpsilon;
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    check(frog_create(&m, &o, device, 0, m.n_images, &ctx), "frog_create");
+    counts.assign(m.n_images, frog_counts{});
+}
+
+// run, imageGroup.cxx:31-157
+void ImageGroup::run()
+{
+    using clk = std::chrono::steady_clock;
+    if (!pairs) { cout << "Error : no pairs" << endl; exit(1); }
+    createContext();                                                    // :36 setupStats
+    check(frog_linear_init(ctx, linearInitializationAnchor), "frog_linear_init");   // :37
+    check(frog_transform_points(ctx, 0), "frog_transform_points");      // :38
+
+    cout << endl << "Linear registration" << endl;
+    auto t0 = clk::now();
+    for (int iteration = 0; iteration < linearIterations; iteration++) {
+        if (!quiet) cout << "Linear registration, iteration " << iteration + 1 << "/" << linearIterations << endl;
+        if (!(iteration % statIntervalUpdate)) check(frog_update_stats(ctx), "frog_update_stats");
+        if (printStats) displayStats();
+        double E = 0;
+        check(frog_linear_step(ctx, &E), "frog_linear_step");
+        float e = (float)E;
+        if (printLinear) displayLinearTransforms();
+        check(frog_transform_points(ctx, 0), "frog_transform_points");
+        computeLandmarkDistances(e);
+    }
+    loopSeconds += std::chrono::duration<double>(clk::now() - t0).count();
+    loopIterations += linearIterations;
+
+    check(frog_transform_points(ctx, 1), "frog_transform_points");      // :70
+    saveDistanceHistograms("histograms_linear.csv");                    // :71
+
+    if (deformableLevels) {
+        cout << endl << "Deformable registration" << endl;
+        countInliers();                                                 // :76
+        for (int level = 0; level < deformableLevels; level++) {
+            cout << endl << "Level " << level + 1 << "/" << deformableLevels << endl;
+            auto setup = [&]() {
+                frog_grid_info info;
+                check(frog_deformable_setup(ctx, level, &info), "frog_deformable_setup");
+                double length[3];
+                for (int k = 0; k < 3; k++) length[k] = info.bbox[2 * k + 1] - info.bbox[2 * k];
+                cout << "Bounding box : "; print(info.bbox, 6);
+                cout << "Box length : "; print(length, 3);
+                cout << "Grid origin : "; print(info.origin, 3);
+                cout << "Grid spacing : "; print(info.spacing, 3);
+                cout << "Grid dimensions (control points): "; print(info.dims, 3);
+            };
+            setup();                                                    // :81
+            check(frog_transform_points(ctx, 0), "frog_transform_points");
+            int numberOfGrids = 1;
+            float alpha = deformableAlpha;
+            cout << "alpha = " << alpha << endl;
+            int numberOfDiffeomorphicIterations = 0;
+            t0 = clk::now();
+            for (int iteration = 0; iteration < deformableIterations; iteration++) {
+                if (!quiet)
+                    cout << "Level " << level + 1 << "/" << deformableLevels << ", Iteration " << iteration + 1 << "/"
+                         << deformableIterations << endl;
+                if (!(iteration % statIntervalUpdate)) check(frog_update_stats(ctx), "frog_update_stats");
+                if (printStats) displayStats();
+                double E = 0;
+                check(frog_deformable_step(ctx, alpha, &E), "frog_deformable_step");
+                float e = (float)E;
+                if (e < 0) {                                            // :97-115
+                    cout << endl << "Diffeomorphism is not guaranteed : Iteration canceled" << endl;
+                    if (numberOfDiffeomorphicIterations == 0) {
+                        alpha /= 2;
+                        cout << "Halving alpha. New Value : " << alpha << endl;
+                    }
+                    cout << " creating new grid" << endl;
+                    numberOfGrids++;
+                    iteration--;
+                    check(frog_transform_points(ctx, 1), "frog_transform_points");
+                    setup();
+                    check(frog_transform_points(ctx, 0), "frog_transform_points");
+                    numberOfDiffeomorphicIterations = 0;
+                    continue;
+                }
+                numberOfDiffeomorphicIterations++;
+                check(frog_transform_points(ctx, 0), "frog_transform_points");
+                computeLandmarkDistances(e);
+            }
+            loopSeconds += std::chrono::duration<double>(clk::now() - t0).count();
+            loopIterations += deformableIterations;
+            countInliers();                                             // :123
+            cout << "Number of grids for this level : " << numberOfGrids << endl;
+            gridsPerLevel.push_back(numberOfGrids);
+            check(frog_transform_points(ctx, 1), "frog_transform_points");
+        }
+        int total = 0;
+        cout << "Grids per level : ";
+        for (int n : gridsPerLevel) { total += n; cout << n << " "; }
+        cout << endl << "Total number of grids : " << total << endl;
+        // saveErrorMaps (:141) needs a NIfTI writer: not part of this build (out of scope)
+    }
+
+    displayStats();                                                     // :144
+    saveDistanceHistograms("histograms.csv");
+    saveMeasures(outputFileName);
+    saveTransforms();
+    saveStatsJSON();
+}
+
+// computeLandmarkDistances without landmarks, imageGroup.cxx:1229-1242
+void ImageGroup::computeLandmarkDistances(float e)
+{
+    if (!quiet) cout << "E = " << e;
+    if (std::isnan(e)) {
+        cout << endl << "Error : NaN" << endl;
+        exit(1);
+    }
+    if (!quiet) cout << endl;
+    measures.push_back(Measure{ e, 0, 0, 0 });
+}
+
+// displayStats, imageGroup.cxx:899-908 + Stats::displayParameters, stats.cxx:72-93
+void ImageGroup::displayStats()
+{
+    const uint32_t n = frog_num_images(ctx);
+    std::vector<float> smp((size_t)std::max(1, statsMaxSize));
+    for (uint32_t i = 0; i < n; i++) {
+        float em[3];
+        check(frog_get_em(ctx, i, em), "frog_get_em");
+        int s = 0;
+        check(frog_get_samples(ctx, i, smp.data(), nullptr, (int)smp.size(), &s), "frog_get_samples");
+        s = std::min<int>(s, (int)smp.size());
+        cout << "Stats " << i << ":";
+        cout << "c1=" << em[0] << ",c2=" << em[1] << ",r=" << em[2] << ",nSamples=" << s;
+        if (s > 0) {
+            double sum = std::accumulate(smp.begin(), smp.begin() + s, 0.0);
+            double mean = sum / s;
+            double sq = std::inner_product(smp.begin(), smp.begin() + s, smp.begin(), 0.0);
+            float mx = *std::max_element(smp.begin(), smp.begin() + s);
+            cout << ",max=" << mx << ",mean=" << mean << ",stdev=" << std::sqrt(sq / s - mean * mean);
+        }
+        cout << endl;
+    }
+}
+
+// displayLinearTransforms, imageGroup.cxx:600-627
+void ImageGroup::displayLinearTransforms()
+{
+    const uint32_t n = frog_num_images(ctx);
+    for (uint32_t i = 0; i < n; i++) {
+        double m[16];
+        check(frog_get_linear(ctx, i, m), "frog_get_linear");
+        cout << "Image " << i << ", translation=" << m[3] << " " << m[7] << " " << m[11] << endl;
+        cout << "scale=" << m[0] << " " << m[5] << " " << m[10] << endl;
+    }
+}
+
+// countInliers, imageGroup.cxx:988-1060
+void ImageGroup::countInliers()
+{
+    check(frog_count_inliers(ctx, counts.data()), "frog_count_inliers");
+    long long nPairs = 0, nInliers = 0, nOutliers = 0;
+    for (const auto &c : counts) { nPairs += c.pairs; nInliers += c.inliers; nOutliers += c.outliers; }
+    cout << "Stats:" << endl;
+    cout << nPairs << " half pairs" << endl;
+    cout << nInliers << " inliers" << endl;
+    cout << nOutliers << " outliers" << endl;
+    cout << "Outlier ratio (%): " << (float)100 * nOutliers / nPairs << endl;
+}
+
+// saveDistanceHistograms, imageGroup.cxx:850-885
+void ImageGroup::saveDistanceHistograms(const char *file)
+{
+    const uint32_t n = frog_num_images(ctx);
+    std::vector<std::vector<float>> hist(n);
+    size_t maxSize = 0;
+    std::fstream fs;
+    fs.open(file, std::fstream::out | std::fstream::trunc);
+    for (uint32_t i = 0; i < n; i++) {
+        int sz = 0;
+        check(frog_get_histogram(ctx, i, nullptr, 0, &sz), "frog_get_histogram");
+        hist[i].assign((size_t)sz, 0.f);
+        if (sz) check(frog_get_histogram(ctx, i, hist[i].data(), sz, &sz), "frog_get_histogram");
+        maxSize = std::max(maxSize, hist[i].size());
+        fs << "image " << i;
+        if (i < n - 1) fs << ","; else fs << endl;
+    }
+    for (size_t d = 0; d < maxSize; d++)
+        for (uint32_t i = 0; i < n; i++) {
+            if (hist[i].size() <= d) fs << 0; else fs << hist[i][d];
+            if (i < n - 1) fs << ","; else fs << endl;
+        }
+    fs.close();
+}
+
+// saveMeasures, imageGroup.cxx:1475-1491
+void ImageGroup::saveMeasures(const char *file)
+{
+    std::fstream fs;
+    fs.open(file, std::fstream::out | std::fstream::trunc);
+    fs << "Iteration, E, landmarkAv, landmarkMax, landmarkSTD" << endl;
+    for (size_t i = 0; i < measures.size(); i++)
+        fs << i << "," << measures[i].E << "," << measures[i].landmarkAv << "," << measures[i].landmarkMax << ','
+           << measures[i].landmarkSTD << endl;
+    fs.close();
+}
+
+// saveTransforms, imageGroup.cxx:1458-1473 -> writeFrogJSON, tools/transformIO.h:163-258.
+// Single-file form ("-j"): matrix + dimensions/origin/spacing/coeffs per lattice, in
+// creation order (PostMultiply chain).  The compact form's .nii.gz sidecars need a
+// NIfTI writer and are not produced by this build: both modes write the -j form.
+void ImageGroup::saveTransforms()
+{
+    std::filesystem::create_directory(transformSubdirectory.c_str());
+    if (!writeSingleFileTransforms)
+        cout << "Note : writing single-file JSON transforms (the compact .nii.gz form is not built)" << endl;
+    const uint32_t n = frog_num_images(ctx);
+    const int nGrids = frog_num_grids(ctx);
+    for (uint32_t image = 0; image < n; image++) {
+        frogjson::Value transforms = frogjson::Value::array();
+        {
+            double m[16];
+            check(frog_get_linear(ctx, image, m), "frog_get_linear");
+            frogjson::Value t = frogjson::Value::object();
+            t["type"] = frogjson::Value("vtkMatrixToLinearTransform");
+            frogjson::Value mat = frogjson::Value::array();
+            for (int k = 0; k < 16; k++) mat.push(frogjson::Value(m[k]));
+            t["matrix"] = mat;
+            transforms.push(t);
+        }
+        for (int k = 0; k < nGrids; k++) {
+            frog_grid_info info;
+            check(frog_get_grid(ctx, image, k, &info, nullptr, 0), "frog_get_grid");
+            const size_t nv = (size_t)3 * info.dims[0] * info.dims[1] * info.dims[2];
+            std::vector<float> c(nv);
+            check(frog_get_grid(ctx, image, k, &info, c.data(), nv), "frog_get_grid");
+            frogjson::Value t = frogjson::Value::object();
+            t["type"] = frogjson::Value("vtkBSplineTransform");
+            frogjson::Value dims = frogjson::Value::array(), ori = frogjson::Value::array(), sp = frogjson::Value::array();
+            for (int a = 0; a < 3; a++) {
+                dims.push(frogjson::Value((double)info.dims[a]));
+                ori.push(frogjson::Value(info.origin[a]));
+                sp.push(frogjson::Value(info.spacing[a]));
+            }
+            t["dimensions"] = dims; t["origin"] = ori; t["spacing"] = sp;
+            frogjson::Value coeffs = frogjson::Value::array();
+            coeffs.arr.reserve(nv);
+            for (size_t j = 0; j < nv; j++) coeffs.arr.push_back(frogjson::Value((double)c[j]));
+            t["coeffs"] = coeffs;
+            transforms.push(t);
+        }
+        frogjson::Value root = frogjson::Value::object();
+        root["transforms"] = transforms;
+        std::ostringstream file;
+        file << transformSubdirectory << "/" << image << ".json";
+        std::fstream fs;
+        fs.open(file.str(), std::fstream::out | std::fstream::trunc);
+        fs << root.serialize();
+        fs.close();
+    }
+}
+
+// bbox.json: the `stats` object of the reference (imageGroup.cxx:152-155) =
+// countInliers' per-image records (:1036-1058) + saveBoundingBox (:1493-1511).
+void ImageGroup::saveStatsJSON()
+{
+    frogjson::Value stats = frogjson::Value::object();
+    const uint32_t n = frog_num_images(ctx);
+    if (deformableLevels) {
+        long long nPairs = 0, nInliers = 0, nOutliers = 0;
+        frogjson::Value images = frogjson::Value::array();
+        for (uint32_t i = 0; i < n; i++) {
+            const frog_counts &c = counts[i];
+            nPairs += c.pairs; nInliers += c.inliers; nOutliers += c.outliers;
+            frogjson::Value s = frogjson::Value::object();
+            s["points"] = frogjson::Value((double)c.points);
+            s["pairs"] = frogjson::Value((double)c.pairs);
+            s["inliers"] = frogjson::Value((double)c.inliers);
+            s["outliers"] = frogjson::Value((double)c.outliers);
+            frogjson::Value em = frogjson::Value::object();
+            em["c1"] = frogjson::Value((double)c.c1);
+            em["c2"] = frogjson::Value((double)c.c2);
+            em["ratio"] = frogjson::Value((double)c.ratio);
+            s["EMStats"] = em;
+            images.push(s);
+        }
+        stats["images"] = images;
+        stats["halfPairs"] = frogjson::Value((double)nPairs);
+        stats["inliers"] = frogjson::Value((double)nInliers);
+        stats["outliers"] = frogjson::Value((double)nOutliers);
+        stats["outlierRatio"] = frogjson::Value((double)nOutliers / (double)nPairs);
+    }
+    // bounding box of every image's xyz (getBoundingBox(box, true))
+    const uint64_t P = frog_num_points(ctx);
+    std::vector<float> xyz(3 * P);
+    check(frog_get_points(ctx, xyz.data(), nullptr), "frog_get_points");
+    double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+    for (uint64_t p = 0; p < P; p++)
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], (double)xyz[3 * p + k]); mx[k] = std::max(mx[k], (double)xyz[3 * p + k]); }
+    frogjson::Value bmin = frogjson::Value::array(), bmax = frogjson::Value::array(), bbox = frogjson::Value::array();
+    for (int k = 0; k < 3; k++) { bmin.push(frogjson::Value(mn[k])); bmax.push(frogjson::Value(mx[k])); }
+    bbox.push(bmin); bbox.push(bmax);
+    stats["bbox"] = bbox;
+    std::fstream fs;
+    fs.open("bbox.json", std::fstream::out | std::fstream::trunc);
+    fs << stats.serialize();
+    fs.close();
+}

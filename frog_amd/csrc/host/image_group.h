@@ -1,0 +1,77 @@
+// image_group.h -- host-side ImageGroup of the MI355X build.
+//
+// Same public surface as the reference's class (registration/imageGroup.h:10-82):
+// option fields with the reference's names and defaults, readPairs(), run().
+// run() keeps the control flow of imageGroup.cxx:31-157 and delegates every
+// numeric step to libfrog_hip.so (include/frog_hip.h).  No solver arithmetic and
+// no CPU fallback live here.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../../include/frog_hip.h"
+#include "../../../include/frog_host.h"
+
+class ImageGroup {
+public:
+    ImageGroup();
+    ~ImageGroup();
+
+    void run();
+    void readPairs(const char *fileName);        // imageGroup.cxx:1353
+    void usePairs(frog_pairs *p);                // adopt an already parsed / synthetic group
+
+    // imageGroup.h:17-50 (same names, same defaults)
+    bool printStats, printLinear;
+    int linearIterations;
+    bool useScale;
+    int deformableLevels, deformableIterations;
+    float linearInitializationAnchor[3];
+    float linearAlpha, deformableAlpha;
+    int statIntervalUpdate;
+    float initialGridSize, boundingBoxMargin, inlierThreshold;
+    bool guaranteeDiffeomorphism;
+    float maxDisplacementRatio;
+    bool invertLandmarksCoordinates;
+    float landmarksConstraintsWeight;
+    const char *outputFileName = "measures.csv";
+    bool writePairs;
+    int numberOfFixedImages;
+    bool useRANSAC;
+    int numberOfRANSACIterations;
+    float RANSACInlierDistance, RANSACMaxScale;
+    char *fixedTransformsDirectory;
+    bool writeSingleFileTransforms;
+    std::string transformSubdirectory, errorMapsSubdirectory;
+    // Stats statics (stats.cxx:10-12), set by -ss / -emi / -se
+    int statsMaxSize, statsMaxIterations;
+    float statsEpsilon;
+
+    int device = 0;              // HIP device ordinal (new: -dev)
+    bool quiet = false;          // suppress per-iteration lines (new: -q)
+
+    // results of run()
+    struct Measure { float E, landmarkAv, landmarkMax, landmarkSTD; };
+    std::vector<Measure> measures;
+    std::vector<int> gridsPerLevel;
+    double loopSeconds = 0;      // time spent inside the two iteration loops
+    int loopIterations = 0;
+
+protected:
+    frog_pairs *pairs = nullptr;
+    bool ownPairs = false;
+    frog_ctx *ctx = nullptr;
+    std::vector<frog_counts> counts;
+
+    void createContext();
+    void check(int rc, const char *what);
+    void computeLandmarkDistances(float e);      // :1229 (no landmarks: records E, exits on NaN)
+    void displayStats();                         // :899
+    void displayLinearTransforms();              // :600
+    void countInliers();                         // :988
+    void saveDistanceHistograms(const char *file);   // :850
+    void saveMeasures(const char *file);         // :1475
+    void saveTransforms();                       // :1458
+    void saveStatsJSON();                        // :152-155, :1493-1511
+};

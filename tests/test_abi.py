@@ -1,0 +1,71 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares; without a
+device the product refuses to run instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from frog_amd import _abi
+
+INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+
+
+def declared(header):
+    text = open(os.path.join(INC, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(frog_[a-z0-9_]+)\s*\(", text)) - {"frog_options_default"})
+
+
+def test_device_library_exports_every_declared_symbol():
+    lib = _abi.hip_lib()
+    names = declared("frog_hip.h")
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_abi.HIP_SYMBOLS) == names        # the ctypes table is complete, nothing undeclared
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = _abi.host_lib()
+    names = declared("frog_host.h")
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_abi.HOST_SYMBOLS) == names
+
+
+def test_struct_layouts_match_the_headers():
+    assert C.sizeof(_abi.FrogOptions) == 4 * 10 + 4 * 6
+    assert C.sizeof(_abi.FrogGridInfo) == 16 + 8 * 12
+    assert C.sizeof(_abi.FrogCounts) == 8 * 4 + 4 * 4
+    assert C.sizeof(_abi.FrogKernelTime) == 16
+    assert C.sizeof(_abi.FrogModel) == 8 + 5 * 8
+
+
+def test_no_cpu_fallback(tiny_pairs):
+    lib = _abi.hip_lib()
+    if lib.frog_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    ctx = C.c_void_p()
+    o = _abi.FrogOptions.default()
+    rc = lib.frog_create(C.byref(tiny_pairs.model), C.byref(o), 0, 0, tiny_pairs.n_images, C.byref(ctx))
+    assert rc == _abi.FROG_E_NODEVICE and not ctx.value
+    assert b"no CPU fallback" in lib.frog_last_error()
+
+
+def test_argument_validation_comes_before_device_use(tiny_pairs):
+    lib = _abi.hip_lib()
+    ctx = C.c_void_p()
+    o = _abi.FrogOptions.default()
+    assert lib.frog_create(C.byref(tiny_pairs.model), C.byref(o), 0, 3, 2, C.byref(ctx)) == _abi.FROG_E_INVALID
+    o.reserved[0] = 1
+    assert lib.frog_create(C.byref(tiny_pairs.model), C.byref(o), 0, 0, 4, C.byref(ctx)) == _abi.FROG_E_INVALID
+
+
+def test_product_does_not_reference_the_oracle():
+    root = os.path.dirname(INC)
+    for base, _, files in os.walk(os.path.join(root, "frog_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle" not in text.replace("(no CPU engine", ""), os.path.join(base, f)

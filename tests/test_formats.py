@@ -1,0 +1,108 @@
+"""pairs.bin reader / writer, the reference-order half-link CSR and the synthetic generator."""
+import struct
+
+import numpy as np
+import pytest
+
+from frog_amd.pairs import Pairs
+
+
+def test_roundtrip_is_byte_identical(tmp_path, tiny_pairs):
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    tiny_pairs.write(a)
+    again = Pairs.read(a)
+    again.write(b)
+    assert a.read_bytes() == b.read_bytes()
+    assert again.n_images == tiny_pairs.n_images and again.n_pairs == tiny_pairs.n_pairs
+    assert np.array_equal(again.xyz, tiny_pairs.xyz)
+    assert np.array_equal(again.row_ptr, tiny_pairs.row_ptr)
+    assert np.array_equal(again.link_image, tiny_pairs.link_image)
+    assert np.array_equal(again.link_point, tiny_pairs.link_point)
+
+
+def test_wire_format_matches_appendix_a(tmp_path):
+    """u16 nImages | per image: u16 len, name, f64[3], u32 nPoints, nPoints x 6 f32 | blocks."""
+    xyz = np.arange(30, dtype=np.float32).reshape(10, 3)
+    p = Pairs.from_arrays([0, 4, 10], xyz, [(0, 1, [0, 3, 3], [5, 0, 2])])
+    f = tmp_path / "p.bin"
+    p.write(f)
+    raw = f.read_bytes()
+    off = 0
+    (n,) = struct.unpack_from("<H", raw, off); off += 2
+    assert n == 2
+    counts = []
+    for i in range(2):
+        (ln,) = struct.unpack_from("<H", raw, off); off += 2 + ln
+        off += 24
+        (npts,) = struct.unpack_from("<I", raw, off); off += 4
+        rec = np.frombuffer(raw, "<f4", npts * 6, off).reshape(npts, 6); off += npts * 24
+        counts.append(npts)
+        assert np.array_equal(rec[:, :3], xyz[sum(counts[:-1]):sum(counts)])
+    assert counts == [4, 6]
+    i1, i2, size = struct.unpack_from("<HHI", raw, off); off += 8
+    assert (i1, i2, size) == (0, 1, 3)
+    assert list(struct.unpack_from("<6I", raw, off)) == [0, 5, 3, 0, 3, 2]
+    assert off + 24 == len(raw)
+
+
+def test_links_follow_readpairs_push_back_order():
+    """imageGroup.cxx:1405-1406: each pair appends (image2,p2) to image1's point and
+    (image1,p1) to image2's point, in file order."""
+    xyz = np.zeros((9, 3), np.float32)
+    blocks = [(0, 1, [0, 1, 1], [2, 0, 2]), (0, 2, [1, 0], [1, 1]), (1, 2, [2], [1])]
+    p = Pairs.from_arrays([0, 2, 5, 9], xyz, blocks)
+    po = [0, 2, 5, 9]
+    links = {}
+    for i1, i2, a, b in blocks:
+        for x, y in zip(a, b):
+            links.setdefault((i1, x), []).append((i2, y))
+            links.setdefault((i2, y), []).append((i1, x))
+    rp, li, lp = p.row_ptr, p.link_image, p.link_point
+    for im in range(3):
+        for pt in range(po[im + 1] - po[im]):
+            g = po[im] + pt
+            got = list(zip(li[rp[g]:rp[g + 1]].tolist(), lp[rp[g]:rp[g + 1]].tolist()))
+            assert got == links.get((im, pt), [])
+    assert rp[-1] == 2 * 6
+
+
+def test_empty_block_is_rejected(tmp_path):
+    """A block with size 0 is the reference's 'Error : number of pairs is 0' exit(1)."""
+    xyz = np.zeros((4, 3), np.float32)
+    p = Pairs.from_arrays([0, 2, 4], xyz, [(0, 1, [0], [1])])
+    f = tmp_path / "p.bin"
+    p.write(f)
+    with open(f, "ab") as fh:
+        fh.write(struct.pack("<HHI", 0, 1, 0))
+    with pytest.raises(ValueError):
+        Pairs.read(f)
+
+
+def test_out_of_range_indices_are_rejected():
+    xyz = np.zeros((4, 3), np.float32)
+    with pytest.raises(ValueError):
+        Pairs.from_arrays([0, 2, 4], xyz, [(0, 1, [2], [0])])
+    with pytest.raises(ValueError):
+        Pairs.from_arrays([0, 2, 4], xyz, [(0, 3, [0], [0])])
+
+
+def test_points_without_links_and_ragged_images():
+    xyz = np.zeros((7, 3), np.float32)
+    p = Pairs.from_arrays([0, 1, 7], xyz, [(0, 1, [0, 0], [5, 5])])   # duplicate pair, 5 unlinked points
+    rp = p.row_ptr
+    assert list(np.diff(rp)) == [2, 0, 0, 0, 0, 0, 2]
+
+
+def test_synthetic_generator_is_deterministic_and_sized():
+    a = Pairs.synthetic(5, 400, 200, seed=9)
+    b = Pairs.synthetic(5, 400, 200, seed=9)
+    c = Pairs.synthetic(5, 400, 200, seed=10)
+    assert np.array_equal(a.xyz, b.xyz) and np.array_equal(a.link_point, b.link_point)
+    assert not np.array_equal(a.xyz, c.xyz)
+    assert a.n_points == 5 * 400 and a.n_blocks == 10
+    assert 0.85 * 10 * 200 < a.n_pairs < 1.15 * 10 * 200
+    for blk in range(a.n_blocks):
+        i1, i2, p1, p2 = a.block(blk)
+        assert i1 < i2 and len(p1) > 0 and np.all(np.diff(p1.astype(np.int64)) >= 0)   # sorted by image1's index
+    sparse = Pairs.synthetic(12, 100, 40, seed=2, partners_per_image=4)
+    assert 0 < sparse.n_blocks < 66
