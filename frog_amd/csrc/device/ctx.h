@@ -158,8 +158,16 @@ struct frog_ctx {
     frog::DevBuf<float4> em;                  // [nI] c1,c2,ratio,0
     frog::DevBuf<frog::EmDerived> emd;        // [nI]
     frog::DevBuf<float> samples;              // [nOwned][cap]
-    frog::DevBuf<uint32_t> sample_ord;        // [nOwned][cap]
-    frog::DevBuf<uint32_t> sample_count;      // [nOwned]
+    // Which ordinals a refresh keeps does not depend on the data (k_stats.hip.h), so the
+    // selection for the NEXT refresh is computed ahead of time on a side stream into the
+    // other buffer of this pair.
+    frog::DevBuf<uint32_t> sample_ord[2];     // [nOwned][cap]
+    frog::DevBuf<uint32_t> sample_count[2];   // [nOwned]
+    int sel_ready = 0;                        // buffer the pending/ready selection is written to
+    int sel_used = 0;                         // buffer the last refresh consumed
+    hipStream_t side = nullptr;
+    hipEvent_t sel_done = nullptr;            // selection `sel_ready` complete (side stream)
+    hipEvent_t ord_read[2] = { nullptr, nullptr };   // last reader of sample_ord[b] done (main stream)
     frog::DevBuf<uint32_t> mt_state;          // [nOwned][625] (624 words + index)
     std::vector<uint32_t> h_virtual;          // per owned image: virtualSize (clamped to 2^32-1)
     frog::DevBuf<uint32_t> d_virtual;         // [nOwned]

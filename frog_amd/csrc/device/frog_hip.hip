@@ -61,6 +61,9 @@ void frog_destroy(frog_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->sel_done) (void)hipEventDestroy(ctx->sel_done);
+    for (int b = 0; b < 2; b++) if (ctx->ord_read[b]) (void)hipEventDestroy(ctx->ord_read[b]);
     for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->h_energy) (void)hipHostFree(ctx->h_energy);
@@ -164,9 +167,14 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     c->sample_cap = (int)cap;
     CREATE_CHECK(c->d_virtual.upload(c->h_virtual, s));
     CREATE_CHECK(c->samples.alloc((size_t)c->n_owned() * cap));
-    CREATE_CHECK(c->sample_ord.alloc((size_t)c->n_owned() * cap));
-    CREATE_CHECK(c->sample_count.alloc(c->n_owned()));
-    CREATE_CHECK(hipMemsetAsync(c->sample_count.p, 0, c->sample_count.bytes(), s));
+    for (int b = 0; b < 2; b++) {
+        CREATE_CHECK(c->sample_ord[b].alloc((size_t)c->n_owned() * cap));
+        CREATE_CHECK(c->sample_count[b].alloc(c->n_owned()));
+        CREATE_CHECK(hipMemsetAsync(c->sample_count[b].p, 0, c->sample_count[b].bytes(), s));
+        CREATE_CHECK(hipEventCreateWithFlags(&c->ord_read[b], hipEventDisableTiming));
+    }
+    CREATE_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    CREATE_CHECK(hipEventCreateWithFlags(&c->sel_done, hipEventDisableTiming));
     {
         // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
         std::vector<uint32_t> st((size_t)c->n_owned() * MT_WORDS);
@@ -189,6 +197,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
+    // selection of the first refresh, ahead of time
+    c->sel_ready = 0; c->sel_used = 1;
+    select_kernel<<<c->n_owned(), 64, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
+    CREATE_CHECK(hipGetLastError());
+    CREATE_CHECK(hipEventRecord(c->sel_done, c->side));
 #undef CREATE_CHECK
     *out = c;
     return FROG_OK;
@@ -268,16 +281,28 @@ int frog_update_stats_local(frog_ctx *ctx)
     const uint32_t nO = ctx->n_owned();
     const uint32_t cap = (uint32_t)ctx->sample_cap;
     hipStream_t s = ctx->stream;
-    Span span(ctx, FROG_K_STATS);
-    select_kernel<<<nO, 64, 0, s>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord.p, ctx->sample_count.p);
+    // consume the selection prepared on the side stream
+    const int cur = ctx->sel_ready;
+    FROG_HIP_CHECK(hipStreamWaitEvent(s, ctx->sel_done, 0));
+    {
+        Span span(ctx, FROG_K_STATS);
+        sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
+            ctx->sample_ord[cur].p, ctx->sample_count[cur].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
+            ctx->ref_rowptr.p, ctx->ref_link.p, ctx->pos2.p, ctx->samples.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        em_kernel<<<nO, 64, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
+                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
+    FROG_HIP_CHECK(hipEventRecord(ctx->ord_read[cur], s));
+    ctx->sel_used = cur;
+    // prepare the next refresh's selection into the other buffer, behind its last reader
+    const int nxt = cur ^ 1;
+    FROG_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ord_read[nxt], 0));
+    select_kernel<<<nO, 64, 0, ctx->side>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p);
     FROG_HIP_CHECK(hipGetLastError());
-    sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
-        ctx->sample_ord.p, ctx->sample_count.p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
-        ctx->ref_rowptr.p, ctx->ref_link.p, ctx->pos2.p, ctx->samples.p);
-    FROG_HIP_CHECK(hipGetLastError());
-    em_kernel<<<nO, 64, 0, s>>>(ctx->samples.p, ctx->sample_count.p, cap, ctx->ib, ctx->em.p,
-                                 ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
-    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipEventRecord(ctx->sel_done, ctx->side));
+    ctx->sel_ready = nxt;
     // rows of other ranks' images: zero, so that an all-reduce(sum) completes the table
     if (ctx->ib > 0) FROG_HIP_CHECK(hipMemsetAsync(ctx->em.p, 0, (size_t)ctx->ib * sizeof(float4), s));
     if (ctx->ie < ctx->nI)
@@ -440,16 +465,18 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     FROG_HIP_CHECK(ctx->brick_cursor.alloc((size_t)n_keys + 1));
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     const GeomDev gd = to_dev(g);
+    uint32_t max_img_pts = 0;
+    for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
+    const dim3 bgrid(std::max(1u, div_up(max_img_pts, BRICK_BLOCK_POINTS)), nO);
     if (nPts) {
-        brick_count_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->ib, gd, counts.p);
+        brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
     brick_scan_kernel<<<1, 1024, 0, s>>>(counts.p, n_keys, ctx->brick_ptr.p, ctx->brick_cursor.p, ctx->brick_cursor.p + n_keys);
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpyAsync(&ctx->max_brick_count, ctx->brick_cursor.p + n_keys, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (nPts) {
-        brick_place_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->ib, gd,
-                                                           ctx->brick_cursor.p, ctx->perm.p);
+        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->brick_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
     FROG_HIP_CHECK(hipStreamSynchronize(s));      // max_brick_count is on the host; `counts` may go
@@ -656,14 +683,15 @@ int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *or
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
     const uint32_t li = image - ctx->ib;
     uint32_t cnt = 0;
-    FROG_HIP_CHECK(hipMemcpyAsync(&cnt, ctx->sample_count.p + li, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    const int ub = ctx->sel_used;
+    FROG_HIP_CHECK(hipMemcpyAsync(&cnt, ctx->sample_count[ub].p + li, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (n) *n = (int)cnt;
     const size_t m = std::min<size_t>(cnt, cap > 0 ? (size_t)cap : 0);
     if (m && samples)
         FROG_HIP_CHECK(hipMemcpyAsync(samples, ctx->samples.p + (size_t)li * ctx->sample_cap, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (m && ordinals)
-        FROG_HIP_CHECK(hipMemcpyAsync(ordinals, ctx->sample_ord.p + (size_t)li * ctx->sample_cap, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FROG_HIP_CHECK(hipMemcpyAsync(ordinals, ctx->sample_ord[ub].p + (size_t)li * ctx->sample_cap, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
 }

@@ -170,18 +170,86 @@ __device__ __forceinline__ uint32_t brick_of(const int ic[3], const GeomDev &g)
     return (uint32_t)(b[0] + g.nbricks[0] * (b[1] + g.nbricks[1] * b[2]));
 }
 
-// brick key count / placement (two launches around a scan)
-__global__ __launch_bounds__(256) void brick_count_kernel(const float4 *pos, uint32_t pt_begin, uint32_t pt_end,
-                                                          uint32_t image_begin, const GeomDev g, uint32_t *counts)
+// brick key count / placement (two launches around a scan).  grid = (chunks of
+// BRICK_BLOCK_POINTS points, owned image): a block sees one image only, so its
+// keys are that image's bricks and are first aggregated in an LDS histogram
+// (integer LDS atomics are full rate); HBM sees one atomic per (block, brick)
+// instead of one per point -- at the coarsest lattice an image has ONE brick.
+constexpr int BRICK_BLOCK_POINTS = 1024;
+constexpr int BRICK_LDS_KEYS = 8192;
+
+__device__ __forceinline__ uint32_t point_brick(const float4 v, const GeomDev &g)
 {
-    uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pt_end) return;
-    const float4 v = pos[p];
     const float in[3] = { v.x, v.y, v.z };
     int ic[3]; float fr[3];
     scatter_cell(in, g, ic, fr);
-    const uint32_t key = (uint32_t)(__float_as_int(v.w) - (int)image_begin) * g.n_bricks + brick_of(ic, g);
-    atomicAdd(&counts[key], 1u);
+    return brick_of(ic, g);
+}
+
+__global__ __launch_bounds__(256) void brick_count_kernel(const float4 *pos, const uint32_t *poff,
+                                                          uint32_t image_begin, const GeomDev g, uint32_t *counts)
+{
+    __shared__ uint32_t h[BRICK_LDS_KEYS];
+    const uint32_t img = blockIdx.y;
+    const uint32_t p0 = poff[image_begin + img] + blockIdx.x * BRICK_BLOCK_POINTS;
+    const uint32_t pe = poff[image_begin + img + 1];
+    if (p0 >= pe) return;
+    const uint32_t p1 = min(p0 + (uint32_t)BRICK_BLOCK_POINTS, pe);
+    const bool lds = g.n_bricks <= BRICK_LDS_KEYS;
+    uint32_t *gc = counts + (size_t)img * g.n_bricks;
+    if (lds) {
+        for (int k = threadIdx.x; k < g.n_bricks; k += 256) h[k] = 0u;
+        __syncthreads();
+    }
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const uint32_t b = point_brick(pos[p], g);
+        if (lds) atomicAdd(&h[b], 1u); else atomicAdd(&gc[b], 1u);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < g.n_bricks; k += 256)
+            if (h[k]) atomicAdd(&gc[k], h[k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, const uint32_t *poff,
+                                                          uint32_t image_begin, const GeomDev g,
+                                                          uint32_t *cursor, uint32_t *perm)
+{
+    __shared__ uint32_t h[BRICK_LDS_KEYS];
+    const uint32_t img = blockIdx.y;
+    const uint32_t p0 = poff[image_begin + img] + blockIdx.x * BRICK_BLOCK_POINTS;
+    const uint32_t pe = poff[image_begin + img + 1];
+    if (p0 >= pe) return;
+    const uint32_t p1 = min(p0 + (uint32_t)BRICK_BLOCK_POINTS, pe);
+    const bool lds = g.n_bricks <= BRICK_LDS_KEYS;
+    uint32_t *gcur = cursor + (size_t)img * g.n_bricks;
+    constexpr int PER = BRICK_BLOCK_POINTS / 256;
+    uint32_t key[PER], rank[PER];
+    if (lds) {
+        for (int k = threadIdx.x; k < g.n_bricks; k += 256) h[k] = 0u;
+        __syncthreads();
+    }
+    #pragma unroll
+    for (int m = 0; m < PER; m++) {
+        const uint32_t p = p0 + threadIdx.x + 256 * m;
+        key[m] = 0xFFFFFFFFu; rank[m] = 0;
+        if (p < p1) {
+            key[m] = point_brick(pos[p], g);
+            if (lds) rank[m] = atomicAdd(&h[key[m]], 1u);           // rank inside this block
+            else perm[atomicAdd(&gcur[key[m]], 1u)] = p;
+        }
+    }
+    if (!lds) return;
+    __syncthreads();
+    for (int k = threadIdx.x; k < g.n_bricks; k += 256)
+        if (h[k]) h[k] = atomicAdd(&gcur[k], h[k]);                 // block's base slot in the brick
+    __syncthreads();
+    #pragma unroll
+    for (int m = 0; m < PER; m++) {
+        const uint32_t p = p0 + threadIdx.x + 256 * m;
+        if (p < p1) perm[h[key[m]] + rank[m]] = p;
+    }
 }
 
 // exclusive scan of n counts -> ptr[0..n], single block; also max count
@@ -212,21 +280,6 @@ __global__ __launch_bounds__(1024) void brick_scan_kernel(const uint32_t *counts
         __syncthreads();
     }
     if (threadIdx.x == 0) { ptr[n] = carry; *max_count = mx; }
-}
-
-__global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, uint32_t pt_begin, uint32_t pt_end,
-                                                          uint32_t image_begin, const GeomDev g,
-                                                          uint32_t *cursor, uint32_t *perm)
-{
-    uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pt_end) return;
-    const float4 v = pos[p];
-    const float in[3] = { v.x, v.y, v.z };
-    int ic[3]; float fr[3];
-    scatter_cell(in, g, ic, fr);
-    const uint32_t key = (uint32_t)(__float_as_int(v.w) - (int)image_begin) * g.n_bricks + brick_of(ic, g);
-    const uint32_t slot = atomicAdd(&cursor[key], 1u);
-    perm[slot] = p;
 }
 
 // ---- K7: scatter of the per-point sums onto the gradient lattice ----------------
