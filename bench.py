@@ -135,6 +135,16 @@ def main():
     # ---- timed region: exactly K iterations --------------------------------------------
     engine.profile_enable(True)
     phase_s = {}
+    phase_k = {}
+    prof = {n: [0.0, 0] for n in _abi.FROG_K_NAMES}
+
+    def take(tag):
+        # HIP-event kernel times of the phase just finished (the events are already complete:
+        # the phase ended with a device synchronisation)
+        cur = engine.profile_read(reset=True)
+        phase_k[tag] = {n: {"ms": round(v[0], 4), "launches": int(v[1])} for n, v in cur.items() if v[1]}
+        for n, v in cur.items():
+            prof[n][0] += v[0]; prof[n][1] += v[1]
     sync()
     t_start = time.perf_counter()
     tp = t_start
@@ -147,6 +157,7 @@ def main():
     grp.transformPoints(True)
     torch.cuda.synchronize()
     phase_s["linear"] = time.perf_counter() - tp
+    take("linear")
     grids = []
     for level in range(3):
         if per_level[level] == 0:
@@ -155,6 +166,7 @@ def main():
         grids.append(grp.run_level(level, per_level[level]))
         torch.cuda.synchronize()
         phase_s[f"level{level}"] = time.perf_counter() - tp
+        take(f"level{level}")
     sync()
     elapsed = time.perf_counter() - t_start
     engine.profile_enable(False)
@@ -166,7 +178,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    prof = engine.profile_read()
     k = n_lin + sum(per_level)
     own_b, own_e = shards[rank]
     po, rp = pairs.point_offset, pairs.row_ptr
@@ -203,6 +214,7 @@ def main():
                        "final_E": e},
             "roofline": roofline,
             "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items()},
+            "kernels_ms_by_phase": phase_k,
             "phase_iterations_per_s": {
                 "linear": n_lin / phase_s["linear"],
                 **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(3) if per_level[l]}},

@@ -187,9 +187,10 @@ struct frog_ctx {
     frog::DevBuf<float4> gradf;               // [nOwned][G] gradient lattice: sum w*sDisp xyz, sum w*sWeight
     frog::DevBuf<double> gridsum;             // [3G]
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)
-    frog::DevBuf<uint32_t> brick_ptr;         // [nOwned*n_bricks + 1]
-    frog::DevBuf<uint32_t> brick_cursor;
-    uint32_t max_brick_count = 0;
+    frog::DevBuf<uint32_t> key_ptr;           // [nOwned*n_bricks*B^3 + 1] (image, brick, cell) -> perm range
+    frog::DevBuf<uint32_t> key_cursor;
+    frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[n_scatter_blocks] (k_grid.hip.h)
+    uint32_t n_scatter_blocks = 0;
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
     frog::DevBuf<unsigned long long> n_big;   // oversize-coefficient counter
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers

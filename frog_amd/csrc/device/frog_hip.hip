@@ -456,13 +456,18 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
 
-    // bin the owned points into bricks
-    const uint32_t n_keys = nO * (uint32_t)nb;
-    frog::DevBuf<uint32_t> counts;
+    // sort the owned points by (image, brick, cell) and build the scatter's block table
+    const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
+    const size_t n_keys64 = (size_t)nO * nb * keys_per_brick;
+    if (n_keys64 >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
+    const uint32_t n_keys = (uint32_t)n_keys64;
+    const uint32_t n_bricks_total = nO * (uint32_t)nb;
+    frog::DevBuf<uint32_t> counts, bptr;
     FROG_HIP_CHECK(counts.alloc(n_keys));
+    FROG_HIP_CHECK(bptr.alloc((size_t)n_bricks_total + 1));
     FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
-    FROG_HIP_CHECK(ctx->brick_ptr.alloc((size_t)n_keys + 1));
-    FROG_HIP_CHECK(ctx->brick_cursor.alloc((size_t)n_keys + 1));
+    FROG_HIP_CHECK(ctx->key_ptr.alloc((size_t)n_keys + 1));
+    FROG_HIP_CHECK(ctx->key_cursor.alloc((size_t)n_keys + 1));
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     const GeomDev gd = to_dev(g);
     uint32_t max_img_pts = 0;
@@ -472,14 +477,27 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    brick_scan_kernel<<<1, 1024, 0, s>>>(counts.p, n_keys, ctx->brick_ptr.p, ctx->brick_cursor.p, ctx->brick_cursor.p + n_keys);
+    brick_scan_kernel<<<1, 1024, 0, s>>>(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
     FROG_HIP_CHECK(hipGetLastError());
-    FROG_HIP_CHECK(hipMemcpyAsync(&ctx->max_brick_count, ctx->brick_cursor.p + n_keys, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    brick_ptr_kernel<<<div_up((size_t)n_bricks_total + 1, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, bptr.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> h_bptr((size_t)n_bricks_total + 1);
+    FROG_HIP_CHECK(hipMemcpyAsync(h_bptr.data(), bptr.p, h_bptr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (nPts) {
-        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->brick_cursor.p, ctx->perm.p);
+        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    FROG_HIP_CHECK(hipStreamSynchronize(s));      // max_brick_count is on the host; `counts` may go
+    FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host; `counts`, `bptr` may go
+    std::vector<ScatterBlock> blocks;
+    for (uint32_t k = 0; k < n_bricks_total; k++)
+        for (uint32_t b0 = h_bptr[k]; b0 < h_bptr[k + 1]; b0 += SCATTER_CHUNK)
+            blocks.push_back(ScatterBlock{ k, b0, std::min(b0 + (uint32_t)SCATTER_CHUNK, h_bptr[k + 1]), 0u });
+    ctx->n_scatter_blocks = (uint32_t)blocks.size();
+    FROG_HIP_CHECK(ctx->scatter_blocks.alloc(std::max<size_t>(1, blocks.size()) * sizeof(ScatterBlock)));
+    if (!blocks.empty()) {
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->scatter_blocks.p, blocks.data(), blocks.size() * sizeof(ScatterBlock), hipMemcpyHostToDevice, s));
+        FROG_HIP_CHECK(hipStreamSynchronize(s));
+    }
 
     GridRecord rec;
     rec.info = info;
@@ -517,12 +535,11 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     FROG_HIP_CHECK(hipGetLastError());
     energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, 2, 0, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
-    const uint32_t n_keys = nO * (uint32_t)ctx->geom.n_bricks;
-    const uint32_t chunks = std::max(1u, div_up(ctx->max_brick_count, SCATTER_CHUNK));
-    if (ctx->max_brick_count) {
+    if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);
-        scatter_kernel<<<dim3(n_keys, chunks), 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p, ctx->brick_ptr.p,
-                                                          ctx->gradf.p, gd);
+        scatter_kernel<<<ctx->n_scatter_blocks, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p,
+                                                           reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
+                                                           ctx->gradf.p, gd);
         FROG_HIP_CHECK(hipGetLastError());
     }
     {

@@ -156,34 +156,36 @@ __device__ __forceinline__ void scatter_cell(const float in[3], const GeomDev &g
     }
 }
 
-__device__ __forceinline__ uint32_t brick_of(const int ic[3], const GeomDev &g)
-{
-    // cells are 1-based (origin = box min - spacing); clamp keeps stray points legal
-    int b[3];
-    #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        int c = ic[k] - 1;
-        c = c < 0 ? 0 : c;
-        int bk = c / g.brick;
-        b[k] = bk >= g.nbricks[k] ? g.nbricks[k] - 1 : bk;
-    }
-    return (uint32_t)(b[0] + g.nbricks[0] * (b[1] + g.nbricks[1] * b[2]));
-}
-
-// brick key count / placement (two launches around a scan).  grid = (chunks of
-// BRICK_BLOCK_POINTS points, owned image): a block sees one image only, so its
-// keys are that image's bricks and are first aggregated in an LDS histogram
-// (integer LDS atomics are full rate); HBM sees one atomic per (block, brick)
-// instead of one per point -- at the coarsest lattice an image has ONE brick.
+// Sort key of a point: (image, brick, cell inside the brick), i.e. points are grouped
+// by brick (the LDS tile of the scatter) and, inside a brick, by cell: consecutive
+// points of one cell share all 64 tap addresses, which the scatter exploits.
+// Count / placement are two launches around a scan.  grid = (chunks of
+// BRICK_BLOCK_POINTS points, owned image): a block sees one image only, so when the
+// image has few keys they are first aggregated in an LDS histogram (integer LDS
+// atomics are full rate) and HBM sees one atomic per (block, key) instead of one per
+// point -- the coarsest lattice has fewer than 100 cells per image.
 constexpr int BRICK_BLOCK_POINTS = 1024;
 constexpr int BRICK_LDS_KEYS = 8192;
 
-__device__ __forceinline__ uint32_t point_brick(const float4 v, const GeomDev &g)
+__device__ __forceinline__ uint32_t point_key(const float4 v, const GeomDev &g)
 {
     const float in[3] = { v.x, v.y, v.z };
     int ic[3]; float fr[3];
     scatter_cell(in, g, ic, fr);
-    return brick_of(ic, g);
+    int b[3], l[3];
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int c = ic[k] - 1;                       // 0-based cell; clamp keeps stray points legal
+        c = c < 0 ? 0 : c;
+        int bk = c / g.brick;
+        bk = bk >= g.nbricks[k] ? g.nbricks[k] - 1 : bk;
+        int lc = c - bk * g.brick;
+        lc = lc >= g.brick ? g.brick - 1 : lc;
+        b[k] = bk; l[k] = lc;
+    }
+    const uint32_t brick = (uint32_t)(b[0] + g.nbricks[0] * (b[1] + g.nbricks[1] * b[2]));
+    const uint32_t local = (uint32_t)(l[0] + g.brick * (l[1] + g.brick * l[2]));
+    return brick * (uint32_t)(g.brick * g.brick * g.brick) + local;
 }
 
 __global__ __launch_bounds__(256) void brick_count_kernel(const float4 *pos, const uint32_t *poff,
@@ -195,19 +197,20 @@ __global__ __launch_bounds__(256) void brick_count_kernel(const float4 *pos, con
     const uint32_t pe = poff[image_begin + img + 1];
     if (p0 >= pe) return;
     const uint32_t p1 = min(p0 + (uint32_t)BRICK_BLOCK_POINTS, pe);
-    const bool lds = g.n_bricks <= BRICK_LDS_KEYS;
-    uint32_t *gc = counts + (size_t)img * g.n_bricks;
+    const int nk = g.n_bricks * g.brick * g.brick * g.brick;      // keys per image
+    const bool lds = nk <= BRICK_LDS_KEYS;
+    uint32_t *gc = counts + (size_t)img * nk;
     if (lds) {
-        for (int k = threadIdx.x; k < g.n_bricks; k += 256) h[k] = 0u;
+        for (int k = threadIdx.x; k < nk; k += 256) h[k] = 0u;
         __syncthreads();
     }
     for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
-        const uint32_t b = point_brick(pos[p], g);
+        const uint32_t b = point_key(pos[p], g);
         if (lds) atomicAdd(&h[b], 1u); else atomicAdd(&gc[b], 1u);
     }
     if (lds) {
         __syncthreads();
-        for (int k = threadIdx.x; k < g.n_bricks; k += 256)
+        for (int k = threadIdx.x; k < nk; k += 256)
             if (h[k]) atomicAdd(&gc[k], h[k]);
     }
 }
@@ -222,12 +225,13 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
     const uint32_t pe = poff[image_begin + img + 1];
     if (p0 >= pe) return;
     const uint32_t p1 = min(p0 + (uint32_t)BRICK_BLOCK_POINTS, pe);
-    const bool lds = g.n_bricks <= BRICK_LDS_KEYS;
-    uint32_t *gcur = cursor + (size_t)img * g.n_bricks;
+    const int nk = g.n_bricks * g.brick * g.brick * g.brick;
+    const bool lds = nk <= BRICK_LDS_KEYS;
+    uint32_t *gcur = cursor + (size_t)img * nk;
     constexpr int PER = BRICK_BLOCK_POINTS / 256;
     uint32_t key[PER], rank[PER];
     if (lds) {
-        for (int k = threadIdx.x; k < g.n_bricks; k += 256) h[k] = 0u;
+        for (int k = threadIdx.x; k < nk; k += 256) h[k] = 0u;
         __syncthreads();
     }
     #pragma unroll
@@ -235,15 +239,15 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
         const uint32_t p = p0 + threadIdx.x + 256 * m;
         key[m] = 0xFFFFFFFFu; rank[m] = 0;
         if (p < p1) {
-            key[m] = point_brick(pos[p], g);
+            key[m] = point_key(pos[p], g);
             if (lds) rank[m] = atomicAdd(&h[key[m]], 1u);           // rank inside this block
             else perm[atomicAdd(&gcur[key[m]], 1u)] = p;
         }
     }
     if (!lds) return;
     __syncthreads();
-    for (int k = threadIdx.x; k < g.n_bricks; k += 256)
-        if (h[k]) h[k] = atomicAdd(&gcur[k], h[k]);                 // block's base slot in the brick
+    for (int k = threadIdx.x; k < nk; k += 256)
+        if (h[k]) h[k] = atomicAdd(&gcur[k], h[k]);                 // block's base slot for the key
     __syncthreads();
     #pragma unroll
     for (int m = 0; m < PER; m++) {
@@ -252,152 +256,186 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
     }
 }
 
-// exclusive scan of n counts -> ptr[0..n], single block; also max count
-__global__ __launch_bounds__(1024) void brick_scan_kernel(const uint32_t *counts, uint32_t n, uint32_t *ptr,
-                                                          uint32_t *cursor, uint32_t *max_count)
+// exclusive scan of n counts -> ptr[0..n] and cursor[0..n), single block of 1024
+// threads, each owning one contiguous segment.
+__global__ __launch_bounds__(1024) void brick_scan_kernel(const uint32_t *counts, uint32_t n, uint32_t *ptr, uint32_t *cursor)
 {
     __shared__ uint32_t sh[1024];
-    __shared__ uint32_t carry;
-    __shared__ uint32_t mx;
-    if (threadIdx.x == 0) { carry = 0; mx = 0; }
+    const uint32_t seg = (n + 1023u) / 1024u;
+    const uint32_t b = min(n, threadIdx.x * seg), e = min(n, b + seg);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += counts[i];
+    sh[threadIdx.x] = sum;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < n ? counts[i] : 0;
-        atomicMax(&mx, v);
-        sh[threadIdx.x] = v;
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t excl = sh[threadIdx.x] - v + carry;
-        if (i < n) { ptr[i] = excl; cursor[i] = excl; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += sh[1023];
+        sh[threadIdx.x] += t;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { ptr[n] = carry; *max_count = mx; }
+    uint32_t run = sh[threadIdx.x] - sum;
+    for (uint32_t i = b; i < e; i++) { ptr[i] = run; cursor[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) ptr[n] = sh[1023];
+}
+
+// ptr at brick granularity (every B^3-th entry) for the host's block table
+__global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_bricks_total) out[i] = ptr[(size_t)i * keys_per_brick];
 }
 
 // ---- K7: scatter of the per-point sums onto the gradient lattice ----------------
-// grid = (n_keys, max chunks per key); block = ONE wavefront with a private LDS
-// tile of the brick's (B+3)^3 control points, float, component-major.
-// Batches of 64 points.  Phase 1, lane = point: cell and the 12 cubic weights
-// (f64, imageGroup.cxx:303-310) go to an LDS scratch.  Phase 2, lane = tap
-// (i + 4j + 16k): w = wx[i]*wy[j]*wz[k] in f64 (imageGroup.cxx:322), then a plain
-// LDS read-add-write per component: the 64 taps of a point are 64 distinct
-// control points and the tile belongs to this wavefront alone, so no atomic is
-// needed.  (ds_add_f32 runs ~25x slower than read+add+write on gfx950 and integer
-// fixed point cannot hold the dynamic range of the tensor weights: control points
-// on the shell of the cloud have gw ~ 1e-10 and still need g/gw to f32 relative
-// precision -- scripts/microbench/lds_atomic.hip)
-// The tile is flushed to HBM with float atomics (memory-side, ~1.3 TB/s).
+// One wavefront per block; block = (image, brick, run of <= SCATTER_CHUNK points of
+// the brick, from the table built at set-up).  LDS: the brick's (B+3)^3 control
+// points as float4 (sum w*sDisp xyz, sum w*sWeight), private to the wavefront.
+//
+// Batches of 64 points.  Phase 1, lane = point: cell, the 12 cubic weights in f64
+// as the reference computes them (imageGroup.cxx:303-310), rounded once to f32, and
+// the tile offset of the point's first tap.  Phase 2, lane = tap (i + 4j + 16k): the
+// point's values are broadcast with v_readlane, w = wx[i]*wy[j]*wz[k]
+// (imageGroup.cxx:322) and the four products are added into REGISTERS; points are
+// sorted by cell, so consecutive points mostly share their 64 tap addresses and the
+// LDS tile is touched (one ds_read_b128 + ds_write_b128, no atomic: the 64 taps are
+// 64 distinct control points and the tile is private) only when the cell changes.
+// Finally the tile goes to HBM with float atomics (memory side).
+//
+// Why not LDS float atomics: ds_add_f32 runs at 0.33 lane-ops/clk/CU on gfx950
+// (scripts/microbench/lds_atomic.hip); why not fixed point: control points on the
+// shell of the cloud have total weights ~1e-10 and need f32 relative precision.
 constexpr int SCATTER_CHUNK = 512;
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 
-struct ScatterScratch {
-    double wts[12][64];     // [axis*4 + tap][point]
-    float4 sums[64];
-    int4 cell[64];          // ic xyz, w = 1 if the point contributes
+struct ScatterBlock {
+    uint32_t key;           // image_local * n_bricks + brick
+    uint32_t begin, end;    // range in perm
+    uint32_t pad_;
 };
 
+__device__ __forceinline__ float bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
-                                                     const uint32_t *perm, const uint32_t *brick_ptr,
+                                                     const uint32_t *perm, const ScatterBlock *blocks,
                                                      float4 *gradf, const GeomDev g)
 {
-    __shared__ float tile[4 * BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX];
-    __shared__ ScatterScratch sc;
-    const uint32_t key = blockIdx.x;
-    const uint32_t begin = brick_ptr[key] + blockIdx.y * SCATTER_CHUNK;
-    const uint32_t end_all = brick_ptr[key + 1];
-    if (begin >= end_all) return;
-    const uint32_t end = min(begin + (uint32_t)SCATTER_CHUNK, end_all);
-
+    __shared__ float4 tile[BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX];
+    const ScatterBlock blk = blocks[blockIdx.x];
     const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
     const int n_tile = E * E * E;
-    for (int k = lane; k < n_tile * 4; k += 64) tile[k] = 0.f;
+    for (int k = lane; k < n_tile; k += 64) tile[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const uint32_t img = key / g.n_bricks;
-    uint32_t bidx = key - img * g.n_bricks;
+    const uint32_t img = blk.key / g.n_bricks;
+    uint32_t bidx = blk.key - img * g.n_bricks;
     const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
     const int by = bidx % g.nbricks[1];
     const int bz = bidx / g.nbricks[1];
     // first control point of the brick: cell c (1-based) uses control points c-1..c+2
     const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
-    float *gimg = reinterpret_cast<float *>(gradf + (size_t)img * g.n_cp);
+    float4 *gimg = gradf + (size_t)img * g.n_cp;
 
     const int ti = lane & 3, tj = (lane >> 2) & 3, tk = lane >> 4;
+    const int tap_off = ti + E * (tj + E * tk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t batch = begin; batch < end; batch += 64) {
-        // phase 1: lane = point
+
+    float4 run = make_float4(0.f, 0.f, 0.f, 0.f);      // contributions of the current cell, this lane's tap
+    int run_base = -1;
+    for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
+        // ---- phase 1: lane = point
         const uint32_t s = batch + lane;
-        int4 cell = make_int4(0, 0, 0, 0);
-        if (s < end) {
+        int base = -1;                               // tile offset of tap (0,0,0); -1: nothing to add
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wx[4] = { 0, 0, 0, 0 }, wy[4] = { 0, 0, 0, 0 }, wz[4] = { 0, 0, 0, 0 };
+        if (s < blk.end) {
             const uint32_t p = perm[s];
-            const float4 sm = point_sums[p];
-            if (sm.w != 0.f) {                   // imageGroup.cxx:299
+            sm = point_sums[p];
+            if (sm.w != 0.f) {                       // imageGroup.cxx:299
                 const float4 v = pos[p];
                 const float in[3] = { v.x, v.y, v.z };
                 int ic[3]; float fr[3];
                 scatter_cell(in, g, ic, fr);
                 double F[4];
+                bspline_weights(F, (double)fr[0]);
                 #pragma unroll
-                for (int ax = 0; ax < 3; ax++) {
-                    bspline_weights(F, (double)fr[ax]);
-                    #pragma unroll
-                    for (int m = 0; m < 4; m++) sc.wts[ax * 4 + m][lane] = F[m];
+                for (int m = 0; m < 4; m++) wx[m] = (float)F[m];
+                bspline_weights(F, (double)fr[1]);
+                #pragma unroll
+                for (int m = 0; m < 4; m++) wy[m] = (float)F[m];
+                bspline_weights(F, (double)fr[2]);
+                #pragma unroll
+                for (int m = 0; m < 4; m++) wz[m] = (float)F[m];
+                const int lx = ic[0] - 1 - cp0[0], ly = ic[1] - 1 - cp0[1], lz = ic[2] - 1 - cp0[2];
+                if (lx >= 0 && ly >= 0 && lz >= 0 && lx + 3 < E && ly + 3 < E && lz + 3 < E) {
+                    base = lx + E * (ly + E * lz);
+                } else {
+                    // stray point clamped into this brick (outside the scaled box): its taps go
+                    // straight to HBM, one lane doing all 64
+                    for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
+                        const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
+                        if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
+                        const float w = wx[i] * wy[j] * wz[k];
+                        float *dst = reinterpret_cast<float *>(gimg + ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)));
+                        atomicAdd(dst + 0, w * sm.x); atomicAdd(dst + 1, w * sm.y);
+                        atomicAdd(dst + 2, w * sm.z); atomicAdd(dst + 3, w * sm.w);
+                    }
                 }
-                sc.sums[lane] = sm;
-                cell = make_int4(ic[0], ic[1], ic[2], 1);
             }
         }
-        sc.cell[lane] = cell;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // this lane's weights for each of the 64 points are picked by (ti,tj,tk) below
+        const unsigned long long live = __ballot(base >= 0);
 
-        // phase 2: lane = tap
-        const int n = (int)min(64u, end - batch);
-        for (int q = 0; q < n; q++) {
-            const int4 c = sc.cell[q];
-            if (!c.w) continue;
-            const double w = sc.wts[ti][q] * sc.wts[4 + tj][q] * sc.wts[8 + tk][q];
-            const float4 sm = sc.sums[q];
-            const float a0 = (float)(w * (double)sm.x), a1 = (float)(w * (double)sm.y);
-            const float a2 = (float)(w * (double)sm.z), a3 = (float)(w * (double)sm.w);
-            const int lx = c.x - 1 - cp0[0] + ti, ly = c.y - 1 - cp0[1] + tj, lz = c.z - 1 - cp0[2] + tk;
-            if (lx >= 0 && ly >= 0 && lz >= 0 && lx < E && ly < E && lz < E) {
-                float *dst = tile + (lx + E * (ly + E * lz));
-                dst[0] += a0; dst[n_tile] += a1; dst[2 * n_tile] += a2; dst[3 * n_tile] += a3;
-            } else {
-                // stray point clamped into this brick (outside the scaled box): straight to HBM
-                const int gx = c.x - 1 + ti, gy = c.y - 1 + tj, gz = c.z - 1 + tk;
-                if (gx >= 0 && gy >= 0 && gz >= 0 && gx < g.dims[0] && gy < g.dims[1] && gz < g.dims[2]) {
-                    float *dst = gimg + 4 * ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz));
-                    atomicAdd(dst + 0, a0); atomicAdd(dst + 1, a1); atomicAdd(dst + 2, a2); atomicAdd(dst + 3, a3);
+        // ---- phase 2: lane = tap, loop over the batch's contributing points
+        unsigned long long todo = live;
+        while (todo) {
+            const int q = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int qb = __builtin_amdgcn_readlane(base, q);
+            const float a = bcast(wx[0], q), b = bcast(wx[1], q), c = bcast(wx[2], q), d = bcast(wx[3], q);
+            const float fx = ti == 0 ? a : ti == 1 ? b : ti == 2 ? c : d;
+            const float a1 = bcast(wy[0], q), b1 = bcast(wy[1], q), c1 = bcast(wy[2], q), d1 = bcast(wy[3], q);
+            const float fy = tj == 0 ? a1 : tj == 1 ? b1 : tj == 2 ? c1 : d1;
+            const float a2 = bcast(wz[0], q), b2 = bcast(wz[1], q), c2 = bcast(wz[2], q), d2 = bcast(wz[3], q);
+            const float fz = tk == 0 ? a2 : tk == 1 ? b2 : tk == 2 ? c2 : d2;
+            const float w = fx * fy * fz;
+            const float sx = bcast(sm.x, q), sy = bcast(sm.y, q), sz = bcast(sm.z, q), sw = bcast(sm.w, q);
+            if (qb != run_base) {                    // wave-uniform: cell changed -> spill the run
+                if (run_base >= 0) {
+                    float4 t = tile[run_base + tap_off];
+                    t.x += run.x; t.y += run.y; t.z += run.z; t.w += run.w;
+                    tile[run_base + tap_off] = t;
                 }
+                run = make_float4(0.f, 0.f, 0.f, 0.f);
+                run_base = qb;
             }
+            run.x += w * sx; run.y += w * sy; run.z += w * sz; run.w += w * sw;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
+    if (run_base >= 0) {
+        float4 t = tile[run_base + tap_off];
+        t.x += run.x; t.y += run.y; t.z += run.z; t.w += run.w;
+        tile[run_base + tap_off] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // flush: consecutive lanes walk components, then x -> contiguous 16-byte control points
+    const float *tf = reinterpret_cast<const float *>(tile);
+    float *gf = reinterpret_cast<float *>(gimg);
     for (int k = lane; k < n_tile * 4; k += 64) {
+        const float val = tf[k];
+        if (val == 0.f) continue;
         const int c = k & 3;
         int q = k >> 2;
-        const float val = tile[c * n_tile + q];
-        if (val == 0.f) continue;
         const int lx = q % E; q /= E;
         const int ly = q % E;
         const int lz = q / E;
         const int gx = cp0[0] + lx, gy = cp0[1] + ly, gz = cp0[2] + lz;
         if (gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
-        atomicAdd(gimg + 4 * ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)) + c, val);
+        atomicAdd(gf + 4 * ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)) + c, val);
     }
 }
 
