@@ -72,12 +72,16 @@ struct Tile {
     uint32_t pad_[3];
 };
 
-// One half-link: global indices of its own point and of the partner point.
-// 8 bytes, the size of the reference's Link (point.h:11-16).
+// One half-link, 8 bytes (the size of the reference's Link, point.h:11-16):
+//   a = (partner image << 8) | index of the own point inside its tile (TILE_POINTS <= 256)
+//   b = global index of the partner point
+// The partner image rides in the record so that its EM constants can be fetched
+// together with the coordinate gathers instead of after them.
 struct LinkRec {
     uint32_t a;
     uint32_t b;
 };
+static_assert(TILE_POINTS <= 256, "own-point index must fit 8 bits of LinkRec::a");
 
 // Per-image constants derived from (c1, c2, ratio) for getInlierProbability
 // (stats.h:84-92): inv1 = 1/(c1+eps), inv2 = 1/(c2+eps),
@@ -145,6 +149,10 @@ struct frog_ctx {
     frog::DevBuf<uint64_t> ref_rowptr;        // [ownP + 1], relative to the first owned link
     frog::DevBuf<uint32_t> ref_link;          // [L_own] partner global index
     // sweep layout
+    std::vector<uint32_t> h_old_of_new, h_new_of_old;   // internal (Morton) <-> reference point numbering
+    frog::DevBuf<uint32_t> new_of_old;        // [ownP] for the owned rows (reservoir: ordinal -> point)
+    frog::DevBuf<uint32_t> tile_order;        // slot -> tile
+    uint32_t n_slots = 0;
     frog::DevBuf<frog::Tile> tiles;
     frog::DevBuf<frog::LinkRec> recs;
     uint32_t n_tiles = 0;

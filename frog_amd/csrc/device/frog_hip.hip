@@ -103,6 +103,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
+    c->n_slots = (uint32_t)lay.tile_order.size();
+    c->h_old_of_new = lay.old_of_new;
+    c->h_new_of_old = lay.new_of_old;
     c->h_img_tile_ptr = lay.img_tile_ptr;
     c->img_link_begin = lay.img_link_begin;
 
@@ -132,7 +135,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             v.x = m->xyz[3 * (size_t)p]; v.y = m->xyz[3 * (size_t)p + 1]; v.z = m->xyz[3 * (size_t)p + 2];
             int id = (int)i;
             std::memcpy(&v.w, &id, 4);
-            hp[p] = v;
+            hp[lay.new_of_old[p]] = v;
             const double q[3] = { v.x, v.y, v.z };
             for (int k = 0; k < 3; k++) { if (q[k] < mn[k]) mn[k] = q[k]; if (q[k] > mx[k]) mx[k] = q[k]; }
         }
@@ -146,6 +149,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
 
     CREATE_CHECK(c->ref_rowptr.upload(lay.ref_rowptr, s));
     CREATE_CHECK(c->ref_link.upload(lay.ref_link, s));
+    {
+        std::vector<uint32_t> own(lay.new_of_old.begin() + c->own_pt_begin, lay.new_of_old.begin() + c->own_pt_end);
+        CREATE_CHECK(c->new_of_old.upload(own, s));
+        CREATE_CHECK(hipStreamSynchronize(s));
+    }
+    CREATE_CHECK(c->tile_order.upload(lay.tile_order, s));
     CREATE_CHECK(c->tiles.upload(lay.tiles, s));
     CREATE_CHECK(c->recs.upload(lay.recs, s));
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
@@ -288,7 +297,7 @@ int frog_update_stats_local(frog_ctx *ctx)
         Span span(ctx, FROG_K_STATS);
         sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
             ctx->sample_ord[cur].p, ctx->sample_count[cur].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
-            ctx->ref_rowptr.p, ctx->ref_link.p, ctx->pos2.p, ctx->samples.p);
+            ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->pos2.p, ctx->samples.p);
         FROG_HIP_CHECK(hipGetLastError());
         em_kernel<<<nO, 64, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
                                      ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
@@ -331,7 +340,7 @@ int frog_update_stats(frog_ctx *ctx)
 static SweepArgs sweep_args(frog_ctx *ctx)
 {
     SweepArgs a;
-    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.tile_order = ctx->tile_order.p; a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.point_sums = ctx->point_sums.p;
     return a;
@@ -344,7 +353,7 @@ int frog_linear_step_local(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     {
         Span span(ctx, FROG_K_SWEEP_LINEAR);
-        sweep_kernel<SWEEP_LINEAR><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+        sweep_kernel<SWEEP_LINEAR><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 64, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
@@ -530,7 +539,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     FROG_HIP_CHECK(hipMemsetAsync(ctx->n_big.p, 0, sizeof(unsigned long long), s));
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
-        sweep_kernel<SWEEP_DEFORMABLE><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+        sweep_kernel<SWEEP_DEFORMABLE><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
     }
     FROG_HIP_CHECK(hipGetLastError());
     energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, 2, 0, ctx->energy.p);
@@ -610,7 +619,7 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
     if (!per_image) return fail(FROG_E_INVALID, "null output");
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned();
-    sweep_kernel<SWEEP_COUNT><<<div_up(ctx->n_tiles, 4), 256, 0, s>>>(sweep_args(ctx));
+    sweep_kernel<SWEEP_COUNT><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
     FROG_HIP_CHECK(hipGetLastError());
     count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
     FROG_HIP_CHECK(hipGetLastError());
@@ -635,7 +644,10 @@ static int download_points(frog_ctx *ctx, const float4 *src, float *dst)
     std::vector<float4> h(ctx->P);
     FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (size_t p = 0; p < ctx->P; p++) { dst[3 * p] = h[p].x; dst[3 * p + 1] = h[p].y; dst[3 * p + 2] = h[p].z; }
+    for (size_t p = 0; p < ctx->P; p++) {          // p: reference numbering
+        const float4 &v = h[ctx->h_new_of_old[p]];
+        dst[3 * p] = v.x; dst[3 * p + 1] = v.y; dst[3 * p + 2] = v.z;
+    }
     return FROG_OK;
 }
 
@@ -657,7 +669,7 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
         for (uint32_t p = ctx->poff[i]; p < ctx->poff[i + 1]; p++) {
             float4 v; v.x = xyz2[3 * (size_t)p]; v.y = xyz2[3 * (size_t)p + 1]; v.z = xyz2[3 * (size_t)p + 2];
             int id = (int)i; std::memcpy(&v.w, &id, 4);
-            h[p] = v;
+            h[ctx->h_new_of_old[p]] = v;
         }
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -765,7 +777,7 @@ int frog_get_point_sums(frog_ctx *ctx, float *out)
     std::vector<float4> h(ctx->P);
     FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->point_sums.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    std::memcpy(out, h.data(), h.size() * sizeof(float4));
+    for (size_t p = 0; p < ctx->P; p++) std::memcpy(out + 4 * p, &h[ctx->h_new_of_old[p]], sizeof(float4));
     return FROG_OK;
 }
 

@@ -16,10 +16,9 @@
 //                   perturbs the exponent by more than this.
 //   linear sums  -- f32 products, f64 accumulation (imageGroup.cxx:1102-1117);
 //                   per-tile partials reduced in a fixed order (deterministic).
-//   deformable   -- f32 products as in imageGroup.cxx:270-278, per-point sums
-//                   accumulated in LDS in 32.32 fixed point with integer atomics
-//                   (exact in the addends, order independent; the reference's
-//                   running f32 sum differs from this by its own rounding).
+//   deformable   -- f32 products and f32 per-point running sums in partner order,
+//                   exactly as imageGroup.cxx:270-278, in LDS (race-free
+//                   read-add-write, see the loop).
 #pragma once
 
 #include "ctx.h"
@@ -30,6 +29,7 @@ enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
 constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
 
 struct SweepArgs {
+    const uint32_t *tile_order;     // slot -> tile or 0xFFFFFFFF
     const Tile *tiles;
     const LinkRec *recs;
     const float4 *pos2;
@@ -71,21 +71,24 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 template <int MODE>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
-    // per-wave accumulators [component][point], 32.32 fixed point (ctx.h)
-    __shared__ unsigned long long acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS * 4 : 1];
+    // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
+    // reference's (imageGroup.cxx:256-257), plus one ownership word per point
+    __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
+    __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * 4 + wave;
+    const uint32_t t = a.tile_order[blockIdx.x * 4 + wave];
     const bool live = t < a.n_tiles;
 
     Tile tl;
     tl.pt_begin = 0; tl.pt_count = 0; tl.rec_begin = 0; tl.rec_count = 0; tl.image = 0;
     if (live) tl = a.tiles[t];
-    unsigned long long *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS * 4 : 0);
+    float4 *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
+    unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
 
     if (MODE == SWEEP_DEFORMABLE) {
-        for (int k = lane; k < TILE_POINTS * 4; k += 64) my[k] = 0ull;
+        for (int k = lane; k < TILE_POINTS; k += 64) { my[k] = make_float4(0.f, 0.f, 0.f, 0.f); own[k] = 0xFFFFFFFFu; }
         __syncthreads();
     }
 
@@ -96,12 +99,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     for (int k = 0; k < ((MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2); k++) s[k] = 0.0;
     long long n_in = 0, n_out = 0;
 
-    const LinkRec *rec = a.recs + tl.rec_begin;
+    // The record stream is read once per pass: non-temporal loads keep it from
+    // evicting the coordinate table from L2; the next record is fetched one step ahead.
+    const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + tl.rec_begin);
+    unsigned long long nxt = 0;
+    if ((uint32_t)lane < tl.rec_count) nxt = rec[lane];
     for (uint32_t r = lane; r < tl.rec_count; r += 64) {
-        const LinkRec lr = rec[r];
-        const float4 pa = a.pos2[lr.a];
-        const float4 pb = a.pos2[lr.b];
-        const EmDerived eB = a.emd[__float_as_int(pb.w)];
+        const unsigned long long cur = nxt;
+        if (r + 64 < tl.rec_count) nxt = rec[r + 64];
+        const uint32_t ra = (uint32_t)cur, rb = (uint32_t)(cur >> 32);
+        const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
+        const float4 pa = a.pos2[tl.pt_begin + ia];
+        const float4 pb = a.pos2[rb];
+        const EmDerived eB = a.emd[ra >> 8];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -119,16 +129,32 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             s[12] += (double)(w * pb.x * pb.x); s[13] += (double)(w * pb.y * pb.y); s[14] += (double)(w * pb.z * pb.z);
             s[15] += (double)w;
         } else if (MODE == SWEEP_DEFORMABLE) {
-            // imageGroup.cxx:270-278
-            if (w >= a.threshold) {
-                const float w2 = w * w;
+            // imageGroup.cxx:270-278.  The tile's accumulators belong to this wavefront alone,
+            // so a plain LDS read-add-write is enough once lanes that hit the SAME point in this
+            // step are serialised: every pending lane bids with ds_min_u32 (integer LDS atomics
+            // are full rate, ds_add_f32 is ~38x slower on gfx950), the lowest lane adds first.
+            // Links are in partner order, so each point's f32 sums are formed in the reference's
+            // order.  Duplicates are rare (two links of one point into one image).
+            const bool inlier = w >= a.threshold;
+            const float w2 = w * w;
+            if (inlier) {
                 s[1] += (double)w2;
                 s[0] += (double)(w2 * d2);
-                unsigned long long *dst = my + (lr.a - tl.pt_begin);
-                atomicAdd(dst, to_fixed32(w2 * dx));
-                atomicAdd(dst + TILE_POINTS, to_fixed32(w2 * dy));
-                atomicAdd(dst + 2 * TILE_POINTS, to_fixed32(w2 * dz));
-                atomicAdd(dst + 3 * TILE_POINTS, to_fixed32(w2));
+            }
+            bool pending = inlier;
+            while (__ballot(pending)) {
+                if (pending) atomicMin(&own[ia], (unsigned int)lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (pending && __hip_atomic_load(&own[ia], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == (unsigned int)lane) {
+                    float4 t = my[ia];
+                    t.x += w2 * dx; t.y += w2 * dy; t.z += w2 * dz; t.w += w2;
+                    my[ia] = t;
+                    own[ia] = 0xFFFFFFFFu;
+                    pending = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
             // imageGroup.cxx:1022-1027
@@ -146,9 +172,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);
         if (lane == 0 && live) { a.tile_partial[(size_t)t * 2] = v0; a.tile_partial[(size_t)t * 2 + 1] = v1; }
         __syncthreads();
-        for (uint32_t k = lane; k < tl.pt_count; k += 64)
-            a.point_sums[tl.pt_begin + k] = make_float4(from_fixed32(my[k]), from_fixed32(my[k + TILE_POINTS]),
-                                                        from_fixed32(my[k + 2 * TILE_POINTS]), from_fixed32(my[k + 3 * TILE_POINTS]));
+        for (uint32_t k = lane; k < tl.pt_count; k += 64) a.point_sums[tl.pt_begin + k] = my[k];
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
         if (lane == 0 && live) { a.tile_counts[(size_t)t * 2] = v0; a.tile_counts[(size_t)t * 2 + 1] = v1; }

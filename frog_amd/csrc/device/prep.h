@@ -9,7 +9,8 @@
 // ascending order and, since all tiles of a launch are resident at once and
 // advance at about the same pace, the whole chip gathers partner coordinates
 // from a window of a few images at a time: the gathers hit the 4 MiB per-XCD L2
-// instead of scattering over the whole coordinate table.  Within a point the
+// instead of scattering over the whole coordinate table.  Points are first renumbered
+// along a Morton curve inside each image (see Layout).  Within a point the
 // order stays partner-ascending, which is the order readPairs produces for
 // files written by match (blocks i-major, j-ascending: imageGroup.cxx:1405-1406,
 // match.cpp:727-742), so per-point f32 sums keep the reference's order.
@@ -23,6 +24,16 @@
 namespace frog {
 
 struct Layout {
+    // Internal point numbering: inside every image the points are renumbered along a
+    // Morton curve of their coordinates normalised to the image's bounding box, so that
+    // (a) a tile is a compact blob and the partner points it links to sit in a narrow
+    // index window of the partner image, and (b) "the k-th eighth of an image" means the
+    // same region of space in every image.  new_of_old / old_of_new map global indices.
+    std::vector<uint32_t> new_of_old, old_of_new;
+    // slot -> tile (0xFFFFFFFF: idle).  Block b runs slots 4b..4b+3; blocks are dealt
+    // round-robin over the 8 XCDs, so block b gets tiles of spatial octant b % 8 of all
+    // images: an XCD's gathers then touch ~1/8 of every partner's table (its L2's size).
+    std::vector<uint32_t> tile_order;
     std::vector<Tile> tiles;
     std::vector<LinkRec> recs;
     std::vector<uint32_t> img_tile_ptr;     // [nI + 1]
@@ -31,10 +42,56 @@ struct Layout {
     std::vector<uint64_t> img_link_begin;   // [nI + 1] (relative, owned images only meaningful)
 };
 
+inline uint32_t spread3(uint32_t v)          // 10 bits -> every third bit
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// Morton permutation of every image (all ranks compute the same one: they all hold the model).
+inline void build_numbering(const frog_model &m, Layout &out)
+{
+    const uint32_t nI = m.n_images;
+    const uint32_t *poff = m.point_offset;
+    const uint64_t P = poff[nI];
+    out.new_of_old.resize(P);
+    out.old_of_new.resize(P);
+    #pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < (int)nI; i++) {
+        const uint32_t b = poff[i], e = poff[i + 1];
+        float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        for (uint32_t p = b; p < e; p++)
+            for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], m.xyz[3 * (size_t)p + k]); mx[k] = std::max(mx[k], m.xyz[3 * (size_t)p + k]); }
+        std::vector<std::pair<uint32_t, uint32_t>> key(e - b);
+        for (uint32_t p = b; p < e; p++) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                const float ext = mx[k] - mn[k];
+                float u = ext > 0 ? (m.xyz[3 * (size_t)p + k] - mn[k]) / ext : 0.f;
+                if (!(u >= 0.f)) u = 0.f;                  // also catches NaN
+                if (u > 1.f) u = 1.f;
+                q[k] = (uint32_t)(u * 1023.0f);
+            }
+            key[p - b] = { spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2), p };
+        }
+        std::sort(key.begin(), key.end());                 // ties broken by the old index
+        for (uint32_t n = 0; n < e - b; n++) {
+            out.old_of_new[b + n] = key[n].second;
+            out.new_of_old[key[n].second] = b + n;
+        }
+    }
+}
+
 inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &out, std::string &err)
 {
     const uint32_t nI = m.n_images;
     const uint32_t *poff = m.point_offset;
+    build_numbering(m, out);
+    const std::vector<uint32_t> &new_of_old = out.new_of_old, &old_of_new = out.old_of_new;
     const uint32_t p0 = poff[ib], p1 = poff[ie];
     const uint64_t l0 = m.row_ptr[p0], l1 = m.row_ptr[p1];
     const uint64_t L = l1 - l0;
@@ -50,7 +107,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
         const uint16_t im = m.link_image[l0 + l];
         const uint32_t pt = m.link_point[l0 + l];
         if (im >= nI || pt >= poff[im + 1] - poff[im]) { bad = 1; out.ref_link[l] = 0; continue; }
-        out.ref_link[l] = poff[im] + pt;
+        out.ref_link[l] = new_of_old[poff[im] + pt];
     }
     if (bad) { err = "link references a point outside its image"; return FROG_E_INVALID; }
     out.img_link_begin.assign(nI + 1, 0);
@@ -60,16 +117,23 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
     }
 
     // tiles
+    uint64_t rec_total = 0;
     out.img_tile_ptr.assign(nI + 1, 0);
     for (uint32_t i = ib; i < ie; i++) {
         const uint32_t np = poff[i + 1] - poff[i];
         const uint32_t nt = (np + TILE_POINTS - 1) / TILE_POINTS;
         for (uint32_t t = 0; t < nt; t++) {
             Tile tl{};
-            tl.pt_begin = poff[i] + t * TILE_POINTS;
+            tl.pt_begin = poff[i] + t * TILE_POINTS;          // NEW numbering
             tl.pt_count = std::min<uint32_t>(TILE_POINTS, poff[i + 1] - tl.pt_begin);
-            tl.rec_begin = (uint32_t)(m.row_ptr[tl.pt_begin] - l0);
-            tl.rec_count = (uint32_t)(m.row_ptr[tl.pt_begin + tl.pt_count] - m.row_ptr[tl.pt_begin]);
+            uint64_t nrec = 0;
+            for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
+                const uint32_t o = old_of_new[n];
+                nrec += m.row_ptr[o + 1] - m.row_ptr[o];
+            }
+            tl.rec_begin = (uint32_t)rec_total;
+            tl.rec_count = (uint32_t)nrec;
+            rec_total += nrec;
             tl.image = i;
             out.tiles.push_back(tl);
         }
@@ -88,18 +152,40 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
         for (long long t = 0; t < nT; t++) {
             const Tile &tl = out.tiles[t];
             std::fill(cnt.begin(), cnt.end(), 0u);
-            const uint64_t a = m.row_ptr[tl.pt_begin], b = m.row_ptr[tl.pt_begin + tl.pt_count];
-            for (uint64_t l = a; l < b; l++) cnt[m.link_image[l] + 1]++;
+            for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
+                const uint32_t o = old_of_new[n];
+                for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) cnt[m.link_image[l] + 1]++;
+            }
             for (uint32_t i = 0; i < nI; i++) cnt[i + 1] += cnt[i];
             LinkRec *dst = out.recs.data() + tl.rec_begin;
-            for (uint32_t p = tl.pt_begin; p < tl.pt_begin + tl.pt_count; p++)
-                for (uint64_t l = m.row_ptr[p]; l < m.row_ptr[p + 1]; l++) {
+            for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
+                const uint32_t o = old_of_new[n];
+                for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) {
                     LinkRec r;
-                    r.a = p;
+                    r.a = ((uint32_t)m.link_image[l] << 8) | (n - tl.pt_begin);
                     r.b = out.ref_link[l - l0];
                     dst[cnt[m.link_image[l]]++] = r;
                 }
+            }
         }
+    }
+
+    // slot order: eight lists (one per spatial octant), interleaved block-wise
+    {
+        std::vector<std::vector<uint32_t>> oct(8);
+        for (uint32_t i = ib; i < ie; i++) {
+            const uint32_t t0 = out.img_tile_ptr[i], T = out.img_tile_ptr[i + 1] - t0;
+            for (uint32_t t = 0; t < T; t++) oct[(size_t)t * 8 / T].push_back(t0 + t);
+        }
+        size_t longest = 0;
+        for (auto &v : oct) longest = std::max(longest, v.size());
+        const size_t blocks_per_oct = (longest + 3) / 4;
+        out.tile_order.assign(blocks_per_oct * 8 * 4, 0xFFFFFFFFu);
+        for (int x = 0; x < 8; x++)
+            for (size_t k = 0; k < oct[x].size(); k++) {
+                const size_t blk = (k / 4) * 8 + x;            // block index: octant = blk % 8
+                out.tile_order[blk * 4 + k % 4] = oct[x][k];
+            }
     }
     return FROG_OK;
 }
