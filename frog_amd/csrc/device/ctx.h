@@ -60,15 +60,21 @@ template <class T> struct DevBuf {
 // ---- link layout (built on the host in prep.h) --------------------------------
 
 constexpr int TILE_POINTS = 256;     // points per sweep tile (one wavefront each)
+constexpr int N_GROUPS = 8;          // partner-image groups = XCDs (each group's xyz2 slice fits one L2)
+
+// xyz2 of a point, packed: the sweep gathers 12 bytes per end point.
+struct P3 {
+    float x, y, z;
+};
 
 // One sweep tile: a run of consecutive points of ONE image and all their
 // half-links, sorted by partner image (then by point).
 struct Tile {
-    uint32_t pt_begin;      // global point index
+    uint32_t pt_begin;      // global point index (internal numbering)
     uint32_t pt_count;
     uint32_t rec_begin;     // index into LinkRec array
-    uint32_t rec_count;
     uint32_t image;
+    uint32_t group_off[N_GROUPS + 1];   // records into partner group g: [rec_begin + off[g], rec_begin + off[g+1])
     uint32_t pad_[3];
 };
 
@@ -143,7 +149,8 @@ struct frog_ctx {
     std::vector<uint64_t> img_link_begin;     // per image: first half-link ordinal base (ref-order CSR, owned rows only)
 
     // points
-    frog::DevBuf<float4> pos, pos2;           // xyz|image, xyz2|image
+    frog::DevBuf<float4> pos;                 // xyz | image id
+    frog::DevBuf<frog::P3> pos2;              // xyz2, packed
     frog::DevBuf<uint32_t> d_poff;            // [nI+1]
     // reference-order CSR of the owned rows (for the reservoir ordinals)
     frog::DevBuf<uint64_t> ref_rowptr;        // [ownP + 1], relative to the first owned link
@@ -151,15 +158,14 @@ struct frog_ctx {
     // sweep layout
     std::vector<uint32_t> h_old_of_new, h_new_of_old;   // internal (Morton) <-> reference point numbering
     frog::DevBuf<uint32_t> new_of_old;        // [ownP] for the owned rows (reservoir: ordinal -> point)
-    frog::DevBuf<uint32_t> tile_order;        // slot -> tile
-    uint32_t n_slots = 0;
     frog::DevBuf<frog::Tile> tiles;
     frog::DevBuf<frog::LinkRec> recs;
     uint32_t n_tiles = 0;
     frog::DevBuf<uint32_t> img_tile_ptr;      // [nI+1] tiles of image (owned only non-empty)
     std::vector<uint32_t> h_img_tile_ptr;
-    frog::DevBuf<double> tile_partial;        // [n_tiles][18]
-    frog::DevBuf<long long> tile_counts;      // [n_tiles][2]
+    frog::DevBuf<double> tile_partial;        // [n_tiles][N_GROUPS][18]
+    frog::DevBuf<long long> tile_counts;      // [n_tiles][N_GROUPS][2]
+    frog::DevBuf<float4> group_sums;          // [N_GROUPS][ownP] per-point partial sums of one partner group
     frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
 
     // statistics

@@ -45,6 +45,18 @@ struct Span {
     }
 };
 
+template <class T> static int download_points(frog_ctx *ctx, const T *src, float *dst)
+{
+    std::vector<T> h(ctx->P);
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src, h.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t p = 0; p < ctx->P; p++) {          // p: reference numbering
+        const T &v = h[ctx->h_new_of_old[p]];
+        dst[3 * p] = v.x; dst[3 * p + 1] = v.y; dst[3 * p + 2] = v.z;
+    }
+    return FROG_OK;
+}
+
 extern "C" {
 
 int frog_device_count(void)
@@ -103,7 +115,6 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
-    c->n_slots = (uint32_t)lay.tile_order.size();
     c->h_old_of_new = lay.old_of_new;
     c->h_new_of_old = lay.new_of_old;
     c->h_img_tile_ptr = lay.img_tile_ptr;
@@ -142,7 +153,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         for (int k = 0; k < 3; k++) { c->h_img_bbox[(size_t)i * 6 + k] = mn[k]; c->h_img_bbox[(size_t)i * 6 + 3 + k] = mx[k]; }
     }
     CREATE_CHECK(c->pos.upload(hp, s));
-    CREATE_CHECK(c->pos2.upload(hp, s));
+    {
+        std::vector<P3> hp2(c->P);
+        for (size_t p = 0; p < c->P; p++) hp2[p] = P3{ hp[p].x, hp[p].y, hp[p].z };
+        CREATE_CHECK(c->pos2.upload(hp2, s));
+        CREATE_CHECK(hipStreamSynchronize(s));
+    }
     CREATE_CHECK(c->d_poff.upload(c->poff, s));
     CREATE_CHECK(c->point_sums.alloc(c->P));
     CREATE_CHECK(hipMemsetAsync(c->point_sums.p, 0, c->point_sums.bytes(), s));
@@ -154,12 +170,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(c->new_of_old.upload(own, s));
         CREATE_CHECK(hipStreamSynchronize(s));
     }
-    CREATE_CHECK(c->tile_order.upload(lay.tile_order, s));
     CREATE_CHECK(c->tiles.upload(lay.tiles, s));
     CREATE_CHECK(c->recs.upload(lay.recs, s));
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
-    CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * LINEAR_SUMS));
-    CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * 2));
+    CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * LINEAR_SUMS));
+    CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * 2));
+    CREATE_CHECK(c->group_sums.alloc((size_t)N_GROUPS * std::max(1u, c->own_pt_end - c->own_pt_begin)));
     CREATE_CHECK(c->img_counts.alloc((size_t)c->n_owned() * 2));
 
     // statistics: Stats ctor (stats.h:94-99) + setupStats (imageGroup.cxx:1151-1159)
@@ -337,12 +353,15 @@ int frog_update_stats(frog_ctx *ctx)
 }
 
 // ---- updateLinearTransforms (imageGroup.cxx:1063-1149) ----------------------------------
+static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_GROUPS; }
+
 static SweepArgs sweep_args(frog_ctx *ctx)
 {
     SweepArgs a;
-    a.tile_order = ctx->tile_order.p; a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
-    a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.point_sums = ctx->point_sums.p;
+    a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
+    a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
     return a;
 }
 
@@ -353,13 +372,13 @@ int frog_linear_step_local(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     {
         Span span(ctx, FROG_K_SWEEP_LINEAR);
-        sweep_kernel<SWEEP_LINEAR><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
+        sweep_kernel<SWEEP_LINEAR><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 64, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
     FROG_HIP_CHECK(hipGetLastError());
-    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, LINEAR_SUMS, 16, ctx->energy.p);
+    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, LINEAR_SUMS, 16, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -539,10 +558,12 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     FROG_HIP_CHECK(hipMemsetAsync(ctx->n_big.p, 0, sizeof(unsigned long long), s));
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
-        sweep_kernel<SWEEP_DEFORMABLE><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
+        sweep_kernel<SWEEP_DEFORMABLE><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
+        combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
+            ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles, 2, 0, ctx->energy.p);
+    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);
@@ -619,7 +640,7 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
     if (!per_image) return fail(FROG_E_INVALID, "null output");
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned();
-    sweep_kernel<SWEEP_COUNT><<<ctx->n_slots / 4, 256, 0, s>>>(sweep_args(ctx));
+    sweep_kernel<SWEEP_COUNT><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
     FROG_HIP_CHECK(hipGetLastError());
     count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
     FROG_HIP_CHECK(hipGetLastError());
@@ -639,18 +660,6 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
 }
 
 // ---- read-back ---------------------------------------------------------------------------------
-static int download_points(frog_ctx *ctx, const float4 *src, float *dst)
-{
-    std::vector<float4> h(ctx->P);
-    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (size_t p = 0; p < ctx->P; p++) {          // p: reference numbering
-        const float4 &v = h[ctx->h_new_of_old[p]];
-        dst[3 * p] = v.x; dst[3 * p + 1] = v.y; dst[3 * p + 2] = v.z;
-    }
-    return FROG_OK;
-}
-
 int frog_get_points(frog_ctx *ctx, float *xyz, float *xyz2)
 {
     CTX_GUARD(ctx);
@@ -664,14 +673,10 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
 {
     CTX_GUARD(ctx);
     if (!xyz2) return fail(FROG_E_INVALID, "null input");
-    std::vector<float4> h(ctx->P);
-    for (uint32_t i = 0; i < ctx->nI; i++)
-        for (uint32_t p = ctx->poff[i]; p < ctx->poff[i + 1]; p++) {
-            float4 v; v.x = xyz2[3 * (size_t)p]; v.y = xyz2[3 * (size_t)p + 1]; v.z = xyz2[3 * (size_t)p + 2];
-            int id = (int)i; std::memcpy(&v.w, &id, 4);
-            h[ctx->h_new_of_old[p]] = v;
-        }
-    FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<P3> h(ctx->P);
+    for (size_t p = 0; p < ctx->P; p++)
+        h[ctx->h_new_of_old[p]] = P3{ xyz2[3 * p], xyz2[3 * p + 1], xyz2[3 * p + 2] };
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(P3), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
 }

@@ -45,7 +45,7 @@ __device__ __forceinline__ void bspline_weights(double F[4], double f)
 }
 
 // ---- K5: linear transform (vtkLinearTransformPoint, f64 row products -> f32) ----
-__global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, float4 *pos2, const double *mat,
+__global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *pos2, const double *mat,
                                                                uint32_t pt_begin, uint32_t pt_end, int apply)
 {
     uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,14 +57,14 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, floa
     o.y = (float)(M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7]);
     o.z = (float)(M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11]);
     o.w = v.w;
-    pos2[p] = o;
+    pos2[p] = P3{ o.x, o.y, o.z };
     if (apply) pos[p] = o;
 }
 
 // ---- K11: cubic B-spline forward transform (vtkBSplineTransform, BorderModeZero) --
 // Thread per point in brick order (perm), so a wavefront's taps fall into a few
 // neighbouring cells and hit L1/L2.
-__global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, float4 *pos2, const float4 *coeff,
+__global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply)
 {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, flo
     o.y = (float)((double)in[1] + disp[1] * 1.0);
     o.z = (float)((double)in[2] + disp[2] * 1.0);
     o.w = v.w;
-    pos2[p] = o;
+    pos2[p] = P3{ o.x, o.y, o.z };
     if (apply) pos[p] = o;
 }
 

@@ -1,10 +1,10 @@
 // k_links.hip.h -- the half-link sweep (K3 / K6 / K14 of SURVEY.md section 2.2) and
 // the per-image linear update (K4).
 //
-// One wavefront per tile (ctx.h): 64 half-links per step, records streamed from
-// HBM as coalesced 8-byte loads, both end points gathered as one 16-byte load
-// each from the xyz2 table (L2 resident thanks to the partner-synchronous order
-// of prep.h).  Nothing here is GEMM shaped: it is a gather + weighted reduction,
+// One wavefront per (tile, partner group) (ctx.h, prep.h): 64 half-links per step,
+// records streamed from HBM as coalesced non-temporal 8-byte loads, both end points
+// gathered as 12-byte loads from the packed xyz2 table; a block only ever touches the
+// coordinates of ONE partner group, which stay in its XCD's L2.  Nothing here is GEMM shaped: it is a gather + weighted reduction,
 // bound by the record stream and the gathers, so no MFMA.
 //
 // Arithmetic contract (reference lines in the comments):
@@ -29,16 +29,16 @@ enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
 constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
 
 struct SweepArgs {
-    const uint32_t *tile_order;     // slot -> tile or 0xFFFFFFFF
     const Tile *tiles;
     const LinkRec *recs;
-    const float4 *pos2;
+    const P3 *pos2;
     const EmDerived *emd;
     uint32_t n_tiles;
     float threshold;
-    double *tile_partial;       // [n_tiles][18] (linear) or [n_tiles][2] (deformable)
-    long long *tile_counts;     // [n_tiles][2]  (count)
-    float4 *point_sums;         // deformable
+    double *tile_partial;       // [n_tiles][N_GROUPS][18] (linear) or [..][2] (deformable)
+    long long *tile_counts;     // [n_tiles][N_GROUPS][2]  (count)
+    float4 *group_sums;         // [N_GROUPS][own points]  (deformable)
+    uint32_t own_pt_begin, own_points;
 };
 
 // getInlierProbability (stats.h:84-92) from precomputed per-image constants.
@@ -78,12 +78,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const uint32_t t = a.tile_order[blockIdx.x * 4 + wave];
+    // block -> (4 consecutive tiles, partner group): group = block % 8 = the XCD the block
+    // lands on under round-robin dispatch (a performance assumption only)
+    const uint32_t grp = blockIdx.x % N_GROUPS;
+    const uint32_t t = (blockIdx.x / N_GROUPS) * 4 + wave;
     const bool live = t < a.n_tiles;
 
-    Tile tl;
-    tl.pt_begin = 0; tl.pt_count = 0; tl.rec_begin = 0; tl.rec_count = 0; tl.image = 0;
-    if (live) tl = a.tiles[t];
+    uint32_t pt_begin = 0, pt_count = 0, rec_lo = 0, rec_n = 0, image = 0;
+    if (live) {
+        const Tile &tl = a.tiles[t];
+        pt_begin = tl.pt_begin; pt_count = tl.pt_count; image = tl.image;
+        rec_lo = tl.rec_begin + tl.group_off[grp];
+        rec_n = tl.group_off[grp + 1] - tl.group_off[grp];
+    }
     float4 *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
     unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
 
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         __syncthreads();
     }
 
-    const EmDerived eA = a.emd[tl.image];
+    const EmDerived eA = a.emd[image];
 
     double s[(MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2];
     #pragma unroll
@@ -101,16 +108,16 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
     // The record stream is read once per pass: non-temporal loads keep it from
     // evicting the coordinate table from L2; the next record is fetched one step ahead.
-    const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + tl.rec_begin);
+    const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + rec_lo);
     unsigned long long nxt = 0;
-    if ((uint32_t)lane < tl.rec_count) nxt = rec[lane];
-    for (uint32_t r = lane; r < tl.rec_count; r += 64) {
+    if ((uint32_t)lane < rec_n) nxt = __builtin_nontemporal_load(rec + lane);
+    for (uint32_t r = lane; r < rec_n; r += 64) {
         const unsigned long long cur = nxt;
-        if (r + 64 < tl.rec_count) nxt = rec[r + 64];
+        if (r + 64 < rec_n) nxt = __builtin_nontemporal_load(rec + r + 64);
         const uint32_t ra = (uint32_t)cur, rb = (uint32_t)(cur >> 32);
         const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
-        const float4 pa = a.pos2[tl.pt_begin + ia];
-        const float4 pb = a.pos2[rb];
+        const P3 pa = a.pos2[pt_begin + ia];
+        const P3 pb = a.pos2[rb];
         const EmDerived eB = a.emd[ra >> 8];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         const float d = sqrtf(d2);
         const float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
 
-        if (MODE == SWEEP_LINEAR) {
+        if constexpr (MODE == SWEEP_LINEAR) {
             // imageGroup.cxx:1102-1117
             s[16] += (double)(w * w * d * d);
             s[17] += (double)(w * w);
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             s[9] += (double)(w * pa.x * pa.x); s[10] += (double)(w * pa.y * pa.y); s[11] += (double)(w * pa.z * pa.z);
             s[12] += (double)(w * pb.x * pb.x); s[13] += (double)(w * pb.y * pb.y); s[14] += (double)(w * pb.z * pb.z);
             s[15] += (double)w;
-        } else if (MODE == SWEEP_DEFORMABLE) {
+        } else if constexpr (MODE == SWEEP_DEFORMABLE) {
             // imageGroup.cxx:270-278.  The tile's accumulators belong to this wavefront alone,
             // so a plain LDS read-add-write is enough once lanes that hit the SAME point in this
             // step are serialised: every pending lane bids with ds_min_u32 (integer LDS atomics
@@ -162,21 +169,44 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         }
     }
 
-    if (MODE == SWEEP_LINEAR) {
+    if constexpr (MODE == SWEEP_LINEAR) {
         #pragma unroll
         for (int k = 0; k < LINEAR_SUMS; k++) {
             double v = wave_sum(s[k]);
-            if (lane == 0 && live) a.tile_partial[(size_t)t * LINEAR_SUMS + k] = v;
+            if (lane == 0 && live) a.tile_partial[((size_t)t * N_GROUPS + grp) * LINEAR_SUMS + k] = v;
         }
-    } else if (MODE == SWEEP_DEFORMABLE) {
+    } else if constexpr (MODE == SWEEP_DEFORMABLE) {
         double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);
-        if (lane == 0 && live) { a.tile_partial[(size_t)t * 2] = v0; a.tile_partial[(size_t)t * 2 + 1] = v1; }
+        if (lane == 0 && live) {
+            a.tile_partial[((size_t)t * N_GROUPS + grp) * 2] = v0;
+            a.tile_partial[((size_t)t * N_GROUPS + grp) * 2 + 1] = v1;
+        }
         __syncthreads();
-        for (uint32_t k = lane; k < tl.pt_count; k += 64) a.point_sums[tl.pt_begin + k] = my[k];
+        float4 *dst = a.group_sums + (size_t)grp * a.own_points + (pt_begin - a.own_pt_begin);
+        for (uint32_t k = lane; k < pt_count; k += 64) dst[k] = my[k];
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
-        if (lane == 0 && live) { a.tile_counts[(size_t)t * 2] = v0; a.tile_counts[(size_t)t * 2 + 1] = v1; }
+        if (lane == 0 && live) {
+            a.tile_counts[((size_t)t * N_GROUPS + grp) * 2] = v0;
+            a.tile_counts[((size_t)t * N_GROUPS + grp) * 2 + 1] = v1;
+        }
     }
+}
+
+// (sDisp, sWeight) of every owned point = sum of its N_GROUPS partner-group partials, in
+// group (= partner) order.
+__global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group_sums, uint32_t own_points,
+                                                             uint32_t own_pt_begin, float4 *point_sums)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= own_points) return;
+    float4 s = group_sums[i];
+    #pragma unroll
+    for (int g = 1; g < N_GROUPS; g++) {
+        const float4 v = group_sums[(size_t)g * own_points + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    point_sums[own_pt_begin + i] = s;
 }
 
 // Sum of the (sDistances, sWeights) tile partials in a fixed order -> energy[0..1].
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(64) void linear_update_kernel(const double *partial
 {
     __shared__ double sums[LINEAR_SUMS];
     const uint32_t image = image_begin + blockIdx.x;
-    const uint32_t t0 = img_tile_ptr[image], t1 = img_tile_ptr[image + 1];
+    const uint32_t t0 = img_tile_ptr[image] * N_GROUPS, t1 = img_tile_ptr[image + 1] * N_GROUPS;
     if (threadIdx.x < LINEAR_SUMS) {
         double v = 0;
         for (uint32_t t = t0; t < t1; t++) v += partial[(size_t)t * LINEAR_SUMS + threadIdx.x];
@@ -243,7 +273,7 @@ __global__ void count_reduce_kernel(const long long *tile_counts, const uint32_t
     if (i >= n_owned) return;
     const uint32_t image = image_begin + i;
     long long a = 0, b = 0;
-    for (uint32_t t = img_tile_ptr[image]; t < img_tile_ptr[image + 1]; t++) { a += tile_counts[(size_t)t * 2]; b += tile_counts[(size_t)t * 2 + 1]; }
+    for (uint32_t t = img_tile_ptr[image] * N_GROUPS; t < img_tile_ptr[image + 1] * N_GROUPS; t++) { a += tile_counts[(size_t)t * 2]; b += tile_counts[(size_t)t * 2 + 1]; }
     out[(size_t)i * 2] = a; out[(size_t)i * 2 + 1] = b;
 }
 

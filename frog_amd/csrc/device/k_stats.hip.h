@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void sample_distance_kernel(
     const uint32_t *sample_ord, const uint32_t *sample_count, uint32_t cap,
     const uint32_t *poff, uint32_t image_begin, uint32_t own_pt_begin,
     const uint64_t *ref_rowptr, const uint32_t *ref_link, const uint32_t *new_of_old,
-    const float4 *pos2, float *samples)
+    const P3 *pos2, float *samples)
 {
     const uint32_t img = blockIdx.y;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void sample_distance_kernel(
         uint32_t mid = (lo + hi) >> 1;
         if (ref_rowptr[mid] <= l) lo = mid; else hi = mid;
     }
-    const float4 a = pos2[new_of_old[lo]];          // rows are in reference order, coordinates in internal order
-    const float4 b = pos2[ref_link[l]];
+    const P3 a = pos2[new_of_old[lo]];              // rows are in reference order, coordinates in internal order
+    const P3 b = pos2[ref_link[l]];
     // vtkMath::Distance2BetweenPoints(pA, pB), f32
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     samples[(size_t)img * cap + slot] = sqrtf(dx * dx + dy * dy + dz * dz);

@@ -30,10 +30,12 @@ struct Layout {
     // index window of the partner image, and (b) "the k-th eighth of an image" means the
     // same region of space in every image.  new_of_old / old_of_new map global indices.
     std::vector<uint32_t> new_of_old, old_of_new;
-    // slot -> tile (0xFFFFFFFF: idle).  Block b runs slots 4b..4b+3; blocks are dealt
-    // round-robin over the 8 XCDs, so block b gets tiles of spatial octant b % 8 of all
-    // images: an XCD's gathers then touch ~1/8 of every partner's table (its L2's size).
-    std::vector<uint32_t> tile_order;
+    // Partner images are split into N_GROUPS contiguous ranges of equal point count;
+    // group_begin[g] is the first image of group g.  A sweep block handles (4 tiles,
+    // ONE group); blocks are dealt round-robin over the 8 XCDs, so with block % 8 = group
+    // every XCD gathers from one group's coordinates only: 1/8 of the table, which fits
+    // its 4 MiB L2 -- also for false matches, whose partner points are uniformly random.
+    std::vector<uint32_t> group_begin;      // [N_GROUPS + 1]
     std::vector<Tile> tiles;
     std::vector<LinkRec> recs;
     std::vector<uint32_t> img_tile_ptr;     // [nI + 1]
@@ -116,6 +118,22 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
         out.img_link_begin[i] = m.row_ptr[poff[c]] - l0;
     }
 
+    // partner groups: contiguous image ranges balanced by point count
+    out.group_begin.assign(N_GROUPS + 1, nI);
+    out.group_begin[0] = 0;
+    {
+        const uint64_t Pall = poff[nI];
+        uint32_t img = 0;
+        for (int g = 1; g < N_GROUPS; g++) {
+            const uint64_t target = Pall * (uint64_t)g / N_GROUPS;
+            while (img < nI && poff[img] < target) img++;
+            out.group_begin[g] = img;
+        }
+    }
+    std::vector<uint8_t> group_of(nI);
+    for (int g = 0; g < N_GROUPS; g++)
+        for (uint32_t i = out.group_begin[g]; i < out.group_begin[g + 1]; i++) group_of[i] = (uint8_t)g;
+
     // tiles
     uint64_t rec_total = 0;
     out.img_tile_ptr.assign(nI + 1, 0);
@@ -132,7 +150,6 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
                 nrec += m.row_ptr[o + 1] - m.row_ptr[o];
             }
             tl.rec_begin = (uint32_t)rec_total;
-            tl.rec_count = (uint32_t)nrec;
             rec_total += nrec;
             tl.image = i;
             out.tiles.push_back(tl);
@@ -157,6 +174,10 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
                 for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) cnt[m.link_image[l] + 1]++;
             }
             for (uint32_t i = 0; i < nI; i++) cnt[i + 1] += cnt[i];
+            {
+                Tile &wt = out.tiles[t];
+                for (int g = 0; g <= N_GROUPS; g++) wt.group_off[g] = cnt[out.group_begin[g]];
+            }
             LinkRec *dst = out.recs.data() + tl.rec_begin;
             for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
                 const uint32_t o = old_of_new[n];
@@ -170,23 +191,6 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
         }
     }
 
-    // slot order: eight lists (one per spatial octant), interleaved block-wise
-    {
-        std::vector<std::vector<uint32_t>> oct(8);
-        for (uint32_t i = ib; i < ie; i++) {
-            const uint32_t t0 = out.img_tile_ptr[i], T = out.img_tile_ptr[i + 1] - t0;
-            for (uint32_t t = 0; t < T; t++) oct[(size_t)t * 8 / T].push_back(t0 + t);
-        }
-        size_t longest = 0;
-        for (auto &v : oct) longest = std::max(longest, v.size());
-        const size_t blocks_per_oct = (longest + 3) / 4;
-        out.tile_order.assign(blocks_per_oct * 8 * 4, 0xFFFFFFFFu);
-        for (int x = 0; x < 8; x++)
-            for (size_t k = 0; k < oct[x].size(); k++) {
-                const size_t blk = (k / 4) * 8 + x;            // block index: octant = blk % 8
-                out.tile_order[blk * 4 + k % 4] = oct[x][k];
-            }
-    }
     return FROG_OK;
 }
 

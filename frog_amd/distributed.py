@@ -78,7 +78,7 @@ class HipEngine:
         torch.cuda.set_device(device)
         check(self._lib.frog_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
               "frog_set_stream")
-        self.xyz2, (self.pt_begin, self.pt_end) = self._buffer(_abi.FROG_BUF_XYZ2, "<f4", 4)
+        self.xyz2, (self.pt_begin, self.pt_end) = self._buffer(_abi.FROG_BUF_XYZ2, "<f4", 3)
         self.em, _ = self._buffer(_abi.FROG_BUF_EM, "<f4", 4)
         self.energy, _ = self._buffer(_abi.FROG_BUF_ENERGY, "<f8", 1)
         self.gridsum = None
@@ -188,7 +188,7 @@ class ShardedImageGroup:
     """ImageGroup's methods (imageGroup.cxx) over image shards, one rank per GPU.
 
     ``engine`` implements the split-phase calls for this rank's images and exposes
-    the collective buffers as torch tensors (``xyz2`` [P,4] f32, ``em`` [nI,4] f32,
+    the collective buffers as torch tensors (``xyz2`` [P,3] f32, ``em`` [nI,4] f32,
     ``energy`` [4] f64, ``gridsum`` [3G] f64 after a lattice exists).  ``shards`` is
     the list of (image_begin, image_end) per rank and ``point_offset`` the model's
     point offsets.  With world_size 1 no collective is issued.

@@ -108,7 +108,8 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out4G, size_t cap_fl
 /* ---- split phases for one-process-per-GPU runs ----------------------------- */
 
 enum {
-    FROG_BUF_XYZ2    = 0,  /* float4[P]   x,y,z,image-id; owned rows written by transform */
+    FROG_BUF_XYZ2    = 0,  /* float[P][3] xyz2 in the library's internal point order (a permutation
+                            * inside each image); owned rows written by transform          */
     FROG_BUF_EM      = 1,  /* float4[n_images]  c1,c2,ratio,0; owned rows written by stats  */
     FROG_BUF_ENERGY  = 2,  /* double[4]   sum w2 d2, sum w2, #oversize coefficients, 0      */
     FROG_BUF_GRIDSUM = 3   /* double[3*G] sum over owned images of the proposed coefficients */
