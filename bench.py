@@ -218,7 +218,7 @@ def main():
             "phase_iterations_per_s": {
                 "linear": n_lin / phase_s["linear"],
                 **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(3) if per_level[l]}},
-            "setup_seconds": {"generate": t_gen, "create": t_create},
+            "setup_seconds": {"generate": t_gen, "create": t_create, "lattice_setups": grp.setup_seconds},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)

@@ -60,7 +60,13 @@ template <class T> struct DevBuf {
 // ---- link layout (built on the host in prep.h) --------------------------------
 
 constexpr int TILE_POINTS = 256;     // points per sweep tile (one wavefront each)
-constexpr int N_GROUPS = 8;          // partner-image groups = XCDs (each group's xyz2 slice fits one L2)
+constexpr int N_XCD = 8;             // blocks are dealt round-robin over the XCDs
+constexpr int N_SUBPASS = 1;         // partner groups handled one after the other on each XCD
+constexpr int N_GROUPS = N_XCD * N_SUBPASS;   // partner-image groups: a group's xyz2 slice must stay in one 4 MiB L2
+                                     // next to the streams passing through it.  Measured at 100 images x 20 000 points:
+                                     // a 3 MB slice is only partly retained (0.24 fabric reads per half-link), a
+                                     // 1.5 MB one is (0.08), but 16 groups cost more in partial-sum traffic and
+                                     // shorter waves than they save (0.86 ms vs 0.74 ms per sweep)
 
 // xyz2 of a point, packed: the sweep gathers 12 bytes per end point.
 struct P3 {
@@ -77,6 +83,7 @@ struct Tile {
     uint32_t group_off[N_GROUPS + 1];   // records into partner group g: [rec_begin + off[g], rec_begin + off[g+1])
     uint32_t pad_[3];
 };
+static_assert(sizeof(Tile) % 16 == 0, "Tile is loaded with vector loads");
 
 // One half-link, 8 bytes (the size of the reference's Link, point.h:11-16):
 //   a = (partner image << 8) | index of the own point inside its tile (TILE_POINTS <= 256)
@@ -210,6 +217,7 @@ struct frog_ctx {
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
     std::vector<frog::GridRecord> grids;
+    bool xyz2_fresh = false;                  // phase_c already ran transformPoints(apply=0) for the current state
     float pending_alpha = 0;
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 

@@ -285,6 +285,8 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
     CTX_GUARD(ctx);
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     if (!n) return FROG_OK;
+    if (ctx->xyz2_fresh && !apply) { ctx->xyz2_fresh = false; return FROG_OK; }    // queued by phase_c already
+    ctx->xyz2_fresh = false;
     Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->mat.p,
@@ -437,6 +439,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
 {
     CTX_GUARD(ctx);
     if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
+    ctx->xyz2_fresh = false;
     int rc = retire_current_grid(ctx);
     if (rc) return rc;
 
@@ -551,11 +554,11 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
 {
     CTX_GUARD(ctx);
     if (!ctx->deformable) return fail(FROG_E_STATE, "deformable step before frog_deformable_setup");
+    ctx->xyz2_fresh = false;
     hipStream_t s = ctx->stream;
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));       // Fill(0), :249
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->n_big.p, 0, sizeof(unsigned long long), s));
+    // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
         sweep_kernel<SWEEP_DEFORMABLE><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
@@ -574,7 +577,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     }
     {
         Span span(ctx, FROG_K_LATTICE);
-        cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->gradf.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+        cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->gradf.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p, ctx->n_big.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
     ctx->pending_alpha = alpha;
@@ -604,21 +607,25 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
 {
     CTX_GUARD(ctx);
     if (ctx->phase != 2) return fail(FROG_E_STATE, "phase_c without phase_b");
-    double e = 0, nbig = 0;
-    int rc = frog_energy_read(ctx, &e, &nbig);
-    if (rc) return rc;
-    ctx->phase = 0;
-    if (ctx->opt.guarantee_diffeomorphism && nbig > 0) {        // :434-439, nothing committed
-        if (E) *E = -1.0;
-        return FROG_OK;
-    }
+    // Commit on the device if the (all-reduced) oversize count allows it, then already
+    // queue the transformPoints() that run() calls next in either case (accepted: :118 with
+    // the new coefficients; rejected: the coefficients are unchanged, so xyz2 comes out the
+    // same) -- the GPU keeps working while the host waits for the three scalars.
     const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
     {
         Span span(ctx, FROG_K_LATTICE);
-        cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n);
+        cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n, ctx->energy.p,
+                                                                 ctx->opt.guarantee_diffeomorphism);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    if (E) *E = e;
+    int rc = frog_transform_points_local(ctx, 0);
+    if (rc) return rc;
+    ctx->xyz2_fresh = true;
+    double e = 0, nbig = 0;
+    rc = frog_energy_read(ctx, &e, &nbig);
+    if (rc) return rc;
+    ctx->phase = 0;
+    if (E) *E = (ctx->opt.guarantee_diffeomorphism && nbig > 0) ? -1.0 : e;      // :434-439
     return FROG_OK;
 }
 
@@ -676,6 +683,7 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
     std::vector<P3> h(ctx->P);
     for (size_t p = 0; p < ctx->P; p++)
         h[ctx->h_new_of_old[p]] = P3{ xyz2[3 * p], xyz2[3 * p + 1], xyz2[3 * p + 2] };
+    ctx->xyz2_fresh = false;
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(P3), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;

@@ -441,16 +441,19 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
 
 // ---- K8 + first half of K9: control-point step and sum over owned images --------
 // thread per control point; images in ascending order (imageGroup.cxx:346-375, :411-415)
-__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, const float4 *gradf,
+__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, float4 *gradf,
                                                          float4 *grad, uint32_t n_owned,
-                                                         int n_cp, float alpha, double *gridsum)
+                                                         int n_cp, float alpha, double *gridsum,
+                                                         unsigned long long *n_big)
 {
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cp == 0) *n_big = 0ull;                 // counted by cp_center_kernel, later in the stream
     if (cp >= n_cp) return;
     double sx = 0, sy = 0, sz = 0;
     for (uint32_t i = 0; i < n_owned; i++) {
         const size_t o = (size_t)i * n_cp + cp;
         const float4 g4 = gradf[o];
+        gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);      // Fill(0) for the next step (imageGroup.cxx:249)
         const float4 c4 = coeff[o];
         float4 n4;
         if (g4.w > 0) {
@@ -506,8 +509,12 @@ __global__ void nbig_publish_kernel(const unsigned long long *n_big, double *ene
 }
 
 // ---- K10: commit (imageGroup.cxx:441-468) -------------------------------------------
-__global__ __launch_bounds__(256) void cp_commit_kernel(float4 *coeff, const float4 *grad, size_t n)
+// The accept / reject decision (imageGroup.cxx:434-439) is taken on the device from the
+// (all-reduced) oversize count, so the host does not have to read it back first.
+__global__ __launch_bounds__(256) void cp_commit_kernel(float4 *coeff, const float4 *grad, size_t n,
+                                                        const double *energy, int guarantee)
 {
+    if (guarantee && energy[2] > 0.0) return;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 v = grad[i];

@@ -78,10 +78,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    // block -> (4 consecutive tiles, partner group): group = block % 8 = the XCD the block
-    // lands on under round-robin dispatch (a performance assumption only)
-    const uint32_t grp = blockIdx.x % N_GROUPS;
-    const uint32_t t = (blockIdx.x / N_GROUPS) * 4 + wave;
+    // block -> (sub-pass, 4 consecutive tiles, XCD): the grid lists all blocks of sub-pass 0
+    // first, so dispatch order keeps the sub-passes apart in time; inside a sub-pass
+    // block % 8 is both the XCD the block lands on under round-robin dispatch (a
+    // performance assumption only) and the partner group it reads.
+    const uint32_t per_pass = gridDim.x / N_SUBPASS;
+    const uint32_t sub = blockIdx.x / per_pass, b1 = blockIdx.x - sub * per_pass;
+    const uint32_t grp = sub * N_XCD + b1 % N_XCD;
+    const uint32_t t = (b1 / N_XCD) * 4 + wave;
     const bool live = t < a.n_tiles;
 
     uint32_t pt_begin = 0, pt_count = 0, rec_lo = 0, rec_n = 0, image = 0;
@@ -106,19 +110,33 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     for (int k = 0; k < ((MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2); k++) s[k] = 0.0;
     long long n_in = 0, n_out = 0;
 
-    // The record stream is read once per pass: non-temporal loads keep it from
-    // evicting the coordinate table from L2; the next record is fetched one step ahead.
+    // Software pipeline, by hand (the loop body is one long dependent chain -- gathers,
+    // ~200 arithmetic instructions, LDS election -- and a wave only has ~50 steps, so the
+    // gather latency must overlap the PREVIOUS step's arithmetic): records are fetched two
+    // steps ahead (non-temporal: read once per pass, they must not evict the coordinate
+    // table from L2), the two 12-byte gathers and the partner's constants one step ahead.
     const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + rec_lo);
-    unsigned long long nxt = 0;
-    if ((uint32_t)lane < rec_n) nxt = __builtin_nontemporal_load(rec + lane);
+    unsigned long long rec0 = 0, rec1 = 0;
+    if ((uint32_t)lane < rec_n) rec0 = __builtin_nontemporal_load(rec + lane);
+    if ((uint32_t)lane + 64 < rec_n) rec1 = __builtin_nontemporal_load(rec + lane + 64);
+    P3 pa_n = { 0.f, 0.f, 0.f }, pb_n = { 0.f, 0.f, 0.f };
+    EmDerived eb_n = eA;
+    if ((uint32_t)lane < rec_n) {
+        pa_n = a.pos2[pt_begin + ((uint32_t)rec0 & 0xFFu)];
+        pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
+        eb_n = a.emd[(uint32_t)rec0 >> 8];
+    }
     for (uint32_t r = lane; r < rec_n; r += 64) {
-        const unsigned long long cur = nxt;
-        if (r + 64 < rec_n) nxt = __builtin_nontemporal_load(rec + r + 64);
-        const uint32_t ra = (uint32_t)cur, rb = (uint32_t)(cur >> 32);
-        const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
-        const P3 pa = a.pos2[pt_begin + ia];
-        const P3 pb = a.pos2[rb];
-        const EmDerived eB = a.emd[ra >> 8];
+        const P3 pa = pa_n, pb = pb_n;
+        const EmDerived eB = eb_n;
+        const uint32_t ia = (uint32_t)rec0 & 0xFFu;     // own point inside the tile
+        rec0 = rec1;
+        if (r + 128 < rec_n) rec1 = __builtin_nontemporal_load(rec + r + 128);
+        if (r + 64 < rec_n) {
+            pa_n = a.pos2[pt_begin + ((uint32_t)rec0 & 0xFFu)];
+            pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
+            eb_n = a.emd[(uint32_t)rec0 >> 8];
+        }
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;

@@ -210,6 +210,7 @@ class ShardedImageGroup:
         self.statIntervalUpdate = 10
         self.measures = []
         self.gridsPerLevel = []
+        self.setup_seconds = []
 
     @property
     def multi(self):
@@ -243,6 +244,14 @@ class ShardedImageGroup:
         return self.engine.energy_read()[0]
 
     def setupDeformableTransforms(self, level):
+        import time
+        t0 = time.perf_counter()
+        info = self._setup(level)
+        self._torch.cuda.synchronize() if hasattr(self.engine, "_ctx") else None
+        self.setup_seconds.append(time.perf_counter() - t0)
+        return info
+
+    def _setup(self, level):
         mn, mx = self.engine.bounds_local()
         if self.multi:
             t = self.engine.make_tensor(list(mx) + [-v for v in mn], self._torch.float64)
