@@ -29,9 +29,12 @@ inline int fail(int code, const std::string &msg)
     } while (0)
 
 // Owning device allocation.
+// alloc() keeps the old block when it is large enough (lattices are re-created many
+// times per run; hipFree/hipMalloc synchronise the device and cost milliseconds).
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t cap = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -39,14 +42,16 @@ template <class T> struct DevBuf {
     void release()
     {
         if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
+        p = nullptr; n = 0; cap = 0;
     }
     hipError_t alloc(size_t count)
     {
+        if (count <= cap && p) { n = count; return hipSuccess; }
         release();
-        n = count;
         if (!count) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T));
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) { n = count; cap = count; }
+        return e;
     }
     hipError_t upload(const std::vector<T> &v, hipStream_t s)
     {
@@ -198,6 +203,7 @@ struct frog_ctx {
     frog::DevBuf<double> mat;                 // [nI][16]; owned rows live
     // energy / counters
     frog::DevBuf<double> energy;              // [4]
+    frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
     double *h_energy = nullptr;               // pinned [4]
 
     // deformable
@@ -210,6 +216,7 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)
     frog::DevBuf<uint32_t> key_ptr;           // [nOwned*n_bricks*B^3 + 1] (image, brick, cell) -> perm range
     frog::DevBuf<uint32_t> key_cursor;
+    frog::DevBuf<uint32_t> key_counts, brick_ptr_scratch, scan_sums;   // set-up scratch, kept between lattices
     frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[n_scatter_blocks] (k_grid.hip.h)
     uint32_t n_scatter_blocks = 0;
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz

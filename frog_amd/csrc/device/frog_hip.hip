@@ -215,6 +215,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     for (uint32_t i = 0; i < c->nI; i++) for (int k = 0; k < 4; k++) hm[(size_t)i * 16 + 5 * k] = 1.0;
     CREATE_CHECK(c->mat.upload(hm, s));
     CREATE_CHECK(c->energy.alloc(4));
+    CREATE_CHECK(c->energy_blocks.alloc(2 * ENERGY_BLOCKS));
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
     CREATE_CHECK(c->n_big.alloc(1));
     CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
@@ -377,10 +378,11 @@ int frog_linear_step_local(frog_ctx *ctx)
         sweep_kernel<SWEEP_LINEAR><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
     }
     FROG_HIP_CHECK(hipGetLastError());
-    linear_update_kernel<<<ctx->n_owned(), 64, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
+    linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
     FROG_HIP_CHECK(hipGetLastError());
-    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, LINEAR_SUMS, 16, ctx->energy.p);
+    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, LINEAR_SUMS, 16, ctx->energy_blocks.p);
+    energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -493,7 +495,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     if (n_keys64 >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
     const uint32_t n_keys = (uint32_t)n_keys64;
     const uint32_t n_bricks_total = nO * (uint32_t)nb;
-    frog::DevBuf<uint32_t> counts, bptr;
+    frog::DevBuf<uint32_t> &counts = ctx->key_counts, &bptr = ctx->brick_ptr_scratch;
     FROG_HIP_CHECK(counts.alloc(n_keys));
     FROG_HIP_CHECK(bptr.alloc((size_t)n_bricks_total + 1));
     FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
@@ -508,8 +510,16 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    brick_scan_kernel<<<1, 1024, 0, s>>>(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
-    FROG_HIP_CHECK(hipGetLastError());
+    {
+        const uint32_t n_scan_blocks = div_up(n_keys, SCAN_BLOCK_ITEMS);
+        frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;
+        FROG_HIP_CHECK(bsums.alloc((size_t)n_scan_blocks + 1));
+        scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(counts.p, n_keys, bsums.p);
+        scan_of_sums_kernel<<<1, 1024, 0, s>>>(bsums.p, n_scan_blocks, bsums.p + n_scan_blocks);
+        scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(counts.p, n_keys, bsums.p, bsums.p + n_scan_blocks,
+                                                         ctx->key_ptr.p, ctx->key_cursor.p);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
     brick_ptr_kernel<<<div_up((size_t)n_bricks_total + 1, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, bptr.p);
     FROG_HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> h_bptr((size_t)n_bricks_total + 1);
@@ -518,7 +528,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host; `counts`, `bptr` may go
+    FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host
     std::vector<ScatterBlock> blocks;
     for (uint32_t k = 0; k < n_bricks_total; k++)
         for (uint32_t b0 = h_bptr[k]; b0 < h_bptr[k + 1]; b0 += SCATTER_CHUNK)
@@ -566,7 +576,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    energy_reduce_kernel<<<1, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy.p);
+    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy_blocks.p);
+    energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);

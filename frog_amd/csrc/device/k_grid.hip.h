@@ -256,16 +256,58 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
     }
 }
 
-// exclusive scan of n counts -> ptr[0..n] and cursor[0..n), single block of 1024
-// threads, each owning one contiguous segment.
-__global__ __launch_bounds__(1024) void brick_scan_kernel(const uint32_t *counts, uint32_t n, uint32_t *ptr, uint32_t *cursor)
+// exclusive scan of n counts -> ptr[0..n] and cursor[0..n), three launches:
+// per-block sums (coalesced), scan of the block sums (one block), per-block scan + base.
+constexpr int SCAN_BLOCK_ITEMS = 4096;      // 1024 threads x 4
+
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *counts, uint32_t n, uint32_t *block_sums)
 {
     __shared__ uint32_t sh[1024];
-    const uint32_t seg = (n + 1023u) / 1024u;
-    const uint32_t b = min(n, threadIdx.x * seg), e = min(n, b + seg);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += counts[i];
-    sh[threadIdx.x] = sum;
+    const uint32_t base = blockIdx.x * SCAN_BLOCK_ITEMS;
+    uint32_t v = 0;
+    #pragma unroll
+    for (int m = 0; m < 4; m++) { const uint32_t i = base + threadIdx.x + 1024 * m; if (i < n) v += counts[i]; }
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) { if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h]; __syncthreads(); }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint32_t *block_sums, uint32_t n_blocks, uint32_t *total)
+{
+    // in-place exclusive scan, chunks of 1024 with a carry
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = sh[threadIdx.x] - v + carry;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *counts, uint32_t n, const uint32_t *block_base,
+                                                          const uint32_t *total, uint32_t *ptr, uint32_t *cursor)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK_ITEMS + threadIdx.x * 4;      // 4 consecutive items per thread
+    uint32_t c[4], v = 0;
+    #pragma unroll
+    for (int m = 0; m < 4; m++) { c[m] = base + m < n ? counts[base + m] : 0; v += c[m]; }
+    sh[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
@@ -273,9 +315,13 @@ __global__ __launch_bounds__(1024) void brick_scan_kernel(const uint32_t *counts
         sh[threadIdx.x] += t;
         __syncthreads();
     }
-    uint32_t run = sh[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; i++) { ptr[i] = run; cursor[i] = run; run += counts[i]; }
-    if (threadIdx.x == 1023) ptr[n] = sh[1023];
+    uint32_t run = sh[threadIdx.x] - v + block_base[blockIdx.x];
+    #pragma unroll
+    for (int m = 0; m < 4; m++) {
+        if (base + m < n) { ptr[base + m] = run; cursor[base + m] = run; }
+        run += c[m];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ptr[n] = *total;
 }
 
 // ptr at brick granularity (every B^3-th entry) for the host's block table

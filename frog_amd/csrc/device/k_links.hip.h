@@ -227,14 +227,19 @@ __global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group
     point_sums[own_pt_begin + i] = s;
 }
 
-// Sum of the (sDistances, sWeights) tile partials in a fixed order -> energy[0..1].
-// One block; the tree is the same on every run.
-__global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partial, uint32_t n_tiles,
-                                                            int stride, int off, double *energy)
+// Sum of the (sDistances, sWeights) tile partials -> energy[0..1], in two stages with a
+// fixed tree (deterministic): ENERGY_BLOCKS blocks reduce contiguous slices, then one
+// block adds their results in order.
+constexpr int ENERGY_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void energy_partial_kernel(const double *partial, uint32_t n, int stride, int off,
+                                                             double *block_sums /*[ENERGY_BLOCKS][2]*/)
 {
     __shared__ double sh[2][256];
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t b = min(n, blockIdx.x * per), e = min(n, b + per);
     double a0 = 0, a1 = 0;
-    for (uint32_t t = threadIdx.x; t < n_tiles; t += 256) {
+    for (uint32_t t = b + threadIdx.x; t < e; t += 256) {
         a0 += partial[(size_t)t * stride + off];
         a1 += partial[(size_t)t * stride + off + 1];
     }
@@ -244,22 +249,39 @@ __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partia
         if ((int)threadIdx.x < h) { sh[0][threadIdx.x] += sh[0][threadIdx.x + h]; sh[1][threadIdx.x] += sh[1][threadIdx.x + h]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { energy[0] = sh[0][0]; energy[1] = sh[1][0]; energy[2] = 0.0; energy[3] = 0.0; }
+    if (threadIdx.x == 0) { block_sums[2 * blockIdx.x] = sh[0][0]; block_sums[2 * blockIdx.x + 1] = sh[1][0]; }
 }
 
-// K4: per-image scale / translation update (imageGroup.cxx:1123-1143).
-// One 64-thread block per owned image: lanes 0..17 add the image's tile partials
-// in tile order, lanes 0..2 then update one axis each.
-__global__ __launch_bounds__(64) void linear_update_kernel(const double *partial, const uint32_t *img_tile_ptr,
-                                                           uint32_t image_begin, double *mat,
-                                                           float linear_alpha, int use_scale)
+__global__ __launch_bounds__(64) void energy_final_kernel(const double *block_sums, int n_blocks, double *energy)
 {
+    if (threadIdx.x == 0) {
+        double a0 = 0, a1 = 0;
+        for (int b = 0; b < n_blocks; b++) { a0 += block_sums[2 * b]; a1 += block_sums[2 * b + 1]; }
+        energy[0] = a0; energy[1] = a1; energy[2] = 0.0; energy[3] = 0.0;
+    }
+}
+
+// K4: per-image scale / translation update (imageGroup.cxx:1123-1143).  One block per owned
+// image: 8 slices x 18 sums add the image's (tile, group) partials in a fixed order, the
+// slices are combined in order, then lanes 0..2 update one axis each.
+__global__ __launch_bounds__(256) void linear_update_kernel(const double *partial, const uint32_t *img_tile_ptr,
+                                                            uint32_t image_begin, double *mat,
+                                                            float linear_alpha, int use_scale)
+{
+    __shared__ double part[8][32];
     __shared__ double sums[LINEAR_SUMS];
     const uint32_t image = image_begin + blockIdx.x;
     const uint32_t t0 = img_tile_ptr[image] * N_GROUPS, t1 = img_tile_ptr[image + 1] * N_GROUPS;
+    const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    if (comp < LINEAR_SUMS) {
+        double v = 0;
+        for (uint32_t t = t0 + slice; t < t1; t += 8) v += partial[(size_t)t * LINEAR_SUMS + comp];
+        part[slice][comp] = v;
+    }
+    __syncthreads();
     if (threadIdx.x < LINEAR_SUMS) {
         double v = 0;
-        for (uint32_t t = t0; t < t1; t++) v += partial[(size_t)t * LINEAR_SUMS + threadIdx.x];
+        for (int sl = 0; sl < 8; sl++) v += part[sl][threadIdx.x];
         sums[threadIdx.x] = v;
     }
     __syncthreads();
