@@ -99,10 +99,18 @@ def main():
 
     if _abi.hip_lib().frog_device_count() < 1:
         raise SystemExit("no HIP device: bench.py measures the HIP path only")
+    # Rehearsal hook for boxes with a single GPU: FROG_BENCH_BACKEND=gloo puts every rank on
+    # device 0 and moves the collectives through gloo.  The driver's runs use RCCL ("nccl").
+    backend = os.environ.get("FROG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend)
 
     t0 = time.perf_counter()
     pairs = Pairs.synthetic(args.images, args.points, args.pairs_per_block, seed=1)

@@ -163,6 +163,7 @@ struct frog_ctx {
     // points
     frog::DevBuf<float4> pos;                 // xyz | image id
     frog::DevBuf<frog::P3> pos2;              // xyz2, packed
+    frog::DevBuf<frog::P3> pos2_spec;         // xyz2 computed ahead of the caller's transformPoints(0) (owned rows)
     frog::DevBuf<uint32_t> d_poff;            // [nI+1]
     // reference-order CSR of the owned rows (for the reservoir ordinals)
     frog::DevBuf<uint64_t> ref_rowptr;        // [ownP + 1], relative to the first owned link
@@ -224,7 +225,7 @@ struct frog_ctx {
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
     std::vector<frog::GridRecord> grids;
-    bool xyz2_fresh = false;                  // phase_c already ran transformPoints(apply=0) for the current state
+    bool xyz2_fresh = false;                  // pos2_spec holds transformPoints(apply=0) of the current state
     float pending_alpha = 0;
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 

@@ -281,23 +281,35 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
 }
 
 // ---- transformPoints (imageGroup.cxx:910-916, image.cxx:3-13) -----------------------
+static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
+{
+    const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    Span span(ctx, FROG_K_TRANSFORM);
+    if (!ctx->deformable) {
+        transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->mat.p,
+                                                                        ctx->own_pt_begin, ctx->own_pt_end, apply);
+    } else {
+        transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
+                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply);
+    }
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
 int frog_transform_points_local(frog_ctx *ctx, int apply)
 {
     CTX_GUARD(ctx);
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     if (!n) return FROG_OK;
-    if (ctx->xyz2_fresh && !apply) { ctx->xyz2_fresh = false; return FROG_OK; }    // queued by phase_c already
-    ctx->xyz2_fresh = false;
-    Span span(ctx, FROG_K_TRANSFORM);
-    if (!ctx->deformable) {
-        transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->mat.p,
-                                                                        ctx->own_pt_begin, ctx->own_pt_end, apply);
-    } else {
-        transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos2.p, ctx->coeff.p,
-                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply);
+    if (ctx->xyz2_fresh && !apply) {
+        // already computed behind the last deformable step (frog_deformable_phase_c): publish it
+        ctx->xyz2_fresh = false;
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p + ctx->own_pt_begin, ctx->pos2_spec.p + ctx->own_pt_begin,
+                                      (size_t)n * sizeof(P3), hipMemcpyDeviceToDevice, ctx->stream));
+        return FROG_OK;
     }
-    FROG_HIP_CHECK(hipGetLastError());
-    return FROG_OK;
+    ctx->xyz2_fresh = false;
+    return launch_transform(ctx, ctx->pos2.p, apply);
 }
 
 int frog_transform_points(frog_ctx *ctx, int apply) { return frog_transform_points_local(ctx, apply); }
@@ -619,9 +631,9 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     CTX_GUARD(ctx);
     if (ctx->phase != 2) return fail(FROG_E_STATE, "phase_c without phase_b");
     // Commit on the device if the (all-reduced) oversize count allows it, then already
-    // queue the transformPoints() that run() calls next in either case (accepted: :118 with
-    // the new coefficients; rejected: the coefficients are unchanged, so xyz2 comes out the
-    // same) -- the GPU keeps working while the host waits for the three scalars.
+    // compute, into a shadow buffer, the transformPoints() that run() calls next in either
+    // case (accepted: :118 with the new coefficients; rejected: the coefficients are
+    // unchanged) -- the GPU keeps working while the host waits for the three scalars.
     const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
     {
         Span span(ctx, FROG_K_LATTICE);
@@ -629,7 +641,8 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
                                                                  ctx->opt.guarantee_diffeomorphism);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    int rc = frog_transform_points_local(ctx, 0);
+    if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
+    int rc = launch_transform(ctx, ctx->pos2_spec.p, 0);        // xyz2 itself changes only when the caller asks
     if (rc) return rc;
     ctx->xyz2_fresh = true;
     double e = 0, nbig = 0;
