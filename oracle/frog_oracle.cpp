@@ -264,6 +264,7 @@ struct frogo_stats { EmStats s; };
 struct frogo_group {
     frog_options opt;
     uint32_t nI = 0;
+    uint32_t ib = 0, ie = 0;              // images this instance updates (all by default); see frogo_set_range
     uint64_t P = 0, L = 0;
     std::vector<uint32_t> poff;
     std::vector<float> xyz, xyz2;
@@ -285,11 +286,11 @@ inline const float *pos2(const frogo_group *g, uint16_t image, uint32_t point)
     return &g->xyz2[3 * ((size_t)g->poff[image] + point)];
 }
 
-// getBoundingBox (imageGroup.cxx:1513-1527); all images are moving (no -fi).
+// getBoundingBox (imageGroup.cxx:1513-1527) over the owned images (no -fi: all are moving).
 void group_bbox(const frogo_group *g, BBox &box)
 {
     box.reset();
-    for (uint32_t i = 0; i < g->nI; i++) {
+    for (uint32_t i = g->ib; i < g->ie; i++) {
         BBox local;
         for (uint32_t p = g->poff[i]; p < g->poff[i + 1]; p++)
             local.add_point(g->xyz[3 * (size_t)p], g->xyz[3 * (size_t)p + 1], g->xyz[3 * (size_t)p + 2]);
@@ -306,6 +307,7 @@ frogo_group *frogo_create(const frog_model *m, const frog_options *o)
     frogo_group *g = new frogo_group;
     g->opt = *o;
     g->nI = m->n_images;
+    g->ib = 0; g->ie = m->n_images;
     g->poff.assign(m->point_offset, m->point_offset + m->n_images + 1);
     g->P = g->poff[g->nI];
     g->xyz.assign(m->xyz, m->xyz + 3 * g->P);
@@ -368,7 +370,7 @@ void frogo_linear_init(frogo_group *g, const float anchor_pos[3])
 void frogo_transform_points(frogo_group *g, int apply)
 {
     #pragma omp parallel for
-    for (int i = 0; i < (int)g->nI; i++) {
+    for (int i = (int)g->ib; i < (int)g->ie; i++) {
         const double *M = &g->matrix[(size_t)i * 16];
         const Grid *grid = g->deformable ? &g->grids.back() : nullptr;
         const float *coeffs = grid ? grid->coeffs[i].data() : nullptr;
@@ -394,7 +396,7 @@ void frogo_transform_points(frogo_group *g, int apply)
 void frogo_update_stats(frogo_group *g)
 {
     #pragma omp parallel for
-    for (int i = 0; i < (int)g->nI; i++) {
+    for (int i = (int)g->ib; i < (int)g->ie; i++) {
         EmStats &st = g->stats[i];
         st.reset();
         for (uint32_t p = g->poff[i]; p < g->poff[i + 1]; p++) {
@@ -409,14 +411,15 @@ void frogo_update_stats(frogo_group *g)
     }
 }
 
-// updateLinearTransforms, imageGroup.cxx:1063-1149.
-double frogo_linear_step(frogo_group *g)
+// updateLinearTransforms, imageGroup.cxx:1063-1149, over the owned images; the two
+// energy sums are returned for the caller to combine across instances.
+void frogo_linear_step_local(frogo_group *g, double out2[2])
 {
     double sDistances = 0, sWeights = 0;
     const float la = g->opt.linear_alpha;
 
     #pragma omp parallel for reduction(+ : sDistances, sWeights)
-    for (int image1 = 0; image1 < (int)g->nI; image1++) {
+    for (int image1 = (int)g->ib; image1 < (int)g->ie; image1++) {
         float diff[3];
         double sDisp[3] = { 0, 0, 0 }, sPosA[3] = { 0, 0, 0 }, sPosA2[3] = { 0, 0, 0 };
         double sPosB[3] = { 0, 0, 0 }, sPosB2[3] = { 0, 0, 0 };
@@ -463,16 +466,30 @@ double frogo_linear_step(frogo_group *g)
                          + sPosA[k] * (double)(1 - newScale) / sWeight;
         }
     }
-    return std::sqrt(sDistances / sWeights);
+    out2[0] = sDistances; out2[1] = sWeights;
 }
 
-// setupDeformableTransforms, imageGroup.cxx:159-218.
-void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out)
+double frogo_linear_step(frogo_group *g)
+{
+    double s[2];
+    frogo_linear_step_local(g, s);
+    return std::sqrt(s[0] / s[1]);
+}
+
+void frogo_bounds_local(frogo_group *g, double mins[3], double maxs[3])
+{
+    BBox box;
+    group_bbox(g, box);
+    for (int k = 0; k < 3; k++) { mins[k] = box.mn[k]; maxs[k] = box.mx[k]; }
+}
+
+// setupDeformableTransforms, imageGroup.cxx:159-218, from the group-wide bounding box.
+void frogo_deformable_setup_bounds(frogo_group *g, int level, const double mins[3], const double maxs[3], frog_grid_info *out)
 {
     Grid grid;
     double size = (double)g->opt.initial_grid_size / std::pow(2, level);
     BBox box;
-    group_bbox(g, box);
+    for (int k = 0; k < 3; k++) { box.mn[k] = mins[k]; box.mx[k] = maxs[k]; }
     float s = 1 + 2 * g->opt.bounding_box_margin;      // int + int*float -> float
     box.scale_about_center((double)s);
     for (int k = 0; k < 3; k++) {
@@ -500,8 +517,20 @@ void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out)
     }
 }
 
-// updateDeformableTransforms, imageGroup.cxx:234-472 (no hardLinks: -lc is out of scope).
-double frogo_deformable_step(frogo_group *g, const float alpha)
+void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out)
+{
+    double mn[3], mx[3];
+    frogo_bounds_local(g, mn, mx);
+    frogo_deformable_setup_bounds(g, level, mn, mx, out);
+}
+
+// updateDeformableTransforms, imageGroup.cxx:234-472 (no hardLinks: -lc is out of scope), in
+// three phases so that several instances owning disjoint image ranges can be combined:
+//   A  :239-377  per owned image: point sums, scatter, control-point step; returns the sum of
+//                the proposals over the owned images (3G doubles, image order) and the energy sums
+//   B  :400-432  given the sum over ALL images: subtract the mean, count oversize coefficients
+//   C  :441-468  commit
+void frogo_deformable_phase_a(frogo_group *g, const float alpha, double *gridsum, double out2[2])
 {
     double sDistances = 0, sWeights = 0;
     Grid &grid = g->grids.back();
@@ -512,7 +541,7 @@ double frogo_deformable_step(frogo_group *g, const float alpha)
     if (g->point_sums.size() != 4 * g->P) g->point_sums.assign(4 * g->P, 0.f);
 
     #pragma omp parallel for reduction(+ : sDistances, sWeights)
-    for (int image1 = 0; image1 < (int)g->nI; image1++) {
+    for (int image1 = (int)g->ib; image1 < (int)g->ie; image1++) {
         float *gradient = g->gradient[image1].data();
         double weights[3][4];
         std::fill(gradient, gradient + 4 * G, 0.f);
@@ -579,35 +608,67 @@ double frogo_deformable_step(frogo_group *g, const float alpha)
         }
     }
 
-    // subtract the cross-image mean, count oversize coefficients, :379-432
+    // sum of the proposals over the owned images, :411-415 (before the division)
+    #pragma omp parallel for
+    for (long i = 0; i < (long)G; i++)
+        for (int j = 0; j < 3; j++) {
+            double sum = 0;
+            for (int im = (int)g->ib; im < (int)g->ie; im++) sum += g->gradient[im][4 * i + j];
+            gridsum[3 * i + j] = sum;
+        }
+    out2[0] = sDistances; out2[1] = sWeights;
+}
+
+// subtract the cross-image mean, count oversize coefficients, :417-428
+long frogo_deformable_phase_b(frogo_group *g, const double *gridsum_all)
+{
+    Grid &grid = g->grids.back();
+    const size_t G = (size_t)grid.dims[0] * grid.dims[1] * grid.dims[2];
     const int nImages = (int)g->nI;
     long nBig = 0;
     const float maxD = g->opt.max_displacement_ratio;
     #pragma omp parallel for reduction(+ : nBig)
     for (long i = 0; i < (long)G; i++) {
         for (int j = 0; j < 3; j++) {
-            double sum = 0;
-            for (int im = 0; im < nImages; im++) sum += g->gradient[im][4 * i + j];
+            double sum = gridsum_all[3 * i + j];
             sum /= nImages;
-            for (int im = 0; im < nImages; im++) {
+            for (int im = (int)g->ib; im < (int)g->ie; im++) {
                 float &v = g->gradient[im][4 * i + j];
                 v = (float)((double)v - sum);
                 if ((double)std::fabs(v) > (double)maxD * grid.spacing[j]) nBig++;
             }
         }
     }
-    if (g->opt.guarantee_diffeomorphism && nBig > 0) return -1;      // :434-439
+    return nBig;
+}
 
-    // commit, :441-468
+// commit, :441-468
+void frogo_deformable_phase_c(frogo_group *g)
+{
+    Grid &grid = g->grids.back();
+    const size_t G = (size_t)grid.dims[0] * grid.dims[1] * grid.dims[2];
     #pragma omp parallel for
-    for (int image1 = 0; image1 < nImages; image1++) {
+    for (int image1 = (int)g->ib; image1 < (int)g->ie; image1++) {
         float *disp = grid.coeffs[image1].data();
         const float *nd = g->gradient[image1].data();
         for (size_t i = 0; i < G; i++)
             for (int j = 0; j < 3; j++) disp[3 * i + j] = nd[4 * i + j];
     }
-    return std::sqrt(sDistances / sWeights);
 }
+
+double frogo_deformable_step(frogo_group *g, const float alpha)
+{
+    const Grid &grid = g->grids.back();
+    std::vector<double> gridsum((size_t)3 * grid.dims[0] * grid.dims[1] * grid.dims[2]);
+    double s[2];
+    frogo_deformable_phase_a(g, alpha, gridsum.data(), s);
+    const long nBig = frogo_deformable_phase_b(g, gridsum.data());
+    if (g->opt.guarantee_diffeomorphism && nBig > 0) return -1;      // :434-439
+    frogo_deformable_phase_c(g);
+    return std::sqrt(s[0] / s[1]);
+}
+
+void frogo_set_range(frogo_group *g, uint32_t image_begin, uint32_t image_end) { g->ib = image_begin; g->ie = image_end; }
 
 // countInliers, imageGroup.cxx:988-1060.
 void frogo_count_inliers(frogo_group *g, frog_counts *out)

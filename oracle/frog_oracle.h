@@ -53,6 +53,16 @@ void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out); /* 
 double frogo_deformable_step(frogo_group *g, float alpha);        /* :234  */
 void frogo_count_inliers(frogo_group *g, frog_counts *per_image); /* :988  */
 
+/* Split phases (several instances owning disjoint image ranges, combined by the caller:
+ * the CPU stand-in for one-process-per-GPU runs in tests/test_distributed_gloo.py). */
+void frogo_set_range(frogo_group *g, uint32_t image_begin, uint32_t image_end);
+void frogo_linear_step_local(frogo_group *g, double out2[2]);
+void frogo_bounds_local(frogo_group *g, double mins[3], double maxs[3]);
+void frogo_deformable_setup_bounds(frogo_group *g, int level, const double mins[3], const double maxs[3], frog_grid_info *out);
+void frogo_deformable_phase_a(frogo_group *g, float alpha, double *gridsum3G, double out2[2]);
+long frogo_deformable_phase_b(frogo_group *g, const double *gridsum_all3G);
+void frogo_deformable_phase_c(frogo_group *g);
+
 /* Whole driver (run(), imageGroup.cxx:31-157) without file output.  E_out
  * receives one value per ACCEPTED iteration (the `measures` vector).
  * Returns the number of values written (<= cap); n_grids_out[level] gets the

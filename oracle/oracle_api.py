@@ -43,6 +43,14 @@ def lib():
         L.frogo_run.restype = C.c_int
         L.frogo_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, dp, C.c_int,
                                 C.POINTER(C.c_int)]
+        L.frogo_set_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.frogo_linear_step_local.argtypes = [C.c_void_p, dp]
+        L.frogo_bounds_local.argtypes = [C.c_void_p, dp, dp]
+        L.frogo_deformable_setup_bounds.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_void_p]
+        L.frogo_deformable_phase_a.argtypes = [C.c_void_p, C.c_float, dp, dp]
+        L.frogo_deformable_phase_b.restype = C.c_long
+        L.frogo_deformable_phase_b.argtypes = [C.c_void_p, dp]
+        L.frogo_deformable_phase_c.argtypes = [C.c_void_p]
         L.frogo_num_points.restype = C.c_uint64
         L.frogo_num_points.argtypes = [C.c_void_p]
         for n in ("frogo_get_xyz", "frogo_get_xyz2", "frogo_set_xyz2", "frogo_get_point_sums"):
@@ -204,6 +212,37 @@ class OracleGroup:
     def count_inliers(self, counts_array):
         self.L.frogo_count_inliers(self.h, counts_array)
         return counts_array
+
+    # split phases (disjoint image ranges combined by the caller)
+    def set_range(self, b, e):
+        self.L.frogo_set_range(self.h, b, e)
+
+    def linear_step_local(self):
+        o = np.empty(2, np.float64)
+        self.L.frogo_linear_step_local(self.h, o.ctypes.data_as(dp))
+        return o
+
+    def bounds_local(self):
+        mn, mx = np.empty(3, np.float64), np.empty(3, np.float64)
+        self.L.frogo_bounds_local(self.h, mn.ctypes.data_as(dp), mx.ctypes.data_as(dp))
+        return mn, mx
+
+    def deformable_setup_bounds(self, level, mn, mx, info):
+        mn = np.ascontiguousarray(mn, np.float64); mx = np.ascontiguousarray(mx, np.float64)
+        self.L.frogo_deformable_setup_bounds(self.h, level, mn.ctypes.data_as(dp), mx.ctypes.data_as(dp), C.byref(info))
+        return info
+
+    def phase_a(self, alpha, gridsum):
+        o = np.empty(2, np.float64)
+        self.L.frogo_deformable_phase_a(self.h, alpha, gridsum.ctypes.data_as(dp), o.ctypes.data_as(dp))
+        return o
+
+    def phase_b(self, gridsum_all):
+        g = np.ascontiguousarray(gridsum_all, np.float64)
+        return int(self.L.frogo_deformable_phase_b(self.h, g.ctypes.data_as(dp)))
+
+    def phase_c(self):
+        self.L.frogo_deformable_phase_c(self.h)
 
     def run(self, li=50, dl=3, di=200, da=0.02, si=10, anchor=(0.5, 0.5, 0.5)):
         cap = li + dl * di + 8

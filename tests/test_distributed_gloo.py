@@ -136,6 +136,142 @@ class ToyEngine:
         return None
 
 
+class OracleEngine:
+    """Engine double backed by the CPU oracle's split phases: real arithmetic, CPU tensors.
+    Lives in tests/ only -- the product has no CPU engine."""
+
+    def __init__(self, pairs, shard, guarantee=True):
+        from frog_amd import _abi
+        from oracle.oracle_api import OracleGroup
+        self._abi = _abi
+        self.opt = _abi.FrogOptions.default()
+        self.g = OracleGroup(pairs.model, self.opt)
+        self.g.setup_stats()
+        self.ib, self.ie = shard
+        self.g.set_range(self.ib, self.ie)
+        self.n_images = pairs.n_images
+        self.po = np.asarray(pairs.point_offset).astype(np.int64)
+        P = int(self.po[-1])
+        self.xyz2 = torch.zeros(P, 3)
+        self.em = torch.zeros(self.n_images, 4)
+        for i in range(self.n_images):
+            self.em[i, :3] = torch.tensor([10.0, 300.0, 0.5])
+        self.energy = torch.zeros(4, dtype=torch.float64)
+        self.gridsum = None
+
+    def rows(self):
+        return slice(int(self.po[self.ib]), int(self.po[self.ie]))
+
+    def _push(self):
+        self.g.set_xyz2(self.xyz2.numpy())
+        for i in range(self.n_images):
+            self.g.set_em(i, self.em[i, :3].numpy())
+
+    def linear_init(self, anchor):
+        self.g.linear_init(anchor)
+
+    def transform_points_local(self, apply):
+        self.g.transform_points(apply)
+        r = self.rows()
+        self.xyz2[r] = torch.from_numpy(self.g.xyz2()[r])
+
+    def update_stats_local(self):
+        self._push()
+        self.g.update_stats()
+        self.em.zero_()
+        for i in range(self.ib, self.ie):
+            self.em[i, :3] = torch.from_numpy(self.g.em(i))
+
+    def stats_publish(self):
+        pass
+
+    def linear_step_local(self):
+        self._push()
+        self.energy.zero_()
+        self.energy[:2] = torch.from_numpy(self.g.linear_step_local())
+
+    def energy_read(self):
+        return float(np.sqrt(self.energy[0] / self.energy[1])), float(self.energy[2])
+
+    def bounds_local(self):
+        mn, mx = self.g.bounds_local()
+        return mn.tolist(), mx.tolist()
+
+    def deformable_setup_bounds(self, level, mins, maxs):
+        info = self.g.deformable_setup_bounds(level, mins, maxs, self._abi.FrogGridInfo())
+        self.gridsum = torch.zeros(3 * info.dims[0] * info.dims[1] * info.dims[2], dtype=torch.float64)
+        return info
+
+    def phase_a(self, alpha):
+        self._push()
+        self.energy.zero_()
+        self.energy[:2] = torch.from_numpy(self.g.phase_a(alpha, self.gridsum.numpy()))
+
+    def phase_b(self):
+        self.energy[2] = float(self.g.phase_b(self.gridsum.numpy()))
+
+    def phase_c(self):
+        e, nbig = self.energy_read()
+        if self.opt.guarantee_diffeomorphism and nbig > 0:
+            return -1.0
+        self.g.phase_c()
+        return e
+
+    def make_tensor(self, values, dtype):
+        return torch.tensor(values, dtype=dtype)
+
+    def count_inliers(self):
+        return None
+
+
+def _oracle_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frog_amd import _abi
+        p = Pairs.synthetic(5, 500, 260, seed=12)
+        shards = plan_shards(p.row_ptr, p.point_offset, world)
+        eng = OracleEngine(p, shards[rank])
+        g = ShardedImageGroup(eng, shards, p.point_offset, rank, world)
+        g.linearIterations, g.deformableLevels, g.deformableIterations = 14, 2, 12
+        E = g.run()
+        b, e = shards[rank]
+        out[rank] = {"E": E, "grids": g.gridsPerLevel, "range": (b, e),
+                     "matrix": {i: eng.g.matrix(i) for i in range(b, e)},
+                     "coeff": {i: [eng.g.grid(i, k, _abi.FrogGridInfo())[1] for k in range(eng.g.num_grids())]
+                               for i in range(b, e)},
+                     "xyz2": eng.xyz2.numpy().copy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_oracle_matches_unsharded_oracle_gloo():
+    """Numerics of the decomposition: two gloo ranks, each an oracle restricted to its image
+    range, driven by the PRODUCT's ShardedImageGroup, against the plain oracle run()."""
+    from frog_amd import _abi
+    from oracle.oracle_api import OracleGroup
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_oracle_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    p = Pairs.synthetic(5, 500, 260, seed=12)
+    ref = OracleGroup(p.model, _abi.FrogOptions.default())
+    E, grids = ref.run(li=14, dl=2, di=12)
+    a, b = out[0], out[1]
+    assert a["E"] == b["E"] and a["grids"] == b["grids"] == grids
+    assert np.allclose(a["E"], E, rtol=1e-6)          # E is carried as f32; f64 partial sums differ in order only
+    assert np.array_equal(a["xyz2"], b["xyz2"])
+    assert np.max(np.abs(a["xyz2"] - ref.xyz2())) <= 1e-5 * np.max(np.abs(ref.xyz2()))
+    for res in (a, b):
+        for i, m in res["matrix"].items():
+            assert np.allclose(m, ref.matrix(i), rtol=1e-9, atol=1e-12)
+        for i, grids_i in res["coeff"].items():
+            for k, c in enumerate(grids_i):
+                rc = ref.grid(i, k, _abi.FrogGridInfo())[1]
+                assert np.max(np.abs(c - rc)) <= 1e-5 * max(np.max(np.abs(rc)), 1e-6)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
