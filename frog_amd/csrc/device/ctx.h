@@ -70,8 +70,9 @@ constexpr int N_SUBPASS = 1;         // partner groups handled one after the oth
 constexpr int N_GROUPS = N_XCD * N_SUBPASS;   // partner-image groups: a group's xyz2 slice must stay in one 4 MiB L2
                                      // next to the streams passing through it.  Measured at 100 images x 20 000 points:
                                      // a 3 MB slice is only partly retained (0.24 fabric reads per half-link), a
-                                     // 1.5 MB one is (0.08), but 16 groups cost more in partial-sum traffic and
-                                     // shorter waves than they save (0.86 ms vs 0.74 ms per sweep)
+                                     // 1.5 MB one is (0.08), but 16 groups (N_SUBPASS = 2: one launch per sub-pass,
+                                     // the second continuing the per-XCD partial sums) halve the steps per wave and
+                                     // the fixed cost per wave then outweighs the saved traffic (0.85 ms vs 0.74 ms)
 
 // xyz2 of a point, packed: the sweep gathers 12 bytes per end point.
 struct P3 {
@@ -178,7 +179,7 @@ struct frog_ctx {
     std::vector<uint32_t> h_img_tile_ptr;
     frog::DevBuf<double> tile_partial;        // [n_tiles][N_GROUPS][18]
     frog::DevBuf<long long> tile_counts;      // [n_tiles][N_GROUPS][2]
-    frog::DevBuf<float4> group_sums;          // [N_GROUPS][ownP] per-point partial sums of one partner group
+    frog::DevBuf<float4> group_sums;          // [N_XCD][ownP] per-point partial sums (one buffer per XCD, continued across sub-passes)
     frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
 
     // statistics

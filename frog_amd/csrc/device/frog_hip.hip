@@ -175,7 +175,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
     CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * LINEAR_SUMS));
     CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * 2));
-    CREATE_CHECK(c->group_sums.alloc((size_t)N_GROUPS * std::max(1u, c->own_pt_end - c->own_pt_begin)));
+    CREATE_CHECK(c->group_sums.alloc((size_t)N_XCD * std::max(1u, c->own_pt_end - c->own_pt_begin)));
     CREATE_CHECK(c->img_counts.alloc((size_t)c->n_owned() * 2));
 
     // statistics: Stats ctor (stats.h:94-99) + setupStats (imageGroup.cxx:1151-1159)
@@ -198,7 +198,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(hipMemsetAsync(c->sample_count[b].p, 0, c->sample_count[b].bytes(), s));
         CREATE_CHECK(hipEventCreateWithFlags(&c->ord_read[b], hipEventDisableTiming));
     }
-    CREATE_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    {
+        // the selection kernel is one wavefront per image and must not starve behind the sweeps
+        int lo = 0, hi = 0;
+        CREATE_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CREATE_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    }
     CREATE_CHECK(hipEventCreateWithFlags(&c->sel_done, hipEventDisableTiming));
     {
         // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
@@ -368,11 +373,12 @@ int frog_update_stats(frog_ctx *ctx)
 }
 
 // ---- updateLinearTransforms (imageGroup.cxx:1063-1149) ----------------------------------
-static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_GROUPS; }
+static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_XCD; }     // per sub-pass
 
-static SweepArgs sweep_args(frog_ctx *ctx)
+static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
 {
     SweepArgs a;
+    a.sub = sub;
     a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
@@ -387,7 +393,8 @@ int frog_linear_step_local(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     {
         Span span(ctx, FROG_K_SWEEP_LINEAR);
-        sweep_kernel<SWEEP_LINEAR><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
+        for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+            sweep_kernel<SWEEP_LINEAR><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
@@ -583,7 +590,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
-        sweep_kernel<SWEEP_DEFORMABLE><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
+        for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+            sweep_kernel<SWEEP_DEFORMABLE><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
         combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
     }
@@ -671,7 +679,8 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
     if (!per_image) return fail(FROG_E_INVALID, "null output");
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned();
-    sweep_kernel<SWEEP_COUNT><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx));
+    for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+        sweep_kernel<SWEEP_COUNT><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
     FROG_HIP_CHECK(hipGetLastError());
     count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
     FROG_HIP_CHECK(hipGetLastError());

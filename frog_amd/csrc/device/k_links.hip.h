@@ -37,8 +37,9 @@ struct SweepArgs {
     float threshold;
     double *tile_partial;       // [n_tiles][N_GROUPS][18] (linear) or [..][2] (deformable)
     long long *tile_counts;     // [n_tiles][N_GROUPS][2]  (count)
-    float4 *group_sums;         // [N_GROUPS][own points]  (deformable)
+    float4 *group_sums;         // [N_XCD][own points]  (deformable)
     uint32_t own_pt_begin, own_points;
+    uint32_t sub;               // sub-pass of this launch
 };
 
 // getInlierProbability (stats.h:84-92) from precomputed per-image constants.
@@ -78,14 +79,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    // block -> (sub-pass, 4 consecutive tiles, XCD): the grid lists all blocks of sub-pass 0
-    // first, so dispatch order keeps the sub-passes apart in time; inside a sub-pass
-    // block % 8 is both the XCD the block lands on under round-robin dispatch (a
-    // performance assumption only) and the partner group it reads.
-    const uint32_t per_pass = gridDim.x / N_SUBPASS;
-    const uint32_t sub = blockIdx.x / per_pass, b1 = blockIdx.x - sub * per_pass;
-    const uint32_t grp = sub * N_XCD + b1 % N_XCD;
-    const uint32_t t = (b1 / N_XCD) * 4 + wave;
+    // One launch per sub-pass.  block -> (4 consecutive tiles, XCD): block % 8 is the XCD the
+    // block lands on under round-robin dispatch (a performance assumption only) and selects
+    // the partner group sub*8 + xcd it reads, so during a launch an XCD's L2 only has to hold
+    // 1/16 of the coordinate table.  Later sub-passes continue the per-XCD partial sums.
+    const uint32_t xcd = blockIdx.x % N_XCD;
+    const uint32_t grp = a.sub * N_XCD + xcd;
+    const uint32_t t = (blockIdx.x / N_XCD) * 4 + wave;
     const bool live = t < a.n_tiles;
 
     uint32_t pt_begin = 0, pt_count = 0, rec_lo = 0, rec_n = 0, image = 0;
@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
 
     if (MODE == SWEEP_DEFORMABLE) {
-        for (int k = lane; k < TILE_POINTS; k += 64) { my[k] = make_float4(0.f, 0.f, 0.f, 0.f); own[k] = 0xFFFFFFFFu; }
+        const float4 *prev = a.group_sums + (size_t)xcd * a.own_points + (pt_begin - a.own_pt_begin);
+        for (int k = lane; k < TILE_POINTS; k += 64) {
+            my[k] = (a.sub > 0 && (uint32_t)k < pt_count) ? prev[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            own[k] = 0xFFFFFFFFu;
+        }
         __syncthreads();
     }
 
@@ -200,8 +204,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             a.tile_partial[((size_t)t * N_GROUPS + grp) * 2 + 1] = v1;
         }
         __syncthreads();
-        float4 *dst = a.group_sums + (size_t)grp * a.own_points + (pt_begin - a.own_pt_begin);
-        for (uint32_t k = lane; k < pt_count; k += 64) dst[k] = my[k];
+        float4 *dst = a.group_sums + (size_t)xcd * a.own_points + (pt_begin - a.own_pt_begin);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        for (uint32_t k = lane; k < pt_count; k += 64) {                 // written once, read once: non-temporal
+            const float4 v = my[k];
+            __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f *>(dst + k));
+        }
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
         if (lane == 0 && live) {
@@ -211,8 +219,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     }
 }
 
-// (sDisp, sWeight) of every owned point = sum of its N_GROUPS partner-group partials, in
-// group (= partner) order.
+// (sDisp, sWeight) of every owned point = sum of its N_XCD partial sums, in a fixed order.
 __global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group_sums, uint32_t own_points,
                                                              uint32_t own_pt_begin, float4 *point_sums)
 {
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group
     if (i >= own_points) return;
     float4 s = group_sums[i];
     #pragma unroll
-    for (int g = 1; g < N_GROUPS; g++) {
+    for (int g = 1; g < N_XCD; g++) {
         const float4 v = group_sums[(size_t)g * own_points + i];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
