@@ -490,7 +490,9 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
     // brick edge: 8 cells while bricks keep enough points to amortise their flush
     auto bricks_for = [&](int B) { size_t n = 1; for (int k = 0; k < 3; k++) n *= (size_t)((g.cells[k] + B - 1) / B); return n; };
-    g.brick = ((double)nPts / ((double)nO * (double)bricks_for(8)) >= 96.0) ? 8 : 4;
+    // brick edge: 4 cells (5.5 KB tile, many resident wavefronts) while bricks keep enough points to
+    // amortise their flush, else 8
+    g.brick = ((double)nPts / ((double)nO * (double)bricks_for(4)) >= 24.0) ? 4 : 8;
     for (int k = 0; k < 3; k++) g.nbricks[k] = (g.cells[k] + g.brick - 1) / g.brick;
     const size_t nb = bricks_for(g.brick);
     if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
