@@ -193,3 +193,76 @@ def test_full_run_parity(small_pairs):
             assert list(info.dims) == list(rinfo.dims)
             assert relerr(c, rc) < REL, f"lattice {k} image {i}"
     assert relerr(g.points()[0], ref.xyz()) < REL
+
+
+def ragged_pairs(seed=5):
+    """Images of 25 .. 1500 points observing subsets of one landmark cloud: true matches between
+    co-observed landmarks, 25 % false matches, points without any link, one image pair with heavy
+    duplication (400 links of ONE point into the same partner image) and one image pair whose
+    block appears twice in the file."""
+    rng = np.random.default_rng(seed)
+    sizes = [1500, 25, 700, 40, 1100, 260]
+    po = np.concatenate([[0], np.cumsum(sizes)])
+    cloud = rng.uniform(0, 300, size=(1500, 3))
+    seen = [rng.permutation(1500)[:n] for n in sizes]            # landmark of every point
+    xyz = np.concatenate([(cloud[seen[i]] * rng.uniform(0.9, 1.1, 3) + rng.uniform(-30, 30, 3)
+                           + rng.normal(0, 1.5, (sizes[i], 3))).astype(np.float32) for i in range(len(sizes))])
+    where = []
+    for i in range(len(sizes)):
+        w = -np.ones(1500, np.int64); w[seen[i]] = np.arange(sizes[i]); where.append(w)
+    blocks = []
+    for i in range(len(sizes)):
+        for j in range(i + 1, len(sizes)):
+            both = np.nonzero((where[i] >= 0) & (where[j] >= 0))[0]
+            both = both[rng.random(len(both)) < 0.8]             # some co-observed landmarks stay unlinked
+            p1, p2 = where[i][both], where[j][both]
+            nf = max(2, len(both) // 3)
+            p1 = np.concatenate([p1, rng.integers(0, sizes[i], nf)])
+            p2 = np.concatenate([p2, rng.integers(0, sizes[j], nf)])
+            if (i, j) == (0, 2):
+                p1 = np.concatenate([p1, np.full(400, 7)])       # 400 links of point 7 of image 0 into image 2
+                p2 = np.concatenate([p2, rng.integers(0, 20, 400)])
+            order = np.argsort(p1, kind="stable")
+            blocks.append((i, j, p1[order].astype(np.uint32), p2[order].astype(np.uint32)))
+    blocks.append(blocks[1])                                     # the same image pair appears twice in the file
+    from frog_amd.pairs import Pairs
+    return Pairs.from_arrays(po, xyz, blocks)
+
+
+def test_ragged_group_with_duplicate_links():
+    pairs = ragged_pairs()
+    g, ref = make(pairs, stats_max_size=500)
+    start(g, ref)
+    assert np.array_equal(g.points()[1], ref.xyz2())
+    for it in range(12):
+        if it % 5 == 0:
+            g.updateStats(); ref.update_stats()
+            for i in range(pairs.n_images):
+                s, o = g.samples(i)
+                rs, ro = ref.samples(i)
+                if it == 0:
+                    assert np.array_equal(o, ro) and np.array_equal(s, rs)
+                else:
+                    assert np.array_equal(o, ro) and np.allclose(s, rs, rtol=1e-3, atol=1e-2)
+        e = g.updateLinearTransforms(); er = ref.linear_step()
+        g.transformPoints(); ref.transform_points()
+        assert abs(e - er) / er < REL
+    g.transformPoints(True); ref.transform_points(True)
+    g.setupDeformableTransforms(1); ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    g.updateStats(); ref.update_stats()
+    for i in range(pairs.n_images):
+        g.set_em(i, ref.em(i))
+    e = g.updateDeformableTransforms(0.02); er = ref.deformable_step(0.02)
+    assert (e < 0) == (er < 0)
+    # per-point sums: point 7 of image 0 receives 400 duplicate links in one partner group
+    ps, rps = g.point_sums(), ref.point_sums()
+    assert relerr(ps, rps) < 1e-5
+    if e >= 0:
+        assert abs(e - er) / er < 1e-5
+        for i in range(pairs.n_images):
+            assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
+    c = g.countInliers()
+    rc = ref.count_inliers((_abi.FrogCounts * pairs.n_images)())
+    for i in range(pairs.n_images):
+        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
