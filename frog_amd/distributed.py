@@ -222,14 +222,22 @@ class ShardedImageGroup:
 
     def transformPoints(self, apply=False):
         self.engine.transform_points_local(apply)
-        if self.multi:
-            # ragged all-gather of the owned xyz2 rows: one broadcast per owner
-            works = []
-            for r, (ib, ie) in enumerate(self.shards):
-                rows = self.engine.xyz2[int(self.po[ib]):int(self.po[ie])]
-                works.append(self._dist.broadcast(rows, src=self._global_rank(r), group=self.group, async_op=True))
-            for w in works:
-                w.wait()
+        if not self.multi:
+            return
+        rows = [(int(self.po[ib]), int(self.po[ie])) for ib, ie in self.shards]
+        if len({e - b for b, e in rows}) == 1 and rows[0][0] == 0 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])):
+            # equal shards: one all-gather (ncclAllGather over xGMI) straight into the replica
+            b, e = rows[self.rank]
+            mine = self.engine.xyz2[b:e].clone()
+            self._dist.all_gather_into_tensor(self.engine.xyz2[:rows[-1][1]], mine, group=self.group)
+            return
+        # ragged: one broadcast per owner, in flight together
+        works = []
+        for r, (b, e) in enumerate(rows):
+            works.append(self._dist.broadcast(self.engine.xyz2[b:e], src=self._global_rank(r), group=self.group,
+                                              async_op=True))
+        for w in works:
+            w.wait()
 
     def updateStats(self):
         self.engine.update_stats_local()

@@ -278,12 +278,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, n_images=5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        p = Pairs.synthetic(5, 60, 30, seed=8)
+        p = Pairs.synthetic(n_images, 60, 30, seed=8)
         shards = plan_shards(p.row_ptr, p.point_offset, world)
         eng = ToyEngine(np.asarray(p.point_offset).copy(), shards[rank], p.n_images)
         g = ShardedImageGroup(eng, shards, p.point_offset, rank, world)
@@ -296,14 +296,15 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_run_world_size_2_gloo():
+@pytest.mark.parametrize("n_images", [5, 4])      # 5: ragged shards (broadcasts); 4: equal shards (one all-gather)
+def test_sharded_run_world_size_2_gloo(n_images):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, n_images), nprocs=world, join=True)
     a, b = out[0], out[1]
     # single-process run of the same toy problem = ground truth
-    p = Pairs.synthetic(5, 60, 30, seed=8)
+    p = Pairs.synthetic(n_images, 60, 30, seed=8)
     eng = ToyEngine(np.asarray(p.point_offset).copy(), (0, p.n_images), p.n_images)
     g = ShardedImageGroup(eng, [(0, p.n_images)], p.point_offset, 0, 1)
     g.linearIterations, g.deformableLevels, g.deformableIterations, g.statIntervalUpdate = 3, 2, 4, 2
