@@ -177,6 +177,7 @@ struct frog_ctx {
     uint32_t n_tiles = 0;
     frog::DevBuf<uint32_t> img_tile_ptr;      // [nI+1] tiles of image (owned only non-empty)
     std::vector<uint32_t> h_img_tile_ptr;
+    uint32_t group_begin[frog::N_GROUPS + 1] = {};   // partner-image groups (prep.h)
     frog::DevBuf<double> tile_partial;        // [n_tiles][N_GROUPS][18]
     frog::DevBuf<long long> tile_counts;      // [n_tiles][N_GROUPS][2]
     frog::DevBuf<float4> group_sums;          // [N_XCD][ownP] per-point partial sums (one buffer per XCD, continued across sub-passes)

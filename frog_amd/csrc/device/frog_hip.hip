@@ -115,6 +115,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
+    for (int g = 0; g <= N_GROUPS; g++) c->group_begin[g] = lay.group_begin[g];
     c->h_old_of_new = lay.old_of_new;
     c->h_new_of_old = lay.new_of_old;
     c->h_img_tile_ptr = lay.img_tile_ptr;
@@ -379,6 +380,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
 {
     SweepArgs a;
     a.sub = sub;
+    for (int g = 0; g <= N_GROUPS; g++) a.group_begin[g] = ctx->group_begin[g];
     a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;

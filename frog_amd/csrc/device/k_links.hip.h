@@ -26,6 +26,7 @@
 namespace frog {
 
 enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
+constexpr int EMD_LDS_IMAGES = 256;     // partner groups up to this many images keep their constants in LDS
 constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
 
 struct SweepArgs {
@@ -40,6 +41,7 @@ struct SweepArgs {
     float4 *group_sums;         // [N_XCD][own points]  (deformable)
     uint32_t own_pt_begin, own_points;
     uint32_t sub;               // sub-pass of this launch
+    uint32_t group_begin[N_GROUPS + 1];   // first image of every partner group
 };
 
 // getInlierProbability (stats.h:84-92) from precomputed per-image constants.
@@ -76,6 +78,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // reference's (imageGroup.cxx:256-257), plus one ownership word per point
     __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
     __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
+    // Scattered vector loads cost ~48 CU-cycles per wave-instruction through the texture
+    // path even when they hit L1 (measured: the sweep takes 0.26 ms without its three
+    // gathers per step, 0.68 ms with them), so everything that can be staged is: the xyz2
+    // of the tile's own points (per wave) and the EM constants of the partner group's
+    // images (per block) live in LDS; only the partner point is gathered from memory.
+    __shared__ float own_x[4 * TILE_POINTS], own_y[4 * TILE_POINTS], own_z[4 * TILE_POINTS];
+    __shared__ EmDerived emd_s[EMD_LDS_IMAGES];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -104,8 +113,17 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             my[k] = (a.sub > 0 && (uint32_t)k < pt_count) ? prev[k] : make_float4(0.f, 0.f, 0.f, 0.f);
             own[k] = 0xFFFFFFFFu;
         }
-        __syncthreads();
     }
+    float *px = own_x + wave * TILE_POINTS, *py = own_y + wave * TILE_POINTS, *pz = own_z + wave * TILE_POINTS;
+    for (uint32_t k = lane; k < pt_count; k += 64) {
+        const P3 p = a.pos2[pt_begin + k];
+        px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+    }
+    const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
+    const bool emd_lds = g_count <= (uint32_t)EMD_LDS_IMAGES;
+    if (emd_lds)
+        for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
+    __syncthreads();
 
     const EmDerived eA = a.emd[image];
 
@@ -114,33 +132,24 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     for (int k = 0; k < ((MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2); k++) s[k] = 0.0;
     long long n_in = 0, n_out = 0;
 
-    // Software pipeline, by hand (the loop body is one long dependent chain -- gathers,
-    // ~200 arithmetic instructions, LDS election -- and a wave only has ~50 steps, so the
-    // gather latency must overlap the PREVIOUS step's arithmetic): records are fetched two
-    // steps ahead (non-temporal: read once per pass, they must not evict the coordinate
-    // table from L2), the two 12-byte gathers and the partner's constants one step ahead.
+    // Software pipeline, by hand: records are fetched two steps ahead (non-temporal: read
+    // once per pass, they must not evict the coordinate table from L2), the partner point's
+    // 12-byte gather one step ahead; own point and partner constants come from LDS.
     const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + rec_lo);
     unsigned long long rec0 = 0, rec1 = 0;
     if ((uint32_t)lane < rec_n) rec0 = __builtin_nontemporal_load(rec + lane);
     if ((uint32_t)lane + 64 < rec_n) rec1 = __builtin_nontemporal_load(rec + lane + 64);
-    P3 pa_n = { 0.f, 0.f, 0.f }, pb_n = { 0.f, 0.f, 0.f };
-    EmDerived eb_n = eA;
-    if ((uint32_t)lane < rec_n) {
-        pa_n = a.pos2[pt_begin + ((uint32_t)rec0 & 0xFFu)];
-        pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
-        eb_n = a.emd[(uint32_t)rec0 >> 8];
-    }
+    P3 pb_n = { 0.f, 0.f, 0.f };
+    if ((uint32_t)lane < rec_n) pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
     for (uint32_t r = lane; r < rec_n; r += 64) {
-        const P3 pa = pa_n, pb = pb_n;
-        const EmDerived eB = eb_n;
-        const uint32_t ia = (uint32_t)rec0 & 0xFFu;     // own point inside the tile
+        const P3 pb = pb_n;
+        const uint32_t ra = (uint32_t)rec0;
+        const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
         rec0 = rec1;
         if (r + 128 < rec_n) rec1 = __builtin_nontemporal_load(rec + r + 128);
-        if (r + 64 < rec_n) {
-            pa_n = a.pos2[pt_begin + ((uint32_t)rec0 & 0xFFu)];
-            pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
-            eb_n = a.emd[(uint32_t)rec0 >> 8];
-        }
+        if (r + 64 < rec_n) pb_n = a.pos2[(uint32_t)(rec0 >> 32)];
+        const P3 pa = { px[ia], py[ia], pz[ia] };
+        const EmDerived eB = emd_lds ? emd_s[(ra >> 8) - g_first] : a.emd[ra >> 8];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
