@@ -338,8 +338,9 @@ __global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, u
 //
 // Batches of 64 points.  Phase 1, lane = point: cell, the 12 cubic weights in f64
 // as the reference computes them (imageGroup.cxx:303-310), rounded once to f32, and
-// the tile offset of the point's first tap.  Phase 2, lane = tap (i + 4j + 16k): the
-// point's values are broadcast with v_readlane, w = wx[i]*wy[j]*wz[k]
+// the tile offset of the point's first tap, written to a small LDS scratch.  Phase 2,
+// lane = tap (i + 4j + 16k): the point's values are read back with lane-constant offsets
+// (one point ahead), w = wx[i]*wy[j]*wz[k]
 // (imageGroup.cxx:322) and the four products are added into REGISTERS; points are
 // sorted by cell, so consecutive points mostly share their 64 tap addresses and the
 // LDS tile is touched (one ds_read_b128 + ds_write_b128, no atomic: the 64 taps are
@@ -358,16 +359,21 @@ struct ScatterBlock {
     uint32_t pad_;
 };
 
-__device__ __forceinline__ float bcast(float v, int lane)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
+// per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS
+struct ScatterPoint {
+    float w[12];            // wx[4], wy[4], wz[4], rounded to f32
+    float sx, sy, sz, sw;   // sDisp xyz, sWeight
+    int base;               // tile offset of tap (0,0,0); < 0: does not contribute
+    int pad_[3];
+};
+static_assert(sizeof(ScatterPoint) == 80, "ScatterPoint layout");
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
                                                      const uint32_t *perm, const ScatterBlock *blocks,
                                                      float4 *gradf, const GeomDev g)
 {
     __shared__ float4 tile[BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX];
+    __shared__ ScatterPoint pts[64];
     const ScatterBlock blk = blocks[blockIdx.x];
     const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
@@ -393,37 +399,34 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
         // ---- phase 1: lane = point
         const uint32_t s = batch + lane;
-        int base = -1;                               // tile offset of tap (0,0,0); -1: nothing to add
-        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-        float wx[4] = { 0, 0, 0, 0 }, wy[4] = { 0, 0, 0, 0 }, wz[4] = { 0, 0, 0, 0 };
+        ScatterPoint me;
+        me.base = -1;
         if (s < blk.end) {
             const uint32_t p = perm[s];
-            sm = point_sums[p];
+            const float4 sm = point_sums[p];
             if (sm.w != 0.f) {                       // imageGroup.cxx:299
                 const float4 v = pos[p];
                 const float in[3] = { v.x, v.y, v.z };
                 int ic[3]; float fr[3];
                 scatter_cell(in, g, ic, fr);
                 double F[4];
-                bspline_weights(F, (double)fr[0]);
                 #pragma unroll
-                for (int m = 0; m < 4; m++) wx[m] = (float)F[m];
-                bspline_weights(F, (double)fr[1]);
-                #pragma unroll
-                for (int m = 0; m < 4; m++) wy[m] = (float)F[m];
-                bspline_weights(F, (double)fr[2]);
-                #pragma unroll
-                for (int m = 0; m < 4; m++) wz[m] = (float)F[m];
+                for (int ax = 0; ax < 3; ax++) {
+                    bspline_weights(F, (double)fr[ax]);
+                    #pragma unroll
+                    for (int m = 0; m < 4; m++) me.w[ax * 4 + m] = (float)F[m];
+                }
+                me.sx = sm.x; me.sy = sm.y; me.sz = sm.z; me.sw = sm.w;
                 const int lx = ic[0] - 1 - cp0[0], ly = ic[1] - 1 - cp0[1], lz = ic[2] - 1 - cp0[2];
                 if (lx >= 0 && ly >= 0 && lz >= 0 && lx + 3 < E && ly + 3 < E && lz + 3 < E) {
-                    base = lx + E * (ly + E * lz);
+                    me.base = lx + E * (ly + E * lz);
                 } else {
                     // stray point clamped into this brick (outside the scaled box): its taps go
                     // straight to HBM, one lane doing all 64
                     for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
-                        const float w = wx[i] * wy[j] * wz[k];
+                        const float w = me.w[i] * me.w[4 + j] * me.w[8 + k];
                         float *dst = reinterpret_cast<float *>(gimg + ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)));
                         atomicAdd(dst + 0, w * sm.x); atomicAdd(dst + 1, w * sm.y);
                         atomicAdd(dst + 2, w * sm.z); atomicAdd(dst + 3, w * sm.w);
@@ -431,34 +434,46 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                 }
             }
         }
-        // this lane's weights for each of the 64 points are picked by (ti,tj,tk) below
-        const unsigned long long live = __ballot(base >= 0);
+        // compact the contributing points to the front of the scratch (order kept)
+        const unsigned long long live = __ballot(me.base >= 0);
+        const int n_live = __popcll(live);
+        if (me.base >= 0) pts[__popcll(live & ((1ull << lane) - 1ull))] = me;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2: lane = tap, loop over the batch's contributing points
-        unsigned long long todo = live;
-        while (todo) {
-            const int q = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int qb = __builtin_amdgcn_readlane(base, q);
-            const float a = bcast(wx[0], q), b = bcast(wx[1], q), c = bcast(wx[2], q), d = bcast(wx[3], q);
-            const float fx = ti == 0 ? a : ti == 1 ? b : ti == 2 ? c : d;
-            const float a1 = bcast(wy[0], q), b1 = bcast(wy[1], q), c1 = bcast(wy[2], q), d1 = bcast(wy[3], q);
-            const float fy = tj == 0 ? a1 : tj == 1 ? b1 : tj == 2 ? c1 : d1;
-            const float a2 = bcast(wz[0], q), b2 = bcast(wz[1], q), c2 = bcast(wz[2], q), d2 = bcast(wz[3], q);
-            const float fz = tk == 0 ? a2 : tk == 1 ? b2 : tk == 2 ? c2 : d2;
-            const float w = fx * fy * fz;
-            const float sx = bcast(sm.x, q), sy = bcast(sm.y, q), sz = bcast(sm.z, q), sw = bcast(sm.w, q);
-            if (qb != run_base) {                    // wave-uniform: cell changed -> spill the run
+        // ---- phase 2: lane = tap.  The point's weights are read with lane-constant offsets
+        // (wx[ti], wy[tj], wz[tk]); the next point's values are fetched while this one is used.
+        float wx = 0, wy = 0, wz = 0;
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+        int qb = -1;
+        if (n_live > 0) {
+            const ScatterPoint &c = pts[0];
+            wx = c.w[ti]; wy = c.w[4 + tj]; wz = c.w[8 + tk];
+            sm = make_float4(c.sx, c.sy, c.sz, c.sw); qb = c.base;
+        }
+        for (int q = 0; q < n_live; q++) {
+            const float cwx = wx, cwy = wy, cwz = wz;
+            const float4 csm = sm;
+            const int cb = qb;
+            if (q + 1 < n_live) {
+                const ScatterPoint &c = pts[q + 1];
+                wx = c.w[ti]; wy = c.w[4 + tj]; wz = c.w[8 + tk];
+                sm = make_float4(c.sx, c.sy, c.sz, c.sw); qb = c.base;
+            }
+            const float w = cwx * cwy * cwz;                // imageGroup.cxx:322
+            if (cb != run_base) {                          // wave-uniform: cell changed -> spill the run
                 if (run_base >= 0) {
                     float4 t = tile[run_base + tap_off];
                     t.x += run.x; t.y += run.y; t.z += run.z; t.w += run.w;
                     tile[run_base + tap_off] = t;
                 }
                 run = make_float4(0.f, 0.f, 0.f, 0.f);
-                run_base = qb;
+                run_base = cb;
             }
-            run.x += w * sx; run.y += w * sy; run.z += w * sz; run.w += w * sw;
+            run.x += w * csm.x; run.y += w * csm.y; run.z += w * csm.z; run.w += w * csm.w;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (run_base >= 0) {
         float4 t = tile[run_base + tap_off];
