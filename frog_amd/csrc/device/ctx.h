@@ -109,26 +109,6 @@ struct EmDerived {
     float inv1, inv2, k1, k2;
 };
 
-// 32.32 fixed point for the order-independent accumulators.  LDS/HBM integer
-// atomics run at full rate on gfx950 whereas ds_add_f32 is ~38x slower
-// (scripts/microbench/lds_atomic.hip); sums are exact in the rounded addends,
-// bitwise reproducible, and at least as accurate as the reference's running f32
-// sums.  Range |sum| < 2^31, resolution 2^-32.
-__host__ __device__ inline unsigned long long to_fixed32(float v)
-{
-    // v = n + r with n = round-to-nearest integer, |r| <= 0.5 (the subtraction is
-    // exact); r * 2^32 fits an int32 (saturating by one unit at r = 0.5).
-    const float n = rintf(v);
-    const float r = v - n;
-    const long long hi = (long long)(int)n << 32;
-    const long long lo = (long long)(int)(r * 4294967296.0f);
-    return (unsigned long long)(hi + lo);
-}
-__host__ __device__ inline float from_fixed32(unsigned long long q)
-{
-    return (float)((double)(long long)q * (1.0 / 4294967296.0));
-}
-
 struct GridGeom {
     int dims[3];
     int n_cp;               // dims[0]*dims[1]*dims[2]

@@ -106,3 +106,20 @@ def test_synthetic_generator_is_deterministic_and_sized():
         assert i1 < i2 and len(p1) > 0 and np.all(np.diff(p1.astype(np.int64)) >= 0)   # sorted by image1's index
     sparse = Pairs.synthetic(12, 100, 40, seed=2, partners_per_image=4)
     assert 0 < sparse.n_blocks < 66
+
+
+def test_cli_usage_and_generator_need_no_gpu(tmp_path):
+    """frog.cxx:12-65: no arguments -> usage text, exit code 1.  The --synth mode writes a
+    pairs.bin that the reader accepts."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "frog")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage : frog inputPairs.bin [options]" in r.stdout and "-lanchor x y z" in r.stdout
+    out = tmp_path / "s.bin"
+    r = subprocess.run([exe, "--synth", str(out), "3", "200", "80", "4"], capture_output=True, text=True)
+    assert r.returncode == 0 and out.exists()
+    p = Pairs.read(out)
+    q = Pairs.synthetic(3, 200, 80, seed=4)
+    assert p.n_images == 3 and p.n_points == 600 and np.array_equal(p.xyz, q.xyz)
+    assert np.array_equal(p.link_point, q.link_point)

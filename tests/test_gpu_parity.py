@@ -266,3 +266,53 @@ def test_ragged_group_with_duplicate_links():
     rc = ref.count_inliers((_abi.FrogCounts * pairs.n_images)())
     for i in range(pairs.n_images):
         assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+
+
+def test_abi_call_order_and_option_validation(tiny_pairs):
+    import ctypes as C
+    lib = _abi.hip_lib()
+    g = ImageGroup(tiny_pairs)
+    e = C.c_double()
+    # deformable entry points before a lattice exists
+    assert lib.frog_deformable_step(g._ctx, 0.02, C.byref(e)) == _abi.FROG_E_STATE
+    assert lib.frog_deformable_phase_b(g._ctx) == _abi.FROG_E_STATE
+    g.setupLinearTransforms(); g.transformPoints(); g.updateStats()
+    g.updateLinearTransforms(); g.transformPoints(True)
+    g.setupDeformableTransforms(0); g.transformPoints()
+    # phase C without B, linear step after the lattice exists
+    assert lib.frog_deformable_phase_a(g._ctx, 0.02) == _abi.FROG_OK
+    assert lib.frog_deformable_phase_c(g._ctx, C.byref(e)) == _abi.FROG_E_STATE
+    assert lib.frog_linear_step(g._ctx, C.byref(e)) == _abi.FROG_E_STATE
+    assert lib.frog_deformable_phase_b(g._ctx) == _abi.FROG_OK
+    assert lib.frog_deformable_phase_c(g._ctx, C.byref(e)) == _abi.FROG_OK and (e.value > 0 or e.value == -1.0)
+    # bad arguments
+    buf = (C.c_float * 3)()
+    assert lib.frog_get_em(g._ctx, 99, buf) == _abi.FROG_E_INVALID
+    assert lib.frog_get_grid(g._ctx, 0, 7, None, None, 0) == _abi.FROG_E_INVALID
+    ctx = C.c_void_p()
+    o = _abi.FrogOptions.default(stats_max_size=0)
+    assert lib.frog_create(C.byref(tiny_pairs.model), C.byref(o), 0, 0, 4, C.byref(ctx)) == _abi.FROG_E_INVALID
+    assert lib.frog_create(C.byref(tiny_pairs.model), C.byref(_abi.FrogOptions.default()), 99, 0, 4, C.byref(ctx)) == _abi.FROG_E_INVALID
+
+
+def test_external_stream_and_sub_range_context(tiny_pairs):
+    """frog_set_stream with a stream owned by the caller; a context that owns only images [1,3)
+    refuses the whole-group entry points (the collectives are the caller's job)."""
+    import ctypes as C
+    import torch
+    lib = _abi.hip_lib()
+    g = ImageGroup(tiny_pairs)
+    s = torch.cuda.Stream()
+    assert lib.frog_set_stream(g._ctx, C.c_void_p(s.cuda_stream)) == _abi.FROG_OK
+    g.setupLinearTransforms(); g.transformPoints(); g.updateStats()
+    e1 = g.updateLinearTransforms()
+    ref = ImageGroup(tiny_pairs)
+    ref.setupLinearTransforms(); ref.transformPoints(); ref.updateStats()
+    assert ref.updateLinearTransforms() == e1
+    part = ImageGroup(tiny_pairs, image_range=(1, 3))
+    e = C.c_double()
+    assert lib.frog_update_stats(part._ctx) == _abi.FROG_E_STATE
+    assert lib.frog_deformable_setup(part._ctx, 0, None) == _abi.FROG_E_STATE
+    assert lib.frog_update_stats_local(part._ctx) == _abi.FROG_OK
+    em = np.array([part.em(i) for i in range(4)])
+    assert not em[0].any() and not em[3].any() and em[1].all() and em[2].all()   # other ranks' rows are zero
