@@ -100,13 +100,15 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
                 if (x < 0 || x >= dx) continue;
                 const float4 c = row[x];
                 const double f = F[0][i];
-                vy[0] += c.x * f; vy[1] += c.y * f; vy[2] += c.z * f;
+                // explicit f64 fma: this kernel is bound by its f64 arithmetic; fusing only removes
+                // one rounding at 1e-16 before the result is rounded to f32 (VTK itself is unpinned)
+                vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
             }
             const double f = F[1][j];
-            vz[0] += vy[0] * f; vz[1] += vy[1] * f; vz[2] += vy[2] * f;
+            vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
         }
         const double f = F[2][k];
-        disp[0] += vz[0] * f; disp[1] += vz[1] * f; disp[2] += vz[2] * f;
+        disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
     }
     float4 o;
     o.x = (float)((double)in[0] + disp[0] * 1.0);
