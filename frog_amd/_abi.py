@@ -171,7 +171,8 @@ _host = None
 def hip_lib():
     global _hip
     if _hip is None:
-        _hip = _load("libfrog_hip.so", HIP_SYMBOLS)
+        # FROG_HIP_LIB: another build of the SAME library (kernel tuning experiments); relative to lib/
+        _hip = _load(os.environ.get("FROG_HIP_LIB", "libfrog_hip.so"), HIP_SYMBOLS)
     return _hip
 
 

@@ -67,6 +67,12 @@ template <class T> struct DevBuf {
 constexpr int TILE_POINTS = 256;     // points per sweep tile (one wavefront each)
 constexpr int N_XCD = 8;             // blocks are dealt round-robin over the XCDs
 constexpr int N_SUBPASS = 1;         // partner groups handled one after the other on each XCD
+// Records are stored in chunks of REC_CHUNK = two sweep steps, transposed so that ONE 16-byte
+// load per lane fetches the lane's records of both steps (8-byte loads run at 0.54-0.70x the rate
+// of 16-byte loads on gfx950): record k of a (tile, group) range lies at
+//   (k / 128) * 128 + (k % 64) * 2 + (k % 128) / 64.
+// Every range is padded with null records to a whole number of chunks.
+constexpr int REC_CHUNK = 128;
 constexpr int N_GROUPS = N_XCD * N_SUBPASS;   // partner-image groups: a group's xyz2 slice must stay in one 4 MiB L2
                                      // next to the streams passing through it.  Measured at 100 images x 20 000 points:
                                      // a 3 MB slice is only partly retained (0.24 fabric reads per half-link), a
@@ -84,10 +90,10 @@ struct P3 {
 struct Tile {
     uint32_t pt_begin;      // global point index (internal numbering)
     uint32_t pt_count;
-    uint32_t rec_begin;     // index into LinkRec array
+    uint32_t rec_begin;     // index into LinkRec array (a multiple of REC_CHUNK)
     uint32_t image;
-    uint32_t group_off[N_GROUPS + 1];   // records into partner group g: [rec_begin + off[g], rec_begin + off[g+1])
-    uint32_t pad_[3];
+    uint32_t group_off[N_GROUPS];   // records into partner group g start at rec_begin + off[g] (a multiple of REC_CHUNK)
+    uint32_t group_cnt[N_GROUPS];   // ... and there are cnt[g] of them
 };
 static_assert(sizeof(Tile) % 16 == 0, "Tile is loaded with vector loads");
 
@@ -138,6 +144,7 @@ struct frog_ctx {
     uint64_t P = 0;                           // all points
     uint32_t own_pt_begin = 0, own_pt_end = 0;
     uint64_t L_own = 0;                       // half-links of owned images
+    uint64_t L_recs = 0;                      // records stored (ranges padded to whole chunks)
     std::vector<uint32_t> poff;               // host copy
     std::vector<uint64_t> img_link_begin;     // per image: first half-link ordinal base (ref-order CSR, owned rows only)
 

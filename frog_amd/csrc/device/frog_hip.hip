@@ -57,6 +57,32 @@ template <class T> static int download_points(frog_ctx *ctx, const T *src, float
     return FROG_OK;
 }
 
+static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_XCD; }     // per sub-pass
+
+static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
+{
+    SweepArgs a;
+    a.sub = sub;
+    for (int g = 0; g <= N_GROUPS; g++) a.group_begin[g] = ctx->group_begin[g];
+    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
+    a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
+    a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
+    a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
+    return a;
+}
+
+template <int MODE>
+static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s)
+{
+    uint32_t widest = 0;
+    for (int g = 0; g < N_GROUPS; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
+    if (widest <= (uint32_t)EMD_LDS_IMAGES)
+        sweep_kernel<MODE, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+    else
+        sweep_kernel<MODE, false><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+}
+
 extern "C" {
 
 int frog_device_count(void)
@@ -113,7 +139,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     std::string err;
     int rc = build_layout(*m, c->ib, c->ie, lay, err);
     if (rc) { delete c; return fail(rc, err); }
-    c->L_own = lay.recs.size();
+    c->L_own = lay.ref_link.size();
+    c->L_recs = lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
     for (int g = 0; g <= N_GROUPS; g++) c->group_begin[g] = lay.group_begin[g];
     c->h_old_of_new = lay.old_of_new;
@@ -374,20 +401,6 @@ int frog_update_stats(frog_ctx *ctx)
 }
 
 // ---- updateLinearTransforms (imageGroup.cxx:1063-1149) ----------------------------------
-static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_XCD; }     // per sub-pass
-
-static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
-{
-    SweepArgs a;
-    a.sub = sub;
-    for (int g = 0; g <= N_GROUPS; g++) a.group_begin[g] = ctx->group_begin[g];
-    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
-    a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
-    a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
-    a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
-    return a;
-}
-
 int frog_linear_step_local(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
@@ -396,7 +409,7 @@ int frog_linear_step_local(frog_ctx *ctx)
     {
         Span span(ctx, FROG_K_SWEEP_LINEAR);
         for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
-            sweep_kernel<SWEEP_LINEAR><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+            launch_sweep<SWEEP_LINEAR>(ctx, sub, s);
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
@@ -595,7 +608,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
         for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
-            sweep_kernel<SWEEP_DEFORMABLE><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
         combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
     }
@@ -684,7 +697,7 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned();
     for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
-        sweep_kernel<SWEEP_COUNT><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+        launch_sweep<SWEEP_COUNT>(ctx, sub, s);
     FROG_HIP_CHECK(hipGetLastError());
     count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
     FROG_HIP_CHECK(hipGetLastError());

@@ -26,7 +26,14 @@
 namespace frog {
 
 enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
-constexpr int PREFETCH = 2;             // steps the partner-point gather runs ahead (1: 0.72 ms, 2: 0.64, 3-6: 0.64-0.65)
+// Prefetch pipeline of the sweep: the record stream runs CHUNK_AHEAD chunks (of two steps)
+// ahead of the arithmetic, the partner-point gather PT_AHEAD steps; the loop is unrolled over
+// one period of both rings.
+constexpr int CHUNK_RING = 3, CHUNK_AHEAD = 2;
+constexpr int PT_RING = 3, PT_AHEAD = 2;
+constexpr int BODY_STEPS = 6;
+static_assert(BODY_STEPS == 2 * CHUNK_RING && BODY_STEPS % PT_RING == 0 && PT_AHEAD < PT_RING && CHUNK_AHEAD < CHUNK_RING
+              && 2 * CHUNK_AHEAD >= PT_AHEAD + 2, "ring periods must divide the unrolled body; a gather needs its record");
 constexpr int EMD_LDS_IMAGES = 256;     // partner groups up to this many images keep their constants in LDS
 constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
 
@@ -36,6 +43,7 @@ struct SweepArgs {
     const P3 *pos2;
     const EmDerived *emd;
     uint32_t n_tiles;
+    uint32_t rec2_last;         // index of the last record PAIR (16 bytes) of the context (prefetch clamp)
     float threshold;
     double *tile_partial;       // [n_tiles][N_GROUPS][18] (linear) or [..][2] (deformable)
     long long *tile_counts;     // [n_tiles][N_GROUPS][2]  (count)
@@ -45,6 +53,51 @@ struct SweepArgs {
     uint32_t group_begin[N_GROUPS + 1];   // first image of every partner group
 };
 
+// The sweep is bound by vector-instruction issue (rocprofv3: ~175 VALU instructions per
+// 64-link step, VALU busy 80 % of the kernel), and more than half of those are the
+// compiler's generic expansions of sqrtf, expf and the f32 division: each carries range
+// handling this kernel cannot need.  The three helpers below are those same expansions
+// (same operations in the same order, so the same bits) without it.
+
+// Correctly rounded sqrt: v_sqrt_f32 (1 ulp) and the two one-ulp corrections.  Dropped: the
+// rescaling of denormal arguments (a denormal d2 means d < 0.1, where the weight is 1).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_lo = __builtin_fmaf(-lo, s, x), e_hi = __builtin_fmaf(-hi, s, x);
+    float r = (0.0f >= e_lo) ? lo : s;
+    r = (0.0f < e_hi) ? hi : r;
+    return r;
+}
+
+// expf(x) for x <= 0: two-word product x*log2(e), v_exp_f32 on the fraction, ldexp.  Dropped:
+// the overflow select (x <= 0) and the underflow select (ldexp already rounds to 0 there;
+// the clamp keeps -inf out of the two-word product).
+__device__ __forceinline__ float exp_nonpos(float x)
+{
+    x = __builtin_amdgcn_fmed3f(x, -200.0f, 0.0f);
+    constexpr float L_hi = __builtin_bit_cast(float, 0x3fb8aa3bu), L_lo = __builtin_bit_cast(float, 0x32a5705fu);
+    const float ph = x * L_hi;
+    float pl = __builtin_fmaf(x, L_hi, -ph);
+    pl = __builtin_fmaf(x, L_lo, pl);
+    const float n = __builtin_rintf(ph);
+    const float f = (ph - n) + pl;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// Correctly rounded n / d for d in the normal range: the Newton sequence of the compiler's
+// division without its operand scaling and special-case fix-up (here d >= 1e-10 and
+// 0 <= n <= d).
+__device__ __forceinline__ float div_rn(float n, float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+
 // getInlierProbability (stats.h:84-92) from precomputed per-image constants.
 __device__ __forceinline__ float inlier_probability(float d, const EmDerived e)
 {
@@ -53,9 +106,9 @@ __device__ __forceinline__ float inlier_probability(float d, const EmDerived e)
     if (d < 0.1f) return 1.0f;
     float u1 = d * e.inv1; u1 *= u1;
     float u2 = d * e.inv2; u2 *= u2;
-    float x1 = e.k1 * u1 * expf(-0.5f * u1);
-    float x2 = e.k2 * u2 * expf(-0.5f * u2);
-    return x1 / (x1 + x2 + 1e-10f);
+    float x1 = e.k1 * u1 * exp_nonpos(-0.5f * u1);
+    float x2 = e.k2 * u2 * exp_nonpos(-0.5f * u2);
+    return div_rn(x1, x1 + x2 + 1e-10f);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -72,7 +125,11 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 
-template <int MODE>
+// EMD_LDS: the partner group's EM constants fit emd_s (always, unless a group holds more than
+// EMD_LDS_IMAGES images).  A template parameter and not a run-time select: a pointer that may
+// be LDS or global compiles to a flat load, whose completion can only be awaited with
+// vmcnt(0) -- which would also wait for the gathers just issued for later steps.
+template <int MODE, bool EMD_LDS>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
     // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
@@ -103,8 +160,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         const Tile &tl = a.tiles[t];
         pt_begin = tl.pt_begin; pt_count = tl.pt_count; image = tl.image;
         rec_lo = tl.rec_begin + tl.group_off[grp];
-        rec_n = tl.group_off[grp + 1] - tl.group_off[grp];
+        rec_n = tl.group_cnt[grp];
     }
+    rec_lo = __builtin_amdgcn_readfirstlane(rec_lo);      // the same in every lane: keep them in SGPRs
+    rec_n = __builtin_amdgcn_readfirstlane(rec_n);
+    pt_begin = __builtin_amdgcn_readfirstlane(pt_begin);
+    pt_count = __builtin_amdgcn_readfirstlane(pt_count);
+    image = __builtin_amdgcn_readfirstlane(image);
     float4 *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
     unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
 
@@ -121,8 +183,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         px[k] = p.x; py[k] = p.y; pz[k] = p.z;
     }
     const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
-    const bool emd_lds = g_count <= (uint32_t)EMD_LDS_IMAGES;
-    if (emd_lds)
+    if (EMD_LDS)
         for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
     __syncthreads();
 
@@ -133,41 +194,40 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     for (int k = 0; k < ((MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2); k++) s[k] = 0.0;
     long long n_in = 0, n_out = 0;
 
-    // Software pipeline, by hand.  The step is one long dependent chain (gather -> ~200
-    // arithmetic instructions -> LDS election) and the kernel is bound by memory LATENCY, not
-    // by bandwidth or issue slots (measured: prefetch depth 1 -> 2 alone gave -11 %), so the
-    // partner point's 12-byte gather runs PREFETCH steps ahead and the record stream
-    // (non-temporal: read once per pass) one step further; own point and partner constants
-    // come from LDS.
-    const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(a.recs + rec_lo);
-    unsigned long long recq[PREFETCH + 1];          // records of steps r .. r+PREFETCH
-    P3 pbq[PREFETCH];                               // partner points of steps r .. r+PREFETCH-1
+    // Software pipeline, by hand.  A step is one long dependent chain (gather -> ~150 vector
+    // instructions -> LDS election), so the partner point's 12-byte gather runs PT_AHEAD steps
+    // ahead and the record stream (non-temporal: read once per pass; one 16-byte load per lane
+    // and chunk of two steps) CHUNK_AHEAD chunks; own point and partner constants come from
+    // LDS.  Two things keep the run-ahead real:
+    //  - the queues are rings indexed by compile-time constants inside an unrolled loop:
+    //    rotating them through registers makes the compiler wait for every outstanding load
+    //    (s_waitcnt vmcnt(0)) at the end of each step;
+    //  - every load is issued unconditionally, from an index clamped into the record array: a
+    //    load under a lane-dependent branch makes the number of loads in flight unknown to the
+    //    compiler, which then also waits with vmcnt(0).  Records read past the end of this
+    //    (tile, group) range are padding (null records: point 0) or a neighbour's: real
+    //    records, whose partner index is a real point, fetched and then ignored.
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 *rec2 = reinterpret_cast<const v2u64 *>(a.recs);
+    const uint32_t rec2_lo = rec_lo / 2u + lane;
+    auto chunk_at = [&](uint32_t c) { return __builtin_nontemporal_load(rec2 + min(rec2_lo + c * (REC_CHUNK / 2), a.rec2_last)); };
+    auto gather = [&](unsigned long long rq) { return a.pos2[(uint32_t)(rq >> 32)]; };
+    v2u64 cq[CHUNK_RING];
+    P3 pbq[PT_RING];
     #pragma unroll
-    for (int k = 0; k <= PREFETCH; k++) {
-        recq[k] = 0;
-        if ((uint32_t)lane + 64 * k < rec_n) recq[k] = __builtin_nontemporal_load(rec + lane + 64 * k);
-    }
+    for (int k = 0; k < CHUNK_RING; k++) cq[k] = (k < CHUNK_AHEAD) ? chunk_at(k) : (v2u64){ 0ull, 0ull };
     #pragma unroll
-    for (int k = 0; k < PREFETCH; k++) {
-        pbq[k] = P3{ 0.f, 0.f, 0.f };
-        if ((uint32_t)lane + 64 * k < rec_n) pbq[k] = a.pos2[(uint32_t)(recq[k] >> 32)];
-    }
-    for (uint32_t r = lane; r < rec_n; r += 64) {
-        const P3 pb = pbq[0];
-        const uint32_t ra = (uint32_t)recq[0];
+    for (int k = 0; k < PT_RING; k++) pbq[k] = (k < PT_AHEAD) ? gather((k & 1) ? cq[k / 2].y : cq[k / 2].x) : P3{ 0.f, 0.f, 0.f };
+
+    auto step = [&](const unsigned long long rq, const P3 pb) __attribute__((always_inline)) {
+        const uint32_t ra = (uint32_t)rq;
         const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
-        #pragma unroll
-        for (int k = 0; k < PREFETCH; k++) recq[k] = recq[k + 1];
-        #pragma unroll
-        for (int k = 0; k + 1 < PREFETCH; k++) pbq[k] = pbq[k + 1];
-        if (r + 64 * (PREFETCH + 1) < rec_n) recq[PREFETCH] = __builtin_nontemporal_load(rec + r + 64 * (PREFETCH + 1));
-        if (r + 64 * PREFETCH < rec_n) pbq[PREFETCH - 1] = a.pos2[(uint32_t)(recq[PREFETCH - 1] >> 32)];
         const P3 pa = { px[ia], py[ia], pz[ia] };
-        const EmDerived eB = emd_lds ? emd_s[(ra >> 8) - g_first] : a.emd[ra >> 8];
+        const EmDerived eB = EMD_LDS ? emd_s[(ra >> 8) - g_first] : a.emd[ra >> 8];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
-        const float d = sqrtf(d2);
+        const float d = sqrt_rn(d2);
         const float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
 
         if constexpr (MODE == SWEEP_LINEAR) {
@@ -189,10 +249,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             // order.  Duplicates are rare (two links of one point into one image).
             const bool inlier = w >= a.threshold;
             const float w2 = w * w;
-            if (inlier) {
-                s[1] += (double)w2;
-                s[0] += (double)(w2 * d2);
-            }
+            s[1] += (double)(inlier ? w2 : 0.0f);         // adding +0.0 leaves the f64 sums unchanged
+            s[0] += (double)(inlier ? w2 * d2 : 0.0f);
             bool pending = inlier;
             while (__ballot(pending)) {
                 if (pending) atomicMin(&own[ia], (unsigned int)lane);
@@ -211,6 +269,20 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         } else {
             // imageGroup.cxx:1022-1027
             if (w < a.threshold) n_out++; else n_in++;
+        }
+    };
+
+    const uint32_t n_steps = (rec_n + 63) / 64;          // wave-uniform
+    for (uint32_t base = 0; base < n_steps; base += BODY_STEPS) {
+        #pragma unroll
+        for (int j = 0; j < BODY_STEPS; j++) {
+            const uint32_t r = lane + 64 * (base + j);   // step base+j, lane -> record r of the range
+            if (j % 2 == 0) cq[(j / 2 + CHUNK_AHEAD) % CHUNK_RING] = chunk_at(base / 2 + j / 2 + CHUNK_AHEAD);
+            {
+                const v2u64 ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
+                pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
+            }
+            if (r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING]);
         }
     }
 

@@ -10,7 +10,8 @@
 // advance at about the same pace, the whole chip gathers partner coordinates
 // from a window of a few images at a time: the gathers hit the 4 MiB per-XCD L2
 // instead of scattering over the whole coordinate table.  Points are first renumbered
-// along a Morton curve inside each image (see Layout).  Within a point the
+// along a Morton curve inside each image (see Layout); inside one (tile, partner image)
+// segment the records are ordered by partner point.  Within a point the
 // order stays partner-ascending, which is the order readPairs produces for
 // files written by match (blocks i-major, j-ascending: imageGroup.cxx:1405-1406,
 // match.cpp:727-742), so per-point f32 sums keep the reference's order.
@@ -135,7 +136,6 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
         for (uint32_t i = out.group_begin[g]; i < out.group_begin[g + 1]; i++) group_of[i] = (uint8_t)g;
 
     // tiles
-    uint64_t rec_total = 0;
     out.img_tile_ptr.assign(nI + 1, 0);
     for (uint32_t i = ib; i < ie; i++) {
         const uint32_t np = poff[i + 1] - poff[i];
@@ -144,13 +144,6 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
             Tile tl{};
             tl.pt_begin = poff[i] + t * TILE_POINTS;          // NEW numbering
             tl.pt_count = std::min<uint32_t>(TILE_POINTS, poff[i + 1] - tl.pt_begin);
-            uint64_t nrec = 0;
-            for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
-                const uint32_t o = old_of_new[n];
-                nrec += m.row_ptr[o + 1] - m.row_ptr[o];
-            }
-            tl.rec_begin = (uint32_t)rec_total;
-            rec_total += nrec;
             tl.image = i;
             out.tiles.push_back(tl);
         }
@@ -159,12 +152,37 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
     for (uint32_t i = 0; i < ib; i++) out.img_tile_ptr[i + 1] = 0;
     for (uint32_t i = ie; i < nI; i++) out.img_tile_ptr[i + 1] = (uint32_t)out.tiles.size();
 
-    // partner-major records, stable counting sort per tile
-    out.recs.resize(L);
+    // records per (tile, group), then the padded offsets
     const long long nT = (long long)out.tiles.size();
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (long long t = 0; t < nT; t++) {
+        Tile &tl = out.tiles[t];
+        for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
+            const uint32_t o = old_of_new[n];
+            for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) tl.group_cnt[group_of[m.link_image[l]]]++;
+        }
+    }
+    uint64_t rec_total = 0;
+    for (long long t = 0; t < nT; t++) {
+        Tile &tl = out.tiles[t];
+        tl.rec_begin = (uint32_t)rec_total;
+        uint32_t off = 0;
+        for (int g = 0; g < N_GROUPS; g++) {
+            tl.group_off[g] = off;
+            off += (tl.group_cnt[g] + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK;
+        }
+        rec_total += off;
+        if (rec_total >= 0xFFFFFFFFull) { err = "more than 2^32-1 link records in one context"; return FROG_E_INVALID; }
+    }
+    if (rec_total == 0) rec_total = REC_CHUNK;               // the sweep's clamped prefetch needs one readable chunk
+
+    // partner-major records, stable counting sort per tile
+    out.recs.assign(rec_total, LinkRec{ 0u, 0u });
     #pragma omp parallel
     {
         std::vector<uint32_t> cnt(nI + 1);
+        std::vector<LinkRec> orig, logical;
+        uint16_t seen[TILE_POINTS];
         #pragma omp for schedule(dynamic, 16)
         for (long long t = 0; t < nT; t++) {
             const Tile &tl = out.tiles[t];
@@ -174,11 +192,10 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
                 for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) cnt[m.link_image[l] + 1]++;
             }
             for (uint32_t i = 0; i < nI; i++) cnt[i + 1] += cnt[i];
-            {
-                Tile &wt = out.tiles[t];
-                for (int g = 0; g <= N_GROUPS; g++) wt.group_off[g] = cnt[out.group_begin[g]];
-            }
-            LinkRec *dst = out.recs.data() + tl.rec_begin;
+            uint32_t group_first[N_GROUPS + 1];               // logical (unpadded) start of every group
+            for (int g = 0; g <= N_GROUPS; g++) group_first[g] = cnt[out.group_begin[g]];
+            logical.resize(cnt[nI]);
+            LinkRec *dst = logical.data();
             for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
                 const uint32_t o = old_of_new[n];
                 for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) {
@@ -187,6 +204,44 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
                     r.b = out.ref_link[l - l0];
                     dst[cnt[m.link_image[l]]++] = r;
                 }
+            }
+            // Inside one (tile, partner image) segment the records are re-ordered by partner
+            // point, so that the 64 gathers of a step fall on few cache lines.  The order in
+            // which ONE own point meets its links must stay the reference's, so records of the
+            // segment that share their own point (rare: two matches of one keypoint into the
+            // same image) keep their original relative order in the slots they get.
+            uint32_t seg_b = 0;
+            for (uint32_t i = 0; i < nI; i++) {
+                const uint32_t seg_e = cnt[i];              // after placement: end of segment i
+                if (seg_e - seg_b > 1) {
+                    LinkRec *sg = dst + seg_b;
+                    const uint32_t n = seg_e - seg_b;
+                    orig.assign(sg, sg + n);
+                    std::stable_sort(sg, sg + n, [](const LinkRec &x, const LinkRec &y) { return x.b < y.b; });
+                    std::fill(seen, seen + TILE_POINTS, (uint16_t)0);
+                    bool dup = false;
+                    for (uint32_t k = 0; k < n; k++) dup |= (++seen[orig[k].a & 0xFFu] > 1);
+                    if (dup) {
+                        // slots (ascending) of every own point in the sorted segment <- its records in original order
+                        for (uint32_t pt = 0; pt < (uint32_t)TILE_POINTS; pt++) {
+                            if (seen[pt] < 2) continue;
+                            uint32_t src = 0;
+                            for (uint32_t k = 0; k < n; k++) {
+                                if ((sg[k].a & 0xFFu) != pt) continue;
+                                while ((orig[src].a & 0xFFu) != pt) src++;
+                                sg[k] = orig[src++];
+                            }
+                        }
+                    }
+                }
+                seg_b = seg_e;
+            }
+            // logical order -> chunked, transposed storage (ctx.h, REC_CHUNK)
+            for (int g = 0; g < N_GROUPS; g++) {
+                LinkRec *phys = out.recs.data() + tl.rec_begin + tl.group_off[g];
+                const LinkRec *src = dst + group_first[g];
+                for (uint32_t k = 0; k < tl.group_cnt[g]; k++)
+                    phys[(k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u] = src[k];
             }
         }
     }
