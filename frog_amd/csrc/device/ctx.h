@@ -97,14 +97,23 @@ struct Tile {
 };
 static_assert(sizeof(Tile) % 16 == 0, "Tile is loaded with vector loads");
 
-// One half-link, 8 bytes (the size of the reference's Link, point.h:11-16):
+// One half-link.  Wide form, 8 bytes (the size of the reference's Link, point.h:11-16):
 //   a = (partner image << 8) | index of the own point inside its tile (TILE_POINTS <= 256)
 //   b = global index of the partner point
 // The partner image rides in the record so that its EM constants can be fetched
 // together with the coordinate gathers instead of after them.
+// Narrow form, 4 bytes, used whenever it fits (RecFormat):
+//   [ partner point inside its image | partner image inside its group | own point ]
+//     pt_bits                          img_bits                         8
+// The sweep is bound by the time its cache misses spend in flight (records come from HBM,
+// ~5x the latency of the L2-resident coordinates), so halving the record stream pays directly.
 struct LinkRec {
     uint32_t a;
     uint32_t b;
+};
+struct RecFormat {
+    uint32_t narrow;        // 1: 4-byte records
+    uint32_t img_bits;      // narrow only
 };
 static_assert(TILE_POINTS <= 256, "own-point index must fit 8 bits of LinkRec::a");
 
@@ -160,7 +169,9 @@ struct frog_ctx {
     std::vector<uint32_t> h_old_of_new, h_new_of_old;   // internal (Morton) <-> reference point numbering
     frog::DevBuf<uint32_t> new_of_old;        // [ownP] for the owned rows (reservoir: ordinal -> point)
     frog::DevBuf<frog::Tile> tiles;
-    frog::DevBuf<frog::LinkRec> recs;
+    frog::DevBuf<frog::LinkRec> recs;         // wide records, or ...
+    frog::DevBuf<uint32_t> recs32;            // ... narrow records (exactly one of the two is filled)
+    frog::RecFormat rec_format{};
     uint32_t n_tiles = 0;
     frog::DevBuf<uint32_t> img_tile_ptr;      // [nI+1] tiles of image (owned only non-empty)
     std::vector<uint32_t> h_img_tile_ptr;

@@ -9,6 +9,7 @@
 #include "k_grid.hip.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <new>
 
@@ -64,8 +65,9 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     SweepArgs a;
     a.sub = sub;
     for (int g = 0; g <= N_GROUPS; g++) a.group_begin[g] = ctx->group_begin[g];
-    a.tiles = ctx->tiles.p; a.recs = ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
+    a.img_bits = ctx->rec_format.img_bits; a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
@@ -77,10 +79,12 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s)
 {
     uint32_t widest = 0;
     for (int g = 0; g < N_GROUPS; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
-    if (widest <= (uint32_t)EMD_LDS_IMAGES)
-        sweep_kernel<MODE, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+    if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
+        sweep_kernel<MODE, true, false><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+    else if (widest <= (uint32_t)EMD_LDS_IMAGES)
+        sweep_kernel<MODE, true, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
     else
-        sweep_kernel<MODE, false><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+        sweep_kernel<MODE, false, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
 }
 
 extern "C" {
@@ -137,10 +141,13 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
 
     Layout lay;
     std::string err;
-    int rc = build_layout(*m, c->ib, c->ie, lay, err);
+    // FROG_WIDE_RECORDS=1 keeps the 8-byte record form where the 4-byte one would fit (test hook)
+    const char *wide_env = getenv("FROG_WIDE_RECORDS");
+    int rc = build_layout(*m, c->ib, c->ie, wide_env && wide_env[0] == '1', lay, err);
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.ref_link.size();
-    c->L_recs = lay.recs.size();
+    c->rec_format = lay.format;
+    c->L_recs = lay.format.narrow ? lay.recs32.size() : lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
     for (int g = 0; g <= N_GROUPS; g++) c->group_begin[g] = lay.group_begin[g];
     c->h_old_of_new = lay.old_of_new;
@@ -199,7 +206,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(hipStreamSynchronize(s));
     }
     CREATE_CHECK(c->tiles.upload(lay.tiles, s));
-    CREATE_CHECK(c->recs.upload(lay.recs, s));
+    if (lay.format.narrow) { CREATE_CHECK(c->recs32.upload(lay.recs32, s)); }
+    else { CREATE_CHECK(c->recs.upload(lay.recs, s)); }
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
     CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * LINEAR_SUMS));
     CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * 2));

@@ -23,6 +23,8 @@
 
 #include "ctx.h"
 
+#include <type_traits>
+
 namespace frog {
 
 enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
@@ -39,7 +41,10 @@ constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sW
 
 struct SweepArgs {
     const Tile *tiles;
-    const LinkRec *recs;
+    const void *recs;           // LinkRec (wide) or uint32_t (narrow) records, ctx.h
+    const uint32_t *poff;       // [n_images + 1] first point of every image
+    uint32_t img_bits;          // narrow records: bits of the partner image field
+    uint32_t point_last;        // index of the last point of the model
     const P3 *pos2;
     const EmDerived *emd;
     uint32_t n_tiles;
@@ -129,7 +134,8 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // EMD_LDS_IMAGES images).  A template parameter and not a run-time select: a pointer that may
 // be LDS or global compiles to a flat load, whose completion can only be awaited with
 // vmcnt(0) -- which would also wait for the gathers just issued for later steps.
-template <int MODE, bool EMD_LDS>
+// WIDE: 8-byte records (ctx.h LinkRec); otherwise the 4-byte form.
+template <int MODE, bool EMD_LDS, bool WIDE>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
     // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // images (per block) live in LDS; only the partner point is gathered from memory.
     __shared__ float own_x[4 * TILE_POINTS], own_y[4 * TILE_POINTS], own_z[4 * TILE_POINTS];
     __shared__ EmDerived emd_s[EMD_LDS_IMAGES];
+    __shared__ uint32_t img_base_s[WIDE ? 1 : EMD_LDS_IMAGES];      // narrow records: first point of the group's images
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -185,6 +192,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
     if (EMD_LDS)
         for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
+    if (!WIDE)
+        for (uint32_t k = threadIdx.x; k < (uint32_t)EMD_LDS_IMAGES; k += 256) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
     __syncthreads();
 
     const EmDerived eA = a.emd[image];
@@ -208,22 +217,36 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     //    (tile, group) range are padding (null records: point 0) or a neighbour's: real
     //    records, whose partner index is a real point, fetched and then ignored.
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
-    const v2u64 *rec2 = reinterpret_cast<const v2u64 *>(a.recs);
+    typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+    using Rec = std::conditional_t<WIDE, unsigned long long, unsigned int>;
+    using Chunk = std::conditional_t<WIDE, v2u64, v2u32>;          // the lane's records of two steps
+    const Chunk *rec2 = reinterpret_cast<const Chunk *>(a.recs);
     const uint32_t rec2_lo = rec_lo / 2u + lane;
+    const uint32_t img_bits = a.img_bits;
     auto chunk_at = [&](uint32_t c) { return __builtin_nontemporal_load(rec2 + min(rec2_lo + c * (REC_CHUNK / 2), a.rec2_last)); };
-    auto gather = [&](unsigned long long rq) { return a.pos2[(uint32_t)(rq >> 32)]; };
-    v2u64 cq[CHUNK_RING];
+    // record fields: own point in the tile, partner image (index into emd_s / img_base_s), partner point
+    auto own_of = [&](Rec rq) { return (uint32_t)rq & 0xFFu; };
+    auto img_of = [&](Rec rq) {
+        if constexpr (WIDE) return ((uint32_t)rq >> 8) - (EMD_LDS ? g_first : 0u);
+        else return __builtin_amdgcn_ubfe((uint32_t)rq, 8u, img_bits);
+    };
+    auto gather = [&](Rec rq) {
+        if constexpr (WIDE) return a.pos2[(uint32_t)(rq >> 32)];
+        // the clamp matters for records prefetched past this range only: a neighbour's record is
+        // relative to ITS group's images and may decode to any index here
+        else return a.pos2[min(img_base_s[img_of(rq)] + ((uint32_t)rq >> (8u + img_bits)), a.point_last)];
+    };
+    Chunk cq[CHUNK_RING];
     P3 pbq[PT_RING];
     #pragma unroll
-    for (int k = 0; k < CHUNK_RING; k++) cq[k] = (k < CHUNK_AHEAD) ? chunk_at(k) : (v2u64){ 0ull, 0ull };
+    for (int k = 0; k < CHUNK_RING; k++) cq[k] = (k < CHUNK_AHEAD) ? chunk_at(k) : Chunk{ 0, 0 };
     #pragma unroll
     for (int k = 0; k < PT_RING; k++) pbq[k] = (k < PT_AHEAD) ? gather((k & 1) ? cq[k / 2].y : cq[k / 2].x) : P3{ 0.f, 0.f, 0.f };
 
-    auto step = [&](const unsigned long long rq, const P3 pb) __attribute__((always_inline)) {
-        const uint32_t ra = (uint32_t)rq;
-        const uint32_t ia = ra & 0xFFu;                 // own point inside the tile
+    auto step = [&](const Rec rq, const P3 pb) __attribute__((always_inline)) {
+        const uint32_t ia = own_of(rq);                 // own point inside the tile
         const P3 pa = { px[ia], py[ia], pz[ia] };
-        const EmDerived eB = EMD_LDS ? emd_s[(ra >> 8) - g_first] : a.emd[ra >> 8];
+        const EmDerived eB = EMD_LDS ? emd_s[img_of(rq)] : a.emd[img_of(rq)];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             const uint32_t r = lane + 64 * (base + j);   // step base+j, lane -> record r of the range
             if (j % 2 == 0) cq[(j / 2 + CHUNK_AHEAD) % CHUNK_RING] = chunk_at(base / 2 + j / 2 + CHUNK_AHEAD);
             {
-                const v2u64 ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
+                const Chunk ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
                 pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
             }
             if (r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING]);

@@ -38,7 +38,9 @@ struct Layout {
     // its 4 MiB L2 -- also for false matches, whose partner points are uniformly random.
     std::vector<uint32_t> group_begin;      // [N_GROUPS + 1]
     std::vector<Tile> tiles;
-    std::vector<LinkRec> recs;
+    std::vector<LinkRec> recs;              // wide records, or
+    std::vector<uint32_t> recs32;           // narrow records (RecFormat)
+    RecFormat format{};
     std::vector<uint32_t> img_tile_ptr;     // [nI + 1]
     std::vector<uint64_t> ref_rowptr;       // owned rows, relative to first owned link
     std::vector<uint32_t> ref_link;         // partner global index, reference order
@@ -89,12 +91,13 @@ inline void build_numbering(const frog_model &m, Layout &out)
     }
 }
 
-inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &out, std::string &err)
+inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool force_wide, Layout &out, std::string &err)
 {
     const uint32_t nI = m.n_images;
     const uint32_t *poff = m.point_offset;
     build_numbering(m, out);
     const std::vector<uint32_t> &new_of_old = out.new_of_old, &old_of_new = out.old_of_new;
+    const uint32_t *new_of_old_base = poff;      // internal numbering keeps every image's index range
     const uint32_t p0 = poff[ib], p1 = poff[ie];
     const uint64_t l0 = m.row_ptr[p0], l1 = m.row_ptr[p1];
     const uint64_t L = l1 - l0;
@@ -176,8 +179,22 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
     }
     if (rec_total == 0) rec_total = REC_CHUNK;               // the sweep's clamped prefetch needs one readable chunk
 
+    // record format: narrow when (own point, partner image in its group, partner point in its image) fit 32 bits
+    {
+        uint32_t widest_group = 1, largest_image = 1;
+        for (int g = 0; g < N_GROUPS; g++) widest_group = std::max(widest_group, out.group_begin[g + 1] - out.group_begin[g]);
+        for (uint32_t i = 0; i < nI; i++) largest_image = std::max(largest_image, poff[i + 1] - poff[i]);
+        auto bits_for = [](uint32_t n) { uint32_t b = 1; while ((1ull << b) < n) b++; return b; };   // values 0 .. n-1
+        const uint32_t img_bits = bits_for(widest_group), pt_bits = bits_for(largest_image);
+        out.format.narrow = (8 + img_bits + pt_bits <= 32 && !force_wide) ? 1u : 0u;
+        out.format.img_bits = img_bits;
+    }
+    const bool narrow = out.format.narrow != 0;
+    const uint32_t img_bits = out.format.img_bits;
+
     // partner-major records, stable counting sort per tile
-    out.recs.assign(rec_total, LinkRec{ 0u, 0u });
+    if (narrow) out.recs32.assign(rec_total, 0u);
+    else out.recs.assign(rec_total, LinkRec{ 0u, 0u });
     #pragma omp parallel
     {
         std::vector<uint32_t> cnt(nI + 1);
@@ -238,10 +255,18 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, Layout &o
             }
             // logical order -> chunked, transposed storage (ctx.h, REC_CHUNK)
             for (int g = 0; g < N_GROUPS; g++) {
-                LinkRec *phys = out.recs.data() + tl.rec_begin + tl.group_off[g];
+                const size_t at = (size_t)tl.rec_begin + tl.group_off[g];
                 const LinkRec *src = dst + group_first[g];
-                for (uint32_t k = 0; k < tl.group_cnt[g]; k++)
-                    phys[(k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u] = src[k];
+                for (uint32_t k = 0; k < tl.group_cnt[g]; k++) {
+                    const size_t phys = at + (k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u;
+                    if (narrow) {
+                        const uint32_t img = src[k].a >> 8;
+                        out.recs32[phys] = ((src[k].b - new_of_old_base[img]) << (8 + img_bits))
+                                         | ((img - out.group_begin[g]) << 8) | (src[k].a & 0xFFu);
+                    } else {
+                        out.recs[phys] = src[k];
+                    }
+                }
             }
         }
     }

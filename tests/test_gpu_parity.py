@@ -316,3 +316,38 @@ def test_external_stream_and_sub_range_context(tiny_pairs):
     assert lib.frog_update_stats_local(part._ctx) == _abi.FROG_OK
     em = np.array([part.em(i) for i in range(4)])
     assert not em[0].any() and not em[3].any() and em[1].all() and em[2].all()   # other ranks' rows are zero
+
+
+@pytest.mark.parametrize("which", ["small", "ragged"])
+def test_wide_and_narrow_link_records_agree_bit_for_bit(small_pairs, which, monkeypatch):
+    # The sweep reads 4-byte link records when the field widths allow it and 8-byte ones
+    # otherwise (ctx.h RecFormat); FROG_WIDE_RECORDS=1 forces the 8-byte form at frog_create.
+    # Same links in the same order, so every observable must be identical.
+    pairs = small_pairs if which == "small" else ragged_pairs()
+
+    def run(wide):
+        if wide:
+            monkeypatch.setenv("FROG_WIDE_RECORDS", "1")
+        else:
+            monkeypatch.delenv("FROG_WIDE_RECORDS", raising=False)
+        g = ImageGroup(pairs, stats_max_size=2000)
+        g.setupLinearTransforms(); g.transformPoints()
+        out = []
+        for it in range(6):
+            if it % 5 == 0:
+                g.updateStats()
+            out.append(g.updateLinearTransforms())
+            g.transformPoints()
+        g.transformPoints(True)
+        g.setupDeformableTransforms(1); g.transformPoints()
+        g.updateStats()
+        out.append(g.updateDeformableTransforms(0.02))
+        sums = g.point_sums().copy()
+        counts = [(c.inliers, c.outliers) for c in g.countInliers()]
+        return out, sums, counts
+
+    e_n, s_n, c_n = run(False)
+    e_w, s_w, c_w = run(True)
+    assert e_n == e_w
+    assert np.array_equal(s_n, s_w)
+    assert c_n == c_w
