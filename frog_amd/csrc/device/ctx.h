@@ -193,6 +193,8 @@ struct frog_ctx {
     int sel_ready = 0;                        // buffer the pending/ready selection is written to
     int sel_used = 0;                         // buffer the last refresh consumed
     hipStream_t side = nullptr;
+    hipEvent_t energy_copied = nullptr;       // the four scalars of the last step are in h_energy
+    bool xyz2_exported = false;               // frog_comm_buffer handed out pos2: its address must not change
     hipEvent_t sel_done = nullptr;            // selection `sel_ready` complete (side stream)
     hipEvent_t ord_read[2] = { nullptr, nullptr };   // last reader of sample_ord[b] done (main stream)
     frog::DevBuf<uint32_t> mt_state;          // [nOwned][625] (624 words + index)

@@ -105,6 +105,7 @@ void frog_destroy(frog_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->sel_done) (void)hipEventDestroy(ctx->sel_done);
+    if (ctx->energy_copied) (void)hipEventDestroy(ctx->energy_copied);
     for (int b = 0; b < 2; b++) if (ctx->ord_read[b]) (void)hipEventDestroy(ctx->ord_read[b]);
     for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -241,6 +242,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
     }
     CREATE_CHECK(hipEventCreateWithFlags(&c->sel_done, hipEventDisableTiming));
+    CREATE_CHECK(hipEventCreateWithFlags(&c->energy_copied, hipEventDisableTiming));
     {
         // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
         std::vector<uint32_t> st((size_t)c->n_owned() * MT_WORDS);
@@ -345,6 +347,11 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
     if (ctx->xyz2_fresh && !apply) {
         // already computed behind the last deformable step (frog_deformable_phase_c): publish it
         ctx->xyz2_fresh = false;
+        if (ctx->n_owned() == ctx->nI && !ctx->xyz2_exported && ctx->pos2_spec.n == ctx->pos2.n) {
+            std::swap(ctx->pos2.p, ctx->pos2_spec.p);           // whole table recomputed, nobody holds its address
+            std::swap(ctx->pos2.cap, ctx->pos2_spec.cap);
+            return FROG_OK;
+        }
         FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p + ctx->own_pt_begin, ctx->pos2_spec.p + ctx->own_pt_begin,
                                       (size_t)n * sizeof(P3), hipMemcpyDeviceToDevice, ctx->stream));
         return FROG_OK;
@@ -667,6 +674,11 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     // compute, into a shadow buffer, the transformPoints() that run() calls next in either
     // case (accepted: :118 with the new coefficients; rejected: the coefficients are
     // unchanged) -- the GPU keeps working while the host waits for the three scalars.
+    // The host only needs the scalars: they are copied out first, and the wait below is for
+    // that copy alone, so commit and transform run while the host is already preparing the
+    // next call.
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipEventRecord(ctx->energy_copied, ctx->stream));
     const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
     {
         Span span(ctx, FROG_K_LATTICE);
@@ -678,9 +690,8 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     int rc = launch_transform(ctx, ctx->pos2_spec.p, 0);        // xyz2 itself changes only when the caller asks
     if (rc) return rc;
     ctx->xyz2_fresh = true;
-    double e = 0, nbig = 0;
-    rc = frog_energy_read(ctx, &e, &nbig);
-    if (rc) return rc;
+    FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
+    const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
     ctx->phase = 0;
     if (E) *E = (ctx->opt.guarantee_diffeomorphism && nbig > 0) ? -1.0 : e;      // :434-439
     return FROG_OK;
@@ -895,7 +906,7 @@ int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t
     size_t b = 0, rb = 0, re = 0;
     void *p = nullptr;
     switch (which) {
-    case FROG_BUF_XYZ2: p = ctx->pos2.p; b = ctx->pos2.bytes(); rb = ctx->own_pt_begin; re = ctx->own_pt_end; break;
+    case FROG_BUF_XYZ2: ctx->xyz2_exported = true; p = ctx->pos2.p; b = ctx->pos2.bytes(); rb = ctx->own_pt_begin; re = ctx->own_pt_end; break;
     case FROG_BUF_EM: p = ctx->em.p; b = ctx->em.bytes(); rb = ctx->ib; re = ctx->ie; break;
     case FROG_BUF_ENERGY: p = ctx->energy.p; b = ctx->energy.bytes(); rb = 0; re = 4; break;
     case FROG_BUF_GRIDSUM:

@@ -10,8 +10,7 @@
 // advance at about the same pace, the whole chip gathers partner coordinates
 // from a window of a few images at a time: the gathers hit the 4 MiB per-XCD L2
 // instead of scattering over the whole coordinate table.  Points are first renumbered
-// along a Morton curve inside each image (see Layout); inside one (tile, partner image)
-// segment the records are ordered by partner point.  Within a point the
+// along a Morton curve inside each image (see Layout).  Within a point the
 // order stays partner-ascending, which is the order readPairs produces for
 // files written by match (blocks i-major, j-ascending: imageGroup.cxx:1405-1406,
 // match.cpp:727-742), so per-point f32 sums keep the reference's order.
@@ -198,8 +197,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     #pragma omp parallel
     {
         std::vector<uint32_t> cnt(nI + 1);
-        std::vector<LinkRec> orig, logical;
-        uint16_t seen[TILE_POINTS];
+        std::vector<LinkRec> logical;
         #pragma omp for schedule(dynamic, 16)
         for (long long t = 0; t < nT; t++) {
             const Tile &tl = out.tiles[t];
@@ -221,37 +219,6 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
                     r.b = out.ref_link[l - l0];
                     dst[cnt[m.link_image[l]]++] = r;
                 }
-            }
-            // Inside one (tile, partner image) segment the records are re-ordered by partner
-            // point, so that the 64 gathers of a step fall on few cache lines.  The order in
-            // which ONE own point meets its links must stay the reference's, so records of the
-            // segment that share their own point (rare: two matches of one keypoint into the
-            // same image) keep their original relative order in the slots they get.
-            uint32_t seg_b = 0;
-            for (uint32_t i = 0; i < nI; i++) {
-                const uint32_t seg_e = cnt[i];              // after placement: end of segment i
-                if (seg_e - seg_b > 1) {
-                    LinkRec *sg = dst + seg_b;
-                    const uint32_t n = seg_e - seg_b;
-                    orig.assign(sg, sg + n);
-                    std::stable_sort(sg, sg + n, [](const LinkRec &x, const LinkRec &y) { return x.b < y.b; });
-                    std::fill(seen, seen + TILE_POINTS, (uint16_t)0);
-                    bool dup = false;
-                    for (uint32_t k = 0; k < n; k++) dup |= (++seen[orig[k].a & 0xFFu] > 1);
-                    if (dup) {
-                        // slots (ascending) of every own point in the sorted segment <- its records in original order
-                        for (uint32_t pt = 0; pt < (uint32_t)TILE_POINTS; pt++) {
-                            if (seen[pt] < 2) continue;
-                            uint32_t src = 0;
-                            for (uint32_t k = 0; k < n; k++) {
-                                if ((sg[k].a & 0xFFu) != pt) continue;
-                                while ((orig[src].a & 0xFFu) != pt) src++;
-                                sg[k] = orig[src++];
-                            }
-                        }
-                    }
-                }
-                seg_b = seg_e;
             }
             // logical order -> chunked, transposed storage (ctx.h, REC_CHUNK)
             for (int g = 0; g < N_GROUPS; g++) {

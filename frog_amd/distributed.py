@@ -78,7 +78,12 @@ class HipEngine:
         torch.cuda.set_device(device)
         check(self._lib.frog_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
               "frog_set_stream")
-        self.xyz2, (self.pt_begin, self.pt_end) = self._buffer(_abi.FROG_BUF_XYZ2, "<f4", 3)
+        # A context that owns every image never exchanges coordinates: leave its xyz2 table
+        # unexported, so that the library may swap buffers instead of copying (frog_transform_points).
+        self.xyz2 = None
+        self.pt_begin, self.pt_end = int(pairs.point_offset[b]), int(pairs.point_offset[e])
+        if (b, e) != (0, pairs.n_images):
+            self.xyz2, _ = self._buffer(_abi.FROG_BUF_XYZ2, "<f4", 3)
         self.em, _ = self._buffer(_abi.FROG_BUF_EM, "<f4", 4)
         self.energy, _ = self._buffer(_abi.FROG_BUF_ENERGY, "<f8", 1)
         self.gridsum = None
@@ -174,6 +179,14 @@ class HipEngine:
 
     def num_grids(self):
         return self._lib.frog_num_grids(self._ctx)
+
+    def points(self):
+        """(xyz, xyz2) of every point in the model's order (rows of other ranks: this rank's replica)."""
+        n = int(self.pairs.point_offset[-1])
+        xyz, xyz2 = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        check(self._lib.frog_get_points(self._ctx, xyz.ctypes.data_as(_abi.c_float_p),
+                                        xyz2.ctypes.data_as(_abi.c_float_p)), "frog_get_points")
+        return xyz, xyz2
 
     def profile_enable(self, on=True):
         check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")

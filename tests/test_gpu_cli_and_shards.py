@@ -123,7 +123,7 @@ b, e = shards[rank]
 res = {"E": E, "grids": g.gridsPerLevel, "range": [b, e],
        "matrix": {i: eng.matrix(i).tolist() for i in range(b, e)},
        "coeff": {i: [eng.grid(i, k)[1].tolist() for k in range(eng.num_grids())] for i in range(b, e)},
-       "xyz2": eng.xyz2.cpu().numpy()[:, :3].tolist()}
+       "xyz2": eng.points()[1].tolist()}
 json.dump(res, open(sys.argv[2] + f".{rank}", "w"))
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
