@@ -503,39 +503,54 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
 }
 
 // ---- K8 + first half of K9: control-point step and sum over owned images --------
-// thread per control point; images in ascending order (imageGroup.cxx:346-375, :411-415)
-__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *coeff, float4 *gradf,
-                                                         float4 *grad, uint32_t n_owned,
-                                                         int n_cp, float alpha, double *gridsum,
+// thread per control point; images in ascending order (imageGroup.cxx:346-375, :411-415).
+// Both kernels walk the images of one control point in order (the f64 sum keeps the
+// reference's order); with one load per step that walk is a chain of ~n_images memory
+// round trips on a handful of wavefronts (46-76 us at every lattice size).  The loads of
+// CP_BATCH images are therefore issued together before any of them is used.
+constexpr int CP_BATCH = 10;
+
+__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *__restrict__ coeff, float4 *__restrict__ gradf,
+                                                         float4 *__restrict__ grad, uint32_t n_owned,
+                                                         int n_cp, float alpha, double *__restrict__ gridsum,
                                                          unsigned long long *n_big)
 {
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
     if (cp == 0) *n_big = 0ull;                 // counted by cp_center_kernel, later in the stream
     if (cp >= n_cp) return;
     double sx = 0, sy = 0, sz = 0;
-    for (uint32_t i = 0; i < n_owned; i++) {
-        const size_t o = (size_t)i * n_cp + cp;
-        const float4 g4 = gradf[o];
-        gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);      // Fill(0) for the next step (imageGroup.cxx:249)
-        const float4 c4 = coeff[o];
-        float4 n4;
-        if (g4.w > 0) {
-            n4.x = c4.x + alpha * g4.x / g4.w;
-            n4.y = c4.y + alpha * g4.y / g4.w;
-            n4.z = c4.z + alpha * g4.z / g4.w;
-        } else {
-            n4.x = c4.x; n4.y = c4.y; n4.z = c4.z;
+    for (uint32_t i0 = 0; i0 < n_owned; i0 += CP_BATCH) {
+        float4 g4[CP_BATCH], c4[CP_BATCH];
+        #pragma unroll
+        for (int b = 0; b < CP_BATCH; b++) {
+            const size_t o = (size_t)min(i0 + b, n_owned - 1) * n_cp + cp;
+            g4[b] = gradf[o];
+            c4[b] = coeff[o];
         }
-        n4.w = g4.w;
-        grad[o] = n4;
-        sx += n4.x; sy += n4.y; sz += n4.z;
+        #pragma unroll
+        for (int b = 0; b < CP_BATCH; b++) {
+            if (i0 + b >= n_owned) break;
+            const size_t o = (size_t)(i0 + b) * n_cp + cp;
+            gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);      // Fill(0) for the next step (imageGroup.cxx:249)
+            float4 n4;
+            if (g4[b].w > 0) {
+                n4.x = c4[b].x + alpha * g4[b].x / g4[b].w;
+                n4.y = c4[b].y + alpha * g4[b].y / g4[b].w;
+                n4.z = c4[b].z + alpha * g4[b].z / g4[b].w;
+            } else {
+                n4.x = c4[b].x; n4.y = c4[b].y; n4.z = c4[b].z;
+            }
+            n4.w = g4[b].w;
+            grad[o] = n4;
+            sx += n4.x; sy += n4.y; sz += n4.z;
+        }
     }
     gridsum[3 * (size_t)cp] = sx; gridsum[3 * (size_t)cp + 1] = sy; gridsum[3 * (size_t)cp + 2] = sz;
 }
 
 // ---- second half of K9: subtract the group mean, count oversize coefficients -----
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
-__global__ __launch_bounds__(256) void cp_center_kernel(float4 *grad, uint32_t n_owned, int n_cp, uint32_t n_images,
+__global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
                                                         unsigned long long *n_big)
 {
@@ -546,14 +561,19 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *grad, uint32_t n
         const double mx = gridsum[3 * (size_t)cp] / n_images;
         const double my = gridsum[3 * (size_t)cp + 1] / n_images;
         const double mz = gridsum[3 * (size_t)cp + 2] / n_images;
-        for (uint32_t i = 0; i < n_owned; i++) {
-            const size_t o = (size_t)i * n_cp + cp;
-            float4 v = grad[o];
-            v.x = (float)((double)v.x - mx);
-            v.y = (float)((double)v.y - my);
-            v.z = (float)((double)v.z - mz);
-            grad[o] = v;
-            cnt += ((double)fabsf(v.x) > lim_x) + ((double)fabsf(v.y) > lim_y) + ((double)fabsf(v.z) > lim_z);
+        for (uint32_t i0 = 0; i0 < n_owned; i0 += CP_BATCH) {
+            float4 v[CP_BATCH];
+            #pragma unroll
+            for (int b = 0; b < CP_BATCH; b++) v[b] = grad[(size_t)min(i0 + b, n_owned - 1) * n_cp + cp];
+            #pragma unroll
+            for (int b = 0; b < CP_BATCH; b++) {
+                if (i0 + b >= n_owned) break;
+                v[b].x = (float)((double)v[b].x - mx);
+                v[b].y = (float)((double)v[b].y - my);
+                v[b].z = (float)((double)v[b].z - mz);
+                grad[(size_t)(i0 + b) * n_cp + cp] = v[b];
+                cnt += ((double)fabsf(v[b].x) > lim_x) + ((double)fabsf(v[b].y) > lim_y) + ((double)fabsf(v[b].z) > lim_z);
+            }
         }
     }
     sh[threadIdx.x] = cnt;
