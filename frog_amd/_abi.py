@@ -82,7 +82,7 @@ class FrogKernelTime(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
 
 
-FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats"]
+FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM = range(6)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 

@@ -624,12 +624,15 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
         for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
             launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
-        combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
-            ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy_blocks.p);
-    energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
+    {
+        Span span(ctx, FROG_K_COMBINE);
+        combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
+            ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
+        energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy_blocks.p);
+        energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);

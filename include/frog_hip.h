@@ -150,6 +150,7 @@ enum {
     FROG_K_LATTICE,            /* control-point step, mean removal, commit      */
     FROG_K_TRANSFORM,          /* transformPoints                               */
     FROG_K_STATS,              /* reservoir + distances + EM fit                */
+    FROG_K_COMBINE,            /* per-point sums of the partner groups added up, energy reduction */
     FROG_K_COUNT_
 };
 typedef struct frog_kernel_time {

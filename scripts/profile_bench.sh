@@ -1,0 +1,24 @@
+#!/bin/bash
+# profile_bench.sh TAG -- on the GPU box: bench line + rocprofv3 kernel stats + HBM/L2 counter passes,
+# condensed into gpurun_out/TAG_bench_n1.{json,txt} (copy the two files into profiles/ to keep them).
+set -e
+TAG=${1:-prof}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+O=gpurun_out/$TAG
+mkdir -p $O
+python3 bench.py --steps 65 --warmup 10 > $O/bench.json 2> $O/bench.err
+ARGS="bench.py --steps 65 --warmup 10 --no-cpu-baseline"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python3 $ARGS > $O/under_rocprof.json 2> $O/trace.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/fetch.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/write.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum -d $O/tcc -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/tcc.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $O/tcp -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/tcp.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/sq -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/sq.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -d $O/ta -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/ta.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum -d $O/lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/lat.log
+python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat > /dev/null
+cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
+cp $O/under_rocprof.json gpurun_out/${TAG}_bench_n1_under_rocprof.json
+head -12 gpurun_out/${TAG}_bench_n1.txt
+python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_n1.json')); print(d['value'], d['roofline'], d['cpu_baseline']['value'])"
