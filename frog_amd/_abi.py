@@ -83,7 +83,7 @@ class FrogKernelTime(C.Structure):
 
 
 FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine"]
-FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM = range(6)
+FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM, FROG_E_IO = range(7)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 
 # name -> (restype, argtypes): every symbol include/frog_hip.h declares
@@ -115,6 +115,8 @@ HIP_SYMBOLS = {
     "frog_get_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_get_point_sums": (C.c_int, [C.c_void_p, c_float_p]),
     "frog_get_gradient": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_size_t]),
+    "frog_residual_sums": (C.c_int, [C.c_void_p]),
+    "frog_get_error_map": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_comm_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "frog_update_stats_local": (C.c_int, [C.c_void_p]),
@@ -147,6 +149,7 @@ HOST_SYMBOLS = {
                                             C.POINTER(C.c_uint64), c_u32_p, c_u32_p]),
     "frog_synth_defaults": (None, [C.POINTER(FrogSynthParams)]),
     "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
+    "frog_nifti_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p, C.c_uint32, c_float_p]),
 }
 
 

@@ -346,7 +346,7 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
     if (!n) return FROG_OK;
     if (ctx->xyz2_fresh && !apply) {
         // already computed behind the last deformable step (frog_deformable_phase_c): publish it
-        ctx->xyz2_fresh = false;
+        ctx->xyz2_fresh = false; ctx->res_valid = false;
         if (ctx->n_owned() == ctx->nI && !ctx->xyz2_exported && ctx->pos2_spec.n == ctx->pos2.n) {
             std::swap(ctx->pos2.p, ctx->pos2_spec.p);           // whole table recomputed, nobody holds its address
             std::swap(ctx->pos2.cap, ctx->pos2_spec.cap);
@@ -356,7 +356,7 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
                                       (size_t)n * sizeof(P3), hipMemcpyDeviceToDevice, ctx->stream));
         return FROG_OK;
     }
-    ctx->xyz2_fresh = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
     return launch_transform(ctx, ctx->pos2.p, apply);
 }
 
@@ -490,7 +490,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
 {
     CTX_GUARD(ctx);
     if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
-    ctx->xyz2_fresh = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
     int rc = retire_current_grid(ctx);
     if (rc) return rc;
 
@@ -615,7 +615,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
 {
     CTX_GUARD(ctx);
     if (!ctx->deformable) return fail(FROG_E_STATE, "deformable step before frog_deformable_setup");
-    ctx->xyz2_fresh = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
     hipStream_t s = ctx->stream;
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
@@ -755,7 +755,7 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
     std::vector<P3> h(ctx->P);
     for (size_t p = 0; p < ctx->P; p++)
         h[ctx->h_new_of_old[p]] = P3{ xyz2[3 * p], xyz2[3 * p + 1], xyz2[3 * p + 2] };
-    ctx->xyz2_fresh = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(P3), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
@@ -853,6 +853,62 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
     FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->coeff.p + li * G, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < nfl; i++) { const float4 &v = h[i / 3]; coeffs[i] = (i % 3 == 0) ? v.x : (i % 3 == 1) ? v.y : v.z; }
+    return FROG_OK;
+}
+
+// saveErrorMaps, imageGroup.cxx:475-567
+int frog_residual_sums(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    if (ctx->phase != 0) return fail(FROG_E_STATE, "residual sums inside a deformable step");
+    hipStream_t s = ctx->stream;
+    const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    for (uint32_t sub = 0; sub < N_SUBPASS; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
+    if (n) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    // host copies of the owned rows (internal numbering): sums and rebased coordinates
+    ctx->h_res_sums.resize(n);
+    ctx->h_res_pos.resize(n);
+    if (n) {
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_res_sums.data(), ctx->point_sums.p + ctx->own_pt_begin, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_res_pos.data(), ctx->pos.p + ctx->own_pt_begin, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s));
+    }
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    ctx->res_valid = true;
+    return FROG_OK;
+}
+
+int frog_get_error_map(frog_ctx *ctx, uint32_t image, frog_grid_info *info, float *out, size_t cap)
+{
+    CTX_GUARD(ctx);
+    if (!ctx->deformable || ctx->grids.empty()) return fail(FROG_E_STATE, "no lattice");
+    if (!ctx->res_valid) return fail(FROG_E_STATE, "frog_get_error_map without frog_residual_sums");
+    if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
+    const frog_grid_info &gi = ctx->grids.back().info;
+    if (info) *info = gi;
+    const size_t G = (size_t)gi.dims[0] * gi.dims[1] * gi.dims[2];
+    if (!out) return FROG_OK;
+    if (cap < 4 * G) return fail(FROG_E_INVALID, "error map buffer too small");
+    std::fill(out, out + 4 * G, 0.f);                                           // :489
+    const long long inc[3] = { 4, 4LL * gi.dims[0], 4LL * gi.dims[0] * gi.dims[1] };
+    for (uint32_t p = ctx->poff[image]; p < ctx->poff[image + 1]; p++) {        // reference point order
+        const uint32_t q = ctx->h_new_of_old[p] - ctx->own_pt_begin;
+        const float4 sm = ctx->h_res_sums[q];
+        if (sm.w == 0.f) continue;                                              // :535
+        const float4 ps = ctx->h_res_pos[q];
+        const float pos[3] = { ps.x, ps.y, ps.z };
+        long long id = 0;
+        for (int k = 0; k < 3; k++) {                                           // :539-544
+            const float coord = (float)(((double)pos[k] - gi.origin[k]) / gi.spacing[k]);
+            id += (long long)std::floor(coord) * inc[k];
+        }
+        if (id < 0 || (size_t)id + 3 >= 4 * G) continue;
+        out[id + 3] += sm.w;
+        out[id] += sm.x; out[id + 1] += sm.y; out[id + 2] += sm.z;
+    }
+    for (size_t i = 0; i < G; i++)                                              // :551-556
+        if (out[4 * i + 3] > 0)
+            for (int k = 0; k < 3; k++) out[4 * i + k] /= out[4 * i + 3];
     return FROG_OK;
 }
 

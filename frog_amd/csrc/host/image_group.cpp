@@ -16,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <zlib.h>
 #include <sstream>
 
 using std::cout;
@@ -211,14 +212,95 @@ void ImageGroup::run()
         cout << "Grids per level : ";
         for (int n : gridsPerLevel) { total += n; cout << n << " "; }
         cout << endl << "Total number of grids : " << total << endl;
-        // saveErrorMaps (:141) needs a NIfTI writer: not part of this build (out of scope)
+        saveErrorMaps();                                                // :141
     }
 
     displayStats();                                                     // :144
     saveDistanceHistograms("histograms.csv");
     saveMeasures(outputFileName);
     saveTransforms();
+    if (writePairs) writeLinksDistances();                              // :151
     saveStatsJSON();
+}
+
+// saveErrorMaps, imageGroup.cxx:475-567: the residual sums come from the device (one sweep),
+// the nearest-node binning keeps the reference's point order (frog_get_error_map).
+void ImageGroup::saveErrorMaps()
+{
+    std::filesystem::create_directory(errorMapsSubdirectory.c_str());
+    check(frog_residual_sums(ctx), "frog_residual_sums");
+    const uint32_t n = frog_num_images(ctx);
+    std::vector<float> map;
+    for (uint32_t image = 0; image < n; image++) {
+        frog_grid_info info;
+        check(frog_get_error_map(ctx, image, &info, nullptr, 0), "frog_get_error_map");
+        map.resize((size_t)4 * info.dims[0] * info.dims[1] * info.dims[2]);
+        check(frog_get_error_map(ctx, image, &info, map.data(), map.size()), "frog_get_error_map");
+        std::ostringstream file;
+        file << errorMapsSubdirectory << "/" << image << ".nii.gz";
+        const uint32_t dims[3] = { (uint32_t)info.dims[0], (uint32_t)info.dims[1], (uint32_t)info.dims[2] };
+        check(frog_nifti_write(file.str().c_str(), dims, info.spacing, info.origin, 4, map.data()), "frog_nifti_write");
+    }
+}
+
+// Stats::getInlierProbability + chipdf, stats.h:10-16,84-92 (promotions as upstream)
+static float inlierProbability(float d, float c1, float c2, float ratio)
+{
+    const float eps = 1e-10;
+    if (d < 0.1) return 1;
+    auto chipdf = [](float x) -> float {
+        float c = 0.797884560802865;
+        float x2 = x * x;
+        return c * x2 * exp(-0.5 * x2);
+    };
+    float x1 = ratio * chipdf(d / (c1 + eps)) / (c1 + eps);
+    float x2 = (1.0 - ratio) * chipdf(d / (c2 + eps)) / (c2 + eps);
+    return x1 / (x1 + x2 + eps);
+}
+
+// writeLinksDistances, imageGroup.cxx:924-986 ("-wp 1"): every half-link as
+// image1,point1,image2,point2,distance,probability(image1's stats only), all six stored as
+// f32 like upstream, sorted by distance, gzip'd CSV without a trailing newline.
+void ImageGroup::writeLinksDistances()
+{
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    const uint64_t P = frog_num_points(ctx);
+    std::vector<float> xyz2(3 * P);
+    check(frog_get_points(ctx, nullptr, xyz2.data()), "frog_get_points");
+    struct Row { float v[6]; };
+    std::vector<Row> rows;
+    rows.reserve(m.row_ptr[P]);
+    for (uint32_t i1 = 0; i1 < m.n_images; i1++) {
+        float em[3];
+        check(frog_get_em(ctx, i1, em), "frog_get_em");
+        for (uint32_t p = m.point_offset[i1]; p < m.point_offset[i1 + 1]; p++) {
+            const float *pA = &xyz2[3 * (size_t)p];
+            for (uint64_t l = m.row_ptr[p]; l < m.row_ptr[p + 1]; l++) {
+                const uint32_t i2 = m.link_image[l], p2 = m.link_point[l];
+                const float *pB = &xyz2[3 * ((size_t)m.point_offset[i2] + p2)];
+                float d2 = 0;
+                for (int k = 0; k < 3; k++) { const float t = pA[k] - pB[k]; d2 += t * t; }     // vtkMath::Distance2BetweenPoints
+                const float dist = std::sqrt(d2);
+                rows.push_back(Row{ { (float)i1, (float)(p - m.point_offset[i1]), (float)i2, (float)p2, dist,
+                                      inlierProbability(dist, em[0], em[1], em[2]) } });
+            }
+        }
+    }
+    std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.v[4] < b.v[4]; });
+    gzFile f = gzopen("pairs.csv.gz", "wb");
+    if (!f) { cout << "Error : cannot write pairs.csv.gz" << endl; exit(1); }
+    std::ostringstream out;
+    for (size_t i = 0; i < rows.size(); i++) {
+        for (int j = 0; j < 6; j++) { out << rows[i].v[j]; if (j < 5) out << ","; }
+        if (i + 1 < rows.size()) out << "\n";
+        if (out.tellp() > (1 << 20) || i + 1 == rows.size()) {
+            const std::string s = out.str();
+            if (!s.empty() && gzwrite(f, s.data(), (unsigned)s.size()) != (int)s.size()) { cout << "Error : cannot write pairs.csv.gz" << endl; exit(1); }
+            out.str(std::string());
+        }
+    }
+    gzclose(f);
 }
 
 // computeLandmarkDistances without landmarks, imageGroup.cxx:1229-1242
@@ -320,14 +402,13 @@ void ImageGroup::saveMeasures(const char *file)
 }
 
 // saveTransforms, imageGroup.cxx:1458-1473 -> writeFrogJSON, tools/transformIO.h:163-258.
-// Single-file form ("-j"): matrix + dimensions/origin/spacing/coeffs per lattice, in
-// creation order (PostMultiply chain).  The compact form's .nii.gz sidecars need a
-// NIfTI writer and are not produced by this build: both modes write the -j form.
+// One entry per transform in creation order (PostMultiply chain): the matrix, then every
+// lattice.  Default ("compact", transformIO.h:196-208): the coefficients go to a sidecar
+// <image>.json.<n>.nii.gz (3-component f32 NIfTI, origin in the qform) and the JSON entry only
+// names it ("file"); with "-j": dimensions/origin/spacing/coeffs inside the JSON.
 void ImageGroup::saveTransforms()
 {
     std::filesystem::create_directory(transformSubdirectory.c_str());
-    if (!writeSingleFileTransforms)
-        cout << "Note : writing single-file JSON transforms (the compact .nii.gz form is not built)" << endl;
     const uint32_t n = frog_num_images(ctx);
     const int nGrids = frog_num_grids(ctx);
     for (uint32_t image = 0; image < n; image++) {
@@ -350,6 +431,16 @@ void ImageGroup::saveTransforms()
             check(frog_get_grid(ctx, image, k, &info, c.data(), nv), "frog_get_grid");
             frogjson::Value t = frogjson::Value::object();
             t["type"] = frogjson::Value("vtkBSplineTransform");
+            if (!writeSingleFileTransforms) {
+                std::ostringstream base;
+                base << image << ".json." << k << ".nii.gz";
+                t["file"] = frogjson::Value(base.str());
+                const std::string path = transformSubdirectory + "/" + base.str();
+                const uint32_t d3[3] = { (uint32_t)info.dims[0], (uint32_t)info.dims[1], (uint32_t)info.dims[2] };
+                check(frog_nifti_write(path.c_str(), d3, info.spacing, info.origin, 3, c.data()), "frog_nifti_write");
+                transforms.push(t);
+                continue;
+            }
             frogjson::Value dims = frogjson::Value::array(), ori = frogjson::Value::array(), sp = frogjson::Value::array();
             for (int a = 0; a < 3; a++) {
                 dims.push(frogjson::Value((double)info.dims[a]));

@@ -73,5 +73,7 @@ protected:
     void saveDistanceHistograms(const char *file);   // :850
     void saveMeasures(const char *file);         // :1475
     void saveTransforms();                       // :1458
+    void saveErrorMaps();                        // :475
+    void writeLinksDistances();                  // :924
     void saveStatsJSON();                        // :152-155, :1493-1511
 };

@@ -230,6 +230,20 @@ class ImageGroup:
         check(self._lib.frog_get_point_sums(self._ctx, out.ctypes.data_as(_abi.c_float_p)), "frog_get_point_sums")
         return out
 
+    def errorMap(self, image):
+        """saveErrorMaps (imageGroup.cxx:475-567) for one image: (grid info, [G,4] float32).
+        Call residualSums() once first (it runs the sweep for all images)."""
+        info = _abi.FrogGridInfo()
+        check(self._lib.frog_get_error_map(self._ctx, image, C.byref(info), None, 0), "frog_get_error_map")
+        g = info.dims[0] * info.dims[1] * info.dims[2]
+        out = np.empty((g, 4), np.float32)
+        check(self._lib.frog_get_error_map(self._ctx, image, C.byref(info), out.ctypes.data_as(_abi.c_float_p), 4 * g),
+              "frog_get_error_map")
+        return info, out
+
+    def residualSums(self):
+        check(self._lib.frog_residual_sums(self._ctx), "frog_residual_sums")
+
     def gradient(self, image, n_cp):
         out = np.empty((n_cp, 4), np.float32)
         check(self._lib.frog_get_gradient(self._ctx, image, out.ctypes.data_as(_abi.c_float_p), 4 * n_cp),

@@ -105,6 +105,18 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info,
 int frog_get_point_sums(frog_ctx *ctx, float *out4P);
 int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out4G, size_t cap_floats);
 
+/* saveErrorMaps (imageGroup.cxx:475-567).  frog_residual_sums runs the half-link sweep on
+ * the CURRENT xyz2 (per-point sDisp/sWeight over inlier links, :493-533) for the owned
+ * images -- no collective, the xyz2 replica is whole after transformPoints.
+ * frog_get_error_map then adds one owned image's sums at the lattice node
+ * floor((xyz - origin) / spacing) of the LAST lattice, in the reference's point order
+ * (host side: 4 f32 adds per point whose order must be the reference's), divides by the
+ * weight (:551-556) and returns 4*G floats (what the reference writes to
+ * errorMaps/<image>.nii.gz).  Points outside the lattice image are skipped (undefined
+ * behaviour upstream).  Any later step invalidates the sums. */
+int frog_residual_sums(frog_ctx *ctx);
+int frog_get_error_map(frog_ctx *ctx, uint32_t image, frog_grid_info *info, float *out4G, size_t cap_floats);
+
 /* ---- split phases for one-process-per-GPU runs ----------------------------- */
 
 enum {

@@ -76,6 +76,17 @@ typedef struct frog_synth_params {
 void frog_synth_defaults(frog_synth_params *p);
 frog_pairs *frog_synth_generate(const frog_synth_params *p);
 
+/* ---- NIfTI-1 writer for lattice images ------------------------------------------
+ * Replaces vtkNIFTIImageWriter at tools/transformIO.h:196-208 (B-spline coefficient
+ * sidecars `<i>.json.<n>.nii.gz`, 3 components) and registration/imageGroup.cxx:559-563
+ * (`errorMaps/<i>.nii.gz`, 4 components).  `interleaved` holds dims[0]*dims[1]*dims[2]
+ * voxels, x fastest, n_components floats each (the vtkImageData layout); the file stores
+ * them plane by plane (dim[5] = n_components), FLOAT32, spacing in pixdim, origin in the
+ * qform/sform offsets (what the reference's readers use, transformIO.h:439-453).
+ * A path ending in ".gz" is gzip-compressed. */
+int frog_nifti_write(const char *path, const uint32_t dims[3], const double spacing[3],
+                     const double origin[3], uint32_t n_components, const float *interleaved);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,7 +79,8 @@ enum {
     FROG_E_NODEVICE    = 2,   /* no usable HIP device: there is no CPU fallback */
     FROG_E_HIP         = 3,   /* a HIP runtime call failed                    */
     FROG_E_STATE       = 4,   /* call sequence violated                       */
-    FROG_E_NOMEM       = 5
+    FROG_E_NOMEM       = 5,
+    FROG_E_IO          = 6    /* a file could not be written                  */
 };
 
 /* Fills *o with the reference defaults listed above. */

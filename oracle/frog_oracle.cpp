@@ -668,6 +668,56 @@ double frogo_deformable_step(frogo_group *g, const float alpha)
     return std::sqrt(s[0] / s[1]);
 }
 
+// saveErrorMaps, imageGroup.cxx:475-567 (without hardLinks: no landmarks on this path): the
+// per-point residual sums of the current xyz2 (inlier links only), each added at the lattice
+// node floor((xyz - origin) / spacing) of the image's gradient image, then divided by the
+// accumulated weight.  Returns 4*G floats (mean residual x, y, z, weight); the reference
+// leaves the result in image.gradient and writes it as errorMaps/<image>.nii.gz.
+int frogo_error_map(frogo_group *g, uint32_t image1, float *out, size_t cap)
+{
+    if (g->grids.empty() || image1 >= g->nI) return -1;
+    const Grid &grid = g->grids.back();
+    const int *dims = grid.dims;
+    const long inc[3] = { 4, 4L * dims[0], 4L * dims[0] * dims[1] };
+    const size_t G = (size_t)dims[0] * dims[1] * dims[2];
+    if (cap < 4 * G) return -1;
+    std::fill(out, out + 4 * G, 0.f);                                   // :489
+    const EmStats &stA = g->stats[image1];
+    const float thr = g->opt.inlier_threshold;
+    for (uint32_t p = g->poff[image1]; p < g->poff[image1 + 1]; p++) {
+        const float *pos = &g->xyz[3 * (size_t)p];
+        const float *pA = &g->xyz2[3 * (size_t)p];
+        float sWeight = 0;
+        float sDisp[3] = { 0, 0, 0 };
+        for (uint64_t l = g->rowp[p]; l < g->rowp[p + 1]; l++) {       // :500-518
+            const uint16_t image2 = g->limg[l];
+            const float *pB = pos2(g, image2, g->lpt[l]);
+            float d2 = dist2_f32(pA, pB);
+            float dist = std::sqrt(d2);
+            float probA = stA.inlier_probability(dist);
+            float probB = g->stats[image2].inlier_probability(dist);
+            float w = std::min(probA, probB);
+            float w2 = w * w;
+            if (w < thr) continue;
+            for (int k = 0; k < 3; k++) sDisp[k] += w2 * (pB[k] - pA[k]);
+            sWeight += w2;
+        }
+        if (sWeight == 0) continue;                                     // :535
+        long id = 0;
+        for (int k = 0; k < 3; k++) {                                   // :539-544
+            float coord = (float)(((double)pos[k] - grid.origin[k]) / grid.spacing[k]);
+            id += (long)std::floor(coord) * inc[k];
+        }
+        if (id < 0 || (size_t)id + 3 >= 4 * G) continue;                // outside the image: UB upstream
+        out[id + 3] += sWeight;
+        for (int k = 0; k < 3; k++) out[id + k] += sDisp[k];
+    }
+    for (size_t i = 0; i < G; i++)                                      // :551-556
+        if (out[4 * i + 3] > 0)
+            for (int k = 0; k < 3; k++) out[4 * i + k] /= out[4 * i + 3];
+    return 0;
+}
+
 void frogo_set_range(frogo_group *g, uint32_t image_begin, uint32_t image_end) { g->ib = image_begin; g->ie = image_end; }
 
 // countInliers, imageGroup.cxx:988-1060.

@@ -52,6 +52,7 @@ double frogo_linear_step(frogo_group *g);                         /* :1063 */
 void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out); /* :159 */
 double frogo_deformable_step(frogo_group *g, float alpha);        /* :234  */
 void frogo_count_inliers(frogo_group *g, frog_counts *per_image); /* :988  */
+int  frogo_error_map(frogo_group *g, uint32_t image, float *out4G, size_t cap_floats); /* :475 */
 
 /* Split phases (several instances owning disjoint image ranges, combined by the caller:
  * the CPU stand-in for one-process-per-GPU runs in tests/test_distributed_gloo.py). */

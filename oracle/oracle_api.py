@@ -40,6 +40,7 @@ def lib():
         L.frogo_deformable_step.restype = C.c_double
         L.frogo_deformable_step.argtypes = [C.c_void_p, C.c_float]
         L.frogo_count_inliers.argtypes = [C.c_void_p, C.c_void_p]
+        L.frogo_error_map.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_size_t]; L.frogo_error_map.restype = C.c_int
         L.frogo_run.restype = C.c_int
         L.frogo_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, fp, dp, C.c_int,
                                 C.POINTER(C.c_int)]
@@ -208,6 +209,12 @@ class OracleGroup:
 
     def deformable_step(self, alpha):
         return self.L.frogo_deformable_step(self.h, alpha)
+
+    def error_map(self, image, n_cp):
+        out = np.empty((n_cp, 4), np.float32)
+        rc = self.L.frogo_error_map(self.h, image, out.ctypes.data_as(fp), out.size)
+        assert rc == 0
+        return out
 
     def count_inliers(self, counts_array):
         self.L.frogo_count_inliers(self.h, counts_array)

@@ -123,3 +123,34 @@ def test_cli_usage_and_generator_need_no_gpu(tmp_path):
     q = Pairs.synthetic(3, 200, 80, seed=4)
     assert p.n_images == 3 and p.n_points == 600 and np.array_equal(p.xyz, q.xyz)
     assert np.array_equal(p.link_point, q.link_point)
+
+
+@pytest.mark.parametrize("name", ["lattice.nii.gz", "lattice.nii"])
+def test_nifti_writer_header_and_plane_order(tmp_path, name):
+    # what the reference's readers take from a sidecar (tools/transformIO.h:439-453): dimensions,
+    # spacing, the components of each voxel and the origin = translation of the qform matrix
+    import ctypes as C
+    from frog_amd import _abi
+    from nifti_util import read_nifti
+    lib = _abi.host_lib()
+    dims = (C.c_uint32 * 3)(5, 4, 3)
+    sp = (C.c_double * 3)(12.5, 25.0, 31.25)
+    ori = (C.c_double * 3)(-112.5, 7.0, 0.125)
+    rng = np.random.default_rng(3)
+    vox = rng.normal(size=(5 * 4 * 3, 3)).astype(np.float32)
+    path = str(tmp_path / name).encode()
+    assert lib.frog_nifti_write(path, dims, sp, ori, 3, vox.ctypes.data_as(_abi.c_float_p)) == 0
+    h, got = read_nifti(tmp_path / name)
+    assert h["sizeof_hdr"] == 348 and h["magic"] == b"n+1\0" and h["vox_offset"] == 352.0
+    assert h["dim"][:6] == (5, 5, 4, 3, 1, 3) and h["datatype"] == 16 and h["bitpix"] == 32
+    assert h["intent_code"] == 1007
+    assert h["pixdim"][0] == 1.0 and h["pixdim"][1:4] == (12.5, 25.0, 31.25)
+    assert h["qform_code"] > 0 and h["quatern"] == (0.0, 0.0, 0.0) and h["qoffset"] == (-112.5, 7.0, 0.125)
+    assert np.array_equal(h["srow"], np.array([[12.5, 0, 0, -112.5], [0, 25.0, 0, 7.0], [0, 0, 31.25, 0.125]]))
+    assert np.array_equal(got, vox)
+    # one component: a plain 3-D volume
+    assert lib.frog_nifti_write(path, dims, sp, ori, 1, vox[:, 0].copy().ctypes.data_as(_abi.c_float_p)) == 0
+    h, got = read_nifti(tmp_path / name)
+    assert h["dim"][:4] == (3, 5, 4, 3) and np.array_equal(got[:, 0], vox[:, 0])
+    assert lib.frog_nifti_write(str(tmp_path / "nodir" / name).encode(), dims, sp, ori, 3,
+                                vox.ctypes.data_as(_abi.c_float_p)) == _abi.FROG_E_IO

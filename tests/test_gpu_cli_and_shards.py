@@ -87,6 +87,48 @@ def test_cli_outputs_match_oracle(tmp_path, small_pairs):
     assert os.path.exists(tmp_path / "histograms.csv")
 
 
+def test_cli_default_surface_sidecars_error_maps_and_pairs_csv(tmp_path, small_pairs):
+    # default mode (no -j): coefficients in <i>.json.<n>.nii.gz sidecars named by "file"
+    # (tools/transformIO.h:196-208), errorMaps/<i>.nii.gz (imageGroup.cxx:475-567), and with
+    # -wp 1 pairs.csv.gz (:924-986).  The -j run of the same input is the cross-check.
+    import gzip
+    from nifti_util import read_nifti
+    exe = os.path.join(ROOT, "bin", "frog")
+    args = ["pairs.bin", "-li", "12", "-dl", "2", "-di", "8", "-q", "1"]
+    for sub, extra in (("compact", ["-wp", "1"]), ("single", ["-j"])):
+        d = tmp_path / sub
+        d.mkdir()
+        small_pairs.write(d / "pairs.bin")
+        r = subprocess.run([exe] + args + extra, cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    n_grids = None
+    for i in range(small_pairs.n_images):
+        tc = json.load(open(tmp_path / "compact" / "transforms" / f"{i}.json"))["transforms"]
+        ts = json.load(open(tmp_path / "single" / "transforms" / f"{i}.json"))["transforms"]
+        assert len(tc) == len(ts) and tc[0] == ts[0] or relerr(tc[0]["matrix"], ts[0]["matrix"]) < 1e-12
+        n_grids = len(tc) - 1
+        for k in range(1, len(tc)):
+            assert tc[k]["type"] == "vtkBSplineTransform" and set(tc[k]) == {"type", "file"}
+            assert tc[k]["file"] == f"{i}.json.{k - 1}.nii.gz"
+            h, vox = read_nifti(tmp_path / "compact" / "transforms" / tc[k]["file"])
+            assert list(h["dim"][1:4]) == ts[k]["dimensions"] and h["dim"][5] == 3
+            np.testing.assert_allclose(h["pixdim"][1:4], ts[k]["spacing"], rtol=1e-6)
+            np.testing.assert_allclose(h["qoffset"], ts[k]["origin"], rtol=1e-6, atol=1e-4)
+            # two runs differ by the order of the lattice's float atomics only
+            assert relerr(vox, np.array(ts[k]["coeffs"]).reshape(-1, 3)) < REL
+        h, vox = read_nifti(tmp_path / "compact" / "errorMaps" / f"{i}.nii.gz")
+        assert list(h["dim"][1:4]) == ts[-1]["dimensions"] and h["dim"][5] == 4
+        assert (vox[:, 3] >= 0).all() and vox[:, 3].sum() > 0
+        assert (vox[vox[:, 3] == 0][:, :3] == 0).all()
+    assert n_grids >= 2
+    rows = gzip.open(tmp_path / "compact" / "pairs.csv.gz", "rt").read().split("\n")
+    assert len(rows) == small_pairs.n_half_links and all(len(r_.split(",")) == 6 for r_ in rows[:50])
+    dist = np.array([float(r_.split(",")[4]) for r_ in rows])
+    prob = np.array([float(r_.split(",")[5]) for r_ in rows])
+    assert (np.diff(dist) >= 0).all() and ((prob >= 0) & (prob <= 1)).all()
+    assert not os.path.exists(tmp_path / "single" / "pairs.csv.gz")
+
+
 def test_cli_usage_and_bad_input(tmp_path):
     exe = os.path.join(ROOT, "bin", "frog")
     r = subprocess.run([exe], capture_output=True, text=True)

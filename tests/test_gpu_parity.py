@@ -351,3 +351,37 @@ def test_wide_and_narrow_link_records_agree_bit_for_bit(small_pairs, which, monk
     assert e_n == e_w
     assert np.array_equal(s_n, s_w)
     assert c_n == c_w
+
+
+def test_error_map_matches_oracle(small_pairs):
+    # saveErrorMaps (imageGroup.cxx:475-567) on identical coordinates and EM parameters: the
+    # per-point sums come from the device sweep, the nearest-node binning keeps the reference's order
+    g, ref = make(small_pairs)
+    _to_deformable(g, ref)
+    info = g.setupDeformableTransforms(1)
+    ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    ref.update_stats()
+    for i in range(ref.n_images):
+        g.set_em(i, ref.em(i))
+    for _ in range(3):
+        assert g.updateDeformableTransforms(0.02) >= 0 and ref.deformable_step(0.02) >= 0
+        g.transformPoints(); ref.transform_points()
+    g.transformPoints(True); ref.transform_points(True)            # run() :126, then :141
+    assert relerr(g.points()[1], ref.xyz2()) < 1e-6
+    g.set_points2(ref.xyz2())                                       # identical inputs for the comparison
+    n_cp = info.dims[0] * info.dims[1] * info.dims[2]
+    with pytest.raises(RuntimeError):
+        g.errorMap(0)                                               # needs residualSums() first
+    g.residualSums()
+    for i in range(ref.n_images):
+        ginfo, m = g.errorMap(i)
+        r = ref.error_map(i, n_cp)
+        assert list(ginfo.dims) == list(info.dims)
+        # same nodes hit, same weights, mean residuals to f32 rounding of the per-point sums
+        assert np.array_equal(m[:, 3] > 0, r[:, 3] > 0)
+        assert relerr(m[:, 3], r[:, 3]) < 1e-5
+        assert np.max(np.abs(m[:, :3] - r[:, :3])) < 1e-4 * max(1.0, np.max(np.abs(r[:, :3])))
+    g.transformPoints()
+    with pytest.raises(RuntimeError):
+        g.errorMap(0)                                               # any later step invalidates the sums
