@@ -87,6 +87,25 @@ FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 
 # name -> (restype, argtypes): every symbol include/frog_hip.h declares
+class FrogKeypoints(C.Structure):
+    """frog_keypoints (include/frog_match.h): host arrays of one image's keypoints."""
+    _fields_ = [("n", C.c_uint32), ("dim", C.c_uint32), ("xyz", c_float_p), ("scale", c_float_p),
+                ("laplacian", c_float_p), ("response", c_float_p), ("desc", c_float_p)]
+
+
+class FrogMatchOptions(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("dist2second", C.c_float), ("anat", C.c_float), ("sym", C.c_int),
+                ("reserved", C.c_int * 4)]
+
+    @classmethod
+    def default(cls, **kw):
+        o = cls()
+        hip_lib().frog_match_options_default(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
 HIP_SYMBOLS = {
     "frog_device_count": (C.c_int, []),
     "frog_last_error": (C.c_char_p, []),
@@ -115,6 +134,14 @@ HIP_SYMBOLS = {
     "frog_get_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_get_point_sums": (C.c_int, [C.c_void_p, c_float_p]),
     "frog_get_gradient": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_size_t]),
+    "frog_match_options_default": (None, [C.POINTER(FrogMatchOptions)]),
+    "frog_matcher_create": (C.c_int, [C.POINTER(FrogKeypoints), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_matcher_destroy": (None, [C.c_void_p]),
+    "frog_matcher_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_size_t,
+                                   C.POINTER(FrogMatchOptions), C.POINTER(C.c_uint64), C.POINTER(c_u32_p),
+                                   C.POINTER(c_u32_p)]),
+    "frog_match_free": (None, [C.c_void_p]),
+    "frog_matcher_last_stats": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "frog_residual_sums": (C.c_int, [C.c_void_p]),
     "frog_get_error_map": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_comm_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),

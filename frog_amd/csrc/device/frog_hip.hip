@@ -16,6 +16,7 @@
 namespace frog {
 thread_local std::string g_last_error;
 constexpr int BOUNDS_BLOCKS = 256;
+void set_last_error(const std::string &s) { g_last_error = s; }     // for the library's other translation units
 }
 
 using namespace frog;

@@ -1,0 +1,415 @@
+// match.hip -- keypoint pairing on MI355X (include/frog_match.h).
+//
+// One thread = one query keypoint, its descriptor in registers; the candidates of the other
+// image stream through LDS in tiles and every lane reads the SAME candidate (broadcast
+// ds_read_b128), so a (query, candidate) distance costs 3 vector instructions per dimension
+// and 1/4 LDS instruction: the kernel is bound by f32 vector-ALU issue (no MFMA: the pair
+// lists must be those of the reference's scalar sum, term by term in dimension order, and a
+// |a|^2 - 2ab + |b|^2 formulation on the matrix cores rounds differently).
+//
+// Exactness (index work, bit-exact): sub / mul / add in dimension order without contraction;
+// strict `<` updates of (d1, d2, match) in candidate order; candidates are split into
+// contiguous ranges over blockIdx.y and the partial (d1, d2, match) triples are merged in
+// range order, which gives the sequential result (d1 = minimum, first index attaining it;
+// d2 = second smallest of the multiset).  The scale-ratio test `s1/s2 > 1.3 || s2/s1 > 1.3`
+// (f32 divisions compared with the double 1.3, match.cpp:273-275) is monotone in the query
+// scale, so it is turned on the host into an exact open interval (lo, hi) per candidate.
+#include <hip/hip_runtime.h>
+
+#include "frog_match.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" const char *frog_last_error(void);
+namespace frog { void set_last_error(const std::string &s); }
+
+namespace {
+
+constexpr int MATCH_BLOCK = 256;        // queries per block
+constexpr int CAND_TILE = 32;           // candidates staged per LDS tile
+
+struct DevImage {
+    uint32_t n = 0;
+    float *desc = nullptr;              // [n][dp], zero padded
+    float *sign = nullptr, *scale = nullptr, *lo = nullptr, *hi = nullptr;
+    float *xyz = nullptr;               // [n][3]
+};
+
+struct Partial { float d1, d2; int j; };
+
+struct MatchArgs {
+    const float *q_desc, *q_sign, *q_scale, *q_xyz;
+    const float *c_desc, *c_sign, *c_lo, *c_hi, *c_xyz;
+    uint32_t nq, nc, per_split;
+    float anat;
+    Partial *partial;                   // [splits][nq]
+    unsigned long long *n_dist;         // distances evaluated (statistics)
+};
+
+template <int D>
+__global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a)
+{
+    __shared__ float cd[CAND_TILE][D];
+    __shared__ float cs[CAND_TILE], clo[CAND_TILE], chi[CAND_TILE], cx[CAND_TILE], cy[CAND_TILE], cz[CAND_TILE];
+    const uint32_t qi = blockIdx.x * MATCH_BLOCK + threadIdx.x;
+    const bool valid = qi < a.nq;
+    float q[D];
+    float qsign = 0.f, qscale = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) {
+        const float4 *row = reinterpret_cast<const float4 *>(a.q_desc + (size_t)qi * D);
+        #pragma unroll
+        for (int k = 0; k < D / 4; k++) { const float4 v = row[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+        qsign = a.q_sign[qi]; qscale = a.q_scale[qi];
+        qx = a.q_xyz[3 * (size_t)qi]; qy = a.q_xyz[3 * (size_t)qi + 1]; qz = a.q_xyz[3 * (size_t)qi + 2];
+    } else {
+        #pragma unroll
+        for (int k = 0; k < D; k++) q[k] = 0.f;
+    }
+    float d1 = FLT_MAX, d2 = FLT_MAX;
+    int match = -1;
+    unsigned int evaluated = 0;
+    const uint32_t c_begin = min(a.nc, blockIdx.y * a.per_split), c_end = min(a.nc, c_begin + a.per_split);
+    for (uint32_t base = c_begin; base < c_end; base += CAND_TILE) {
+        const uint32_t cnt = min((uint32_t)CAND_TILE, c_end - base);
+        __syncthreads();
+        {   // stage the tile: cnt rows of D floats, contiguous in memory
+            const float4 *src = reinterpret_cast<const float4 *>(a.c_desc + (size_t)base * D);
+            float4 *dst = reinterpret_cast<float4 *>(&cd[0][0]);
+            for (uint32_t k = threadIdx.x; k < cnt * (D / 4); k += MATCH_BLOCK) dst[k] = src[k];
+            if (threadIdx.x < cnt) {
+                const uint32_t c = base + threadIdx.x;
+                cs[threadIdx.x] = a.c_sign[c]; clo[threadIdx.x] = a.c_lo[c]; chi[threadIdx.x] = a.c_hi[c];
+                cx[threadIdx.x] = a.c_xyz[3 * (size_t)c]; cy[threadIdx.x] = a.c_xyz[3 * (size_t)c + 1]; cz[threadIdx.x] = a.c_xyz[3 * (size_t)c + 2];
+            }
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < cnt; c++) {
+            bool pass = valid && qsign == cs[c]                         // match.cpp:270
+                              && qscale > clo[c] && qscale < chi[c];    // :273-275 as an exact interval
+            if (a.anat != 0.f && pass) {                                // :278-291
+                const float ex = qx - cx[c], ey = qy - cy[c], ez = qz - cz[c];
+                const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
+                if (eucl > a.anat) pass = false;
+            }
+            if (!__any(pass)) continue;                                 // the whole wavefront skips this candidate
+            float dist = 0.f;                                           // norm, :242-251
+            const float4 *row = reinterpret_cast<const float4 *>(&cd[c][0]);
+            #pragma unroll
+            for (int k = 0; k < D / 4; k++) {
+                const float4 v = row[k];
+                float t;
+                t = q[4 * k] - v.x;     dist += t * t;
+                t = q[4 * k + 1] - v.y; dist += t * t;
+                t = q[4 * k + 2] - v.z; dist += t * t;
+                t = q[4 * k + 3] - v.w; dist += t * t;
+            }
+            if (pass) {
+                evaluated++;
+                if (dist < d1) { d2 = d1; d1 = dist; match = (int)(base + c); }         // :303-313
+                else if (dist < d2) { d2 = dist; }
+            }
+        }
+    }
+    if (valid) a.partial[(size_t)blockIdx.y * a.nq + qi] = Partial{ d1, d2, match };
+    // statistics: one atomic per wavefront
+    unsigned int total = evaluated;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.n_dist, (unsigned long long)total);
+}
+
+// merge the candidate ranges in order, then the acceptance test (match.cpp:320-321).
+// out[q]: accepted -> candidate index (>= 0), or -2 when no candidate had a distance below
+// FLT_MAX (upstream then emits its `match` variable, which is declared outside the query loop
+// and still holds the previous queries' value: resolved on the host, which walks the queries
+// in order); rejected -> -1 without candidate, -(index + 3) with one (it updates `match` too).
+__global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_t splits, float threshold,
+                                    float dist2second, int *out)
+{
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    float d1 = FLT_MAX, d2 = FLT_MAX;
+    int match = -1;
+    for (uint32_t s = 0; s < splits; s++) {
+        const Partial p = partial[(size_t)s * nq + qi];
+        // the later range's values enter as the sequential scan would see them: its minimum
+        // first (ties keep the earlier index: strict <), then its second
+        if (p.d1 < d1) { d2 = d1; d1 = p.d1; match = p.j; }
+        else if (p.d1 < d2) { d2 = p.d1; }
+        if (p.d2 < d2) d2 = p.d2;
+    }
+    const bool ok = (sqrtf(d1 / d2) < dist2second || d2 == FLT_MAX) && (sqrtf(d1) < threshold);
+    out[qi] = ok ? (match >= 0 ? match : -2) : (match >= 0 ? -(match + 3) : -1);
+}
+
+#define MCHECK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));         \
+            return FROG_E_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+int fail(int code, const std::string &msg) { frog::set_last_error(msg); return code; }
+
+// smallest positive float s with (double)(s / sc) > 1.3  (reject when s >= hi), +inf if none
+float scale_hi(float sc)
+{
+    auto rej = [sc](float s) { return (double)(s / sc) > 1.3; };
+    uint32_t lo = 1u, hi = 0x7F7FFFFFu;                 // positive floats are ordered like their bits
+    auto f = [](uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; };
+    if (!rej(f(hi))) return INFINITY;
+    if (rej(f(lo))) return f(lo);
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (rej(f(mid))) hi = mid; else lo = mid; }
+    return f(hi);
+}
+
+// largest positive float s with (double)(sc / s) > 1.3  (reject when s <= lo), 0 if none
+float scale_lo(float sc)
+{
+    auto rej = [sc](float s) { return (double)(sc / s) > 1.3; };
+    uint32_t lo = 1u, hi = 0x7F7FFFFFu;
+    auto f = [](uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; };
+    if (!rej(f(lo))) return 0.f;
+    if (rej(f(hi))) return f(hi);
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (rej(f(mid))) lo = mid; else hi = mid; }
+    return f(lo);
+}
+
+} // namespace
+
+struct frog_matcher {
+    int device = 0;
+    uint32_t dim = 0, dp = 0;
+    std::vector<DevImage> img;
+    hipStream_t stream = nullptr;
+    unsigned long long *n_dist = nullptr;
+    double last_ms = 0, last_dist = 0;
+};
+
+extern "C" {
+
+void frog_match_options_default(frog_match_options *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->threshold = 0.22f;           // match.cpp:357
+    o->dist2second = 1.0f;          // :358
+}
+
+void frog_matcher_destroy(frog_matcher *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (DevImage &d : m->img) {
+        if (d.desc) (void)hipFree(d.desc);
+        if (d.sign) (void)hipFree(d.sign);
+        if (d.scale) (void)hipFree(d.scale);
+        if (d.lo) (void)hipFree(d.lo);
+        if (d.hi) (void)hipFree(d.hi);
+        if (d.xyz) (void)hipFree(d.xyz);
+    }
+    if (m->n_dist) (void)hipFree(m->n_dist);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int device, frog_matcher **out)
+{
+    if (!images || !out || n_images == 0 || n_images > 65535) return fail(FROG_E_INVALID, "bad arguments to frog_matcher_create");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(FROG_E_NODEVICE, "no HIP device: the matcher has no CPU fallback");
+    if (device < 0 || device >= count) return fail(FROG_E_INVALID, "bad device index");
+    const uint32_t dim = images[0].dim;
+    if (dim == 0 || dim > 128) return fail(FROG_E_INVALID, "descriptor length must be 1..128");
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (images[i].dim != dim) return fail(FROG_E_INVALID, "all images must share one descriptor length");
+        if (images[i].n && (!images[i].xyz || !images[i].scale || !images[i].laplacian || !images[i].desc))
+            return fail(FROG_E_INVALID, "null keypoint array");
+        for (uint32_t p = 0; p < images[i].n; p++)
+            if (!(images[i].scale[p] > 0.f) || !std::isfinite(images[i].scale[p]))
+                return fail(FROG_E_INVALID, "keypoint scales must be finite and positive");
+    }
+    MCHECK(hipSetDevice(device));
+    frog_matcher *m = new (std::nothrow) frog_matcher;
+    if (!m) return fail(FROG_E_NOMEM, "out of host memory");
+    m->device = device;
+    m->dim = dim;
+    m->dp = dim <= 48 ? 48 : dim <= 64 ? 64 : dim <= 96 ? 96 : 128;
+    m->img.resize(n_images);
+#define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
+    CCHECK(hipStreamCreate(&m->stream));
+    CCHECK(hipMalloc((void **)&m->n_dist, sizeof(unsigned long long)));
+    std::vector<float> pad, lo, hi;
+    for (uint32_t i = 0; i < n_images; i++) {
+        const frog_keypoints &k = images[i];
+        DevImage &d = m->img[i];
+        d.n = k.n;
+        const size_t n = std::max<uint32_t>(1, k.n);
+        pad.assign(n * m->dp, 0.f);
+        lo.assign(n, 0.f); hi.assign(n, 0.f);
+        for (uint32_t p = 0; p < k.n; p++) {
+            std::memcpy(&pad[(size_t)p * m->dp], k.desc + (size_t)p * dim, dim * sizeof(float));
+            lo[p] = scale_lo(k.scale[p]); hi[p] = scale_hi(k.scale[p]);
+        }
+        CCHECK(hipMalloc((void **)&d.desc, n * m->dp * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.sign, n * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.scale, n * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.lo, n * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.hi, n * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.xyz, n * 3 * sizeof(float)));
+        CCHECK(hipMemcpy(d.desc, pad.data(), n * m->dp * sizeof(float), hipMemcpyHostToDevice));
+        if (k.n) {
+            CCHECK(hipMemcpy(d.sign, k.laplacian, k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.scale, k.scale, k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.lo, lo.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.hi, hi.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.xyz, k.xyz, (size_t)k.n * 3 * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+#undef CCHECK
+    *out = m;
+    return FROG_OK;
+}
+
+int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *distances)
+{
+    if (!m) return FROG_E_INVALID;
+    if (kernel_ms) *kernel_ms = m->last_ms;
+    if (distances) *distances = m->last_dist;
+    return FROG_OK;
+}
+
+void frog_match_free(void *p) { std::free(p); }
+
+int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *second, size_t n_jobs,
+                     const frog_match_options *o, uint64_t *offset, uint32_t **p_first, uint32_t **p_second)
+{
+    if (!m || !o || !offset || !p_first || !p_second || (n_jobs && (!first || !second)))
+        return fail(FROG_E_INVALID, "bad arguments to frog_matcher_run");
+    for (size_t k = 0; k < n_jobs; k++)
+        if (first[k] >= m->img.size() || second[k] >= m->img.size()) return fail(FROG_E_INVALID, "image index out of range");
+    MCHECK(hipSetDevice(m->device));
+    *p_first = *p_second = nullptr;
+
+    // a job = up to two passes (forward, and the reverse one with -sym); passes run back to back on
+    // one stream, results come back through a ring of pinned buffers while the next passes compute
+    struct Pass { uint32_t job, cand, query; bool sym; };
+    std::vector<Pass> passes;
+    uint32_t max_n = 1;
+    for (size_t k = 0; k < n_jobs; k++) {
+        passes.push_back(Pass{ (uint32_t)k, first[k], second[k], false });
+        if (o->sym) passes.push_back(Pass{ (uint32_t)k, second[k], first[k], true });
+        max_n = std::max(max_n, std::max(m->img[first[k]].n, m->img[second[k]].n));
+    }
+    constexpr int RING = 8;
+    const uint32_t splits_max = 64;
+    Partial *partial = nullptr;
+    int *d_out = nullptr, *h_out = nullptr;
+    hipEvent_t done[RING] = {}, t0 = nullptr, t1 = nullptr;
+    std::vector<std::vector<uint32_t>> ja(n_jobs), jb(n_jobs);
+    int rc = FROG_OK;
+    auto cleanup = [&]() {
+        if (partial) (void)hipFree(partial);
+        if (d_out) (void)hipFree(d_out);
+        if (h_out) (void)hipHostFree(h_out);
+        for (int r = 0; r < RING; r++) if (done[r]) (void)hipEventDestroy(done[r]);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+    };
+#define RCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return FROG_E_HIP; } } while (0)
+    RCHECK(hipMalloc((void **)&partial, (size_t)RING * splits_max * max_n * sizeof(Partial)));
+    RCHECK(hipMalloc((void **)&d_out, (size_t)RING * max_n * sizeof(int)));
+    RCHECK(hipHostMalloc((void **)&h_out, (size_t)RING * max_n * sizeof(int)));
+    for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
+    RCHECK(hipEventCreate(&t0));
+    RCHECK(hipEventCreate(&t1));
+    RCHECK(hipMemsetAsync(m->n_dist, 0, sizeof(unsigned long long), m->stream));
+    RCHECK(hipEventRecord(t0, m->stream));
+
+    // upstream's `match` variable lives across the queries of one ComputeMatches call
+    auto collect = [&](size_t pi) {
+        const Pass &ps = passes[pi];
+        const int *res = h_out + (size_t)(pi % RING) * max_n;
+        const uint32_t nq = m->img[ps.query].n;
+        int stale = 0;                                  // `int match = 0;`, match.cpp:259
+        for (uint32_t q = 0; q < nq; q++) {
+            int v = res[q];
+            if (v <= -3) { stale = -(v + 3); continue; }
+            if (v == -1) continue;
+            if (v >= 0) stale = v; else v = stale;      // -2: accepted, no candidate
+            if (ps.sym) { ja[ps.job].push_back(q); jb[ps.job].push_back((uint32_t)v); }     // make_pair(i, match)
+            else { ja[ps.job].push_back((uint32_t)v); jb[ps.job].push_back(q); }           // make_pair(match, i)
+        }
+    };
+
+    for (size_t pi = 0; pi < passes.size(); pi++) {
+        const int slot = (int)(pi % RING);
+        if (pi >= RING) {
+            RCHECK(hipEventSynchronize(done[slot]));
+            collect(pi - RING);
+        }
+        const Pass &ps = passes[pi];
+        const DevImage &Q = m->img[ps.query], &C = m->img[ps.cand];
+        const uint32_t nq = Q.n;
+        if (nq) {
+            const uint32_t q_blocks = (nq + MATCH_BLOCK - 1) / MATCH_BLOCK;
+            // enough blocks to fill the chip; ranges are whole tiles
+            uint32_t splits = std::max(1u, std::min(splits_max, (2048u + q_blocks - 1) / q_blocks));
+            uint32_t per = (C.n + splits - 1) / splits;
+            per = std::max<uint32_t>(CAND_TILE, (per + CAND_TILE - 1) / CAND_TILE * CAND_TILE);
+            splits = std::max(1u, (C.n + per - 1) / per);
+            MatchArgs a;
+            a.q_desc = Q.desc; a.q_sign = Q.sign; a.q_scale = Q.scale; a.q_xyz = Q.xyz;
+            a.c_desc = C.desc; a.c_sign = C.sign; a.c_lo = C.lo; a.c_hi = C.hi; a.c_xyz = C.xyz;
+            a.nq = nq; a.nc = C.n; a.per_split = per; a.anat = o->anat;
+            a.partial = partial + (size_t)slot * splits_max * max_n;
+            a.n_dist = m->n_dist;
+            const dim3 grid(q_blocks, splits);
+            switch (m->dp) {
+            case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
+            case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
+            case 96: match_kernel<96><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
+            default: match_kernel<128><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
+            }
+            match_decide_kernel<<<(nq + 255) / 256, 256, 0, m->stream>>>(a.partial, nq, splits, o->threshold, o->dist2second,
+                                                                         d_out + (size_t)slot * max_n);
+            RCHECK(hipGetLastError());
+            RCHECK(hipMemcpyAsync(h_out + (size_t)slot * max_n, d_out + (size_t)slot * max_n, (size_t)nq * sizeof(int),
+                                  hipMemcpyDeviceToHost, m->stream));
+        }
+        RCHECK(hipEventRecord(done[slot], m->stream));
+    }
+    RCHECK(hipEventRecord(t1, m->stream));
+    RCHECK(hipStreamSynchronize(m->stream));
+    for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
+    float ms = 0;
+    RCHECK(hipEventElapsedTime(&ms, t0, t1));
+    unsigned long long nd = 0;
+    RCHECK(hipMemcpy(&nd, m->n_dist, sizeof nd, hipMemcpyDeviceToHost));
+    m->last_ms = ms; m->last_dist = (double)nd;
+#undef RCHECK
+    cleanup();
+
+    offset[0] = 0;
+    for (size_t k = 0; k < n_jobs; k++) offset[k + 1] = offset[k] + ja[k].size();
+    *p_first = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
+    *p_second = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
+    if (!*p_first || !*p_second) { std::free(*p_first); std::free(*p_second); *p_first = *p_second = nullptr; return fail(FROG_E_NOMEM, "out of host memory"); }
+    for (size_t k = 0; k < n_jobs; k++) {
+        if (ja[k].empty()) continue;
+        std::memcpy(*p_first + offset[k], ja[k].data(), ja[k].size() * sizeof(uint32_t));
+        std::memcpy(*p_second + offset[k], jb[k].data(), jb[k].size() * sizeof(uint32_t));
+    }
+    return rc;
+}
+
+} // extern "C"

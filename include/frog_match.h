@@ -1,0 +1,80 @@
+/* frog_match.h -- C ABI of the keypoint matcher (the producer of pairs.bin).
+ *
+ * Replaces the pairing stage of the reference's `match` tool (match/match.cpp):
+ *   ComputeMatches(points2, points1, threshold, dist2second, matchAll, anatVal, sym)
+ *                                                            match.cpp:255-336
+ * called once per image pair (first < second) from main (match.cpp:640-660) as
+ *   ComputeMatches(*allPoints[first], *allPoints[second], dist, dist2second, ...)
+ * i.e. every keypoint of image `second` (the query) scans all keypoints of image `first`
+ * (the candidates) that pass the Laplacian-sign, scale-ratio and optional anatomical
+ * tests, keeps the nearest and the second nearest descriptor (squared L2, f32, summed
+ * in dimension order as the scalar `norm`, match.cpp:242-251) and emits the pair
+ * (candidate, query) when sqrt(d1/d2) < dist2second (or there is no second) and
+ * sqrt(d1) < threshold.  Pairs come out in query order, as upstream.
+ *
+ * Arithmetic contract: every comparison the reference makes is made on the same f32
+ * values (no FMA contraction, IEEE division and square root), so the pair lists are
+ * identical to the scalar build of the reference -- index work, bit-exact.  (Upstream's
+ * USE_SSE_FOR_MATCHING build sums the dimensions in another order; it is a different
+ * reference.)
+ *
+ * Not built: matchAll (`-all`, variable-length output) and `-transformPrefix` (the
+ * anatomical test then uses the untransformed coordinates, as upstream without it).
+ */
+#ifndef FROG_MATCH_H
+#define FROG_MATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "frog_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One image's keypoints, host arrays (the rows of a surf3d .csv/.csv.gz/.bin file,
+ * match.cpp:48-83: x, y, z, scale, laplacianSign, response, descriptor...). */
+typedef struct frog_keypoints {
+    uint32_t n;                 /* keypoints                                   */
+    uint32_t dim;               /* descriptor length (48 for surf3d)           */
+    const float *xyz;           /* [n][3]                                      */
+    const float *scale;         /* [n], > 0                                    */
+    const float *laplacian;     /* [n]                                         */
+    const float *response;      /* [n] (not used by the pairing)               */
+    const float *desc;          /* [n][dim]                                    */
+} frog_keypoints;
+
+typedef struct frog_match_options {
+    float threshold;            /* -d   (match.cpp:357: 0.22)                  */
+    float dist2second;          /* -d2  (1)                                    */
+    float anat;                 /* -anat (0 = off)                             */
+    int sym;                    /* -sym: also match first against second       */
+    int reserved[4];
+} frog_match_options;
+
+void frog_match_options_default(frog_match_options *o);
+
+typedef struct frog_matcher frog_matcher;
+
+/* Copies every image's keypoints to `device` (they stay resident for all pairs). */
+int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int device, frog_matcher **out);
+void frog_matcher_destroy(frog_matcher *m);
+
+/* ComputeMatches for `n_jobs` image pairs (first[k], second[k]); with o->sym the reverse
+ * direction is appended as upstream (match.cpp:645-648).  Job k's pairs are returned in
+ * p_first[offset[k] .. offset[k+1]) / p_second[...] (indices inside image first[k] /
+ * second[k]); `offset` has n_jobs+1 entries.  The two arrays are allocated by the library
+ * (free them with frog_match_free).  Jobs are pipelined on the device. */
+int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *second, size_t n_jobs,
+                     const frog_match_options *o, uint64_t *offset, uint32_t **p_first, uint32_t **p_second);
+void frog_match_free(void *p);
+
+/* HIP-event time of the pairing kernels of the last frog_matcher_run (ms) and the number of
+ * (query, candidate) descriptor distances it evaluated. */
+int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *distances);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

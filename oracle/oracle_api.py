@@ -319,3 +319,34 @@ class OracleGroup:
         o = np.empty((n_cp, 4), np.float32)
         self.L.frogo_get_gradient(self.h, image, o.ctypes.data_as(fp), 4 * n_cp)
         return o
+
+
+# ---- pairing stage of the reference's `match` tool (oracle/match_oracle.cpp) ---------------
+def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, threads=None):
+    """ComputeMatches (match/match.cpp:255-336) per (first, second) job on the CPU.
+    `images`: frog_amd.match.Keypoints.  Returns per job (indices in first, indices in second)."""
+    from frog_amd import _abi
+    L = lib()
+    L.frogo_match_run.restype = C.c_int
+    L.frogo_match_run.argtypes = [C.POINTER(_abi.FrogKeypoints), C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                  C.c_size_t, C.POINTER(_abi.FrogMatchOptions), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32))]
+    L.frogo_match_free.argtypes = [C.c_void_p]
+    L.frogo_match_free.restype = None
+    if threads:
+        L.frogo_match_set_threads(int(threads))
+    views = (_abi.FrogKeypoints * len(images))(*[k.view() for k in images])
+    o = _abi.FrogMatchOptions()
+    o.threshold, o.dist2second, o.anat, o.sym = threshold, dist2second, anat, sym
+    n = len(jobs)
+    f = (C.c_uint16 * max(n, 1))(*[j[0] for j in jobs])
+    s = (C.c_uint16 * max(n, 1))(*[j[1] for j in jobs])
+    offset = (C.c_uint64 * (n + 1))()
+    pa, pb = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+    rc = L.frogo_match_run(views, len(images), f, s, n, C.byref(o), offset, C.byref(pa), C.byref(pb))
+    assert rc == 0
+    total = int(offset[n])
+    a = np.ctypeslib.as_array(pa, shape=(max(total, 1),))[:total].copy()
+    b = np.ctypeslib.as_array(pb, shape=(max(total, 1),))[:total].copy()
+    L.frogo_match_free(pa); L.frogo_match_free(pb)
+    return [(a[int(offset[k]):int(offset[k + 1])], b[int(offset[k]):int(offset[k + 1])]) for k in range(n)]
