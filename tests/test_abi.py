@@ -19,8 +19,8 @@ def declared(header):
 
 def test_device_library_exports_every_declared_symbol():
     lib = _abi.hip_lib()
-    names = declared("frog_hip.h")
-    assert len(names) >= 35
+    names = sorted(declared("frog_hip.h") + declared("frog_match.h"))      # one library, two headers
+    assert len(names) >= 41
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_abi.HIP_SYMBOLS) == names        # the ctypes table is complete, nothing undeclared
@@ -40,6 +40,8 @@ def test_struct_layouts_match_the_headers():
     assert C.sizeof(_abi.FrogCounts) == 8 * 4 + 4 * 4
     assert C.sizeof(_abi.FrogKernelTime) == 16
     assert C.sizeof(_abi.FrogModel) == 8 + 5 * 8
+    assert C.sizeof(_abi.FrogKeypoints) == 8 + 5 * 8
+    assert C.sizeof(_abi.FrogMatchOptions) == 4 * 4 + 4 * 4
 
 
 def test_no_cpu_fallback(tiny_pairs):
