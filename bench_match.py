@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""bench_match.py -- the keypoint matcher (producer of pairs.bin) on one MI355X.
+
+Auxiliary bench (the repo's headline metric is bench.py's).  Workload: the matching stage of
+the same pipeline configuration as bench.py -- N images x 20 000 keypoints x 48-float
+descriptors, every image pair (first < second) through ComputeMatches (match/match.cpp:255-336),
+default flags of run.sh (-d 1, -d2 1).  Keypoints are resident in HBM before the timed region;
+the timed region covers all pairing kernels, the per-query decisions and the return of the
+pair lists to the host.
+
+Prints ONE JSON line.  `roofline` here is the f32 vector-ALU roofline (the kernel is pure
+sub/mul/add in dimension order, no MFMA: see frog_amd/csrc/device/match.hip): 3 lane-operations
+per descriptor dimension per evaluated (query, candidate) pair against 256 CUs x 64 lanes x
+2.4 GHz.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=100)
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--dim", type=int, default=48)
+    ap.add_argument("--jobs", type=int, default=0, help="image pairs to match (0 = all)")
+    ap.add_argument("--threshold", type=float, default=1.0)
+    ap.add_argument("--cpu-jobs", type=int, default=2, help="image pairs timed with the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    from frog_amd.match import Matcher, all_pairs, synthetic_keypoints
+
+    t0 = time.perf_counter()
+    imgs = synthetic_keypoints(args.images, args.points, dim=args.dim, seed=1)
+    t_gen = time.perf_counter() - t0
+    jobs = all_pairs(args.images)
+    if args.jobs:
+        jobs = jobs[:args.jobs]
+    t0 = time.perf_counter()
+    m = Matcher(imgs)
+    t_upload = time.perf_counter() - t0
+    m.run(jobs[:2], threshold=args.threshold)                      # warm-up
+    t0 = time.perf_counter()
+    res = m.run(jobs, threshold=args.threshold)
+    elapsed = time.perf_counter() - t0
+    ms, nd = m.last_stats()
+    n_pairs = int(sum(len(a) for a, _ in res))
+    lane_ops = 3.0 * args.dim * nd
+    peak = 256 * 64 * 2.4e9
+    out = {
+        "metric": "image pairs matched/sec (20 000 x 20 000 keypoints, 48-D)",
+        "value": len(jobs) / elapsed, "unit": "image pairs/s", "n_gpus": 1, "higher_is_better": True,
+        "seconds": elapsed, "kernel_seconds": ms * 1e-3, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.images} images x {args.points} keypoints x {args.dim} floats, {len(jobs)} image pairs, "
+                               f"-d {args.threshold} -d2 1", "matches": n_pairs,
+                   "candidate_pairs": float(sum(imgs[a].n * imgs[b].n for a, b in jobs)), "distances_evaluated": nd},
+        "roofline": {"bound": "valu", "kernel": "match_kernel", "achieved": lane_ops / (ms * 1e-3) / 1e12,
+                     "peak": peak / 1e12, "unit": "T lane-op/s", "frac": lane_ops / (ms * 1e-3) / peak},
+        "setup_seconds": {"generate": t_gen, "upload": t_upload},
+    }
+    if args.cpu_jobs:
+        from oracle.oracle_api import lib, match_run
+        sample = jobs[:args.cpu_jobs]
+        t0 = time.perf_counter()
+        ref = match_run(imgs, sample, threshold=args.threshold)
+        t_cpu = time.perf_counter() - t0
+        same = all(np.array_equal(a, c) and np.array_equal(b, d) for (a, b), (c, d) in zip(res[:len(sample)], ref))
+        out["cpu_baseline"] = {"value": len(sample) / t_cpu, "unit": "image pairs/s", "cores": lib().frogo_match_get_max_threads(),
+                               "kind": "port", "sample": f"the first {len(sample)} image pairs with the oracle "
+                               "(oracle/match_oracle.cpp; one thread per image pair, as upstream's omp loop)",
+                               "identical_pairs": bool(same)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,19 +1,28 @@
 // match.hip -- keypoint pairing on MI355X (include/frog_match.h).
 //
-// One thread = one query keypoint, its descriptor in registers; the candidates of the other
-// image stream through LDS in tiles and every lane reads the SAME candidate (broadcast
-// ds_read_b128), so a (query, candidate) distance costs 3 vector instructions per dimension
-// and 1/4 LDS instruction: the kernel is bound by f32 vector-ALU issue (no MFMA: the pair
-// lists must be those of the reference's scalar sum, term by term in dimension order, and a
+// One thread = one query keypoint, its descriptor in registers; every lane of a wavefront meets
+// the SAME candidate at the same time, so the candidate's descriptor is wave-uniform and comes
+// through the scalar path (s_load_dwordx16 into SGPRs that feed the vector instructions directly):
+// a (query, candidate) distance costs 3 vector instructions per dimension and nothing else.
+// The kernel is f32 vector-ALU work with scalar-load latency to hide (no MFMA: the pair lists
+// must be those of the reference's scalar sum, term by term in dimension order, and a
 // |a|^2 - 2ab + |b|^2 formulation on the matrix cores rounds differently).
 //
 // Exactness (index work, bit-exact): sub / mul / add in dimension order without contraction;
-// strict `<` updates of (d1, d2, match) in candidate order; candidates are split into
-// contiguous ranges over blockIdx.y and the partial (d1, d2, match) triples are merged in
-// range order, which gives the sequential result (d1 = minimum, first index attaining it;
+// (d1, d2, match) updated per candidate; candidates are split into contiguous ranges over
+// blockIdx.y and the partial (d1, d2, match) triples are merged, which gives the sequential result (d1 = minimum, first index attaining it;
 // d2 = second smallest of the multiset).  The scale-ratio test `s1/s2 > 1.3 || s2/s1 > 1.3`
 // (f32 divisions compared with the double 1.3, match.cpp:273-275) is monotone in the query
 // scale, so it is turned on the host into an exact open interval (lo, hi) per candidate.
+//
+// Work avoided, not approximated: every image is kept sorted by (Laplacian sign, scale), so
+// the 256 queries of a block share their sign and a narrow scale window, and the candidates
+// that can pass the two filters form ONE contiguous index range (lo and hi grow with the
+// scale), found by binary search per block.  Only that range is streamed (about 1/5 of the
+// candidates for surf3d-like scales); the per-candidate tests inside stay the exact ones, so
+// the range only has to be a superset.  Sorting changes the scan order, hence the rule
+// "first index attaining the minimum" is kept explicitly: ties on d1 go to the smaller
+// ORIGINAL index.
 #include <hip/hip_runtime.h>
 
 #include "frog_match.h"
@@ -21,6 +30,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -32,13 +42,14 @@ namespace frog { void set_last_error(const std::string &s); }
 namespace {
 
 constexpr int MATCH_BLOCK = 256;        // queries per block
-constexpr int CAND_TILE = 32;           // candidates staged per LDS tile
 
 struct DevImage {
     uint32_t n = 0;
     float *desc = nullptr;              // [n][dp], zero padded
     float *sign = nullptr, *scale = nullptr, *lo = nullptr, *hi = nullptr;
     float *xyz = nullptr;               // [n][3]
+    uint32_t *orig = nullptr;           // sorted position -> index in the caller's order
+    std::vector<uint32_t> h_orig;
 };
 
 struct Partial { float d1, d2; int j; };
@@ -46,17 +57,48 @@ struct Partial { float d1, d2; int j; };
 struct MatchArgs {
     const float *q_desc, *q_sign, *q_scale, *q_xyz;
     const float *c_desc, *c_sign, *c_lo, *c_hi, *c_xyz;
-    uint32_t nq, nc, per_split;
+    const uint32_t *c_orig;
+    uint32_t nq, nc, splits;
     float anat;
     Partial *partial;                   // [splits][nq]
     unsigned long long *n_dist;         // distances evaluated (statistics)
 };
 
-template <int D>
-__global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a)
+// The candidates the queries of one block can pass (a superset): images are sorted by (sign, scale).
+__global__ void match_range_kernel(const MatchArgs a, uint32_t q_blocks, uint2 *ranges)
 {
-    __shared__ float cd[CAND_TILE][D];
-    __shared__ float cs[CAND_TILE], clo[CAND_TILE], chi[CAND_TILE], cx[CAND_TILE], cy[CAND_TILE], cz[CAND_TILE];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= q_blocks) return;
+    const uint32_t q0 = b * MATCH_BLOCK, q1 = min(a.nq, q0 + MATCH_BLOCK) - 1;
+    uint32_t cb = 0, ce = a.nc;
+    const float sg = a.q_sign[q0];
+    if (sg == a.q_sign[q1]) {                          // the block has one sign
+        const float s_min = a.q_scale[q0], s_max = a.q_scale[q1];
+        uint32_t lo = 0, hi = a.nc;                    // first candidate with sign >= sg
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_sign[mid] < sg) lo = mid + 1; else hi = mid; }
+        const uint32_t sb = lo;
+        hi = a.nc;                                     // first candidate with sign > sg
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_sign[mid] <= sg) lo = mid + 1; else hi = mid; }
+        const uint32_t se = lo;
+        lo = sb; hi = se;                              // first candidate whose upper bound exceeds the smallest query scale
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (!(a.c_hi[mid] > s_min)) lo = mid + 1; else hi = mid; }
+        cb = lo;
+        hi = se;                                       // first candidate whose lower bound reaches the largest query scale
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_lo[mid] < s_max) lo = mid + 1; else hi = mid; }
+        ce = lo;
+    }
+    ranges[b] = make_uint2(cb, ce);
+}
+
+template <int D>
+__global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a, const uint2 *ranges)
+{
+    // Every lane of a wavefront meets the SAME candidate at the same time, so the candidate's
+    // descriptor and filter constants are wave-uniform: they are read straight from global memory
+    // with uniform addresses, which the compiler turns into scalar loads (s_load_dwordx8/16 through
+    // the scalar cache) whose SGPRs feed the vector instructions directly -- no LDS tile, no
+    // staging, no barrier.  (An LDS tile read back with broadcast ds_read_b128 was 6x slower: each
+    // read's latency sat in the dependency chain of one wavefront with 2 wavefronts per SIMD.)
     const uint32_t qi = blockIdx.x * MATCH_BLOCK + threadIdx.x;
     const bool valid = qi < a.nq;
     float q[D];
@@ -73,46 +115,35 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a)
     }
     float d1 = FLT_MAX, d2 = FLT_MAX;
     int match = -1;
-    unsigned int evaluated = 0;
-    const uint32_t c_begin = min(a.nc, blockIdx.y * a.per_split), c_end = min(a.nc, c_begin + a.per_split);
-    for (uint32_t base = c_begin; base < c_end; base += CAND_TILE) {
-        const uint32_t cnt = min((uint32_t)CAND_TILE, c_end - base);
-        __syncthreads();
-        {   // stage the tile: cnt rows of D floats, contiguous in memory
-            const float4 *src = reinterpret_cast<const float4 *>(a.c_desc + (size_t)base * D);
-            float4 *dst = reinterpret_cast<float4 *>(&cd[0][0]);
-            for (uint32_t k = threadIdx.x; k < cnt * (D / 4); k += MATCH_BLOCK) dst[k] = src[k];
-            if (threadIdx.x < cnt) {
-                const uint32_t c = base + threadIdx.x;
-                cs[threadIdx.x] = a.c_sign[c]; clo[threadIdx.x] = a.c_lo[c]; chi[threadIdx.x] = a.c_hi[c];
-                cx[threadIdx.x] = a.c_xyz[3 * (size_t)c]; cy[threadIdx.x] = a.c_xyz[3 * (size_t)c + 1]; cz[threadIdx.x] = a.c_xyz[3 * (size_t)c + 2];
-            }
+    unsigned int evaluated = 0, computed = 0;
+    // this block's share of the candidates its queries can pass
+    const uint2 rg = ranges[blockIdx.x];
+    uint32_t per = (rg.y - rg.x + a.splits - 1) / a.splits;
+    const uint32_t c_begin = min(rg.y, rg.x + blockIdx.y * per), c_end = min(rg.y, c_begin + per);
+    for (uint32_t c = c_begin; c < c_end; c++) {
+        bool pass = valid && qsign == a.c_sign[c]                          // match.cpp:270
+                          && qscale > a.c_lo[c] && qscale < a.c_hi[c];     // :273-275 as an exact interval
+        if (a.anat != 0.f && pass) {                                        // :278-291
+            const float ex = qx - a.c_xyz[3 * (size_t)c], ey = qy - a.c_xyz[3 * (size_t)c + 1], ez = qz - a.c_xyz[3 * (size_t)c + 2];
+            const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
+            if (eucl > a.anat) pass = false;
         }
-        __syncthreads();
-        for (uint32_t c = 0; c < cnt; c++) {
-            bool pass = valid && qsign == cs[c]                         // match.cpp:270
-                              && qscale > clo[c] && qscale < chi[c];    // :273-275 as an exact interval
-            if (a.anat != 0.f && pass) {                                // :278-291
-                const float ex = qx - cx[c], ey = qy - cy[c], ez = qz - cz[c];
-                const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
-                if (eucl > a.anat) pass = false;
-            }
-            if (!__any(pass)) continue;                                 // the whole wavefront skips this candidate
-            float dist = 0.f;                                           // norm, :242-251
-            const float4 *row = reinterpret_cast<const float4 *>(&cd[c][0]);
-            #pragma unroll
-            for (int k = 0; k < D / 4; k++) {
-                const float4 v = row[k];
-                float t;
-                t = q[4 * k] - v.x;     dist += t * t;
-                t = q[4 * k + 1] - v.y; dist += t * t;
-                t = q[4 * k + 2] - v.z; dist += t * t;
-                t = q[4 * k + 3] - v.w; dist += t * t;
-            }
-            if (pass) {
-                evaluated++;
-                if (dist < d1) { d2 = d1; d1 = dist; match = (int)(base + c); }         // :303-313
-                else if (dist < d2) { d2 = dist; }
+        if (!__any(pass)) continue;                 // the whole wavefront skips this candidate
+        computed++;
+        const float *crow = a.c_desc + (size_t)c * D;
+        float dist = 0.f;                           // norm, :242-251
+        #pragma unroll
+        for (int k = 0; k < D; k++) {
+            const float t = q[k] - crow[k];
+            dist += t * t;
+        }
+        if (pass) {
+            evaluated++;
+            const int orig = (int)a.c_orig[c];
+            if (dist < d1) { d2 = d1; d1 = dist; match = orig; }                // :303-313
+            else {
+                if (dist < d2) d2 = dist;
+                if (dist == d1 && orig < match) match = orig;   // upstream scans in original order: first index wins
             }
         }
     }
@@ -122,6 +153,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a)
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.n_dist, (unsigned long long)total);
+    if ((threadIdx.x & 63) == 0 && computed) atomicAdd(a.n_dist + 1, 64ull * computed);
 }
 
 // merge the candidate ranges in order, then the acceptance test (match.cpp:320-321).
@@ -138,10 +170,13 @@ __global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_
     int match = -1;
     for (uint32_t s = 0; s < splits; s++) {
         const Partial p = partial[(size_t)s * nq + qi];
-        // the later range's values enter as the sequential scan would see them: its minimum
-        // first (ties keep the earlier index: strict <), then its second
+        // a range's values enter as a sequential scan would see them: its minimum first (ties on
+        // the minimum go to the smaller original index), then its second
         if (p.d1 < d1) { d2 = d1; d1 = p.d1; match = p.j; }
-        else if (p.d1 < d2) { d2 = p.d1; }
+        else {
+            if (p.d1 < d2) d2 = p.d1;
+            if (p.d1 == d1 && p.j >= 0 && p.j < match) match = p.j;
+        }
         if (p.d2 < d2) d2 = p.d2;
     }
     const bool ok = (sqrtf(d1 / d2) < dist2second || d2 == FLT_MAX) && (sqrtf(d1) < threshold);
@@ -191,7 +226,7 @@ struct frog_matcher {
     std::vector<DevImage> img;
     hipStream_t stream = nullptr;
     unsigned long long *n_dist = nullptr;
-    double last_ms = 0, last_dist = 0;
+    double last_ms = 0, last_dist = 0, last_computed = 0;
 };
 
 extern "C" {
@@ -215,6 +250,7 @@ void frog_matcher_destroy(frog_matcher *m)
         if (d.lo) (void)hipFree(d.lo);
         if (d.hi) (void)hipFree(d.hi);
         if (d.xyz) (void)hipFree(d.xyz);
+        if (d.orig) (void)hipFree(d.orig);
     }
     if (m->n_dist) (void)hipFree(m->n_dist);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -234,9 +270,11 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
         if (images[i].dim != dim) return fail(FROG_E_INVALID, "all images must share one descriptor length");
         if (images[i].n && (!images[i].xyz || !images[i].scale || !images[i].laplacian || !images[i].desc))
             return fail(FROG_E_INVALID, "null keypoint array");
-        for (uint32_t p = 0; p < images[i].n; p++)
+        for (uint32_t p = 0; p < images[i].n; p++) {
             if (!(images[i].scale[p] > 0.f) || !std::isfinite(images[i].scale[p]))
                 return fail(FROG_E_INVALID, "keypoint scales must be finite and positive");
+            if (std::isnan(images[i].laplacian[p])) return fail(FROG_E_INVALID, "NaN Laplacian sign");
+        }
     }
     MCHECK(hipSetDevice(device));
     frog_matcher *m = new (std::nothrow) frog_matcher;
@@ -247,18 +285,29 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     m->img.resize(n_images);
 #define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
     CCHECK(hipStreamCreate(&m->stream));
-    CCHECK(hipMalloc((void **)&m->n_dist, sizeof(unsigned long long)));
-    std::vector<float> pad, lo, hi;
+    CCHECK(hipMalloc((void **)&m->n_dist, 2 * sizeof(unsigned long long)));
+    std::vector<float> pad, lo, hi, sg, sc, xyz;
     for (uint32_t i = 0; i < n_images; i++) {
         const frog_keypoints &k = images[i];
         DevImage &d = m->img[i];
         d.n = k.n;
         const size_t n = std::max<uint32_t>(1, k.n);
+        // device order: by (Laplacian sign, scale, original index)
+        d.h_orig.resize(k.n);
+        for (uint32_t p = 0; p < k.n; p++) d.h_orig[p] = p;
+        std::sort(d.h_orig.begin(), d.h_orig.end(), [&k](uint32_t x, uint32_t y) {
+            if (k.laplacian[x] != k.laplacian[y]) return k.laplacian[x] < k.laplacian[y];
+            if (k.scale[x] != k.scale[y]) return k.scale[x] < k.scale[y];
+            return x < y;
+        });
         pad.assign(n * m->dp, 0.f);
-        lo.assign(n, 0.f); hi.assign(n, 0.f);
+        lo.assign(n, 0.f); hi.assign(n, 0.f); sg.assign(n, 0.f); sc.assign(n, 0.f); xyz.assign(3 * n, 0.f);
         for (uint32_t p = 0; p < k.n; p++) {
-            std::memcpy(&pad[(size_t)p * m->dp], k.desc + (size_t)p * dim, dim * sizeof(float));
-            lo[p] = scale_lo(k.scale[p]); hi[p] = scale_hi(k.scale[p]);
+            const uint32_t o = d.h_orig[p];
+            std::memcpy(&pad[(size_t)p * m->dp], k.desc + (size_t)o * dim, dim * sizeof(float));
+            lo[p] = scale_lo(k.scale[o]); hi[p] = scale_hi(k.scale[o]);
+            sg[p] = k.laplacian[o]; sc[p] = k.scale[o];
+            for (int c = 0; c < 3; c++) xyz[3 * (size_t)p + c] = k.xyz[3 * (size_t)o + c];
         }
         CCHECK(hipMalloc((void **)&d.desc, n * m->dp * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.sign, n * sizeof(float)));
@@ -266,13 +315,15 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
         CCHECK(hipMalloc((void **)&d.lo, n * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.hi, n * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.xyz, n * 3 * sizeof(float)));
+        CCHECK(hipMalloc((void **)&d.orig, n * sizeof(uint32_t)));
         CCHECK(hipMemcpy(d.desc, pad.data(), n * m->dp * sizeof(float), hipMemcpyHostToDevice));
         if (k.n) {
-            CCHECK(hipMemcpy(d.sign, k.laplacian, k.n * sizeof(float), hipMemcpyHostToDevice));
-            CCHECK(hipMemcpy(d.scale, k.scale, k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.sign, sg.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.scale, sc.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
             CCHECK(hipMemcpy(d.lo, lo.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
             CCHECK(hipMemcpy(d.hi, hi.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
-            CCHECK(hipMemcpy(d.xyz, k.xyz, (size_t)k.n * 3 * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.xyz, xyz.data(), (size_t)k.n * 3 * sizeof(float), hipMemcpyHostToDevice));
+            CCHECK(hipMemcpy(d.orig, d.h_orig.data(), k.n * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
 #undef CCHECK
@@ -285,6 +336,7 @@ int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *di
     if (!m) return FROG_E_INVALID;
     if (kernel_ms) *kernel_ms = m->last_ms;
     if (distances) *distances = m->last_dist;
+    if (getenv("FROG_MATCH_DEBUG")) fprintf(stderr, "match: evaluated %.4g  computed (lane slots) %.4g\n", m->last_dist, m->last_computed);
     return FROG_OK;
 }
 
@@ -312,13 +364,16 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     }
     constexpr int RING = 8;
     const uint32_t splits_max = 64;
+    const uint32_t q_blocks_max = (max_n + MATCH_BLOCK - 1) / MATCH_BLOCK;
     Partial *partial = nullptr;
+    uint2 *ranges = nullptr;
     int *d_out = nullptr, *h_out = nullptr;
     hipEvent_t done[RING] = {}, t0 = nullptr, t1 = nullptr;
     std::vector<std::vector<uint32_t>> ja(n_jobs), jb(n_jobs);
     int rc = FROG_OK;
     auto cleanup = [&]() {
         if (partial) (void)hipFree(partial);
+        if (ranges) (void)hipFree(ranges);
         if (d_out) (void)hipFree(d_out);
         if (h_out) (void)hipHostFree(h_out);
         for (int r = 0; r < RING; r++) if (done[r]) (void)hipEventDestroy(done[r]);
@@ -327,22 +382,27 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     };
 #define RCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return FROG_E_HIP; } } while (0)
     RCHECK(hipMalloc((void **)&partial, (size_t)RING * splits_max * max_n * sizeof(Partial)));
+    RCHECK(hipMalloc((void **)&ranges, (size_t)RING * q_blocks_max * sizeof(uint2)));
     RCHECK(hipMalloc((void **)&d_out, (size_t)RING * max_n * sizeof(int)));
     RCHECK(hipHostMalloc((void **)&h_out, (size_t)RING * max_n * sizeof(int)));
     for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
     RCHECK(hipEventCreate(&t0));
     RCHECK(hipEventCreate(&t1));
-    RCHECK(hipMemsetAsync(m->n_dist, 0, sizeof(unsigned long long), m->stream));
+    RCHECK(hipMemsetAsync(m->n_dist, 0, 2 * sizeof(unsigned long long), m->stream));
     RCHECK(hipEventRecord(t0, m->stream));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
+    std::vector<int> by_query;
     auto collect = [&](size_t pi) {
         const Pass &ps = passes[pi];
         const int *res = h_out + (size_t)(pi % RING) * max_n;
-        const uint32_t nq = m->img[ps.query].n;
+        const DevImage &Q = m->img[ps.query];
+        const uint32_t nq = Q.n;
+        by_query.resize(nq);
+        for (uint32_t s = 0; s < nq; s++) by_query[Q.h_orig[s]] = res[s];     // back to the caller's query order
         int stale = 0;                                  // `int match = 0;`, match.cpp:259
         for (uint32_t q = 0; q < nq; q++) {
-            int v = res[q];
+            int v = by_query[q];
             if (v <= -3) { stale = -(v + 3); continue; }
             if (v == -1) continue;
             if (v >= 0) stale = v; else v = stale;      // -2: accepted, no candidate
@@ -362,23 +422,25 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
         const uint32_t nq = Q.n;
         if (nq) {
             const uint32_t q_blocks = (nq + MATCH_BLOCK - 1) / MATCH_BLOCK;
-            // enough blocks to fill the chip; ranges are whole tiles
-            uint32_t splits = std::max(1u, std::min(splits_max, (2048u + q_blocks - 1) / q_blocks));
-            uint32_t per = (C.n + splits - 1) / splits;
-            per = std::max<uint32_t>(CAND_TILE, (per + CAND_TILE - 1) / CAND_TILE * CAND_TILE);
-            splits = std::max(1u, (C.n + per - 1) / per);
+            // every query block splits ITS candidate range over `splits` blocks (whole tiles)
+            // (measured on 20 000 x 20 000: 13 splits 709, 26: 1036, 52: 1136 image pairs/s -- a wavefront's
+            // chain of scalar-load waits is hidden by more wavefronts, not by a longer range per block)
+            const uint32_t splits = std::max(1u, std::min(splits_max, (4096u + q_blocks - 1) / q_blocks));
             MatchArgs a;
             a.q_desc = Q.desc; a.q_sign = Q.sign; a.q_scale = Q.scale; a.q_xyz = Q.xyz;
             a.c_desc = C.desc; a.c_sign = C.sign; a.c_lo = C.lo; a.c_hi = C.hi; a.c_xyz = C.xyz;
-            a.nq = nq; a.nc = C.n; a.per_split = per; a.anat = o->anat;
+            a.c_orig = C.orig;
+            a.nq = nq; a.nc = C.n; a.splits = splits; a.anat = o->anat;
             a.partial = partial + (size_t)slot * splits_max * max_n;
             a.n_dist = m->n_dist;
             const dim3 grid(q_blocks, splits);
+            uint2 *rg = ranges + (size_t)slot * q_blocks_max;
+            match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, m->stream>>>(a, q_blocks, rg);
             switch (m->dp) {
-            case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
-            case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
-            case 96: match_kernel<96><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
-            default: match_kernel<128><<<grid, MATCH_BLOCK, 0, m->stream>>>(a); break;
+            case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
+            case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
+            case 96: match_kernel<96><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
+            default: match_kernel<128><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
             }
             match_decide_kernel<<<(nq + 255) / 256, 256, 0, m->stream>>>(a.partial, nq, splits, o->threshold, o->dist2second,
                                                                          d_out + (size_t)slot * max_n);
@@ -393,9 +455,9 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
     float ms = 0;
     RCHECK(hipEventElapsedTime(&ms, t0, t1));
-    unsigned long long nd = 0;
-    RCHECK(hipMemcpy(&nd, m->n_dist, sizeof nd, hipMemcpyDeviceToHost));
-    m->last_ms = ms; m->last_dist = (double)nd;
+    unsigned long long nd[2] = { 0, 0 };
+    RCHECK(hipMemcpy(nd, m->n_dist, sizeof nd, hipMemcpyDeviceToHost));
+    m->last_ms = ms; m->last_dist = (double)nd[0]; m->last_computed = (double)nd[1];
 #undef RCHECK
     cleanup();
 
