@@ -176,6 +176,12 @@ HOST_SYMBOLS = {
                                             C.POINTER(C.c_uint64), c_u32_p, c_u32_p]),
     "frog_synth_defaults": (None, [C.POINTER(FrogSynthParams)]),
     "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
+    "frog_keypoints_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "frog_keypoints_free": (None, [C.c_void_p]),
+    "frog_keypoints_count": (C.c_uint32, [C.c_void_p]),
+    "frog_keypoints_view": (None, [C.c_void_p, C.POINTER(FrogKeypoints)]),
+    "frog_keypoints_select": (C.c_int, [C.c_void_p, c_u32_p, C.c_uint32]),
+    "frog_keypoints_write": (C.c_int, [C.c_char_p, C.POINTER(FrogKeypoints)]),
     "frog_nifti_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p, C.c_uint32, c_float_p]),
 }
 

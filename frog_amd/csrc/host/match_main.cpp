@@ -1,0 +1,239 @@
+// match_main.cpp -- `match`: the reference's pairing tool on the GPU (match/match.cpp main, :338-747).
+//
+//   match pointFiles.txt|directory [options]
+//
+// Same flags (-n -sp -np -nt -d -d2 -zmin -zmax -o -p -anat -sym -targ), same input files, same
+// pairs.bin.  Not built: -all (every pair below the threshold) and -transformPrefix; both exit 1.
+// A directory is read in sorted name order (upstream: the file system's order).
+#include "frog_host.h"
+#include "frog_match.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace fs = std::filesystem;
+using std::cout;
+using std::endl;
+
+extern "C" const char *frog_last_error(void);
+
+int main(int argc, char *argv[])
+{
+    int N = 1000000;
+    float sp = 0;
+    int np = 1000000;
+    if (argc < 2) {
+        std::cout << "Usage : match pointFiles.txt [options] " << std::endl;
+        return 1;
+    }
+    const fs::path full_path = fs::absolute(fs::path(argv[1]));
+    float dist = 0.22f, dist2second = 1, zmin = -1e20f, zmax = 1e20f, anatVal = 0.0f;
+    bool writePoints = false, symFlag = false;
+    char *outputFileName = 0;
+    int target = -1, device = 0;
+    int argumentsIndex = 2;
+    while (argumentsIndex < argc) {                                         // match.cpp:367-435
+        char *key = argv[argumentsIndex];
+        char *value = argumentsIndex + 1 < argc ? argv[argumentsIndex + 1] : (char *)"";
+        if (strcmp(key, "-n") == 0) N = atoi(value);
+        if (strcmp(key, "-sp") == 0) sp = atof(value);
+        if (strcmp(key, "-np") == 0) np = atoi(value);
+        if (strcmp(key, "-nt") == 0) { /* host threads: the pairing runs on the GPU */ }
+        if (strcmp(key, "-d") == 0) dist = atof(value);
+        if (strcmp(key, "-d2") == 0) dist2second = atof(value);
+        if (strcmp(key, "-zmin") == 0) zmin = atof(value);
+        if (strcmp(key, "-zmax") == 0) zmax = atof(value);
+        if (strcmp(key, "-o") == 0) outputFileName = value;
+        if (strcmp(key, "-dev") == 0) device = atoi(value);
+        if (strcmp(key, "-all") == 0) { cout << "Error : -all is not supported by this build" << endl; return 1; }
+        if (strcmp(key, "-p") == 0) writePoints = true;
+        if (strcmp(key, "-anat") == 0) anatVal = atof(value);
+        if (strcmp(key, "-sym") == 0) { symFlag = true; argumentsIndex -= 1; }
+        if (strcmp(key, "-targ") == 0) target = atoi(value);
+        if (strcmp(key, "-transformPrefix") == 0) { cout << "Error : -transformPrefix is not supported by this build" << endl; return 1; }
+        argumentsIndex += 2;
+    }
+
+    std::vector<std::string> filenames;
+    std::vector<std::array<double, 3>> rigids;
+    if (fs::is_directory(full_path)) {                                      // :443-457
+        for (const auto &e : fs::directory_iterator(full_path))
+            if (fs::is_regular_file(e.status())) filenames.push_back(e.path().string());
+        std::sort(filenames.begin(), filenames.end());
+    } else if (fs::is_regular_file(full_path)) {                            // :459-494
+        std::string line;
+        std::ifstream file(full_path.string());
+        while (std::getline(file, line)) {
+            std::stringstream lineStream(line);
+            std::string cell;
+            std::getline(lineStream, cell, ',');
+            if (cell.find("/") == 0) {
+                filenames.push_back(cell);
+                cout << cell << endl;
+            } else {
+                filenames.push_back(full_path.parent_path().string() + "/" + cell + ".csv");
+                cout << full_path.parent_path().string() + cell << endl;
+            }
+            std::array<double, 3> point = { 0, 0, 0 };
+            try {
+                for (int k = 0; k < 3; k++) { std::getline(lineStream, cell, ','); point[k] = std::stof(cell); }
+            } catch (...) {}
+            rigids.push_back(point);
+        }
+    } else {
+        std::cerr << "Bad argument, first arg must be a valid file or a directory" << endl;
+        return 1;
+    }
+
+    cout << "Found " << filenames.size() << " files, loading : " << fmin(N, filenames.size()) << endl;
+    auto start = std::chrono::system_clock::now();
+    if ((int)filenames.size() > N) filenames.resize(N);
+    const int nb = (int)filenames.size();
+    if (nb == 0) { std::cerr << "no keypoint file" << endl; return 1; }
+    std::vector<frog_keypoint_file *> allPoints(nb, nullptr);
+    bool bad = false;
+    #pragma omp parallel for schedule(dynamic)
+    for (int it = 0; it < nb; ++it) {                                       // :509-556
+        int status = 0;
+        frog_keypoint_file *points = frog_keypoints_read(filenames[it].c_str(), &status);
+        if (!points) {
+            #pragma omp critical
+            { std::cerr << "Bad file format or unreadable file : " << filenames[it] << endl; bad = true; }
+            continue;
+        }
+        const float zT = rigids.size() ? (float)rigids[it][2] : 0;
+        frog_keypoints v;
+        frog_keypoints_view(points, &v);
+        std::vector<uint32_t> keep;
+        for (uint32_t p = 0; p < v.n; p++) {
+            const float z = v.xyz[3 * (size_t)p + 2] + zT;
+            if (!(z < zmin || z > zmax)) keep.push_back(p);
+        }
+        const uint32_t before = v.n;
+        if (keep.size() != v.n) frog_keypoints_select(points, keep.data(), (uint32_t)keep.size());
+        #pragma omp critical
+        cout << "image " << it << " rigid : " << (rigids.size() ? rigids[it][0] : 0.0) << ", " << (rigids.size() ? rigids[it][1] : 0.0)
+             << ", " << (rigids.size() ? rigids[it][2] : 0.0) << " before : " << before << " points, after : "
+             << frog_keypoints_count(points) << endl << std::flush;
+        allPoints[it] = points;
+    }
+    if (bad) return 1;
+    auto end = std::chrono::system_clock::now();
+    cout << " : " << std::chrono::duration<float>(end - start).count() << "s" << endl;
+    start = end;
+    {
+        frog_keypoints v;
+        frog_keypoints_view(allPoints[0], &v);
+        cout << v.dim << " values per descriptor" << endl;
+    }
+    cout << "Sorting and pruning..." << endl;
+    for (int it = 0; it < nb; ++it) {                                       // :566-596
+        frog_keypoints v;
+        frog_keypoints_view(allPoints[it], &v);
+        std::vector<uint32_t> keep;
+        for (uint32_t p = 0; p < v.n; p++)
+            if (!(v.response[p] < sp)) keep.push_back(p);
+        if ((int)keep.size() > np) {
+            std::partial_sort(keep.begin(), keep.begin() + np, keep.end(),
+                              [&v](uint32_t a, uint32_t b) { return v.response[a] > v.response[b]; });
+            keep.resize(np);
+        }
+        if (keep.size() != v.n || (int)v.n > np) frog_keypoints_select(allPoints[it], keep.data(), (uint32_t)keep.size());
+        cout << ". (" << frog_keypoints_count(allPoints[it]) << ")" << std::flush;
+        if (writePoints) {
+            std::stringstream outfilename;
+            outfilename << "points" << it << ".csv";
+            cout << " writing " << outfilename.str() << endl;
+            frog_keypoints_view(allPoints[it], &v);
+            frog_keypoints_write(outfilename.str().c_str(), &v);
+        }
+    }
+    end = std::chrono::system_clock::now();
+    cout << " : " << std::chrono::duration<float>(end - start).count() << "s" << endl;
+    start = end;
+
+    std::vector<uint16_t> first, second;                                    // :603-614
+    for (int i = 0; i < nb - 1; i++) {
+        if (target >= 0) {
+            if (i != target) { first.push_back((uint16_t)i); second.push_back((uint16_t)target); }
+        } else {
+            for (int j = i + 1; j < nb; j++) { first.push_back((uint16_t)i); second.push_back((uint16_t)j); }
+        }
+    }
+
+    cout << "Pairing... " << endl;
+    std::vector<frog_keypoints> views(nb);
+    for (int it = 0; it < nb; ++it) frog_keypoints_view(allPoints[it], &views[it]);
+    frog_matcher *m = nullptr;
+    if (frog_matcher_create(views.data(), (uint32_t)nb, device, &m)) { cout << "Error : " << frog_last_error() << endl; return 1; }
+    frog_match_options o;
+    frog_match_options_default(&o);
+    o.threshold = dist; o.dist2second = dist2second; o.anat = anatVal; o.sym = symFlag ? 1 : 0;
+    std::vector<uint64_t> offset(first.size() + 1, 0);
+    uint32_t *pa = nullptr, *pb = nullptr;
+    if (frog_matcher_run(m, first.data(), second.data(), first.size(), &o, offset.data(), &pa, &pb)) {
+        cout << "Error : " << frog_last_error() << endl;
+        return 1;
+    }
+    for (size_t k = 0; k < first.size(); k++) cout << "." << std::flush;
+    const uint64_t sum = offset[first.size()];
+    end = std::chrono::system_clock::now();
+    cout << " : " << std::chrono::duration<float>(end - start).count() << "s" << endl;
+    cout << "Nb Match : " << sum << endl;
+
+    std::stringstream outfilename;                                          // :668-682
+    if (outputFileName) outfilename << outputFileName;
+    else outfilename << "out_" << full_path.stem().string() << "_" << filenames.size() << ".bin";
+    FILE *file = fopen(outfilename.str().c_str(), "wb");
+    if (file == NULL) { cout << "write error : " << outfilename.str() << endl; exit(1); }
+    unsigned short nbAcq = (unsigned short)filenames.size();
+    fwrite(&nbAcq, sizeof(unsigned short), 1, file);
+    for (int it = 0; it < nb; it++) {                                       // :686-722
+        const size_t found = filenames[it].find_last_of("/\\");
+        const std::string currFile = filenames[it].substr(found + 1);
+        unsigned short sizeString = (unsigned short)currFile.size();
+        fwrite(&sizeString, sizeof(unsigned short), 1, file);
+        fwrite(currFile.c_str(), sizeof(char), currFile.size(), file);
+        double tmp[3] = { 0, 0, 0 };
+        if (rigids.size() > 0) for (int k = 0; k < 3; k++) tmp[k] = rigids[it][k];
+        fwrite(tmp, sizeof(double), 3, file);
+        const frog_keypoints &v = views[it];
+        uint32_t nbPoints = v.n;
+        fwrite(&nbPoints, sizeof(uint32_t), 1, file);
+        for (uint32_t r = 0; r < v.n; r++) {
+            fwrite(v.xyz + 3 * (size_t)r, sizeof(float), 3, file);
+            fwrite(&v.scale[r], sizeof(float), 1, file);
+            fwrite(&v.laplacian[r], sizeof(float), 1, file);
+            fwrite(&v.response[r], sizeof(float), 1, file);
+        }
+    }
+    // blocks i-major, j ascending (:724-742); jobs were generated in that order unless -targ is set
+    std::vector<size_t> order(first.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        return first[x] != first[y] ? first[x] < first[y] : second[x] < second[y]; });
+    for (size_t k : order) {
+        const unsigned short i = first[k], j = second[k];
+        const unsigned int size = (unsigned int)(offset[k + 1] - offset[k]);
+        fwrite(&i, sizeof(unsigned short), 1, file);
+        fwrite(&j, sizeof(unsigned short), 1, file);
+        fwrite(&size, sizeof(unsigned int), 1, file);
+        for (uint64_t r = offset[k]; r < offset[k + 1]; r++) { fwrite(&pa[r], sizeof(uint32_t), 1, file); fwrite(&pb[r], sizeof(uint32_t), 1, file); }
+    }
+    fclose(file);
+    cout << "Output file : " << outfilename.str() << endl;
+    frog_match_free(pa); frog_match_free(pb);
+    frog_matcher_destroy(m);
+    for (auto *p : allPoints) frog_keypoints_free(p);
+    return 0;
+}

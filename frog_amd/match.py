@@ -129,3 +129,28 @@ class Matcher:
         ms, nd = C.c_double(), C.c_double()
         check(self._lib.frog_matcher_last_stats(self._h, C.byref(ms), C.byref(nd)), "frog_matcher_last_stats")
         return ms.value, nd.value
+
+
+def read_keypoints(path):
+    """A surf3d keypoint file (.csv / .csv.gz / .bin) as match.cpp reads it."""
+    lib = _abi.host_lib()
+    status = C.c_int()
+    h = lib.frog_keypoints_read(str(path).encode(), C.byref(status))
+    if not h:
+        raise RuntimeError(f"cannot read keypoints from {path} (status {status.value})")
+    try:
+        v = _abi.FrogKeypoints()
+        lib.frog_keypoints_view(h, C.byref(v))
+        n, d = v.n, v.dim
+
+        def arr(p, shape):
+            return np.ctypeslib.as_array(p, shape=shape).copy() if n else np.zeros(shape, np.float32)
+        return Keypoints(arr(v.xyz, (n, 3)), arr(v.scale, (n,)), arr(v.laplacian, (n,)), arr(v.response, (n,)),
+                         arr(v.desc, (n, d)) if n else np.zeros((0, max(d, 1)), np.float32))
+    finally:
+        lib.frog_keypoints_free(h)
+
+
+def write_keypoints(path, kp):
+    v = kp.view()
+    check(_abi.host_lib().frog_keypoints_write(str(path).encode(), C.byref(v)), "frog_keypoints_write")

@@ -20,6 +20,7 @@
 #define FROG_HOST_H
 
 #include "frog_types.h"
+#include "frog_match.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -86,6 +87,21 @@ frog_pairs *frog_synth_generate(const frog_synth_params *p);
  * A path ending in ".gz" is gzip-compressed. */
 int frog_nifti_write(const char *path, const uint32_t dims[3], const double spacing[3],
                      const double origin[3], uint32_t n_components, const float *interleaved);
+
+/* ---- surf3d keypoint files (the inputs of `match`) ----------------------------------
+ * Rows x, y, z, scale, laplacianSign, response, descriptor... as match.cpp reads them:
+ * ".csv" (match.cpp:117-146), ".csv.gz" (:48-83), ".bin" (24 + 48 floats per row,
+ * :149-179 -- including upstream's extra row at end of file, see keypoints_io.cpp).
+ * frog_keypoints_view fills a frog_keypoints (frog_match.h) pointing into the file
+ * object; frog_keypoints_select keeps the listed rows (the pruning of match.cpp:548-590);
+ * frog_keypoints_write writes the same formats (writeCSV, :85-114). */
+typedef struct frog_keypoint_file frog_keypoint_file;
+frog_keypoint_file *frog_keypoints_read(const char *path, int *status);
+void frog_keypoints_free(frog_keypoint_file *f);
+uint32_t frog_keypoints_count(const frog_keypoint_file *f);
+void frog_keypoints_view(const frog_keypoint_file *f, frog_keypoints *out);
+int frog_keypoints_select(frog_keypoint_file *f, const uint32_t *keep, uint32_t n_keep);
+int frog_keypoints_write(const char *path, const frog_keypoints *k);
 
 #ifdef __cplusplus
 }

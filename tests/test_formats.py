@@ -154,3 +154,34 @@ def test_nifti_writer_header_and_plane_order(tmp_path, name):
     assert h["dim"][:4] == (3, 5, 4, 3) and np.array_equal(got[:, 0], vox[:, 0])
     assert lib.frog_nifti_write(str(tmp_path / "nodir" / name).encode(), dims, sp, ori, 3,
                                 vox.ctypes.data_as(_abi.c_float_p)) == _abi.FROG_E_IO
+
+
+@pytest.mark.parametrize("ext", ["csv", "csv.gz", "bin"])
+def test_keypoint_files_round_trip(tmp_path, ext):
+    # the inputs of `match` (match/match.cpp:48-83, :117-146, :149-179)
+    from frog_amd.match import read_keypoints, synthetic_keypoints, write_keypoints
+    kp = synthetic_keypoints(1, 57, seed=3)[0]
+    path = tmp_path / f"points.{ext}"
+    write_keypoints(path, kp)
+    got = read_keypoints(path)
+    n = kp.n
+    if ext == "bin":
+        # upstream's `while (!feof(file))` makes one more pass after the last row: a point built from the
+        # last float read (the previous response) with a zero descriptor
+        assert got.n == n + 1
+        assert np.all(got.xyz[n] == kp.response[-1]) and got.scale[n] == kp.response[-1] and not got.desc[n].any()
+    else:
+        assert got.n == n
+    assert got.dim == 48
+    for a, b in ((got.xyz, kp.xyz), (got.scale, kp.scale), (got.laplacian, kp.laplacian), (got.response, kp.response),
+                 (got.desc, kp.desc)):
+        assert np.array_equal(a[:n], b)          # %.9g text round-trips f32 exactly
+
+
+def test_keypoint_csv_skips_short_rows_and_carriage_returns(tmp_path):
+    from frog_amd.match import read_keypoints
+    (tmp_path / "p.csv").write_text("1,2,3,1.5,-1,0.25,0.5,0.25\r\n\n7,8,9,2,1,0.5\n4,5,6,2.5,1,0.75,1,2\n")
+    kp = read_keypoints(tmp_path / "p.csv")
+    assert kp.n == 2 and kp.dim == 2                      # the 6-value row has no descriptor: dropped (count > 6)
+    assert kp.xyz.tolist() == [[1, 2, 3], [4, 5, 6]] and kp.desc.tolist() == [[0.5, 0.25], [1, 2]]
+    assert kp.laplacian.tolist() == [-1, 1]

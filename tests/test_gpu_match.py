@@ -101,3 +101,78 @@ def test_argument_validation():
         Matcher([imgs[0], synthetic_keypoints(1, 50, dim=32)[0]])
     with pytest.raises(RuntimeError):
         Matcher(imgs).run([(0, 5)])
+
+
+def _read_pairs_bin(path):
+    """pairs.bin as match writes it (match.cpp:684-742)."""
+    import struct
+    raw = open(path, "rb").read()
+    off = 0
+    n_img, = struct.unpack_from("<H", raw, off); off += 2
+    images = []
+    for _ in range(n_img):
+        ln, = struct.unpack_from("<H", raw, off); off += 2
+        name = raw[off:off + ln].decode(); off += ln
+        rigid = struct.unpack_from("<3d", raw, off); off += 24
+        npts, = struct.unpack_from("<I", raw, off); off += 4
+        pts = np.frombuffer(raw, "<f4", count=6 * npts, offset=off).reshape(npts, 6); off += 24 * npts
+        images.append((name, rigid, pts))
+    blocks = []
+    while off < len(raw):
+        i, j, size = struct.unpack_from("<HHI", raw, off); off += 8
+        pr = np.frombuffer(raw, "<u4", count=2 * size, offset=off).reshape(size, 2); off += 8 * size
+        blocks.append((i, j, pr))
+    return images, blocks
+
+
+def test_match_cli_end_to_end(tmp_path):
+    import os
+    import subprocess
+    from frog_amd.match import write_keypoints
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imgs = synthetic_keypoints(4, 900, seed=21)
+    names = []
+    for i, (kp, ext) in enumerate(zip(imgs, ["csv.gz", "csv", "csv.gz", "csv.gz"])):
+        p = tmp_path / f"points{i}.{ext}"
+        write_keypoints(p, kp)
+        names.append(str(p))
+    # list file: absolute paths, optional rigid translation (match.cpp:459-494)
+    (tmp_path / "list.txt").write_text("".join(f"{n},0,0,{5.0 * i}\n" for i, n in enumerate(names)))
+    exe = os.path.join(root, "bin", "match")
+    r = subprocess.run([exe, "list.txt", "-o", "pairs.bin", "-d", "1", "-np", "700", "-sp", "0.05"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Pairing..." in r.stdout and "Nb Match :" in r.stdout and "48 values per descriptor" in r.stdout
+    images, blocks = _read_pairs_bin(tmp_path / "pairs.bin")
+    assert [im[0] for im in images] == [os.path.basename(n) for n in names]
+    assert [im[1][2] for im in images] == [0.0, 5.0, 10.0, 15.0]
+    # the pruning of match.cpp:566-581: response >= sp, then the np best responses (partial_sort, descending)
+    pruned = []
+    for kp, (_, _, pts) in zip(imgs, images):
+        rows = kp.rows()
+        rows = rows[rows[:, 5] >= np.float32(0.05)]
+        rows = rows[np.argsort(-rows[:, 5], kind="stable")][:700]
+        assert len(pts) == len(rows) and np.array_equal(pts[:, 5], rows[:, 5]) and np.array_equal(pts[:, :3], rows[:, :3])
+        pruned.append(Keypoints.from_rows(rows))
+    want = match_run(pruned, all_pairs(4), threshold=1.0)
+    assert [(b[0], b[1]) for b in blocks] == all_pairs(4)
+    for (i, j, pr), (wa, wb) in zip(blocks, want):
+        assert np.array_equal(pr[:, 0], wa) and np.array_equal(pr[:, 1], wb)
+    assert sum(len(b[2]) for b in blocks) == int(r.stdout.split("Nb Match :")[1].split()[0]) > 500
+    # -sym and -targ
+    r = subprocess.run([exe, "list.txt", "-o", "sym.bin", "-d", "1", "-sym", "-targ", "2"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    _, blocks = _read_pairs_bin(tmp_path / "sym.bin")
+    jobs = [(0, 2), (1, 2)]
+    want = match_run(imgs, jobs, threshold=1.0, sym=1)
+    assert [(b[0], b[1]) for b in blocks] == jobs
+    for (i, j, pr), (wa, wb) in zip(blocks, want):
+        assert np.array_equal(pr[:, 0], wa) and np.array_equal(pr[:, 1], wb)
+    # the pairs file feeds frog as is
+    r = subprocess.run([os.path.join(root, "bin", "frog"), "pairs.bin", "-li", "3", "-dl", "0", "-q", "1"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "pairs read" in r.stdout, r.stdout[-1500:]
+    for flag in (["-all", "1"], ["-transformPrefix", "x"]):
+        assert subprocess.run([exe, "list.txt"] + flag, cwd=tmp_path, capture_output=True).returncode == 1
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.startswith("Usage : match pointFiles.txt")
