@@ -90,15 +90,20 @@ __global__ void match_range_kernel(const MatchArgs a, uint32_t q_blocks, uint2 *
     ranges[b] = make_uint2(cb, ce);
 }
 
+constexpr int CAND_TILE = 64;           // candidates staged per LDS tile (D must be a multiple of 8)
+
 template <int D>
 __global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a, const uint2 *ranges)
 {
-    // Every lane of a wavefront meets the SAME candidate at the same time, so the candidate's
-    // descriptor and filter constants are wave-uniform: they are read straight from global memory
-    // with uniform addresses, which the compiler turns into scalar loads (s_load_dwordx8/16 through
-    // the scalar cache) whose SGPRs feed the vector instructions directly -- no LDS tile, no
-    // staging, no barrier.  (An LDS tile read back with broadcast ds_read_b128 was 6x slower: each
-    // read's latency sat in the dependency chain of one wavefront with 2 wavefronts per SIMD.)
+    // Every lane of a wavefront meets the SAME candidate at the same time: the candidate tile is
+    // staged in LDS with coalesced loads and read back with broadcast ds_read_b128 (all lanes one
+    // address).  The reads of one half descriptor are issued while the other half is being
+    // subtracted / squared / summed (register arrays A / B, branch-free body), so their latency
+    // overlaps arithmetic instead of sitting in front of every group of four dimensions -- which is
+    // what a plain loop compiles to, several times slower.
+    __shared__ float4 tile[CAND_TILE][D / 4];
+    __shared__ float cs[CAND_TILE], clo[CAND_TILE], chi[CAND_TILE], cx[CAND_TILE], cy[CAND_TILE], cz[CAND_TILE];
+    __shared__ int co[CAND_TILE];
     const uint32_t qi = blockIdx.x * MATCH_BLOCK + threadIdx.x;
     const bool valid = qi < a.nq;
     float q[D];
@@ -116,35 +121,76 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a, c
     float d1 = FLT_MAX, d2 = FLT_MAX;
     int match = -1;
     unsigned int evaluated = 0, computed = 0;
+    const bool use_anat = a.anat != 0.f;
+
+    // the filters and the (d1, d2, match) update of one candidate (match.cpp:270-313), as selects
+    auto finish = [&](float dist, uint32_t c) {
+        bool pass = valid && qsign == cs[c]                             // match.cpp:270
+                          && qscale > clo[c] && qscale < chi[c];        // :273-275 as an exact interval
+        if (use_anat) {                                                 // :278-291
+            const float ex = qx - cx[c], ey = qy - cy[c], ez = qz - cz[c];
+            const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
+            pass = pass && !(eucl > a.anat);
+        }
+        const int orig = co[c];
+        const bool better = pass && dist < d1;                          // :303-313
+        const bool second = pass && !better && dist < d2;
+        const bool tie = pass && !better && dist == d1 && orig < match; // upstream scans in original order: first index wins
+        d2 = better ? d1 : (second ? dist : d2);
+        d1 = better ? dist : d1;
+        match = (better || tie) ? orig : match;
+        evaluated += pass ? 1u : 0u;
+    };
+
     // this block's share of the candidates its queries can pass
     const uint2 rg = ranges[blockIdx.x];
-    uint32_t per = (rg.y - rg.x + a.splits - 1) / a.splits;
+    const uint32_t per = (rg.y - rg.x + a.splits - 1) / a.splits;
     const uint32_t c_begin = min(rg.y, rg.x + blockIdx.y * per), c_end = min(rg.y, c_begin + per);
-    for (uint32_t c = c_begin; c < c_end; c++) {
-        bool pass = valid && qsign == a.c_sign[c]                          // match.cpp:270
-                          && qscale > a.c_lo[c] && qscale < a.c_hi[c];     // :273-275 as an exact interval
-        if (a.anat != 0.f && pass) {                                        // :278-291
-            const float ex = qx - a.c_xyz[3 * (size_t)c], ey = qy - a.c_xyz[3 * (size_t)c + 1], ez = qz - a.c_xyz[3 * (size_t)c + 2];
-            const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
-            if (eucl > a.anat) pass = false;
-        }
-        if (!__any(pass)) continue;                 // the whole wavefront skips this candidate
-        computed++;
-        const float *crow = a.c_desc + (size_t)c * D;
-        float dist = 0.f;                           // norm, :242-251
-        #pragma unroll
-        for (int k = 0; k < D; k++) {
-            const float t = q[k] - crow[k];
-            dist += t * t;
-        }
-        if (pass) {
-            evaluated++;
-            const int orig = (int)a.c_orig[c];
-            if (dist < d1) { d2 = d1; d1 = dist; match = orig; }                // :303-313
-            else {
-                if (dist < d2) d2 = dist;
-                if (dist == d1 && orig < match) match = orig;   // upstream scans in original order: first index wins
+    constexpr int HQ = D / 8;                           // float4 registers per half descriptor
+    for (uint32_t base = c_begin; base < c_end; base += CAND_TILE) {
+        const uint32_t cnt = min((uint32_t)CAND_TILE, c_end - base);
+        __syncthreads();
+        {   // stage the tile: cnt rows of D floats, contiguous in memory
+            const float4 *src = reinterpret_cast<const float4 *>(a.c_desc + (size_t)base * D);
+            float4 *dst = &tile[0][0];
+            for (uint32_t k = threadIdx.x; k < cnt * (D / 4); k += MATCH_BLOCK) dst[k] = src[k];
+            if (threadIdx.x < cnt) {
+                const uint32_t c = base + threadIdx.x;
+                cs[threadIdx.x] = a.c_sign[c]; clo[threadIdx.x] = a.c_lo[c]; chi[threadIdx.x] = a.c_hi[c];
+                co[threadIdx.x] = (int)a.c_orig[c];
+                cx[threadIdx.x] = a.c_xyz[3 * (size_t)c]; cy[threadIdx.x] = a.c_xyz[3 * (size_t)c + 1]; cz[threadIdx.x] = a.c_xyz[3 * (size_t)c + 2];
             }
+        }
+        __syncthreads();
+        computed += cnt;
+        // A = first half of a descriptor, B = second half; each is read while the other is used
+        float4 A[HQ], B[HQ];
+        #pragma unroll
+        for (int k = 0; k < HQ; k++) A[k] = tile[0][k];
+        for (uint32_t c = 0; c < cnt; c++) {
+            #pragma unroll
+            for (int k = 0; k < HQ; k++) B[k] = tile[c][HQ + k];        // in flight during the first half
+            float dist = 0.f;                                           // norm, match.cpp:242-251
+            #pragma unroll
+            for (int k = 0; k < HQ; k++) {
+                float t;
+                t = q[4 * k] - A[k].x;     dist += t * t;
+                t = q[4 * k + 1] - A[k].y; dist += t * t;
+                t = q[4 * k + 2] - A[k].z; dist += t * t;
+                t = q[4 * k + 3] - A[k].w; dist += t * t;
+            }
+            const uint32_t cn = min(c + 1, cnt - 1);
+            #pragma unroll
+            for (int k = 0; k < HQ; k++) A[k] = tile[cn][k];            // in flight during the second half
+            #pragma unroll
+            for (int k = 0; k < HQ; k++) {
+                float t;
+                t = q[4 * (HQ + k)] - B[k].x;     dist += t * t;
+                t = q[4 * (HQ + k) + 1] - B[k].y; dist += t * t;
+                t = q[4 * (HQ + k) + 2] - B[k].z; dist += t * t;
+                t = q[4 * (HQ + k) + 3] - B[k].w; dist += t * t;
+            }
+            finish(dist, c);
         }
     }
     if (valid) a.partial[(size_t)blockIdx.y * a.nq + qi] = Partial{ d1, d2, match };
@@ -336,7 +382,6 @@ int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *di
     if (!m) return FROG_E_INVALID;
     if (kernel_ms) *kernel_ms = m->last_ms;
     if (distances) *distances = m->last_dist;
-    if (getenv("FROG_MATCH_DEBUG")) fprintf(stderr, "match: evaluated %.4g  computed (lane slots) %.4g\n", m->last_dist, m->last_computed);
     return FROG_OK;
 }
 
@@ -423,8 +468,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
         if (nq) {
             const uint32_t q_blocks = (nq + MATCH_BLOCK - 1) / MATCH_BLOCK;
             // every query block splits ITS candidate range over `splits` blocks (whole tiles)
-            // (measured on 20 000 x 20 000: 13 splits 709, 26: 1036, 52: 1136 image pairs/s -- a wavefront's
-            // chain of scalar-load waits is hidden by more wavefronts, not by a longer range per block)
+            // (measured on 20 000 x 20 000 x 48: 8 splits 655, 13: 905, 26: 1318, 52: 1387 image pairs/s)
             const uint32_t splits = std::max(1u, std::min(splits_max, (4096u + q_blocks - 1) / q_blocks));
             MatchArgs a;
             a.q_desc = Q.desc; a.q_sign = Q.sign; a.q_scale = Q.scale; a.q_xyz = Q.xyz;

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("frog::", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("frog::", "")
 
 
 def main():
