@@ -167,15 +167,18 @@ __device__ __forceinline__ float chi_pdf_ref(float x)
     return (float)((double)cx2 * exp(-0.5 * (double)x2));
 }
 
-// K2: Stats::estimateDistribution (stats.cxx:14-70), one wavefront per owned image.
+// K2: Stats::estimateDistribution (stats.cxx:14-70), one block of four wavefronts per owned image.
 // The reference adds the per-sample terms SEQUENTIALLY into f32 accumulators
 // (sum3/sum4 through an f64 add that is rounded back to f32 each step); the fit's
 // stop test makes the result sensitive to that order at the 1e-5 level, which is
-// amplified in the fine lattices.  So the order is kept: the 64 lanes compute the
-// terms of 64 consecutive samples in parallel (the two f64 exps per sample are the
-// expensive part), then every lane runs the same four dependent chains over them
-// in sample order, reading term k with v_readlane.  After the first refresh the
-// fit converges in 1-3 iterations (it is warm-started), so the chain is cheap.
+// amplified in the fine lattices.  So the order is kept, and the kernel is a chain of
+// 10^4 dependent additions per sum and EM iteration: pure latency, on as many wavefronts
+// as there are images.  What can run side by side does: wavefront 3 computes the
+// membership t of the NEXT 64 samples (two f64 exps each, the expensive part) into LDS
+// while wavefronts 0-2 each run their own chain(s) over the current 64 -- wavefront 0
+// sum1 and sum2 (f32), wavefront 1 sum3, wavefront 2 sum4 (f64 add, rounded to f32 each
+// step) -- reading term k of the batch with v_readlane.  Same terms, same order, same
+// bits as one wavefront doing everything (which took 1.9x as long).
 __device__ __forceinline__ float lane_f32(float v, int k)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
@@ -188,49 +191,80 @@ __device__ __forceinline__ double lane_f64(double v, int k)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-#define FROG_EM_STEP(k)                                                   \
-    do {                                                                  \
-        sum1 += lane_f32(a, (k));                                         \
-        sum2 += lane_f32(t, (k));                                         \
-        sum3 = (float)((double)sum3 + lane_f64(b, (k)));                  \
-        sum4 = (float)((double)sum4 + lane_f64(c, (k)));                  \
-    } while (0)
-
-__global__ __launch_bounds__(64) void em_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
-                                                uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
+__global__ __launch_bounds__(256) void em_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
+                                                 uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
 {
+    __shared__ float t_s[2][64];
+    __shared__ float sums_s[4];
     const uint32_t img = blockIdx.x;
     const uint32_t n = sample_count[img];
     const float *smp = samples + (size_t)img * cap;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 e0 = em[image_begin + img];
     float c1 = e0.x, c2 = e0.y, ratio = e0.z;
     const float esp = 1.59576912160573f;
+    const uint32_t n_batches = (n + 63) / 64;
     int iteration = 0;
     while (iteration++ < max_iterations) {
-        float sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0;
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t i = base + lane;
-            float t = 0, a = 0;
-            double b = 0, c = 0;
+        // membership of sample i under the current parameters (stats.cxx:30-32)
+        auto membership = [&](uint32_t i) {
+            float t = 0.f;
             if (i < n) {
                 const float x = smp[i];
                 const float f1 = ratio * chi_pdf_ref(x / c1) / c1;
                 const float f2 = (float)((1.0 - (double)ratio) * (double)chi_pdf_ref(x / c2) / (double)c2);
                 t = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
-                const float p = x * 1.0f;               // weights are all 1 (addSample's default)
-                a = t * p;
-                b = (1.0 - (double)t) * (double)p;
-                c = (1.0 - (double)t) * 1.0;
             }
-            const uint32_t cnt = min(64u, n - base);
-            if (cnt == 64u) {
-                #pragma unroll
-                for (int k = 0; k < 64; k++) FROG_EM_STEP(k);
+            return t;
+        };
+        float sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0;
+        if (wave == 3 && n_batches) t_s[0][lane] = membership(lane);
+        __syncthreads();
+        for (uint32_t b = 0; b < n_batches; b++) {
+            const uint32_t base = b * 64;
+            if (wave == 3) {
+                if (b + 1 < n_batches) t_s[(b + 1) & 1][lane] = membership(base + 64 + lane);
             } else {
-                for (uint32_t k = 0; k < cnt; k++) FROG_EM_STEP((int)k);
+                const uint32_t i = base + lane;
+                const float t = t_s[b & 1][lane];
+                const float p = (i < n ? smp[i] : 0.f) * 1.0f;      // weights are all 1 (addSample's default)
+                const int cnt = (int)min(64u, n - base);
+                if (wave == 0) {                                     // sum1 += t*p; sum2 += t*w   (:33-35)
+                    const float a = t * p;
+                    if (cnt == 64) {
+                        #pragma unroll
+                        for (int k = 0; k < 64; k++) { sum1 += lane_f32(a, k); sum2 += lane_f32(t, k); }
+                    } else {
+                        for (int k = 0; k < cnt; k++) { sum1 += lane_f32(a, k); sum2 += lane_f32(t, k); }
+                    }
+                } else if (wave == 1) {                              // sum3 += (1.0 - t) * p         (:36)
+                    const double v = (1.0 - (double)t) * (double)p;
+                    if (cnt == 64) {
+                        #pragma unroll
+                        for (int k = 0; k < 64; k++) sum3 = (float)((double)sum3 + lane_f64(v, k));
+                    } else {
+                        for (int k = 0; k < cnt; k++) sum3 = (float)((double)sum3 + lane_f64(v, k));
+                    }
+                } else {                                             // sum4 += (1.0 - t) * w         (:37)
+                    const double v = (1.0 - (double)t) * 1.0;
+                    if (cnt == 64) {
+                        #pragma unroll
+                        for (int k = 0; k < 64; k++) sum4 = (float)((double)sum4 + lane_f64(v, k));
+                    } else {
+                        for (int k = 0; k < cnt; k++) sum4 = (float)((double)sum4 + lane_f64(v, k));
+                    }
+                }
             }
+            __syncthreads();
         }
+        if (lane == 0) {
+            if (wave == 0) { sums_s[0] = sum1; sums_s[1] = sum2; }
+            if (wave == 1) sums_s[2] = sum3;
+            if (wave == 2) sums_s[3] = sum4;
+        }
+        __syncthreads();
+        sum1 = sums_s[0]; sum2 = sums_s[1]; sum3 = sums_s[2]; sum4 = sums_s[3];
+        __syncthreads();                                // sums_s is rewritten by the next iteration
         float sum5 = (float)n;                          // n additions of 1.0f, exact below 2^24
         sum2 = fmaxf(sum2, epsilon);
         sum3 = fmaxf(sum3, epsilon);
@@ -244,9 +278,8 @@ __global__ __launch_bounds__(64) void em_kernel(const float *samples, const uint
         c1 = nc1; c2 = nc2; ratio = nr;
         if (done) break;
     }
-    if (lane == 0) em[image_begin + img] = make_float4(c1, c2, ratio, 0.f);
+    if (threadIdx.x == 0) em[image_begin + img] = make_float4(c1, c2, ratio, 0.f);
 }
-#undef FROG_EM_STEP
 
 // (c1,c2,ratio) -> constants of inlier_probability for ALL images (after the
 // EM table has been made whole by the all-reduce in multi-rank runs).
