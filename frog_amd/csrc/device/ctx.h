@@ -66,19 +66,23 @@ template <class T> struct DevBuf {
 
 constexpr int TILE_POINTS = 256;     // points per sweep tile (one wavefront each)
 constexpr int N_XCD = 8;             // blocks are dealt round-robin over the XCDs
-constexpr int N_SUBPASS = 1;         // partner groups handled one after the other on each XCD
+constexpr int MAX_SUBPASS = 8;       // partner groups handled one after the other on each XCD: at most this many
+constexpr int MAX_GROUPS = N_XCD * MAX_SUBPASS;
 // Records are stored in chunks of REC_CHUNK = two sweep steps, transposed so that ONE 16-byte
 // load per lane fetches the lane's records of both steps (8-byte loads run at 0.54-0.70x the rate
 // of 16-byte loads on gfx950): record k of a (tile, group) range lies at
 //   (k / 128) * 128 + (k % 64) * 2 + (k % 128) / 64.
 // Every range is padded with null records to a whole number of chunks.
 constexpr int REC_CHUNK = 128;
-constexpr int N_GROUPS = N_XCD * N_SUBPASS;   // partner-image groups: a group's xyz2 slice must stay in one 4 MiB L2
-                                     // next to the streams passing through it.  Measured at 100 images x 20 000 points:
-                                     // a 3 MB slice is only partly retained (0.24 fabric reads per half-link), a
-                                     // 1.5 MB one is (0.08), but 16 groups (N_SUBPASS = 2: one launch per sub-pass,
-                                     // the second continuing the per-XCD partial sums) halve the steps per wave and
-                                     // the fixed cost per wave then outweighs the saved traffic (0.85 ms vs 0.74 ms)
+// Partner-image groups: n_groups = 8 * n_sub.  The sweep is launched n_sub times; launch `sub`
+// lets XCD x read group sub*8 + x and continues XCD x's partial sums, so that a group's xyz2 slice
+// can be made small enough to stay in one 4 MiB L2.  n_sub is 1 unless FROG_SUBPASSES sets it:
+// splitting further has not paid anywhere it was measured --
+//   100 images x 20 000 points (24 MB of xyz2, 8 slices of 3 MB): 16 groups 0.85 ms vs 0.74 ms;
+//   400 images x 20 000 points, 4.8e8 half-links (96 MB, 8 slices of 12 MB): 32 groups in 4 launches
+//   5.56 ms vs 5.16 ms (deformable), 4.43 vs 5.06 ms (linear).  There the sweep costs 2x per link
+//   because an image pair holds 3 000 matches instead of 10 000: the 64 gathers of a step fall on
+//   ~64 different lines whatever the slice size.
 
 // xyz2 of a point, packed: the sweep gathers 12 bytes per end point.
 struct P3 {
@@ -92,8 +96,8 @@ struct Tile {
     uint32_t pt_count;
     uint32_t rec_begin;     // index into LinkRec array (a multiple of REC_CHUNK)
     uint32_t image;
-    uint32_t group_off[N_GROUPS];   // records into partner group g start at rec_begin + off[g] (a multiple of REC_CHUNK)
-    uint32_t group_cnt[N_GROUPS];   // ... and there are cnt[g] of them
+    uint32_t group_off[MAX_GROUPS]; // records into partner group g start at rec_begin + off[g] (a multiple of REC_CHUNK)
+    uint32_t group_cnt[MAX_GROUPS]; // ... and there are cnt[g] of them
 };
 static_assert(sizeof(Tile) % 16 == 0, "Tile is loaded with vector loads");
 
@@ -175,9 +179,10 @@ struct frog_ctx {
     uint32_t n_tiles = 0;
     frog::DevBuf<uint32_t> img_tile_ptr;      // [nI+1] tiles of image (owned only non-empty)
     std::vector<uint32_t> h_img_tile_ptr;
-    uint32_t group_begin[frog::N_GROUPS + 1] = {};   // partner-image groups (prep.h)
-    frog::DevBuf<double> tile_partial;        // [n_tiles][N_GROUPS][18]
-    frog::DevBuf<long long> tile_counts;      // [n_tiles][N_GROUPS][2]
+    uint32_t n_sub = 1, n_groups = frog::N_XCD;      // sweep launches per pass, partner groups (= 8 * n_sub)
+    uint32_t group_begin[frog::MAX_GROUPS + 1] = {}; // partner-image groups (prep.h)
+    frog::DevBuf<double> tile_partial;        // [n_tiles][n_groups][18]
+    frog::DevBuf<long long> tile_counts;      // [n_tiles][n_groups][2]
     frog::DevBuf<float4> group_sums;          // [N_XCD][ownP] per-point partial sums (one buffer per XCD, continued across sub-passes)
     frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
 

@@ -65,7 +65,8 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
 {
     SweepArgs a;
     a.sub = sub;
-    for (int g = 0; g <= N_GROUPS; g++) a.group_begin[g] = ctx->group_begin[g];
+    a.n_groups = ctx->n_groups;
+    for (uint32_t g = 0; g <= ctx->n_groups; g++) a.group_begin[g] = ctx->group_begin[g];
     a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
     a.img_bits = ctx->rec_format.img_bits; a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
@@ -79,7 +80,7 @@ template <int MODE>
 static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s)
 {
     uint32_t widest = 0;
-    for (int g = 0; g < N_GROUPS; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
+    for (uint32_t g = 0; g < ctx->n_groups; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
     if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
         sweep_kernel<MODE, true, false><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
     else if (widest <= (uint32_t)EMD_LDS_IMAGES)
@@ -145,13 +146,18 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     std::string err;
     // FROG_WIDE_RECORDS=1 keeps the 8-byte record form where the 4-byte one would fit (test hook)
     const char *wide_env = getenv("FROG_WIDE_RECORDS");
-    int rc = build_layout(*m, c->ib, c->ie, wide_env && wide_env[0] == '1', lay, err);
+    // partner groups: 8 (one sweep launch per pass) unless FROG_SUBPASSES asks for 8 * n launches-worth
+    // (ctx.h: measured no gain from keeping the slices L2-sized, so it is not automatic)
+    c->n_sub = 1;
+    if (const char *e = getenv("FROG_SUBPASSES")) c->n_sub = (uint32_t)std::min(MAX_SUBPASS, std::max(1, atoi(e)));
+    c->n_groups = N_XCD * c->n_sub;
+    int rc = build_layout(*m, c->ib, c->ie, wide_env && wide_env[0] == '1', (int)c->n_groups, lay, err);
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.ref_link.size();
     c->rec_format = lay.format;
     c->L_recs = lay.format.narrow ? lay.recs32.size() : lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
-    for (int g = 0; g <= N_GROUPS; g++) c->group_begin[g] = lay.group_begin[g];
+    for (uint32_t g = 0; g <= c->n_groups; g++) c->group_begin[g] = lay.group_begin[g];
     c->h_old_of_new = lay.old_of_new;
     c->h_new_of_old = lay.new_of_old;
     c->h_img_tile_ptr = lay.img_tile_ptr;
@@ -211,8 +217,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (lay.format.narrow) { CREATE_CHECK(c->recs32.upload(lay.recs32, s)); }
     else { CREATE_CHECK(c->recs.upload(lay.recs, s)); }
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
-    CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * LINEAR_SUMS));
-    CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * N_GROUPS * 2));
+    CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * c->n_groups * LINEAR_SUMS));
+    CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * c->n_groups * 2));
     CREATE_CHECK(c->group_sums.alloc((size_t)N_XCD * std::max(1u, c->own_pt_end - c->own_pt_begin)));
     CREATE_CHECK(c->img_counts.alloc((size_t)c->n_owned() * 2));
 
@@ -424,14 +430,14 @@ int frog_linear_step_local(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     {
         Span span(ctx, FROG_K_SWEEP_LINEAR);
-        for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+        for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
             launch_sweep<SWEEP_LINEAR>(ctx, sub, s);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->ib, ctx->mat.p,
+    linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
     FROG_HIP_CHECK(hipGetLastError());
-    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, LINEAR_SUMS, 16, ctx->energy_blocks.p);
+    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, LINEAR_SUMS, 16, ctx->energy_blocks.p);
     energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -623,7 +629,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
-        for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+        for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
             launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
     }
     FROG_HIP_CHECK(hipGetLastError());
@@ -631,7 +637,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         Span span(ctx, FROG_K_COMBINE);
         combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
-        energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * N_GROUPS, 2, 0, ctx->energy_blocks.p);
+        energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p);
         energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
@@ -719,10 +725,10 @@ int frog_count_inliers(frog_ctx *ctx, frog_counts *per_image)
     if (!per_image) return fail(FROG_E_INVALID, "null output");
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned();
-    for (uint32_t sub = 0; sub < N_SUBPASS; sub++)
+    for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
         launch_sweep<SWEEP_COUNT>(ctx, sub, s);
     FROG_HIP_CHECK(hipGetLastError());
-    count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->ib, nO, ctx->img_counts.p);
+    count_reduce_kernel<<<div_up(nO, 64), 64, 0, s>>>(ctx->tile_counts.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, nO, ctx->img_counts.p);
     FROG_HIP_CHECK(hipGetLastError());
     std::vector<long long> h((size_t)nO * 2);
     std::vector<float4> hem(ctx->nI);
@@ -864,7 +870,7 @@ int frog_residual_sums(frog_ctx *ctx)
     if (ctx->phase != 0) return fail(FROG_E_STATE, "residual sums inside a deformable step");
     hipStream_t s = ctx->stream;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
-    for (uint32_t sub = 0; sub < N_SUBPASS; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
+    for (uint32_t sub = 0; sub < ctx->n_sub; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
     if (n) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
     FROG_HIP_CHECK(hipGetLastError());
     // host copies of the owned rows (internal numbering): sums and rebased coordinates

@@ -50,12 +50,13 @@ struct SweepArgs {
     uint32_t n_tiles;
     uint32_t rec2_last;         // index of the last record PAIR (16 bytes) of the context (prefetch clamp)
     float threshold;
-    double *tile_partial;       // [n_tiles][N_GROUPS][18] (linear) or [..][2] (deformable)
-    long long *tile_counts;     // [n_tiles][N_GROUPS][2]  (count)
+    double *tile_partial;       // [n_tiles][n_groups][18] (linear) or [..][2] (deformable)
+    long long *tile_counts;     // [n_tiles][n_groups][2]  (count)
     float4 *group_sums;         // [N_XCD][own points]  (deformable)
     uint32_t own_pt_begin, own_points;
     uint32_t sub;               // sub-pass of this launch
-    uint32_t group_begin[N_GROUPS + 1];   // first image of every partner group
+    uint32_t n_groups;
+    uint32_t group_begin[MAX_GROUPS + 1];   // first image of every partner group
 };
 
 // The sweep is bound by vector-instruction issue (rocprofv3: ~175 VALU instructions per
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // One launch per sub-pass.  block -> (4 consecutive tiles, XCD): block % 8 is the XCD the
     // block lands on under round-robin dispatch (a performance assumption only) and selects
     // the partner group sub*8 + xcd it reads, so during a launch an XCD's L2 only has to hold
-    // 1/16 of the coordinate table.  Later sub-passes continue the per-XCD partial sums.
+    // 1/n_groups of the coordinate table.  Later sub-passes continue the per-XCD partial sums.
     const uint32_t xcd = blockIdx.x % N_XCD;
     const uint32_t grp = a.sub * N_XCD + xcd;
     const uint32_t t = (blockIdx.x / N_XCD) * 4 + wave;
@@ -313,13 +314,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         #pragma unroll
         for (int k = 0; k < LINEAR_SUMS; k++) {
             double v = wave_sum(s[k]);
-            if (lane == 0 && live) a.tile_partial[((size_t)t * N_GROUPS + grp) * LINEAR_SUMS + k] = v;
+            if (lane == 0 && live) a.tile_partial[((size_t)t * a.n_groups + grp) * LINEAR_SUMS + k] = v;
         }
     } else if constexpr (MODE == SWEEP_DEFORMABLE) {
         double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);
         if (lane == 0 && live) {
-            a.tile_partial[((size_t)t * N_GROUPS + grp) * 2] = v0;
-            a.tile_partial[((size_t)t * N_GROUPS + grp) * 2 + 1] = v1;
+            a.tile_partial[((size_t)t * a.n_groups + grp) * 2] = v0;
+            a.tile_partial[((size_t)t * a.n_groups + grp) * 2 + 1] = v1;
         }
         __syncthreads();
         float4 *dst = a.group_sums + (size_t)xcd * a.own_points + (pt_begin - a.own_pt_begin);
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
         if (lane == 0 && live) {
-            a.tile_counts[((size_t)t * N_GROUPS + grp) * 2] = v0;
-            a.tile_counts[((size_t)t * N_GROUPS + grp) * 2 + 1] = v1;
+            a.tile_counts[((size_t)t * a.n_groups + grp) * 2] = v0;
+            a.tile_counts[((size_t)t * a.n_groups + grp) * 2 + 1] = v1;
         }
     }
 }
@@ -390,13 +391,13 @@ __global__ __launch_bounds__(64) void energy_final_kernel(const double *block_su
 // image: 8 slices x 18 sums add the image's (tile, group) partials in a fixed order, the
 // slices are combined in order, then lanes 0..2 update one axis each.
 __global__ __launch_bounds__(256) void linear_update_kernel(const double *partial, const uint32_t *img_tile_ptr,
-                                                            uint32_t image_begin, double *mat,
+                                                            uint32_t n_groups, uint32_t image_begin, double *mat,
                                                             float linear_alpha, int use_scale)
 {
     __shared__ double part[8][32];
     __shared__ double sums[LINEAR_SUMS];
     const uint32_t image = image_begin + blockIdx.x;
-    const uint32_t t0 = img_tile_ptr[image] * N_GROUPS, t1 = img_tile_ptr[image + 1] * N_GROUPS;
+    const uint32_t t0 = img_tile_ptr[image] * n_groups, t1 = img_tile_ptr[image + 1] * n_groups;
     const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
     if (comp < LINEAR_SUMS) {
         double v = 0;
@@ -431,14 +432,14 @@ __global__ __launch_bounds__(256) void linear_update_kernel(const double *partia
 }
 
 // per-image census from the tile counters (imageGroup.cxx:1033-1046)
-__global__ void count_reduce_kernel(const long long *tile_counts, const uint32_t *img_tile_ptr,
+__global__ void count_reduce_kernel(const long long *tile_counts, const uint32_t *img_tile_ptr, uint32_t n_groups,
                                     uint32_t image_begin, uint32_t n_owned, long long *out /*[n_owned][2]*/)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_owned) return;
     const uint32_t image = image_begin + i;
     long long a = 0, b = 0;
-    for (uint32_t t = img_tile_ptr[image] * N_GROUPS; t < img_tile_ptr[image + 1] * N_GROUPS; t++) { a += tile_counts[(size_t)t * 2]; b += tile_counts[(size_t)t * 2 + 1]; }
+    for (uint32_t t = img_tile_ptr[image] * n_groups; t < img_tile_ptr[image + 1] * n_groups; t++) { a += tile_counts[(size_t)t * 2]; b += tile_counts[(size_t)t * 2 + 1]; }
     out[(size_t)i * 2] = a; out[(size_t)i * 2 + 1] = b;
 }
 

@@ -30,12 +30,12 @@ struct Layout {
     // index window of the partner image, and (b) "the k-th eighth of an image" means the
     // same region of space in every image.  new_of_old / old_of_new map global indices.
     std::vector<uint32_t> new_of_old, old_of_new;
-    // Partner images are split into N_GROUPS contiguous ranges of equal point count;
+    // Partner images are split into n_groups contiguous ranges of equal point count;
     // group_begin[g] is the first image of group g.  A sweep block handles (4 tiles,
     // ONE group); blocks are dealt round-robin over the 8 XCDs, so with block % 8 = group
     // every XCD gathers from one group's coordinates only: 1/8 of the table, which fits
     // its 4 MiB L2 -- also for false matches, whose partner points are uniformly random.
-    std::vector<uint32_t> group_begin;      // [N_GROUPS + 1]
+    std::vector<uint32_t> group_begin;      // [n_groups + 1]
     std::vector<Tile> tiles;
     std::vector<LinkRec> recs;              // wide records, or
     std::vector<uint32_t> recs32;           // narrow records (RecFormat)
@@ -90,7 +90,7 @@ inline void build_numbering(const frog_model &m, Layout &out)
     }
 }
 
-inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool force_wide, Layout &out, std::string &err)
+inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool force_wide, int n_groups, Layout &out, std::string &err)
 {
     const uint32_t nI = m.n_images;
     const uint32_t *poff = m.point_offset;
@@ -122,19 +122,19 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     }
 
     // partner groups: contiguous image ranges balanced by point count
-    out.group_begin.assign(N_GROUPS + 1, nI);
+    out.group_begin.assign(n_groups + 1, nI);
     out.group_begin[0] = 0;
     {
         const uint64_t Pall = poff[nI];
         uint32_t img = 0;
-        for (int g = 1; g < N_GROUPS; g++) {
-            const uint64_t target = Pall * (uint64_t)g / N_GROUPS;
+        for (int g = 1; g < n_groups; g++) {
+            const uint64_t target = Pall * (uint64_t)g / n_groups;
             while (img < nI && poff[img] < target) img++;
             out.group_begin[g] = img;
         }
     }
     std::vector<uint8_t> group_of(nI);
-    for (int g = 0; g < N_GROUPS; g++)
+    for (int g = 0; g < n_groups; g++)
         for (uint32_t i = out.group_begin[g]; i < out.group_begin[g + 1]; i++) group_of[i] = (uint8_t)g;
 
     // tiles
@@ -169,7 +169,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
         Tile &tl = out.tiles[t];
         tl.rec_begin = (uint32_t)rec_total;
         uint32_t off = 0;
-        for (int g = 0; g < N_GROUPS; g++) {
+        for (int g = 0; g < n_groups; g++) {
             tl.group_off[g] = off;
             off += (tl.group_cnt[g] + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK;
         }
@@ -181,7 +181,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     // record format: narrow when (own point, partner image in its group, partner point in its image) fit 32 bits
     {
         uint32_t widest_group = 1, largest_image = 1;
-        for (int g = 0; g < N_GROUPS; g++) widest_group = std::max(widest_group, out.group_begin[g + 1] - out.group_begin[g]);
+        for (int g = 0; g < n_groups; g++) widest_group = std::max(widest_group, out.group_begin[g + 1] - out.group_begin[g]);
         for (uint32_t i = 0; i < nI; i++) largest_image = std::max(largest_image, poff[i + 1] - poff[i]);
         auto bits_for = [](uint32_t n) { uint32_t b = 1; while ((1ull << b) < n) b++; return b; };   // values 0 .. n-1
         const uint32_t img_bits = bits_for(widest_group), pt_bits = bits_for(largest_image);
@@ -207,8 +207,8 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
                 for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) cnt[m.link_image[l] + 1]++;
             }
             for (uint32_t i = 0; i < nI; i++) cnt[i + 1] += cnt[i];
-            uint32_t group_first[N_GROUPS + 1];               // logical (unpadded) start of every group
-            for (int g = 0; g <= N_GROUPS; g++) group_first[g] = cnt[out.group_begin[g]];
+            uint32_t group_first[MAX_GROUPS + 1];               // logical (unpadded) start of every group
+            for (int g = 0; g <= n_groups; g++) group_first[g] = cnt[out.group_begin[g]];
             logical.resize(cnt[nI]);
             LinkRec *dst = logical.data();
             for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
@@ -221,7 +221,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
                 }
             }
             // logical order -> chunked, transposed storage (ctx.h, REC_CHUNK)
-            for (int g = 0; g < N_GROUPS; g++) {
+            for (int g = 0; g < n_groups; g++) {
                 const size_t at = (size_t)tl.rec_begin + tl.group_off[g];
                 const LinkRec *src = dst + group_first[g];
                 for (uint32_t k = 0; k < tl.group_cnt[g]; k++) {

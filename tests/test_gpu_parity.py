@@ -385,3 +385,27 @@ def test_error_map_matches_oracle(small_pairs):
     g.transformPoints()
     with pytest.raises(RuntimeError):
         g.errorMap(0)                                               # any later step invalidates the sums
+
+
+@pytest.mark.parametrize("n_sub", [2, 8])
+def test_sweep_sub_passes_match_the_oracle(small_pairs, n_sub, monkeypatch):
+    # Large models split the partner images into 8 * n_sub groups and launch the sweep n_sub times,
+    # each launch continuing the per-XCD partial sums (ctx.h); FROG_SUBPASSES forces it on a small one.
+    monkeypatch.setenv("FROG_SUBPASSES", str(n_sub))
+    g, ref = make(small_pairs)
+    _to_deformable(g, ref, iters=12)
+    info = g.setupDeformableTransforms(1)
+    ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    ref.update_stats()
+    for i in range(ref.n_images):
+        g.set_em(i, ref.em(i))
+    e = g.updateDeformableTransforms(0.02); er = ref.deformable_step(0.02)
+    assert er > 0 and abs(e - er) / er < 1e-5
+    assert relerr(g.point_sums(), ref.point_sums()) < 1e-5
+    for i in range(ref.n_images):
+        assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
+    c = g.countInliers()
+    rc = ref.count_inliers((_abi.FrogCounts * small_pairs.n_images)())
+    for i in range(small_pairs.n_images):
+        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
