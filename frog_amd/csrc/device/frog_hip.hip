@@ -591,6 +591,11 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     for (uint32_t k = 0; k < n_bricks_total; k++)
         for (uint32_t b0 = h_bptr[k]; b0 < h_bptr[k + 1]; b0 += SCATTER_CHUNK)
             blocks.push_back(ScatterBlock{ k, b0, std::min(b0 + (uint32_t)SCATTER_CHUNK, h_bptr[k + 1]), 0u });
+    // longest blocks first: a block is one wavefront whose time grows with its point count, and
+    // bricks on the rim of the cloud hold few points -- dispatching the full chunks first shortens
+    // the tail (the lattice is flushed with atomics, so the order of the blocks does not matter)
+    std::stable_sort(blocks.begin(), blocks.end(), [](const ScatterBlock &x, const ScatterBlock &y) {
+        return x.end - x.begin > y.end - y.begin; });
     ctx->n_scatter_blocks = (uint32_t)blocks.size();
     FROG_HIP_CHECK(ctx->scatter_blocks.alloc(std::max<size_t>(1, blocks.size()) * sizeof(ScatterBlock)));
     if (!blocks.empty()) {

@@ -352,7 +352,10 @@ __global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, u
 // Why not LDS float atomics: ds_add_f32 runs at 0.33 lane-ops/clk/CU on gfx950
 // (scripts/microbench/lds_atomic.hip); why not fixed point: control points on the
 // shell of the cloud have total weights ~1e-10 and need f32 relative precision.
-constexpr int SCATTER_CHUNK = 512;
+#ifndef FROG_SCATTER_CHUNK
+#define FROG_SCATTER_CHUNK 384
+#endif
+constexpr int SCATTER_CHUNK = FROG_SCATTER_CHUNK;
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 
 struct ScatterBlock {
