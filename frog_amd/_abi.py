@@ -93,6 +93,12 @@ class FrogKeypoints(C.Structure):
                 ("laplacian", c_float_p), ("response", c_float_p), ("desc", c_float_p)]
 
 
+class FrogChainLink(C.Structure):
+    """frog_chain_link (include/frog_chain.h)."""
+    _fields_ = [("type", C.c_int), ("matrix", C.c_double * 16), ("dims", C.c_uint32 * 3), ("origin", C.c_double * 3),
+                ("spacing", C.c_double * 3), ("coeffs", c_float_p)]
+
+
 class FrogMatchOptions(C.Structure):
     _fields_ = [("threshold", C.c_float), ("dist2second", C.c_float), ("anat", C.c_float), ("sym", C.c_int),
                 ("reserved", C.c_int * 4)]
@@ -134,6 +140,12 @@ HIP_SYMBOLS = {
     "frog_get_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_get_point_sums": (C.c_int, [C.c_void_p, c_float_p]),
     "frog_get_gradient": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_size_t]),
+    "frog_chain_create": (C.c_int, [C.POINTER(FrogChainLink), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_chain_destroy": (None, [C.c_void_p]),
+    "frog_chain_num_links": (C.c_uint32, [C.c_void_p]),
+    "frog_chain_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_size_t]),
+    "frog_chain_check": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                   c_double_p]),
     "frog_match_options_default": (None, [C.POINTER(FrogMatchOptions)]),
     "frog_matcher_create": (C.c_int, [C.POINTER(FrogKeypoints), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "frog_matcher_destroy": (None, [C.c_void_p]),
@@ -182,6 +194,11 @@ HOST_SYMBOLS = {
     "frog_keypoints_view": (None, [C.c_void_p, C.POINTER(FrogKeypoints)]),
     "frog_keypoints_select": (C.c_int, [C.c_void_p, c_u32_p, C.c_uint32]),
     "frog_keypoints_write": (C.c_int, [C.c_char_p, C.POINTER(FrogKeypoints)]),
+    "frog_transform_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "frog_transform_free": (None, [C.c_void_p]),
+    "frog_transform_num_links": (C.c_uint32, [C.c_void_p]),
+    "frog_transform_links": (C.POINTER(FrogChainLink), [C.c_void_p]),
+    "frog_volume_geometry": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p]),
     "frog_nifti_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p, C.c_uint32, c_float_p]),
 }
 

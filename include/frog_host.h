@@ -21,6 +21,7 @@
 
 #include "frog_types.h"
 #include "frog_match.h"
+#include "frog_chain.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -102,6 +103,19 @@ uint32_t frog_keypoints_count(const frog_keypoint_file *f);
 void frog_keypoints_view(const frog_keypoint_file *f, frog_keypoints *out);
 int frog_keypoints_select(frog_keypoint_file *f, const uint32_t *keep, uint32_t n_keep);
 int frog_keypoints_write(const char *path, const frog_keypoints *k);
+
+/* ---- transform files (what frog writes; tools/transformIO.h:375-460 reads) -----------
+ * frog_transform_read parses transforms/<i>.json in either form (coefficients inline, or in
+ * the .nii.gz sidecars named by "file", looked up next to the JSON) into the link list of
+ * include/frog_chain.h; the object owns the coefficient arrays the links point to.
+ * frog_volume_geometry returns the voxel grid of a NIfTI-1 (.nii/.nii.gz) or MetaImage (.mhd)
+ * volume: the sampling grid of CheckDiffeomorphism. */
+typedef struct frog_transform_file frog_transform_file;
+frog_transform_file *frog_transform_read(const char *json_path, int *status);
+void frog_transform_free(frog_transform_file *f);
+uint32_t frog_transform_num_links(const frog_transform_file *f);
+const frog_chain_link *frog_transform_links(const frog_transform_file *f);
+int frog_volume_geometry(const char *path, uint32_t dims[3], double spacing[3], double origin[3]);
 
 #ifdef __cplusplus
 }

@@ -350,3 +350,32 @@ def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, th
     b = np.ctypeslib.as_array(pb, shape=(max(total, 1),))[:total].copy()
     L.frogo_match_free(pa); L.frogo_match_free(pb)
     return [(a[int(offset[k]):int(offset[k + 1])], b[int(offset[k]):int(offset[k + 1])]) for k in range(n)]
+
+
+# ---- transform chains (oracle/chain_oracle.cpp) --------------------------------------------
+def chain_apply(links, points, jacobian=False):
+    """Forward evaluation (and Jacobians) of a chain of frog_amd.chain.Link on the CPU."""
+    from frog_amd import _abi
+    L = lib()
+    L.frogo_chain_apply.restype = None
+    L.frogo_chain_apply.argtypes = [C.POINTER(_abi.FrogChainLink), C.c_uint32, dp, dp, dp, C.c_size_t]
+    views = (_abi.FrogChainLink * max(1, len(links)))(*[l.view() for l in links])
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    out = np.empty_like(p)
+    jac = np.empty((len(p), 3, 3), np.float64) if jacobian else None
+    L.frogo_chain_apply(views, len(links), p.ctypes.data_as(dp), out.ctypes.data_as(dp),
+                        jac.ctypes.data_as(dp) if jacobian else None, len(p))
+    return (out, jac) if jacobian else out
+
+
+def chain_check(links, origin, spacing, dims):
+    from frog_amd import _abi
+    L = lib()
+    L.frogo_chain_check.restype = None
+    L.frogo_chain_check.argtypes = [C.POINTER(_abi.FrogChainLink), C.c_uint32, dp, dp, C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint64), dp]
+    views = (_abi.FrogChainLink * max(1, len(links)))(*[l.view() for l in links])
+    o = (C.c_double * 3)(*origin); s = (C.c_double * 3)(*spacing); d = (C.c_uint32 * 3)(*dims)
+    n, m = C.c_uint64(), C.c_double()
+    L.frogo_chain_check(views, len(links), o, s, d, C.byref(n), C.byref(m))
+    return int(n.value), float(m.value)

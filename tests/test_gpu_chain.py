@@ -1,0 +1,117 @@
+"""HIP transform-chain evaluation / Jacobian check (include/frog_chain.h) vs the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from frog_amd.chain import Chain, Link, read_transform
+from oracle.oracle_api import chain_apply, chain_check
+from test_chain import linear_lattice
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def random_chain(rng, n_lattices, amplitude):
+    M = np.eye(4); M[:3, :3] = np.diag(rng.uniform(0.8, 1.2, 3)); M[:3, 3] = rng.uniform(-5, 5, 3)
+    links = [Link.linear(M)]
+    for k in range(n_lattices):
+        n = 6 * 2 ** k
+        dims = (n + 3, n + 3, n + 4)
+        sp = tuple(120.0 / n for _ in range(3))
+        links.append(Link.bspline(dims, tuple(-10.0 - s for s in sp), sp,
+                                  (amplitude * rng.normal(size=(dims[0] * dims[1] * dims[2], 3))).astype(np.float32)))
+    return links
+
+
+@pytest.mark.parametrize("amplitude", [0.5, 20.0])
+def test_apply_and_check_match_oracle(amplitude):
+    rng = np.random.default_rng(7)
+    links = random_chain(rng, 3, amplitude)
+    pts = rng.uniform(-30, 140, (5000, 3))                  # some outside the lattices
+    c = Chain(links)
+    got, want = c.apply(pts), chain_apply(links, pts)
+    assert np.max(np.abs(got - want)) < 1e-9 * max(1.0, np.max(np.abs(want)))
+    grid = ((-5.0, -5.0, -5.0), (2.5, 2.5, 2.5), (41, 40, 39))
+    n, m = c.check(*grid)
+    rn, rm = chain_check(links, *grid)
+    # determinants within rounding of zero may fall on either side: allow a handful
+    assert abs(n - rn) <= 2 and abs(m - rm) < 1e-9 * max(1.0, abs(rm))
+    if amplitude > 1:
+        assert n > 100                                       # a wild lattice folds space
+    else:
+        assert n == 0 and m > 0
+
+
+def test_closed_form_cases():
+    A = np.array([[0.25, 0, 0], [0, 0, -0.5], [0.1, 0.2, 0]])
+    L = linear_lattice((9, 8, 10), (-12.0, -10.0, -15.0), (5.0, 4.0, 6.0), A, [1.0, -2.0, 0.5])
+    pts = np.random.default_rng(2).uniform(-2, 10, (300, 3))
+    assert np.allclose(Chain([L]).apply(pts), pts + pts @ A.T + [1.0, -2.0, 0.5], atol=1e-5)
+    n, m = Chain([L]).check((-2, -2, -2), (1, 1, 1), (12, 12, 12))
+    assert n == 0 and abs(m - np.linalg.det(np.eye(3) + A)) < 1e-6
+    assert np.array_equal(Chain([]).apply(pts), pts)
+    with pytest.raises(RuntimeError):
+        Chain([Link.bspline((2, 2, 2), (0, 0, 0), (0, 1, 1), np.zeros((8, 3), np.float32))])
+
+
+def test_chain_written_by_frog_in_both_forms(tmp_path, small_pairs):
+    # the chain frog writes (compact sidecars / single JSON) read back and applied: the two forms agree,
+    # the diffeomorphism guard (-gd 1) leaves no negative Jacobian on the lattice's own grid, and the
+    # chain moves the original keypoints of image i like the solver did
+    out = {}
+    for sub, extra in (("compact", []), ("single", ["-j"])):
+        d = tmp_path / sub
+        d.mkdir()
+        small_pairs.write(d / "pairs.bin")
+        r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-li", "12", "-dl", "2", "-di", "8", "-q", "1"] + extra,
+                           cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[sub] = [read_transform(d / "transforms" / f"{i}.json") for i in range(small_pairs.n_images)]
+    po = small_pairs.point_offset
+    for i in range(small_pairs.n_images):
+        links = out["compact"][i]
+        assert len(links) == len(out["single"][i]) >= 3
+        pts = small_pairs.xyz[po[i]:po[i + 1]].astype(np.float64)
+        a, b = Chain(links).apply(pts), Chain(out["single"][i]).apply(pts)
+        assert np.max(np.abs(a - b)) < 1e-3                  # two runs: float-atomic order of the lattice only
+        assert np.max(np.abs(a - chain_apply(links, pts))) < 1e-9 * np.max(np.abs(a))
+        last = links[-1]
+        n, m = Chain(links).check(tuple(o + s for o, s in zip(last.origin, last.spacing)), last.spacing,
+                                  tuple(d - 3 for d in last.dims))
+        assert n == 0 and m > 0
+
+
+def test_tools_points_transform_and_check_diffeomorphism(tmp_path):
+    import ctypes as C
+    import json
+    from frog_amd import _abi
+    lib = _abi.host_lib()
+    A = np.diag([-1.5, 0.0, 0.0])
+    fold = linear_lattice((10, 10, 10), (-20.0, -20.0, -20.0), (5.0, 5.0, 5.0), A, [0, 0, 0])
+    M = np.eye(4); M[:3, 3] = [1.0, 2.0, 3.0]
+    (tmp_path / "t.json").write_text(json.dumps({"transforms": [
+        {"type": "vtkMatrixToLinearTransform", "matrix": M.ravel().tolist()},
+        {"type": "vtkBSplineTransform", "dimensions": list(fold.dims), "origin": list(fold.origin), "spacing": list(fold.spacing),
+         "coeffs": fold.coeffs.ravel().tolist()}]}))
+    r = subprocess.run([os.path.join(ROOT, "bin", "PointsTransform"), "-p", "1", "1", "1", "-t", "t.json"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Input point : 1 1 1" in r.stdout, r.stdout + r.stderr
+    got = [float(v) for v in r.stdout.split("Output point :")[1].split()[:3]]
+    assert np.allclose(got, chain_apply(read_transform(tmp_path / "t.json"), [[1, 1, 1]])[0], atol=1e-4)
+    assert np.allclose(got, [2 - 1.5 * 2, 3, 4], atol=1e-4)          # translate, then x - 1.5 x
+    # the sampling grid comes from a volume header
+    d = (C.c_uint32 * 3)(12, 11, 10); s = (C.c_double * 3)(1.0, 1.0, 1.0); o = (C.c_double * 3)(-6.0, -6.0, -6.0)
+    vox = np.zeros(12 * 11 * 10, np.float32)
+    assert lib.frog_nifti_write(str(tmp_path / "vol.nii.gz").encode(), d, s, o, 1, vox.ctypes.data_as(_abi.c_float_p)) == 0
+    exe = os.path.join(ROOT, "bin", "CheckDiffeomorphism")
+    r = subprocess.run([exe, "vol.nii.gz", "t.json"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and f"{12 * 11 * 10} negative jacobian determinant values (100%)" in r.stdout, r.stdout
+    r = subprocess.run([exe, "vol.nii.gz", "t.json", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Resizing image with spacing : 2" in r.stdout and f"{6 * 6 * 5} negative" in r.stdout, r.stdout
+    (tmp_path / "id.json").write_text(json.dumps({"transforms": [{"type": "vtkMatrixToLinearTransform", "matrix": np.eye(4).ravel().tolist()}]}))
+    r = subprocess.run([exe, "vol.nii.gz", "id.json"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 negative jacobian determinant values (0%)" in r.stdout
+    assert subprocess.run([os.path.join(ROOT, "bin", "PointsTransform"), "-p", "1", "1", "1", "-ti", "t.json"], cwd=tmp_path,
+                          capture_output=True).returncode == 1
