@@ -10,6 +10,7 @@
 #include "pairs_store.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 
 namespace {
@@ -64,6 +65,11 @@ frog_pairs *frog_pairs_read(const char *path, int *status)
     if (status) *status = FROG_OK;
     FILE *f = fopen(path, "rb");
     if (!f) { if (status) *status = FROG_E_INVALID; return nullptr; }
+    // counts read from the file are checked against what is left of it before anything is allocated
+    fseek(f, 0, SEEK_END);
+    const long long file_size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    auto remaining = [&]() { return (unsigned long long)std::max(0LL, file_size - (long long)ftell(f)); };
     Reader r{ f };
     frog_pairs *p = new frog_pairs;
     uint16_t n = 0;
@@ -82,6 +88,8 @@ frog_pairs *frog_pairs_read(const char *path, int *status)
         uint32_t np = 0;
         r.get(&np);
         if (!r.ok) break;
+        if ((unsigned long long)np * 24ull > remaining()) { r.ok = false; break; }
+        if ((unsigned long long)p->point_offset.back() + np > 0xFFFFFFFFull) { r.ok = false; break; }
         std::vector<float> rec((size_t)np * 6);
         if (np) r.get(rec.data(), rec.size());
         const size_t base = p->xyz.size();
@@ -104,6 +112,7 @@ frog_pairs *frog_pairs_read(const char *path, int *status)
         if (!r.get(&i2) || !r.get(&size)) { err = FROG_E_INVALID; break; }
         if (!size) { err = FROG_E_INVALID; break; }            // imageGroup.cxx:1393-1398
         if (i1 >= n || i2 >= n) { err = FROG_E_INVALID; break; }
+        if ((unsigned long long)size * 8ull > remaining()) { err = FROG_E_INVALID; break; }
         std::vector<uint32_t> rec((size_t)size * 2);
         if (!r.get(rec.data(), rec.size())) { err = FROG_E_INVALID; break; }
         const uint32_t n1 = p->point_offset[i1 + 1] - p->point_offset[i1];
