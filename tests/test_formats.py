@@ -185,3 +185,20 @@ def test_keypoint_csv_skips_short_rows_and_carriage_returns(tmp_path):
     assert kp.n == 2 and kp.dim == 2                      # the 6-value row has no descriptor: dropped (count > 6)
     assert kp.xyz.tolist() == [[1, 2, 3], [4, 5, 6]] and kp.desc.tolist() == [[0.5, 0.25], [1, 2]]
     assert kp.laplacian.tolist() == [-1, 1]
+
+
+def test_pairs_reader_rejects_counts_larger_than_the_file(tmp_path):
+    # a corrupt header must be refused before anything is allocated from it (found by scripts/fuzz_host_parsers.cpp)
+    import ctypes as C
+    from frog_amd import _abi
+    p = Pairs.synthetic(3, 40, 20, seed=2)
+    p.write(tmp_path / "ok.bin")
+    raw = bytearray(open(tmp_path / "ok.bin", "rb").read())
+    name_len = struct.unpack_from("<H", raw, 2)[0]
+    npts_at = 2 + 2 + name_len + 24
+    assert struct.unpack_from("<I", raw, npts_at)[0] == 40
+    struct.pack_into("<I", raw, npts_at, 0xFFFFFF00)
+    (tmp_path / "bad.bin").write_bytes(bytes(raw))
+    status = C.c_int()
+    assert not _abi.host_lib().frog_pairs_read(str(tmp_path / "bad.bin").encode(), C.byref(status))
+    assert status.value == _abi.FROG_E_INVALID
