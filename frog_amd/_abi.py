@@ -154,6 +154,7 @@ HIP_SYMBOLS = {
                                    C.POINTER(c_u32_p)]),
     "frog_match_free": (None, [C.c_void_p]),
     "frog_matcher_last_stats": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "frog_get_points2_subset": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, c_float_p]),
     "frog_residual_sums": (C.c_int, [C.c_void_p]),
     "frog_get_error_map": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(FrogGridInfo), c_float_p, C.c_size_t]),
     "frog_comm_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -188,6 +189,7 @@ HOST_SYMBOLS = {
                                             C.POINTER(C.c_uint64), c_u32_p, c_u32_p]),
     "frog_synth_defaults": (None, [C.POINTER(FrogSynthParams)]),
     "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
+    "frog_pairs_append_points": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_uint32]),
     "frog_keypoints_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
     "frog_keypoints_free": (None, [C.c_void_p]),
     "frog_keypoints_count": (C.c_uint32, [C.c_void_p]),

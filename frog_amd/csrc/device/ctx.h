@@ -232,6 +232,8 @@ struct frog_ctx {
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
     std::vector<frog::GridRecord> grids;
+    frog::DevBuf<uint32_t> subset_idx;        // frog_get_points2_subset scratch
+    frog::DevBuf<float> subset_out;
     std::vector<float4> h_res_sums, h_res_pos; // frog_residual_sums: owned rows, internal numbering
     bool res_valid = false;
     bool xyz2_fresh = false;                  // pos2_spec holds transformPoints(apply=0) of the current state

@@ -773,6 +773,35 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
     return FROG_OK;
 }
 
+__global__ void gather_points_kernel(const P3 *pos2, const uint32_t *idx, uint32_t n, float *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const P3 p = pos2[idx[i]];
+    out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+}
+
+int frog_get_points2_subset(frog_ctx *ctx, const uint64_t *points, size_t n, float *xyz2)
+{
+    CTX_GUARD(ctx);
+    if (n && (!points || !xyz2)) return fail(FROG_E_INVALID, "null argument");
+    if (!n) return FROG_OK;
+    std::vector<uint32_t> idx(n);
+    for (size_t k = 0; k < n; k++) {
+        if (points[k] >= ctx->P) return fail(FROG_E_INVALID, "point index out of range");
+        idx[k] = ctx->h_new_of_old[points[k]];
+    }
+    FROG_HIP_CHECK(ctx->subset_idx.alloc(n));
+    FROG_HIP_CHECK(ctx->subset_out.alloc(3 * n));
+    hipStream_t s = ctx->stream;
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->subset_idx.p, idx.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    gather_points_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->pos2.p, ctx->subset_idx.p, (uint32_t)n, ctx->subset_out.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpyAsync(xyz2, ctx->subset_out.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    return FROG_OK;
+}
+
 int frog_get_linear(frog_ctx *ctx, uint32_t image, double m16[16])
 {
     CTX_GUARD(ctx);

@@ -219,6 +219,8 @@ void ImageGroup::run()
     saveDistanceHistograms("histograms.csv");
     saveMeasures(outputFileName);
     saveTransforms();
+    saveLandmarkDistances();                                            // :149
+    saveTransformedLandmarks();                                         // :150
     if (writePairs) writeLinksDistances();                              // :151
     saveStatsJSON();
 }
@@ -303,16 +305,143 @@ void ImageGroup::writeLinksDistances()
     gzclose(f);
 }
 
-// computeLandmarkDistances without landmarks, imageGroup.cxx:1229-1242
+// addLandmarks, imageGroup.cxx:1161-1227, validation landmarks (-l): one file per image in the
+// directory (sorted names), lines "name,x,y,z" ('#' comments); every landmark becomes an extra,
+// link-less point of its image -- so it is moved by transformPoints and enters the bounding boxes,
+// exactly as upstream.  Constraint landmarks (-lc, hardLinks) are not built.
+void ImageGroup::addLandmarks(const char *path, bool asConstraints)
+{
+    if (asConstraints) { cout << "Error : landmark constraints (-lc) are not supported by this build" << endl; exit(1); }
+    if (!pairs) { cout << "Error : no pairs" << endl; exit(1); }
+    std::vector<std::string> files;
+    for (const auto &p : std::filesystem::directory_iterator(path)) files.push_back(p.path().string());
+    std::sort(files.begin(), files.end());
+    const uint32_t nImages = frog_pairs_num_images(pairs);
+    for (size_t i = 0; i < files.size(); i++) {
+        std::ifstream infile(files[i]);
+        std::string line;
+        if (i + 1 > nImages) continue;                                  // `i > images.size() - 1`
+        frog_model m;
+        frog_pairs_model(pairs, &m);
+        uint32_t count = m.point_offset[i + 1] - m.point_offset[i];     // landmark.point = points.size()
+        std::vector<float> xyz;
+        while (std::getline(infile, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            size_t pos = line.find(',');
+            const std::string name = line.substr(0, pos);
+            line.erase(0, pos + 1);
+            float pt[3];
+            for (int j = 0; j < 3; j++) {
+                pos = line.find(',');
+                const std::string coord = line.substr(0, pos);
+                line.erase(0, pos == std::string::npos ? line.size() : pos + 1);
+                pt[j] = std::stof(coord);
+                if (j < 2 && invertLandmarksCoordinates) pt[j] *= -1;   // get opposite x and y coordinates!
+            }
+            xyz.insert(xyz.end(), pt, pt + 3);
+            landmarks[name].push_back(Landmark{ (uint32_t)i, count++ });
+        }
+        if (!xyz.empty()) check(frog_pairs_append_points(pairs, (uint32_t)i, xyz.data(), (uint32_t)(xyz.size() / 3)), "frog_pairs_append_points");
+    }
+}
+
+// xyz2 of every landmark, in the order of the map (name, then entry)
+void ImageGroup::fetchLandmarks()
+{
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    std::vector<uint64_t> idx;
+    for (const auto &kv : landmarks)
+        for (const Landmark &l : kv.second) idx.push_back((uint64_t)m.point_offset[l.image] + l.point);
+    landmarkXyz2.resize(3 * idx.size());
+    check(frog_get_points2_subset(ctx, idx.data(), idx.size(), landmarkXyz2.data()), "frog_get_points2_subset");
+}
+
+// computeLandmarkDistances, imageGroup.cxx:1229-1282
 void ImageGroup::computeLandmarkDistances(float e)
 {
-    if (!quiet) cout << "E = " << e;
+    if (!quiet || !landmarks.empty()) cout << "E = " << e;
     if (std::isnan(e)) {
         cout << endl << "Error : NaN" << endl;
         exit(1);
     }
-    if (!quiet) cout << endl;
-    measures.push_back(Measure{ e, 0, 0, 0 });
+    if (landmarks.empty()) {
+        if (!quiet) cout << endl;
+        measures.push_back(Measure{ e, 0, 0, 0 });
+        return;
+    }
+    fetchLandmarks();
+    std::vector<float> distances;
+    size_t at = 0;
+    for (const auto &kv : landmarks) {
+        const size_t n = kv.second.size();
+        float center[3] = { 0, 0, 0 };
+        for (size_t l = 0; l < n; l++)
+            for (int k = 0; k < 3; k++) center[k] += landmarkXyz2[3 * (at + l) + k] / n;
+        for (size_t l = 0; l < n; l++) {
+            float d2 = 0;
+            for (int k = 0; k < 3; k++) { const float t = landmarkXyz2[3 * (at + l) + k] - center[k]; d2 += t * t; }
+            distances.push_back(std::sqrt(d2));
+        }
+        at += n;
+    }
+    double sum = std::accumulate(distances.begin(), distances.end(), 0.0);
+    double mean = sum / distances.size();
+    auto max = std::max_element(distances.begin(), distances.end());
+    double sq_sum = std::inner_product(distances.begin(), distances.end(), distances.begin(), 0.0);
+    double stdev = std::sqrt(sq_sum / distances.size() - mean * mean);
+    cout << ", " << distances.size() << " landmarks:max=" << *max << ",average=" << mean << ",stdev=" << stdev << endl;
+    measures.push_back(Measure{ e, (float)mean, *max, (float)stdev });
+}
+
+// saveTransformedLandmarks, imageGroup.cxx:1284-1316
+bool ImageGroup::saveTransformedLandmarks()
+{
+    if (landmarks.empty()) return false;
+    fetchLandmarks();
+    frogjson::Value root = frogjson::Value::object();
+    size_t at = 0;
+    for (const auto &kv : landmarks) {
+        frogjson::Value arr = frogjson::Value::array();
+        for (const Landmark &l : kv.second) {
+            frogjson::Value land = frogjson::Value::object();
+            land["image"] = frogjson::Value((double)l.image);
+            frogjson::Value coords = frogjson::Value::array();
+            for (int i = 0; i < 3; i++) coords.push(frogjson::Value((double)landmarkXyz2[3 * at + i]));
+            land["xyz"] = coords;
+            arr.push(land);
+            at++;
+        }
+        root[kv.first] = arr;
+    }
+    std::fstream fs;
+    fs.open("transformedLandmarks.json", std::fstream::out | std::fstream::trunc);
+    fs << root.serialize();
+    fs.close();
+    return true;
+}
+
+// saveLandmarkDistances, imageGroup.cxx:1318-1351
+void ImageGroup::saveLandmarkDistances()
+{
+    if (landmarks.empty()) return;
+    fetchLandmarks();
+    std::fstream fs;
+    fs.open("distances.txt", std::fstream::out | std::fstream::trunc);
+    size_t at = 0;
+    for (const auto &kv : landmarks) {
+        const size_t n = kv.second.size();
+        float center[3] = { 0, 0, 0 };
+        for (size_t l = 0; l < n; l++)
+            for (int k = 0; k < 3; k++) center[k] += landmarkXyz2[3 * (at + l) + k] / n;
+        for (size_t l = 0; l < n; l++) {
+            float d2 = 0;
+            for (int k = 0; k < 3; k++) { const float t = landmarkXyz2[3 * (at + l) + k] - center[k]; d2 += t * t; }
+            fs << std::sqrt(d2) << "," << kv.first << "," << kv.second[l].image << endl;
+        }
+        at += n;
+    }
+    fs.close();
 }
 
 // displayStats, imageGroup.cxx:899-908 + Stats::displayParameters, stats.cxx:72-93

@@ -7,6 +7,7 @@
 // no CPU fallback live here.
 #pragma once
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,7 @@ public:
     ~ImageGroup();
 
     void run();
+    void addLandmarks(const char *path, bool asConstraints = false);   // :1161 (validation landmarks only)
     void readPairs(const char *fileName);        // imageGroup.cxx:1353
     void usePairs(frog_pairs *p);                // adopt an already parsed / synthetic group
 
@@ -53,6 +55,10 @@ public:
 
     // results of run()
     struct Measure { float E, landmarkAv, landmarkMax, landmarkSTD; };
+    struct Landmark { uint32_t image, point; };      // point = index inside the image (an appended, link-less point)
+    std::map<std::string, std::vector<Landmark>> landmarks;
+    std::vector<float> landmarkXyz2;                 // xyz2 of all landmarks, in map order (filled per iteration)
+    void fetchLandmarks();
     std::vector<Measure> measures;
     std::vector<int> gridsPerLevel;
     double loopSeconds = 0;      // time spent inside the two iteration loops
@@ -66,7 +72,9 @@ protected:
 
     void createContext();
     void check(int rc, const char *what);
-    void computeLandmarkDistances(float e);      // :1229 (no landmarks: records E, exits on NaN)
+    void computeLandmarkDistances(float e);      // :1229
+    bool saveTransformedLandmarks();             // :1284
+    void saveLandmarkDistances();                // :1318
     void displayStats();                         // :899
     void displayLinearTransforms();              // :600
     void countInliers();                         // :988

@@ -133,6 +133,19 @@ frog_pairs *frog_pairs_read(const char *path, int *status)
     return p;
 }
 
+int frog_pairs_append_points(frog_pairs *p, uint32_t image, const float *xyz, uint32_t n)
+{
+    if (!p || image >= p->n_images || (n && !xyz)) return FROG_E_INVALID;
+    if (!n) return FROG_OK;
+    if (p->num_points() + n > 0xFFFFFFFFull) return FROG_E_INVALID;
+    const size_t at = 3 * (size_t)p->point_offset[image + 1];
+    p->xyz.insert(p->xyz.begin() + at, xyz, xyz + 3 * (size_t)n);
+    p->other.insert(p->other.begin() + at, 3 * (size_t)n, 0.f);
+    for (uint32_t i = image + 1; i <= p->n_images; i++) p->point_offset[i] += n;
+    p->build_links();                       // point indices inside an image are unchanged; rows shift
+    return FROG_OK;
+}
+
 int frog_pairs_write(const frog_pairs *p, const char *path)
 {
     FILE *f = fopen(path, "wb");

@@ -122,6 +122,15 @@ class Pairs:
     def link_point(self):
         return self._view(self.model.link_point, C.c_uint32, self.n_half_links)
 
+    def append_points(self, image, xyz):
+        """Extra link-less points at the end of `image` (how the reference stores landmarks,
+        imageGroup.cxx:1185-1201); the model views are refreshed."""
+        a = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        rc = self._lib.frog_pairs_append_points(self._h, image, a.ctypes.data_as(_abi.c_float_p), len(a))
+        if rc:
+            raise ValueError(f"frog_pairs_append_points failed ({rc})")
+        self._lib.frog_pairs_model(self._h, C.byref(self.model))
+
     def block(self, b):
         i1, i2, n = C.c_uint16(), C.c_uint16(), C.c_uint32()
         p1, p2 = _abi.c_u32_p(), _abi.c_u32_p()

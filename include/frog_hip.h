@@ -87,6 +87,10 @@ int frog_get_points(frog_ctx *ctx, float *xyz, float *xyz2);
 /* Overwrite xyz2 (3*P floats) -- test hook to start two implementations from
  * identical coordinates. */
 int frog_set_points2(frog_ctx *ctx, const float *xyz2);
+/* xyz2 of the listed points (global indices in the model's order), 3 floats each: what the
+ * reference reads from a handful of Point::xyz2 per iteration (landmark measures,
+ * imageGroup.cxx:1229-1281) without copying the whole table back. */
+int frog_get_points2_subset(frog_ctx *ctx, const uint64_t *points, size_t n, float *xyz2_out3n);
 int frog_get_linear(frog_ctx *ctx, uint32_t image, double matrix16[16]);
 int frog_get_em(frog_ctx *ctx, uint32_t image, float c1_c2_ratio[3]);
 int frog_set_em(frog_ctx *ctx, uint32_t image, const float c1_c2_ratio[3]);

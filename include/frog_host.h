@@ -78,6 +78,12 @@ typedef struct frog_synth_params {
 void frog_synth_defaults(frog_synth_params *p);
 frog_pairs *frog_synth_generate(const frog_synth_params *p);
 
+/* Appends n points without links to `image` (after its existing points; later images' points
+ * shift).  This is how the reference stores landmarks: extra entries of Image::points
+ * (imageGroup.cxx:1185-1201), moved by transformPoints like every keypoint and counted in
+ * the bounding boxes. */
+int frog_pairs_append_points(frog_pairs *p, uint32_t image, const float *xyz, uint32_t n);
+
 /* ---- NIfTI-1 writer for lattice images ------------------------------------------
  * Replaces vtkNIFTIImageWriter at tools/transformIO.h:196-208 (B-spline coefficient
  * sidecars `<i>.json.<n>.nii.gz`, 3 components) and registration/imageGroup.cxx:559-563

@@ -202,3 +202,101 @@ def test_two_ranks_match_one_rank(tmp_path):
         for i, grids in res["coeff"].items():
             for k, c in enumerate(grids):
                 assert relerr(c, one["coeff"][i][k]) < 1e-5
+
+
+def test_cli_validation_landmarks(tmp_path):
+    # -l <dir>: one file per image (sorted names), "name,x,y,z" lines with x and y inverted (-il 1 is
+    # the default); landmarks become link-less points of their image (imageGroup.cxx:1161-1227), the
+    # per-iteration measures and the two landmark reports come from their xyz2 (:1229-1351)
+    pairs = Pairs.synthetic(5, 2500, 1200, seed=13)
+    pairs.write(tmp_path / "pairs.bin")
+    rng = np.random.default_rng(3)
+    po = np.asarray(pairs.point_offset)
+    ld = tmp_path / "landmarks"
+    ld.mkdir()
+    # anatomical correspondences: keypoints of image 0 whose nearest matched partners in every other image
+    # sit at the same common-space place (the partners of a true match), slightly jittered
+    rp, li, lp = np.asarray(pairs.row_ptr), np.asarray(pairs.link_image), np.asarray(pairs.link_point)
+    xyz_all = np.asarray(pairs.xyz)
+    chosen = []
+    for p0 in range(po[1]):
+        links = {int(li[l]): int(lp[l]) for l in range(rp[p0], rp[p0 + 1])}
+        if set(links) == {1, 2, 3, 4}:
+            chosen.append((p0, links))
+        if len(chosen) == 3:
+            break
+    assert len(chosen) == 3
+    extra = []
+    for i in range(5):
+        pick = np.array([xyz_all[p0] if i == 0 else xyz_all[po[i] + links[i]] for p0, links in chosen], np.float32)
+        pick = pick + rng.normal(0, 0.5, pick.shape).astype(np.float32)
+        names = ["apex", "base", "carina"]
+        if i == 0:                                            # one image may hold a landmark twice
+            names = names + ["apex"]; pick = np.concatenate([pick, pick[:1] + np.float32(0.25)])
+        extra.append((names, pick.astype(np.float32)))
+        with open(ld / f"img{i:02d}.csv", "w") as f:
+            f.write("# name,x,y,z\n")
+            for n_, p in zip(names, pick):
+                f.write(f"{n_},{-p[0]:.9g},{-p[1]:.9g},{p[2]:.9g}\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-l", "landmarks", "-li", "12", "-dl", "1", "-di", "6", "-j"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    n_land = sum(len(n_) for n_, _ in extra)
+    assert f", {n_land} landmarks:max=" in r.stdout
+
+    # the same group in the oracle: landmarks appended as link-less points
+    ref_pairs = Pairs.synthetic(5, 2500, 1200, seed=13)
+    for i, (_, pick) in enumerate(extra):
+        ref_pairs.append_points(i, pick)
+    rpo = np.asarray(ref_pairs.point_offset)
+    assert list(np.diff(rpo)) == [2500 + len(n_) for n_, _ in extra]
+    groups = {}
+    for i, (names, _) in enumerate(extra):
+        for k, n_ in enumerate(names):
+            groups.setdefault(n_, []).append(rpo[i] + 2500 + k)
+    order = sorted(groups)                                   # std::map iterates in key order
+
+    def measure(xyz2):
+        d = []
+        for n_ in order:
+            pts = xyz2[groups[n_]].astype(np.float32)
+            c = np.zeros(3, np.float32)
+            for p in pts:
+                c += p / np.float32(len(pts))
+            d += list(np.sqrt(((pts - c) ** 2).sum(1)))
+        d = np.array(d, np.float64)
+        return d.mean(), d.max(), np.sqrt((d * d).mean() - d.mean() ** 2), d
+
+    ref = OracleGroup(ref_pairs.model, _abi.FrogOptions.default())
+    ref.setup_stats(); ref.linear_init(); ref.transform_points()
+    want = []
+    for it in range(12):
+        if it % 10 == 0:
+            ref.update_stats()
+        ref.linear_step(); ref.transform_points(); want.append(measure(ref.xyz2())[:3])
+    ref.transform_points(True)
+    ref.deformable_setup(0, _abi.FrogGridInfo()); ref.transform_points()
+    for it in range(6):
+        if it % 10 == 0:
+            ref.update_stats()
+        assert ref.deformable_step(0.02) >= 0
+        ref.transform_points(); want.append(measure(ref.xyz2())[:3])
+    ref.transform_points(True)
+    rows = list(csv.reader(open(tmp_path / "measures.csv")))[1:]
+    assert len(rows) == len(want)
+    got = np.array([[float(v) for v in r_[2:5]] for r_ in rows])
+    assert np.max(np.abs(got - np.array(want)) / np.maximum(np.array(want), 1e-3)) < 2e-3        # 6 printed digits, f32 coordinates
+    assert got[-1, 0] < got[0, 0]                               # registration brings the landmarks together
+    # reports
+    final = measure(ref.xyz2())[3]
+    lines = [l.split(",") for l in open(tmp_path / "distances.txt").read().split()]
+    assert [l[1] for l in lines] == [n_ for n_ in order for _ in groups[n_]]
+    assert np.allclose([float(l[0]) for l in lines], final, rtol=2e-3, atol=1e-3)
+    tl = json.load(open(tmp_path / "transformedLandmarks.json"))
+    assert sorted(tl) == order and [e["image"] for e in tl["apex"]] == [0, 0, 1, 2, 3, 4] and len(tl["base"]) == 5
+    assert np.allclose(tl["carina"][0]["xyz"], ref.xyz2()[groups["carina"][0]], rtol=1e-4, atol=1e-3)
+    bbox = json.load(open(tmp_path / "bbox.json"))
+    assert not bbox.get("images") or bbox["images"][0]["points"] == 2504
+    # -lc (constraints) is refused
+    assert subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-lc", "landmarks"], cwd=tmp_path,
+                          capture_output=True).returncode == 1
