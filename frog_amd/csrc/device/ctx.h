@@ -232,6 +232,11 @@ struct frog_ctx {
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
     std::vector<frog::GridRecord> grids;
+    // hard links (landmark constraints) of owned points, internal numbering: hl_point[n_hard], CSR hl_ptr, partners
+    uint32_t n_hard = 0;
+    float hard_weight2 = 0;
+    frog::DevBuf<uint32_t> hl_point, hl_ptr, hl_partner;
+    frog::DevBuf<double> hl_partial;          // [n_hard][2]
     frog::DevBuf<uint32_t> subset_idx;        // frog_get_points2_subset scratch
     frog::DevBuf<float> subset_out;
     std::vector<float4> h_res_sums, h_res_pos; // frog_residual_sums: owned rows, internal numbering

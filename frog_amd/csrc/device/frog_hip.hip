@@ -644,6 +644,11 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
         energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p);
         energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
+        if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
+            hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
+                                                                    ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, ctx->hl_partial.p);
+            hard_energy_kernel<<<1, 1, 0, s>>>(ctx->hl_partial.p, ctx->n_hard, ctx->energy.p);
+        }
     }
     FROG_HIP_CHECK(hipGetLastError());
     if (ctx->n_scatter_blocks) {
@@ -897,6 +902,35 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
     return FROG_OK;
 }
 
+int frog_set_hard_links(frog_ctx *ctx, const uint64_t *point, const uint64_t *partner, size_t n, float weight2)
+{
+    CTX_GUARD(ctx);
+    if (n && (!point || !partner)) return fail(FROG_E_INVALID, "null argument");
+    // keep the links of owned points, grouped by point in first-appearance order, link order preserved
+    std::vector<uint32_t> pts, ptr(1, 0), prt;
+    std::vector<std::vector<uint32_t>> per;
+    std::vector<int64_t> slot(ctx->P, -1);
+    for (size_t k = 0; k < n; k++) {
+        if (point[k] >= ctx->P || partner[k] >= ctx->P) return fail(FROG_E_INVALID, "hard link point out of range");
+        if (point[k] < ctx->own_pt_begin || point[k] >= ctx->own_pt_end) continue;
+        if (slot[point[k]] < 0) { slot[point[k]] = (int64_t)pts.size(); pts.push_back(ctx->h_new_of_old[point[k]]); per.emplace_back(); }
+        per[(size_t)slot[point[k]]].push_back(ctx->h_new_of_old[partner[k]]);
+    }
+    for (const auto &v : per) { prt.insert(prt.end(), v.begin(), v.end()); ptr.push_back((uint32_t)prt.size()); }
+    hipStream_t s = ctx->stream;
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    ctx->n_hard = (uint32_t)pts.size();
+    ctx->hard_weight2 = weight2;
+    ctx->res_valid = false;
+    if (!ctx->n_hard) return FROG_OK;
+    FROG_HIP_CHECK(ctx->hl_point.upload(pts, s));
+    FROG_HIP_CHECK(ctx->hl_ptr.upload(ptr, s));
+    FROG_HIP_CHECK(ctx->hl_partner.upload(prt, s));
+    FROG_HIP_CHECK(ctx->hl_partial.alloc((size_t)2 * ctx->n_hard));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    return FROG_OK;
+}
+
 // saveErrorMaps, imageGroup.cxx:475-567
 int frog_residual_sums(frog_ctx *ctx)
 {
@@ -906,6 +940,9 @@ int frog_residual_sums(frog_ctx *ctx)
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     for (uint32_t sub = 0; sub < ctx->n_sub; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
     if (n) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
+    if (ctx->n_hard)                                            // :520-533
+        hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
+                                                                ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, nullptr);
     FROG_HIP_CHECK(hipGetLastError());
     // host copies of the owned rows (internal numbering): sums and rebased coordinates
     ctx->h_res_sums.resize(n);

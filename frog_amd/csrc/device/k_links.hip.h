@@ -353,6 +353,39 @@ __global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group
     point_sums[own_pt_begin + i] = s;
 }
 
+// Landmark constraints (Point::hardLinks): after the regular links of a point, each hard link adds
+// weight2 * (pB - pA) and weight2 to its f32 sums, in the order stored (imageGroup.cxx:280-295).  One
+// thread per constrained point (a few hundred); its energy terms go to partial[t] = (sDistances, sWeights).
+__global__ void hard_links_kernel(const P3 *pos2, float4 *point_sums, const uint32_t *point, const uint32_t *ptr,
+                                  const uint32_t *partner, uint32_t n_hard, float w2, double *partial)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_hard) return;
+    const uint32_t a = point[t];
+    const P3 pA = pos2[a];
+    float4 s = point_sums[a];
+    double sd = 0, sw = 0;
+    for (uint32_t l = ptr[t]; l < ptr[t + 1]; l++) {
+        const P3 pB = pos2[partner[l]];
+        const float dx = pB.x - pA.x, dy = pB.y - pA.y, dz = pB.z - pA.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        sd += (double)(w2 * d2);
+        sw += (double)w2;
+        s.x += w2 * dx; s.y += w2 * dy; s.z += w2 * dz; s.w += w2;
+    }
+    point_sums[a] = s;
+    if (partial) { partial[2 * t] = sd; partial[2 * t + 1] = sw; }
+}
+
+// adds the constrained points' energy terms, in order, to energy[0..1]
+__global__ void hard_energy_kernel(const double *partial, uint32_t n_hard, double *energy)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    double a = 0, b = 0;
+    for (uint32_t t = 0; t < n_hard; t++) { a += partial[2 * t]; b += partial[2 * t + 1]; }
+    energy[0] += a; energy[1] += b;
+}
+
 // Sum of the (sDistances, sWeights) tile partials -> energy[0..1], in two stages with a
 // fixed tree (deterministic): ENERGY_BLOCKS blocks reduce contiguous slices, then one
 // block adds their results in order.

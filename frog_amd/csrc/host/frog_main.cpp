@@ -120,10 +120,7 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-t") == 0) group.inlierThreshold = atof(value);
         if (strcmp(key, "-ts") == 0) group.transformSubdirectory = std::string(value);
         if (strcmp(key, "-l") == 0) group.addLandmarks(value);          // at parse time, as upstream (frog.cxx:187-190)
-        if (strcmp(key, "-lc") == 0) {
-            cout << "Error : landmark constraints (-lc) are not supported by this build" << endl;
-            return 1;
-        }
+        if (strcmp(key, "-lc") == 0) group.addLandmarks(value, true);   // frog.cxx:191-193
         if (strcmp(key, "-lcw") == 0) group.landmarksConstraintsWeight = atof(value);
         if (strcmp(key, "-mf") == 0) group.outputFileName = value;
         if (strcmp(key, "-wp") == 0) group.writePairs = atoi(value);

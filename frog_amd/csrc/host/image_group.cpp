@@ -119,6 +119,15 @@ void ImageGroup::createContext()
     frog_model m;
     frog_pairs_model(pairs, &m);
     check(frog_create(&m, &o, device, 0, m.n_images, &ctx), "frog_create");
+    if (!hardLinks.empty()) {                                           // Point::hardLinks, weight :237
+        std::vector<uint64_t> a, b;
+        for (const auto &hl : hardLinks) {
+            a.push_back((uint64_t)m.point_offset[hl.first.image] + hl.first.point);
+            b.push_back((uint64_t)m.point_offset[hl.second.image] + hl.second.point);
+        }
+        const float constraintWeight = m.n_images * landmarksConstraintsWeight;
+        check(frog_set_hard_links(ctx, a.data(), b.data(), a.size(), constraintWeight * constraintWeight), "frog_set_hard_links");
+    }
     counts.assign(m.n_images, frog_counts{});
 }
 
@@ -308,11 +317,11 @@ void ImageGroup::writeLinksDistances()
 // addLandmarks, imageGroup.cxx:1161-1227, validation landmarks (-l): one file per image in the
 // directory (sorted names), lines "name,x,y,z" ('#' comments); every landmark becomes an extra,
 // link-less point of its image -- so it is moved by transformPoints and enters the bounding boxes,
-// exactly as upstream.  Constraint landmarks (-lc, hardLinks) are not built.
+// exactly as upstream.  With -lc the landmarks of one name are also hard-linked to each other.
 void ImageGroup::addLandmarks(const char *path, bool asConstraints)
 {
-    if (asConstraints) { cout << "Error : landmark constraints (-lc) are not supported by this build" << endl; exit(1); }
     if (!pairs) { cout << "Error : no pairs" << endl; exit(1); }
+    std::map<std::string, std::vector<Landmark>> constraints;
     std::vector<std::string> files;
     for (const auto &p : std::filesystem::directory_iterator(path)) files.push_back(p.path().string());
     std::sort(files.begin(), files.end());
@@ -339,10 +348,20 @@ void ImageGroup::addLandmarks(const char *path, bool asConstraints)
                 if (j < 2 && invertLandmarksCoordinates) pt[j] *= -1;   // get opposite x and y coordinates!
             }
             xyz.insert(xyz.end(), pt, pt + 3);
-            landmarks[name].push_back(Landmark{ (uint32_t)i, count++ });
+            landmarks[name].push_back(Landmark{ (uint32_t)i, count });
+            constraints[name].push_back(Landmark{ (uint32_t)i, count });
+            count++;
         }
         if (!xyz.empty()) check(frog_pairs_append_points(pairs, (uint32_t)i, xyz.data(), (uint32_t)(xyz.size() / 3)), "frog_pairs_append_points");
     }
+    if (!asConstraints) return;
+    // :1210-1225: every landmark is hard-linked to every other landmark of the same name
+    for (const auto &kv : constraints)
+        for (const Landmark &landmark : kv.second)
+            for (const Landmark &landmark2 : kv.second) {
+                if (landmark.image == landmark2.image && landmark.point == landmark2.point) continue;
+                hardLinks.push_back({ landmark, landmark2 });
+            }
 }
 
 // xyz2 of every landmark, in the order of the map (name, then entry)

@@ -57,6 +57,7 @@ public:
     struct Measure { float E, landmarkAv, landmarkMax, landmarkSTD; };
     struct Landmark { uint32_t image, point; };      // point = index inside the image (an appended, link-less point)
     std::map<std::string, std::vector<Landmark>> landmarks;
+    std::vector<std::pair<Landmark, Landmark>> hardLinks;   // (point, partner) in upstream's push order (-lc)
     std::vector<float> landmarkXyz2;                 // xyz2 of all landmarks, in map order (filled per iteration)
     void fetchLandmarks();
     std::vector<Measure> measures;

@@ -241,6 +241,13 @@ class ImageGroup:
               "frog_get_error_map")
         return info, out
 
+    def set_hard_links(self, point, partner, weight2):
+        """Landmark constraints (Point::hardLinks): directed links point <- partner, global indices."""
+        a = np.ascontiguousarray(point, np.uint64); b = np.ascontiguousarray(partner, np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        check(self._lib.frog_set_hard_links(self._ctx, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), len(a), float(weight2)),
+              "frog_set_hard_links")
+
     def residualSums(self):
         check(self._lib.frog_residual_sums(self._ctx), "frog_residual_sums")
 

@@ -109,6 +109,14 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info,
 int frog_get_point_sums(frog_ctx *ctx, float *out4P);
 int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out4G, size_t cap_floats);
 
+/* Landmark constraints (-lc): Point::hardLinks (imageGroup.cxx:1210-1225).  n directed links
+ * point <- partner (global point indices in the model's order; the links of one point are used in
+ * the order given).  In every deformable step and in the error maps each adds
+ * weight2 * (partner.xyz2 - point.xyz2) / weight2 to the point's sums after its regular links,
+ * and weight2 * dist2 / weight2 to the energy sums (:280-295, :520-533); weight2 =
+ * (nImages * landmarksConstraintsWeight)^2 (:237).  n = 0 removes them. */
+int frog_set_hard_links(frog_ctx *ctx, const uint64_t *point, const uint64_t *partner, size_t n, float weight2);
+
 /* saveErrorMaps (imageGroup.cxx:475-567).  frog_residual_sums runs the half-link sweep on
  * the CURRENT xyz2 (per-point sDisp/sWeight over inlier links, :493-533) for the owned
  * images -- no collective, the xyz2 replica is whole after transformPoints.

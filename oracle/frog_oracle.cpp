@@ -277,6 +277,10 @@ struct frogo_group {
     std::vector<Grid> grids;              // allTransforms[1..]
     std::vector<std::vector<float>> gradient;   // per image 4*G (image.gradient)
     std::vector<float> point_sums;        // 4*P, oracle-only: sDisp xyz + sWeight of the last step
+    // Point::hardLinks (landmark constraints, imageGroup.cxx:1210-1225): CSR over all points, partner = global point
+    std::vector<uint64_t> hard_rowp;      // P + 1 (empty: none)
+    std::vector<uint64_t> hard_partner;
+    float hard_weight2 = 0;               // (nImages * landmarksConstraintsWeight)^2, :237, :287
 };
 
 namespace {
@@ -567,6 +571,16 @@ void frogo_deformable_phase_a(frogo_group *g, const float alpha, double *gridsum
                 for (int k = 0; k < 3; k++) sDisp[k] += w2 * (pB[k] - pA[k]);
                 sWeight += w2;
             }
+            if (!g->hard_rowp.empty())                                   // hardLinks, :280-295
+                for (uint64_t l = g->hard_rowp[p]; l < g->hard_rowp[p + 1]; l++) {
+                    const float *pB = &g->xyz2[3 * g->hard_partner[l]];
+                    float d2 = dist2_f32(pA, pB);
+                    float w2 = g->hard_weight2;
+                    sDistances += w2 * d2;
+                    sWeights += w2;
+                    for (int k = 0; k < 3; k++) sDisp[k] += w2 * (pB[k] - pA[k]);
+                    sWeight += w2;
+                }
             float *ps = &g->point_sums[4 * (size_t)p];
             ps[0] = sDisp[0]; ps[1] = sDisp[1]; ps[2] = sDisp[2]; ps[3] = sWeight;
             if (sWeight == 0) continue;
@@ -702,6 +716,13 @@ int frogo_error_map(frogo_group *g, uint32_t image1, float *out, size_t cap)
             for (int k = 0; k < 3; k++) sDisp[k] += w2 * (pB[k] - pA[k]);
             sWeight += w2;
         }
+        if (!g->hard_rowp.empty())                                      // hardLinks, :520-533
+            for (uint64_t l = g->hard_rowp[p]; l < g->hard_rowp[p + 1]; l++) {
+                const float *pB = &g->xyz2[3 * g->hard_partner[l]];
+                float w2 = g->hard_weight2;
+                for (int k = 0; k < 3; k++) sDisp[k] += w2 * (pB[k] - pA[k]);
+                sWeight += w2;
+            }
         if (sWeight == 0) continue;                                     // :535
         long id = 0;
         for (int k = 0; k < 3; k++) {                                   // :539-544
@@ -715,6 +736,20 @@ int frogo_error_map(frogo_group *g, uint32_t image1, float *out, size_t cap)
     for (size_t i = 0; i < G; i++)                                      // :551-556
         if (out[4 * i + 3] > 0)
             for (int k = 0; k < 3; k++) out[4 * i + k] /= out[4 * i + 3];
+    return 0;
+}
+
+// hardLinks of the landmark constraints (-lc, imageGroup.cxx:1210-1225): n directed links
+// (point <- partner, global point indices), grouped by point in the order they are given.
+int frogo_set_hard_links(frogo_group *g, const uint64_t *point, const uint64_t *partner, size_t n, float weight2)
+{
+    g->hard_rowp.assign(g->P + 1, 0);
+    g->hard_partner.resize(n);
+    for (size_t k = 0; k < n; k++) { if (point[k] >= g->P || partner[k] >= g->P) return -1; g->hard_rowp[point[k] + 1]++; }
+    for (uint64_t p = 0; p < g->P; p++) g->hard_rowp[p + 1] += g->hard_rowp[p];
+    std::vector<uint64_t> cur(g->hard_rowp.begin(), g->hard_rowp.end() - 1);
+    for (size_t k = 0; k < n; k++) g->hard_partner[cur[point[k]]++] = partner[k];
+    g->hard_weight2 = weight2;
     return 0;
 }
 

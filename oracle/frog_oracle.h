@@ -52,6 +52,7 @@ double frogo_linear_step(frogo_group *g);                         /* :1063 */
 void frogo_deformable_setup(frogo_group *g, int level, frog_grid_info *out); /* :159 */
 double frogo_deformable_step(frogo_group *g, float alpha);        /* :234  */
 void frogo_count_inliers(frogo_group *g, frog_counts *per_image); /* :988  */
+int  frogo_set_hard_links(frogo_group *g, const uint64_t *point, const uint64_t *partner, size_t n, float weight2); /* :1210 */
 int  frogo_error_map(frogo_group *g, uint32_t image, float *out4G, size_t cap_floats); /* :475 */
 
 /* Split phases (several instances owning disjoint image ranges, combined by the caller:

@@ -216,6 +216,13 @@ class OracleGroup:
         assert rc == 0
         return out
 
+    def set_hard_links(self, point, partner, weight2):
+        a = np.ascontiguousarray(point, np.uint64); b = np.ascontiguousarray(partner, np.uint64)
+        self.L.frogo_set_hard_links.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t, C.c_float]
+        self.L.frogo_set_hard_links.restype = C.c_int
+        assert self.L.frogo_set_hard_links(self.h, a.ctypes.data_as(C.POINTER(C.c_uint64)), b.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           len(a), float(weight2)) == 0
+
     def count_inliers(self, counts_array):
         self.L.frogo_count_inliers(self.h, counts_array)
         return counts_array

@@ -297,6 +297,10 @@ def test_cli_validation_landmarks(tmp_path):
     assert np.allclose(tl["carina"][0]["xyz"], ref.xyz2()[groups["carina"][0]], rtol=1e-4, atol=1e-3)
     bbox = json.load(open(tmp_path / "bbox.json"))
     assert not bbox.get("images") or bbox["images"][0]["points"] == 2504
-    # -lc (constraints) is refused
-    assert subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-lc", "landmarks"], cwd=tmp_path,
-                          capture_output=True).returncode == 1
+    # -lc: the same landmarks as constraints pull their copies together much harder than the matches alone
+    r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-lc", "landmarks", "-li", "12", "-dl", "1", "-di", "6", "-j",
+                        "-mf", "measures_lc.csv"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lc = np.array([[float(v) for v in r_[2:5]] for r_ in list(csv.reader(open(tmp_path / "measures_lc.csv")))[1:]])
+    assert np.allclose(lc[:12], got[:12], rtol=1e-5)          # the linear stage ignores hard links
+    assert lc[-1, 0] < 0.95 * got[-1, 0]

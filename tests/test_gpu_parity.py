@@ -409,3 +409,53 @@ def test_sweep_sub_passes_match_the_oracle(small_pairs, n_sub, monkeypatch):
     rc = ref.count_inliers((_abi.FrogCounts * small_pairs.n_images)())
     for i in range(small_pairs.n_images):
         assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+
+
+def test_hard_links_of_landmark_constraints(small_pairs):
+    # -lc: every landmark is hard-linked to the other landmarks of its name; in the deformable step and the
+    # error maps a hard link adds weight2 * (pB - pA) and weight2 after the regular links, and
+    # weight2 * dist2 / weight2 to the energy sums (imageGroup.cxx:280-295, :520-533)
+    from frog_amd.pairs import Pairs
+    pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+    po0 = np.asarray(pairs.point_offset).copy()
+    rng = np.random.default_rng(8)
+    for i in range(6):                                   # 3 landmarks per image, as link-less points
+        pts = np.asarray(pairs.xyz)[po0[i]:po0[i + 1]]
+        pairs.append_points(i, pts[rng.choice(3000, 3, replace=False)])
+    po = np.asarray(pairs.point_offset)
+    point, partner = [], []
+    for k in range(3):                                   # name k: the k-th landmark of every image
+        ids = [po[i] + 3000 + k for i in range(6)]
+        for a in ids:
+            for b in ids:
+                if a != b:
+                    point.append(a); partner.append(b)
+    w2 = np.float32(6 * 50.0) ** 2
+    g, ref = make(pairs)
+    _to_deformable(g, ref, iters=12)
+    info = g.setupDeformableTransforms(1)
+    ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    ref.update_stats()
+    for i in range(ref.n_images):
+        g.set_em(i, ref.em(i))
+    e0 = g.updateDeformableTransforms(0.0)               # alpha 0: state unchanged, E without constraints
+    g.transformPoints()
+    g.set_hard_links(point, partner, w2); ref.set_hard_links(point, partner, w2)
+    e = g.updateDeformableTransforms(0.02); er = ref.deformable_step(0.02)
+    assert er > 0 and abs(e - er) / er < 1e-5 and e > 2 * e0      # the constraint terms dominate the energy sums
+    ps, rps = g.point_sums(), ref.point_sums()
+    assert relerr(ps, rps) < 1e-5
+    assert all(rps[a, 3] >= 5 * w2 * 0.999 for a in set(point))  # 5 hard links each
+    for i in range(ref.n_images):
+        assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
+    g.transformPoints(); ref.transform_points()
+    g.set_points2(ref.xyz2())
+    g.residualSums()
+    n_cp = info.dims[0] * info.dims[1] * info.dims[2]
+    for i in range(ref.n_images):
+        m, r = g.errorMap(i)[1], ref.error_map(i, n_cp)
+        assert relerr(m[:, 3], r[:, 3]) < 1e-5 and np.max(np.abs(m[:, :3] - r[:, :3])) < 1e-4 * max(1.0, np.max(np.abs(r[:, :3])))
+    g.set_hard_links([], [], 0.0)                        # n = 0 removes them
+    e2 = g.updateDeformableTransforms(0.0)
+    assert e2 < 0.5 * e
