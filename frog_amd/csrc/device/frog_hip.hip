@@ -653,7 +653,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     FROG_HIP_CHECK(hipGetLastError());
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);
-        scatter_kernel<<<ctx->n_scatter_blocks, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p,
+        const size_t tile_bytes = (size_t)(gd.brick + 3) * (gd.brick + 3) * (gd.brick + 3) * sizeof(float4);
+        scatter_kernel<<<ctx->n_scatter_blocks, 64, tile_bytes, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p,
                                                            reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                                                            ctx->gradf.p, gd);
         FROG_HIP_CHECK(hipGetLastError());

@@ -407,7 +407,9 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                                                      const uint32_t *perm, const ScatterBlock *blocks,
                                                      float4 *gradf, const GeomDev g)
 {
-    __shared__ float4 tile[BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX];
+    // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
+    // take 5.4 KB instead of the 21 KB of the largest brick and 15 instead of 6 blocks fit a CU
+    extern __shared__ float4 tile[];
     __shared__ ScatterPoint pts[64];
     const ScatterBlock blk = blocks[blockIdx.x];
     const int lane = threadIdx.x;
