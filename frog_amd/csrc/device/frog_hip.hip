@@ -275,7 +275,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     // selection of the first refresh, ahead of time
     c->sel_ready = 0; c->sel_used = 1;
-    select_kernel<<<c->n_owned(), 64, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
+    select_kernel<<<c->n_owned(), SELECT_THREADS, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipEventRecord(c->sel_done, c->side));
 #undef CREATE_CHECK
@@ -394,7 +394,7 @@ int frog_update_stats_local(frog_ctx *ctx)
     // prepare the next refresh's selection into the other buffer, behind its last reader
     const int nxt = cur ^ 1;
     FROG_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ord_read[nxt], 0));
-    select_kernel<<<nO, 64, 0, ctx->side>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p);
+    select_kernel<<<nO, SELECT_THREADS, 0, ctx->side>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p);
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipEventRecord(ctx->sel_done, ctx->side));
     ctx->sel_ready = nxt;

@@ -25,32 +25,26 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Regenerates all 624 state words in place (std::mt19937's _M_gen_rand), one
-// wavefront, state in LDS.  Four dependency phases: [0,227) [227,454) [454,623) {623}.
-__device__ __forceinline__ void mt_regenerate(uint32_t *x, int lane)
+// Regenerates all 624 state words in place (std::mt19937's _M_gen_rand), one block of
+// SELECT_THREADS threads, state in LDS.  Four dependency phases: [0,227) [227,454) [454,623) {623};
+// each fits one pass of the block.
+constexpr int SELECT_THREADS = 256;
+
+__device__ __forceinline__ void mt_regenerate(uint32_t *x, int tid)
 {
     const int starts[5] = { 0, 227, 454, 623, 624 };
     #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
-        uint32_t v[4];
-        #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            int k = starts[ph] + lane + 64 * m;
-            if (k < starts[ph + 1]) {
-                int k1 = (k + 1 == MT_N) ? 0 : k + 1;
-                int km = (k + MT_M >= MT_N) ? k + MT_M - MT_N : k + MT_M;
-                v[m] = mt_twist(x[k], x[k1], x[km]);
-            }
+        const int k = starts[ph] + tid;
+        uint32_t v = 0;
+        if (k < starts[ph + 1]) {
+            const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
+            const int km = (k + MT_M >= MT_N) ? k + MT_M - MT_N : k + MT_M;
+            v = mt_twist(x[k], x[k1], x[km]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            int k = starts[ph] + lane + 64 * m;
-            if (k < starts[ph + 1]) x[k] = v[m];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (k < starts[ph + 1]) x[k] = v;
+        __syncthreads();
     }
 }
 
@@ -63,72 +57,84 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
     return y;
 }
 
-// One wavefront (block of 64) per owned image.
+// One block of 256 threads per owned image.
 //   virtual_size[i] <= cap : every ordinal is kept, no draw (needsRandom false).
 //   else                   : replay draws until the buffer is full or the
 //                            image's half-links are exhausted.
-__global__ __launch_bounds__(64) void select_kernel(uint32_t *mt_state, const uint32_t *virtual_size,
-                                                    uint32_t cap, uint32_t *sample_ord, uint32_t *sample_count)
+// The replay of one image is a chain (every block of 624 outputs needs the previous one) and the
+// kernel is pure latency: with a single wavefront per image a refresh of 10^6 draws took 8 ms,
+// more than ten iterations last once the images are spread over several GPUs.  With 256 threads a
+// regeneration phase is one pass, and 256 draws are tested, ranked (ballot + a 4-entry prefix) and
+// stored per round.
+__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_state, const uint32_t *virtual_size,
+                                                                uint32_t cap, uint32_t *sample_ord, uint32_t *sample_count)
 {
     __shared__ uint32_t x[MT_N];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t wave_cnt[SELECT_THREADS / 64];
+    __shared__ int jstar_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t img = blockIdx.x;
     const uint32_t vs = virtual_size[img];
     uint32_t *ord = sample_ord + (size_t)img * cap;
 
     if (vs <= cap) {
-        for (uint32_t k = lane; k < vs; k += 64) ord[k] = k;
-        if (lane == 0) sample_count[img] = vs;
+        for (uint32_t k = tid; k < vs; k += SELECT_THREADS) ord[k] = k;
+        if (tid == 0) sample_count[img] = vs;
         return;
     }
 
     uint32_t *st = mt_state + (size_t)img * MT_WORDS;
-    for (int k = lane; k < MT_N; k += 64) x[k] = st[k];
-    uint32_t idx = st[MT_N];                       // wave-uniform
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int k = tid; k < MT_N; k += SELECT_THREADS) x[k] = st[k];
+    uint32_t idx = st[MT_N];                       // block-uniform, like everything that steers the loop
+    __syncthreads();
 
     const float thresh = (float)cap / (float)vs;   // (float) samples.size() / virtualSize
     uint32_t count = 0;                            // kept so far
     uint32_t ordinal = 0;                          // draws consumed this refresh
     bool done = false;
     while (!done && ordinal < vs) {
-        if (idx >= (uint32_t)MT_N) { mt_regenerate(x, lane); idx = 0; }
-        // consume up to 64 words [idx, idx+64) of the current block
+        if (idx >= (uint32_t)MT_N) { mt_regenerate(x, tid); idx = 0; }
+        // consume up to 256 words [idx, idx+256) of the current block
         const uint32_t avail = min((uint32_t)MT_N - idx, vs - ordinal);
-        const uint32_t n = min(avail, 64u);
+        const uint32_t n = min(avail, (uint32_t)SELECT_THREADS);
         bool keep = false;
-        if ((uint32_t)lane < n) {
-            const uint32_t y = mt_temper(x[idx + lane]);
+        if ((uint32_t)tid < n) {
+            const uint32_t y = mt_temper(x[idx + tid]);
             const float r = (float)y / 4294967296.0f;   // (float) rng() / rng.max(); (float)0xFFFFFFFF == 2^32
             keep = !(r > thresh);
         }
         const unsigned long long mask = __ballot(keep);
-        const uint32_t kept = (uint32_t)__popcll(mask);
-        const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+        if (tid == 0) jstar_s = -1;
+        __syncthreads();
+        uint32_t kept = 0, rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        #pragma unroll
+        for (int w = 0; w < SELECT_THREADS / 64; w++) {
+            const uint32_t c = wave_cnt[w];
+            kept += c;
+            if (w < wave) rank += c;
+        }
         if (count + kept >= cap) {
-            // the buffer fills inside this group: keep the first (cap - count)
+            // the buffer fills inside this round: keep the first (cap - count)
             const uint32_t need = cap - count;
-            if (keep && before < need) ord[count + before] = ordinal + lane;
-            // lane holding the need-th kept draw = last draw consumed
-            const bool last = keep && (before == need - 1);
-            const unsigned long long lm = __ballot(last);
-            const uint32_t jstar = (uint32_t)__ffsll((long long)lm) - 1u;
+            if (keep && rank < need) ord[count + rank] = ordinal + tid;
+            if (keep && rank == need - 1) jstar_s = tid;            // the need-th kept draw = last draw consumed
+            __syncthreads();
+            const uint32_t jstar = (uint32_t)jstar_s;
             idx += jstar + 1;
             ordinal += jstar + 1;
             count = cap;
             done = true;
         } else {
-            if (keep) ord[count + before] = ordinal + lane;
+            if (keep) ord[count + rank] = ordinal + tid;
             count += kept;
             idx += n;
             ordinal += n;
         }
+        __syncthreads();                           // wave_cnt / jstar_s are reused, the state may be regenerated
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < MT_N; k += 64) st[k] = x[k];
-    if (lane == 0) { st[MT_N] = idx; sample_count[img] = count; }
+    for (int k = tid; k < MT_N; k += SELECT_THREADS) st[k] = x[k];
+    if (tid == 0) { st[MT_N] = idx; sample_count[img] = count; }
 }
 
 // K1: distance of every kept half-link (imageGroup.cxx:579-590), thread per slot.
