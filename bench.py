@@ -74,7 +74,8 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=65)
+    ap.add_argument("--steps", type=int, default=650,
+                    help="timed iterations; 650 = the reference's default schedule -li 50 -dl 3 -di 200")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--images", type=int, default=100)
     ap.add_argument("--points", type=int, default=20000)

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/$TAG
 mkdir -p $O
-python3 bench.py --steps 65 --warmup 10 > $O/bench.json 2> $O/bench.err
+python3 bench.py > $O/bench.json 2> $O/bench.err
 ARGS="bench.py --steps 65 --warmup 10 --no-cpu-baseline"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python3 $ARGS > $O/under_rocprof.json 2> $O/trace.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/fetch.log
