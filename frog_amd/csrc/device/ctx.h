@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../../include/frog_hip.h"
@@ -141,7 +142,7 @@ struct GridGeom {
 
 struct GridRecord {         // a finished or current lattice of the chain
     frog_grid_info info;
-    std::vector<float> host_coeffs;     // [owned images][G][3], filled when the lattice is retired
+    std::shared_ptr<DevBuf<float4>> kept;   // [owned images][G] coefficients, filled (device copy) when the lattice is retired
     bool retired = false;
 };
 

@@ -484,11 +484,11 @@ static int retire_current_grid(frog_ctx *ctx)
     GridRecord &gr = ctx->grids.back();
     const size_t G = (size_t)ctx->geom.n_cp;
     const size_t n = (size_t)ctx->n_owned() * G;
-    std::vector<float4> h(n);
-    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    gr.host_coeffs.resize(n * 3);
-    for (size_t i = 0; i < n; i++) { gr.host_coeffs[3 * i] = h[i].x; gr.host_coeffs[3 * i + 1] = h[i].y; gr.host_coeffs[3 * i + 2] = h[i].z; }
+    // the finished lattice stays on the device (a copy on the stream: no host round trip inside the
+    // regrid path; 43 MB per lattice at level 2 of the 100-image group); frog_get_grid reads it back on demand
+    gr.kept = std::make_shared<DevBuf<float4>>();
+    FROG_HIP_CHECK(gr.kept->alloc(std::max<size_t>(1, n)));
+    if (n) FROG_HIP_CHECK(hipMemcpyAsync(gr.kept->p, ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     gr.retired = true;
     return FROG_OK;
 }
@@ -892,12 +892,9 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
     const size_t G = (size_t)gr.info.dims[0] * gr.info.dims[1] * gr.info.dims[2];
     const size_t li = image - ctx->ib;
     const size_t nfl = std::min(cap, 3 * G);
-    if (gr.retired) {
-        std::memcpy(coeffs, gr.host_coeffs.data() + li * 3 * G, nfl * sizeof(float));
-        return FROG_OK;
-    }
+    const float4 *src = gr.retired ? gr.kept->p : ctx->coeff.p;
     std::vector<float4> h(G);
-    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->coeff.p + li * G, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src + li * G, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < nfl; i++) { const float4 &v = h[i / 3]; coeffs[i] = (i % 3 == 0) ? v.x : (i % 3 == 1) ? v.y : v.z; }
     return FROG_OK;
