@@ -1,16 +1,19 @@
 // k_links.hip.h -- the half-link sweep (K3 / K6 / K14 of SURVEY.md section 2.2) and
 // the per-image linear update (K4).
 //
-// One wavefront per (tile, partner group) (ctx.h, prep.h): 64 half-links per step,
-// records streamed from HBM as coalesced non-temporal 8-byte loads, both end points
-// gathered as 12-byte loads from the packed xyz2 table; a block only ever touches the
-// coordinates of ONE partner group, which stay in its XCD's L2.  Nothing here is GEMM shaped: it is a gather + weighted reduction,
-// bound by the record stream and the gathers, so no MFMA.
+// One wavefront per (tile, partner group) (ctx.h, prep.h): 64 half-links per step, records
+// (4 bytes each when the field widths allow, else 8) streamed from HBM as coalesced non-temporal
+// loads of two steps at a time, the partner point gathered as a 12-byte load from the packed xyz2
+// table, the own point and the partner image's constants read from LDS; a block only ever
+// touches the coordinates of ONE partner group, which stay in its XCD's L2.  Nothing here is
+// GEMM shaped: it is a gather + weighted reduction, no MFMA.  What bounds it (rocprofv3, DESIGN.md
+// section 4): the ~64 cache-line requests a CU's L1 keeps in flight and, about equally, vector-ALU
+// issue (136 instructions per step, most of them the two inlier probabilities).
 //
 // Arithmetic contract (reference lines in the comments):
 //   dist2, dist  -- f32, no FMA contraction, correctly rounded sqrt: bit-exact
 //                   with the reference, so `d < 0.1` and the sample values agree.
-//   inlier weight -- f32 with reciprocals and expf: within a few f32 ulps of the
+//   inlier weight -- f32 with reciprocals and exp (exp_nonpos, div_rn below): within a few f32 ulps of the
 //                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92);
 //                   the reference rounds d/c to f32 before squaring, which already
 //                   perturbs the exponent by more than this.
