@@ -126,3 +126,30 @@ def test_config3_properties(config3):
         for a, b in zip(ga, gb):
             assert relerr(a, b) < 1e-5
     assert np.max(np.abs(np.array(E1) - np.array(E2)) / np.array(E2)) < 1e-6
+
+
+def test_matcher_at_pipeline_size():
+    # the matching stage of the same configuration: 20 000 keypoints x 48-float descriptors per image.
+    # One image pair through the oracle (4e8 candidate pairs on one host thread), several through the GPU;
+    # size-independent properties for the rest: every pair passes upstream's own filters and tests.
+    from frog_amd.match import Matcher, synthetic_keypoints
+    from oracle.oracle_api import match_run
+    imgs = synthetic_keypoints(4, 20000, seed=3)
+    jobs = [(0, 1), (0, 2), (1, 3), (2, 3)]
+    m = Matcher(imgs)
+    got = m.run(jobs, threshold=1.0)
+    (wa, wb), = match_run(imgs, jobs[:1], threshold=1.0)
+    assert np.array_equal(got[0][0], wa) and np.array_equal(got[0][1], wb) and len(wa) > 10000
+    for (f, s), (a, b) in zip(jobs, got):
+        A, B = imgs[f], imgs[s]
+        assert np.all(np.diff(b.astype(np.int64)) > 0)                          # one pair per query at most, in query order
+        assert np.array_equal(A.laplacian[a], B.laplacian[b])                   # match.cpp:270
+        ratio = B.scale[b] / A.scale[a]
+        assert np.all(ratio.astype(np.float64) <= 1.3) and np.all((A.scale[a] / B.scale[b]).astype(np.float64) <= 1.3)   # :273-275
+        d = np.sqrt(((A.desc[a].astype(np.float64) - B.desc[b]) ** 2).sum(1))
+        assert np.all(d < 1.0 + 1e-5)                                           # :321
+    # symmetric run: the forward half is unchanged, the reverse half lists (i, match) for the queries of `first`
+    sym = m.run(jobs[:1], threshold=1.0, sym=1)[0]
+    n = len(got[0][0])
+    assert np.array_equal(sym[0][:n], got[0][0]) and np.array_equal(sym[1][:n], got[0][1])
+    assert np.all(np.diff(sym[0][n:].astype(np.int64)) > 0)
