@@ -67,7 +67,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.sub = sub;
     a.n_groups = ctx->n_groups;
     for (uint32_t g = 0; g <= ctx->n_groups; g++) a.group_begin[g] = ctx->group_begin[g];
-    a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p;
+    a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p; a.em = ctx->em.p;
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
     a.img_bits = ctx->rec_format.img_bits; a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
@@ -588,12 +588,20 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     }
     FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host
     std::vector<ScatterBlock> blocks;
-    for (uint32_t k = 0; k < n_bricks_total; k++)
+    std::vector<uint32_t> slot_ptr(n_bricks_total + 1, 0);        // staging slots of every (image, brick), brick-major
+    for (uint32_t k = 0; k < n_bricks_total; k++) {
         for (uint32_t b0 = h_bptr[k]; b0 < h_bptr[k + 1]; b0 += SCATTER_CHUNK)
-            blocks.push_back(ScatterBlock{ k, b0, std::min(b0 + (uint32_t)SCATTER_CHUNK, h_bptr[k + 1]), 0u });
+            blocks.push_back(ScatterBlock{ k, b0, std::min(b0 + (uint32_t)SCATTER_CHUNK, h_bptr[k + 1]), (uint32_t)blocks.size() });
+        slot_ptr[k + 1] = (uint32_t)blocks.size();
+    }
+    FROG_HIP_CHECK(ctx->brick_slot_ptr.upload(slot_ptr, s));
+    {
+        const size_t E = (size_t)g.brick + 3;
+        FROG_HIP_CHECK(ctx->scatter_stage.alloc(std::max<size_t>(1, blocks.size()) * E * E * E));
+    }
     // longest blocks first: a block is one wavefront whose time grows with its point count, and
     // bricks on the rim of the cloud hold few points -- dispatching the full chunks first shortens
-    // the tail (the lattice is flushed with atomics, so the order of the blocks does not matter)
+    // the tail (every block writes its own staging slot, so the launch order does not matter)
     std::stable_sort(blocks.begin(), blocks.end(), [](const ScatterBlock &x, const ScatterBlock &y) {
         return x.end - x.begin > y.end - y.begin; });
     ctx->n_scatter_blocks = (uint32_t)blocks.size();
@@ -656,7 +664,9 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         const size_t tile_bytes = (size_t)(gd.brick + 3) * (gd.brick + 3) * (gd.brick + 3) * sizeof(float4);
         scatter_kernel<<<ctx->n_scatter_blocks, 64, tile_bytes, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p,
                                                            reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
-                                                           ctx->gradf.p, gd);
+                                                           ctx->gradf.p, ctx->scatter_stage.p, gd);
+        lattice_reduce_kernel<<<div_up((size_t)nO * gd.n_cp, 256), 256, 0, s>>>(ctx->scatter_stage.p, ctx->brick_slot_ptr.p,
+                                                                                ctx->gradf.p, nO, gd);
         FROG_HIP_CHECK(hipGetLastError());
     }
     {

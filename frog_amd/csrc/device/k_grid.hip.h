@@ -377,7 +377,7 @@ __global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, u
 // sorted by cell, so consecutive points mostly share their 64 tap addresses and the
 // LDS tile is touched (one ds_read_b128 + ds_write_b128, no atomic: the 64 taps are
 // 64 distinct control points and the tile is private) only when the cell changes.
-// Finally the tile goes to HBM with float atomics (memory side).
+// Finally the tile goes to a staging slot; lattice_reduce_kernel sums the slots in a fixed order.
 //
 // Why not LDS float atomics: ds_add_f32 runs at 0.33 lane-ops/clk/CU on gfx950
 // (scripts/microbench/lds_atomic.hip); why not fixed point: control points on the
@@ -391,7 +391,7 @@ constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 struct ScatterBlock {
     uint32_t key;           // image_local * n_bricks + brick
     uint32_t begin, end;    // range in perm
-    uint32_t pad_;
+    uint32_t slot;          // index of the block's tile in the staging buffer (brick-major order)
 };
 
 // per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS
@@ -405,7 +405,7 @@ static_assert(sizeof(ScatterPoint) == 80, "ScatterPoint layout");
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
                                                      const uint32_t *perm, const ScatterBlock *blocks,
-                                                     float4 *gradf, const GeomDev g)
+                                                     float4 *gradf, float4 *stage, const GeomDev g)
 {
     // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
     // take 5.4 KB instead of the 21 KB of the largest brick and 15 instead of 6 blocks fit a CU
@@ -520,21 +520,46 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // flush: consecutive lanes walk components, then x -> contiguous 16-byte control points
-    const float *tf = reinterpret_cast<const float *>(tile);
-    float *gf = reinterpret_cast<float *>(gimg);
-    for (int k = lane; k < n_tile * 4; k += 64) {
-        const float val = tf[k];
-        if (val == 0.f) continue;
-        const int c = k & 3;
-        int q = k >> 2;
-        const int lx = q % E; q /= E;
-        const int ly = q % E;
-        const int lz = q / E;
-        const int gx = cp0[0] + lx, gy = cp0[1] + ly, gz = cp0[2] + lz;
-        if (gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
-        atomicAdd(gf + 4 * ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)) + c, val);
+    // the tile goes to the block's slot of the staging buffer as it is; lattice_reduce_kernel adds the
+    // slots that cover a control point in a fixed order (a flush with float atomics is as fast, but its
+    // order changes from run to run, and one ulp in a coefficient can move a half-link across the
+    // inlier threshold a few iterations later)
+    float4 *dst = stage + (size_t)blk.slot * n_tile;
+    for (int k = lane; k < n_tile; k += 64) dst[k] = tile[k];
+}
+
+// Gradient lattice = sum of the staged tiles that cover each control point, in a fixed order: bricks in
+// (z, y, x) order, the blocks of a brick in point order.  Added to what is already there (zero, or the
+// atomics of stray points).  Thread per (owned image, control point).
+__global__ __launch_bounds__(256) void lattice_reduce_kernel(const float4 *stage, const uint32_t *brick_slot_ptr,
+                                                             float4 *gradf, uint32_t n_owned, const GeomDev g)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_owned * g.n_cp) return;
+    const uint32_t img = (uint32_t)(idx / g.n_cp);
+    int q = (int)(idx % g.n_cp);
+    const int c[3] = { q % g.dims[0], (q / g.dims[0]) % g.dims[1], q / (g.dims[0] * g.dims[1]) };
+    const int B = g.brick, E = B + 3, n_tile = E * E * E;
+    int lo[3], hi[3];
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {                       // brick b holds control points b*B .. b*B + B + 2
+        lo[k] = c[k] <= 2 ? 0 : max(0, (c[k] - 2 + B - 1) / B - 1);     // smallest b with b*B + B + 2 >= c
+        hi[k] = min(g.nbricks[k] - 1, c[k] / B);                        // largest b with b*B <= c
     }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int bz = lo[2]; bz <= hi[2]; bz++)
+        for (int by = lo[1]; by <= hi[1]; by++)
+            for (int bx = lo[0]; bx <= hi[0]; bx++) {
+                const uint32_t key = img * g.n_bricks + (uint32_t)(bx + g.nbricks[0] * (by + g.nbricks[1] * bz));
+                const int local = (c[0] - bx * B) + E * ((c[1] - by * B) + E * (c[2] - bz * B));
+                for (uint32_t sl = brick_slot_ptr[key]; sl < brick_slot_ptr[key + 1]; sl++) {
+                    const float4 v = stage[(size_t)sl * n_tile + local];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+    float4 o = gradf[idx];
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    gradf[idx] = o;
 }
 
 // ---- K8 + first half of K9: control-point step and sum over owned images --------

@@ -50,6 +50,7 @@ struct SweepArgs {
     uint32_t point_last;        // index of the last point of the model
     const P3 *pos2;
     const EmDerived *emd;
+    const float4 *em;           // (c1, c2, ratio) per image: the exact re-evaluation near the inlier threshold
     uint32_t n_tiles;
     uint32_t rec2_last;         // index of the last record PAIR (16 bytes) of the context (prefetch clamp)
     float threshold;
@@ -105,6 +106,29 @@ __device__ __forceinline__ float div_rn(float n, float d)
     float q = n * r;
     q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
     return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+
+// getInlierProbability with the reference's own promotions (stats.h:10-16, 84-92: f32 quotients, the exp
+// and one product chain in f64).  Ten times the work of the f32 form below, so it only decides the cases
+// that form cannot be trusted with: weights within THRESHOLD_BAND of the inlier threshold, where a few
+// f32 ulps would put a half-link on the other side of `weight < inlierThreshold` than the reference --
+// a discontinuity that the solver amplifies (one link entering or leaving a point's sums moves a weakly
+// supported control point by 1e-4 of the lattice's range).
+constexpr float THRESHOLD_BAND = 1e-4f;
+__device__ __forceinline__ float chi_pdf_exact(float x)
+{
+    const float c = 0.797884560802865f;
+    const float x2 = x * x;
+    return (float)((double)(c * x2) * exp(-0.5 * (double)x2));
+}
+__device__ __noinline__ float inlier_probability_exact(float d, const float4 em)
+{
+    const float eps = 1e-10f;
+    if (d < 0.1f) return 1.0f;
+    const float c1 = em.x + eps, c2 = em.y + eps;
+    const float x1 = em.z * chi_pdf_exact(d / c1) / c1;
+    const float x2 = (float)((1.0 - (double)em.z) * (double)chi_pdf_exact(d / c2) / (double)c2);
+    return x1 / (x1 + x2 + eps);
 }
 
 // getInlierProbability (stats.h:84-92) from precomputed per-image constants.
@@ -255,7 +279,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         const float d = sqrt_rn(d2);
-        const float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
+        float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
+        if constexpr (MODE != SWEEP_LINEAR) {
+            // the threshold decision is taken on the reference's own arithmetic when it is close
+            if (fabsf(w - a.threshold) < THRESHOLD_BAND) {
+                const uint32_t imgB = img_of(rq) + (WIDE && !EMD_LDS ? 0u : g_first);
+                w = fminf(inlier_probability_exact(d, a.em[image]), inlier_probability_exact(d, a.em[imgB]));
+            }
+        }
 
         if constexpr (MODE == SWEEP_LINEAR) {
             // imageGroup.cxx:1102-1117
