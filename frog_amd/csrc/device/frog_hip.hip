@@ -585,6 +585,13 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     if (nPts) {
         brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
+        // canonical order inside every cell (the placement's atomics make it arbitrary): reproducible sums
+        FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
+        cell_order_kernel<<<div_up(n_keys, 4), 256, 0, s>>>(ctx->key_ptr.p, n_keys, ctx->perm.p, ctx->perm_tmp.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        std::swap(ctx->perm.p, ctx->perm_tmp.p);
+        std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
+        std::swap(ctx->perm.n, ctx->perm_tmp.n);
     }
     FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host
     std::vector<ScatterBlock> blocks;

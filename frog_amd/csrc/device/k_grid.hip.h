@@ -356,6 +356,25 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *counts
     if (blockIdx.x == 0 && threadIdx.x == 0) ptr[n] = *total;
 }
 
+// The placement above hands out slots with atomics, so the order of the points INSIDE a cell changes
+// from run to run -- and with it the order of the f32 additions of the scatter.  This pass puts every
+// cell's points in ascending index order (one wavefront per cell; rank = number of smaller entries,
+// O(n^2 / 64) reads that hit L1: cells hold 5 to a few hundred points, and it runs once per lattice).
+__global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr, uint32_t n_keys,
+                                                         const uint32_t *perm_in, uint32_t *perm_out)
+{
+    const uint32_t key = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (key >= n_keys) return;
+    const uint32_t b = key_ptr[key], n = key_ptr[key + 1] - b;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t v = perm_in[b + i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += perm_in[b + j] < v ? 1u : 0u;
+        perm_out[b + rank] = v;
+    }
+}
+
 // ptr at brick granularity (every B^3-th entry) for the host's block table
 __global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t *out)
 {
