@@ -37,7 +37,8 @@ class FrogOptions(C.Structure):
                 ("stats_max_size", C.c_int32),
                 ("stats_max_iterations", C.c_int32),
                 ("stats_epsilon", C.c_float),
-                ("reserved", C.c_int32 * 6)]
+                ("n_fixed_images", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
     @classmethod
     def default(cls, **kw):

@@ -257,4 +257,10 @@ struct frog_ctx {
     frog_kernel_time ktime[FROG_K_COUNT_] = {};
 
     uint32_t n_owned() const { return ie - ib; }
+    // -fi: the first nf images are fixed.  This context then owns [nf, nI) and `helper` (stats only,
+    // same stream) owns [0, nf): updateStats refreshes every image's mixture (imageGroup.cxx:569-598
+    // loops from 0), everything else loops from numberOfFixedImages.
+    uint32_t nf = 0;
+    frog_ctx *helper = nullptr;
+    bool whole_group() const { return ib == nf && ie == nI; }
 };

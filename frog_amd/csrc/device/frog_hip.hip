@@ -103,6 +103,7 @@ const char *frog_last_error(void) { return g_last_error.c_str(); }
 void frog_destroy(frog_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -126,6 +127,27 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     for (size_t i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++)
         if (o->reserved[i]) return fail(FROG_E_INVALID, "reserved option fields must be 0");
     if (o->stats_max_size < 1) return fail(FROG_E_INVALID, "stats_max_size < 1");
+    if (o->n_fixed_images) {
+        // fixed images (-fi, imageGroup.cxx:34): a context for the moving images plus a stats-only one
+        const uint32_t nf = (uint32_t)o->n_fixed_images;
+        if (o->n_fixed_images < 0 || nf >= m->n_images) return fail(FROG_E_INVALID, "n_fixed_images must leave at least one moving image");
+        if (image_begin != 0 || image_end != m->n_images)
+            return fail(FROG_E_INVALID, "n_fixed_images needs the whole group in one context");
+        frog_options o2 = *o;
+        o2.n_fixed_images = 0;
+        frog_ctx *moving = nullptr, *fixed = nullptr;
+        int rc = frog_create(m, &o2, device, nf, m->n_images, &moving);
+        if (rc) return rc;
+        rc = frog_create(m, &o2, device, 0, nf, &fixed);
+        if (rc) { frog_destroy(moving); return rc; }
+        rc = frog_set_stream(fixed, moving->stream);
+        if (rc) { frog_destroy(fixed); frog_destroy(moving); return rc; }
+        moving->helper = fixed;
+        moving->nf = nf;
+        moving->opt.n_fixed_images = o->n_fixed_images;
+        *out = moving;
+        return FROG_OK;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(FROG_E_NODEVICE, "no HIP device: libfrog_hip has no CPU fallback");
@@ -290,6 +312,7 @@ int frog_set_stream(frog_ctx *ctx, void *hip_stream)
     if (ctx->own_stream) FROG_HIP_CHECK(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    if (ctx->helper) return frog_set_stream(ctx->helper, hip_stream);
     return FROG_OK;
 }
 
@@ -317,7 +340,8 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
             const double lo = ctx->h_img_bbox[(size_t)i * 6 + j], hi = ctx->h_img_bbox[(size_t)i * 6 + 3 + j];
             const float a = (float)((double)(1 - cpos) * lo + (double)cpos * hi);
             anchors[3 * (size_t)i + j] = a;
-            average[j] += a / (float)nI;
+            // :823-824: with fixed images the mean runs over the FIRST nI - nf images (upstream's indexing)
+            if (i < nI - ctx->nf) average[j] += a / (float)(nI - ctx->nf);
         }
     std::vector<double> hm((size_t)nI * 16, 0.0);
     for (uint32_t i = 0; i < nI; i++) {
@@ -415,10 +439,20 @@ int frog_stats_publish(frog_ctx *ctx)
 
 int frog_update_stats(frog_ctx *ctx)
 {
-    if (ctx && ctx->n_owned() != ctx->nI)
+    if (ctx && !ctx->whole_group())
         return fail(FROG_E_STATE, "context owns a sub-range of images: use frog_update_stats_local + all-reduce + frog_stats_publish");
     int rc = frog_update_stats_local(ctx);
     if (rc) return rc;
+    if (ctx->helper) {
+        // the fixed images' mixtures: their half-links see the moving points where they are now
+        frog_ctx *h = ctx->helper;
+        const size_t n = ctx->own_pt_end - ctx->own_pt_begin;
+        FROG_HIP_CHECK(hipMemcpyAsync(h->pos2.p + ctx->own_pt_begin, ctx->pos2.p + ctx->own_pt_begin, n * sizeof(P3),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+        rc = frog_update_stats_local(h);
+        if (rc) return rc;
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->em.p, h->em.p, (size_t)ctx->nf * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     return frog_stats_publish(ctx);
 }
 
@@ -629,7 +663,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
 
 int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out)
 {
-    if (ctx && ctx->n_owned() != ctx->nI)
+    if (ctx && !ctx->whole_group())
         return fail(FROG_E_STATE, "context owns a sub-range of images: use frog_bounds_local + all-reduce + frog_deformable_setup_bounds");
     double mn[3], mx[3];
     int rc = frog_bounds_local(ctx, mn, mx);
@@ -694,7 +728,8 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     const GridGeom &g = ctx->geom;
     const float maxD = ctx->opt.max_displacement_ratio;
     Span span(ctx, FROG_K_LATTICE);
-    cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nI, ctx->gridsum.p,
+    // :398: the group mean is removed only when no image is fixed
+    cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
                                                         (double)maxD * g.spacing[2], ctx->n_big.p);
     FROG_HIP_CHECK(hipGetLastError());
@@ -737,7 +772,7 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
 
 int frog_deformable_step(frog_ctx *ctx, float alpha, double *E)
 {
-    if (ctx && ctx->n_owned() != ctx->nI)
+    if (ctx && !ctx->whole_group())
         return fail(FROG_E_STATE, "context owns a sub-range of images: use the phase_a/b/c entry points");
     int rc = frog_deformable_phase_a(ctx, alpha);
     if (rc) return rc;
@@ -858,6 +893,7 @@ int frog_set_em(frog_ctx *ctx, uint32_t image, const float in[3])
 int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *ordinals, int cap, int *n)
 {
     CTX_GUARD(ctx);
+    if (ctx->helper && image < ctx->nf) return frog_get_samples(ctx->helper, image, samples, ordinals, cap, n);
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
     const uint32_t li = image - ctx->ib;
     uint32_t cnt = 0;

@@ -637,9 +637,10 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int cnt = 0;
     if (cp < n_cp) {
-        const double mx = gridsum[3 * (size_t)cp] / n_images;
-        const double my = gridsum[3 * (size_t)cp + 1] / n_images;
-        const double mz = gridsum[3 * (size_t)cp + 2] / n_images;
+        // n_images == 0: fixed images present, `sum` stays 0 (imageGroup.cxx:398,409-419)
+        const double mx = n_images ? gridsum[3 * (size_t)cp] / n_images : 0.0;
+        const double my = n_images ? gridsum[3 * (size_t)cp + 1] / n_images : 0.0;
+        const double mz = n_images ? gridsum[3 * (size_t)cp + 2] / n_images : 0.0;
         for (uint32_t i0 = 0; i0 < n_owned; i0 += CP_BATCH) {
             float4 v[CP_BATCH];
             #pragma unroll

@@ -50,7 +50,9 @@ typedef struct frog_options {
     int32_t stats_max_size;             /* -ss   10000  stats.cxx:10    */
     int32_t stats_max_iterations;       /* -emi  10000  stats.cxx:11    */
     float   stats_epsilon;              /* -se   1e-6   stats.cxx:12    */
-    int32_t reserved[6];                /* must be 0                      */
+    int32_t n_fixed_images;             /* -fi   0      imageGroup.h:69: the first n images are already
+                                         * registered (their xyz is final) and never move            */
+    int32_t reserved[5];                /* must be 0                      */
 } frog_options;
 
 /* Geometry of one B-spline control-point lattice
@@ -97,6 +99,7 @@ static inline void frog_options_default(frog_options *o)
     o->stats_max_size = 10000;
     o->stats_max_iterations = 10000;
     o->stats_epsilon = 1e-6f;
+    o->n_fixed_images = 0;
     for (i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++) o->reserved[i] = 0;
 }
 

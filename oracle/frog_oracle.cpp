@@ -264,6 +264,7 @@ struct frogo_stats { EmStats s; };
 struct frogo_group {
     frog_options opt;
     uint32_t nI = 0;
+    uint32_t nf = 0;                          // numberOfFixedImages
     uint32_t ib = 0, ie = 0;              // images this instance updates (all by default); see frogo_set_range
     uint64_t P = 0, L = 0;
     std::vector<uint32_t> poff;
@@ -311,11 +312,15 @@ frogo_group *frogo_create(const frog_model *m, const frog_options *o)
     frogo_group *g = new frogo_group;
     g->opt = *o;
     g->nI = m->n_images;
-    g->ib = 0; g->ie = m->n_images;
+    g->nf = o->n_fixed_images > 0 ? (uint32_t)o->n_fixed_images : 0;   // -fi, imageGroup.h:40,69
+    g->ib = g->nf; g->ie = m->n_images;
     g->poff.assign(m->point_offset, m->point_offset + m->n_images + 1);
     g->P = g->poff[g->nI];
     g->xyz.assign(m->xyz, m->xyz + 3 * g->P);
     g->xyz2.assign(3 * g->P, 0.f);
+    // readAndApplyFixedImagesTransforms (:1445-1450): a fixed image's xyz2 is its registered position (the
+    // caller passes xyz already transformed) and transformPoints never touches it again
+    std::copy(g->xyz.begin(), g->xyz.begin() + 3 * (size_t)g->poff[g->nf], g->xyz2.begin());
     g->rowp.assign(m->row_ptr, m->row_ptr + g->P + 1);
     g->L = g->rowp[g->P];
     g->limg.assign(m->link_image, m->link_image + g->L);
@@ -357,7 +362,7 @@ void frogo_linear_init(frogo_group *g, const float anchor_pos[3])
             float c = anchor_pos[j];
             float a = (float)((double)(1 - c) * box.bound(2 * j) + (double)c * box.bound(1 + 2 * j));
             anchors[3 * (size_t)i + j] = a;
-            average[j] += a / (float)g->nI;
+            if (i < g->nI - g->nf) average[j] += a / (float)(g->nI - g->nf);      // :823-824
         }
     }
     for (uint32_t i = 0; i < g->nI; i++) {
@@ -399,8 +404,9 @@ void frogo_transform_points(frogo_group *g, int apply)
 // updateStats, imageGroup.cxx:569-598.
 void frogo_update_stats(frogo_group *g)
 {
+    // :573 loops over every image, fixed ones included
     #pragma omp parallel for
-    for (int i = (int)g->ib; i < (int)g->ie; i++) {
+    for (int i = (int)(g->nf ? 0 : g->ib); i < (int)g->ie; i++) {
         EmStats &st = g->stats[i];
         st.reset();
         for (uint32_t p = g->poff[i]; p < g->poff[i + 1]; p++) {
@@ -644,8 +650,11 @@ long frogo_deformable_phase_b(frogo_group *g, const double *gridsum_all)
     #pragma omp parallel for reduction(+ : nBig)
     for (long i = 0; i < (long)G; i++) {
         for (int j = 0; j < 3; j++) {
-            double sum = gridsum_all[3 * i + j];
-            sum /= nImages;
+            double sum = 0;
+            if (g->nf == 0) {                     // :398 `apply`
+                sum = gridsum_all[3 * i + j];
+                sum /= nImages;
+            }
             for (int im = (int)g->ib; im < (int)g->ie; im++) {
                 float &v = g->gradient[im][4 * i + j];
                 v = (float)((double)v - sum);
@@ -760,7 +769,7 @@ void frogo_count_inliers(frogo_group *g, frog_counts *out)
 {
     const float thr = g->opt.inlier_threshold;
     #pragma omp parallel for
-    for (int image1 = 0; image1 < (int)g->nI; image1++) {
+    for (int image1 = (int)g->nf; image1 < (int)g->nI; image1++) {      // :1003
         const EmStats &stA = g->stats[image1];
         int64_t nPairs = 0, nOut = 0, nIn = 0;
         for (uint32_t p = g->poff[image1]; p < g->poff[image1 + 1]; p++) {

@@ -459,3 +459,45 @@ def test_hard_links_of_landmark_constraints(small_pairs):
     g.set_hard_links([], [], 0.0)                        # n = 0 removes them
     e2 = g.updateDeformableTransforms(0.0)
     assert e2 < 0.5 * e
+
+
+@pytest.mark.parametrize("n_fixed", [1, 4])
+def test_fixed_images_match_oracle(small_pairs, n_fixed):
+    """-fi n (imageGroup.cxx:34,195,240,385,398,442,823,913,1003,1068): the first n images keep their
+    position, every loop but updateStats starts at image n and the group mean is not removed."""
+    n = small_pairs.n_images
+    g = ImageGroup(small_pairs, n_fixed_images=n_fixed)
+    ref = OracleGroup(small_pairs.model, _abi.FrogOptions.default(n_fixed_images=n_fixed))
+    g.linearIterations, g.deformableLevels, g.deformableIterations = 20, 2, 20
+    E = np.array(g.run())
+    Er, grids_r = ref.run(li=20, dl=2, di=20)
+    assert g.gridsPerLevel == grids_r and len(E) == len(Er)
+    assert np.max(np.abs(E - Er) / Er) < REL
+    xyz, xyz2 = g.points()
+    po = small_pairs.point_offset
+    assert np.array_equal(xyz[:po[n_fixed]], small_pairs.xyz[:po[n_fixed]])          # fixed images never move
+    assert np.array_equal(xyz2[:po[n_fixed]], small_pairs.xyz[:po[n_fixed]])
+    assert relerr(xyz, ref.xyz()) < REL and relerr(xyz2, ref.xyz2()) < REL
+    for i in range(n):
+        assert np.allclose(g.em(i), ref.em(i), rtol=1e-5), f"mixture of image {i}"
+        s, o = g.samples(i)
+        rs, ro = ref.samples(i)
+        assert np.array_equal(o, ro), f"sample ordinals of image {i}"
+    for i in range(n_fixed, n):
+        m, mr = g.matrix(i), ref.matrix(i)
+        assert relerr(np.diag(m)[:3], np.diag(mr)[:3]) < REL and relerr(m[:3, 3], mr[:3, 3]) < REL
+        for k in range(ref.num_grids()):
+            assert relerr(g.grid(i, k)[1], ref.grid(i, k, _abi.FrogGridInfo())[1]) < REL, f"lattice {k} image {i}"
+    # the lattices no longer sum to zero over the images (no mean removal)
+    tot = sum(g.grid(i, 0)[1].astype(np.float64) for i in range(n_fixed, n))
+    assert np.max(np.abs(tot)) > 1e-3
+    c = g.countInliers()
+    rc = ref.count_inliers((_abi.FrogCounts * n)())
+    for i in range(n_fixed, n):
+        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+    # a context cannot be given a sub-range together with fixed images
+    ctx = C.c_void_p()
+    o = _abi.FrogOptions.default(n_fixed_images=1)
+    assert _abi.hip_lib().frog_create(C.byref(small_pairs.model), C.byref(o), 0, 1, n, C.byref(ctx)) == _abi.FROG_E_INVALID
+    o = _abi.FrogOptions.default(n_fixed_images=n)
+    assert _abi.hip_lib().frog_create(C.byref(small_pairs.model), C.byref(o), 0, 0, n, C.byref(ctx)) == _abi.FROG_E_INVALID
