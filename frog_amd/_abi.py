@@ -58,6 +58,12 @@ class FrogGridInfo(C.Structure):
                 ("bbox", C.c_double * 6)]
 
 
+class FrogRansacOptions(C.Structure):
+    """frog_ransac_options; defaults = imageGroup.h:70-74."""
+    _fields_ = [("iterations", C.c_int32), ("batches", C.c_int32),
+                ("inlier_distance", C.c_float), ("max_scale", C.c_float)]
+
+
 class FrogCounts(C.Structure):
     _fields_ = [("points", C.c_int64), ("pairs", C.c_int64),
                 ("inliers", C.c_int64), ("outliers", C.c_int64),
@@ -125,6 +131,8 @@ HIP_SYMBOLS = {
     "frog_transform_points": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_update_stats": (C.c_int, [C.c_void_p]),
     "frog_linear_step": (C.c_int, [C.c_void_p, c_double_p]),
+    "frog_ransac": (C.c_int, [C.c_void_p, C.POINTER(FrogModel), C.c_uint32, C.POINTER(FrogRansacOptions),
+                              C.POINTER(C.c_int64)]),
     "frog_deformable_setup": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(FrogGridInfo)]),
     "frog_deformable_step": (C.c_int, [C.c_void_p, C.c_float, c_double_p]),
     "frog_count_inliers": (C.c_int, [C.c_void_p, C.POINTER(FrogCounts)]),
@@ -192,6 +200,7 @@ HOST_SYMBOLS = {
     "frog_synth_defaults": (None, [C.POINTER(FrogSynthParams)]),
     "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
     "frog_pairs_append_points": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_uint32]),
+    "frog_pairs_set_points": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
     "frog_keypoints_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
     "frog_keypoints_free": (None, [C.c_void_p]),
     "frog_keypoints_count": (C.c_uint32, [C.c_void_p]),

@@ -7,9 +7,12 @@
 #include "k_links.hip.h"
 #include "k_stats.hip.h"
 #include "k_grid.hip.h"
+#include "k_ransac.hip.h"
+#include "similarity.h"
 
 #include <cmath>
 #include <cstdlib>
+#include <random>
 #include <limits>
 #include <new>
 
@@ -454,6 +457,117 @@ int frog_update_stats(frog_ctx *ctx)
         FROG_HIP_CHECK(hipMemcpyAsync(ctx->em.p, h->em.p, (size_t)ctx->nf * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return frog_stats_publish(ctx);
+}
+
+// ---- RANSAC + RANSACBatch (imageGroup.cxx:629-804) -----------------------------------------
+int frog_ransac(frog_ctx *ctx, const frog_model *m, uint32_t image, const frog_ransac_options *o, int64_t *n_inliers)
+{
+    CTX_GUARD(ctx);
+    if (!m || !o) return fail(FROG_E_INVALID, "null argument");
+    if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
+    if (m->n_images != ctx->nI || m->point_offset[ctx->nI] != ctx->P) return fail(FROG_E_INVALID, "model does not match the context");
+    if (ctx->deformable) return fail(FROG_E_STATE, "RANSAC after deformable set-up");
+    if (o->iterations < 0 || o->batches < 1) return fail(FROG_E_INVALID, "bad RANSAC options");
+    hipStream_t s = ctx->stream;
+    const uint32_t pb = ctx->poff[image], nPoints = ctx->poff[image + 1] - pb;
+    const int perBatch = o->iterations / o->batches;                         // :636
+    const float maxDistance2 = (float)std::pow((double)o->inlier_distance, 2);   // :677,:730
+    auto xyz_of = [&](uint16_t img, uint32_t pt) { return m->xyz + 3 * ((size_t)m->point_offset[img] + pt); };
+
+    // candidates: 4 random correspondences each (:743-760).  A draw that lands on a point without
+    // links is repeated, so an image without any link would never return: refuse it.
+    if (nPoints == 0 || m->row_ptr[pb + nPoints] == m->row_ptr[pb]) return fail(FROG_E_INVALID, "image has no link");
+    std::vector<double> cand;                    // 12 doubles per candidate (rows 0..2)
+    std::vector<uint8_t> usable;                 // determinant inside [1/maxScale, maxScale] and a defined rotation
+    cand.reserve((size_t)perBatch * o->batches * 12);
+    for (int batch = 0; batch < o->batches; batch++) {
+        std::mt19937 rng((uint32_t)(batch * 1000));
+        for (int it = 0; it < perBatch; it++) {
+            float src[4][3], tgt[4][3];
+            for (int j = 0; j < 4; j++) {
+                while (true) {
+                    const uint32_t pt = (uint32_t)(rng() % nPoints);
+                    const uint64_t r0 = m->row_ptr[pb + pt], size = m->row_ptr[pb + pt + 1] - r0;
+                    if (size == 0) continue;
+                    const uint64_t l = r0 + rng() % size;
+                    std::memcpy(src[j], m->xyz + 3 * ((size_t)pb + pt), sizeof src[j]);
+                    std::memcpy(tgt[j], xyz_of(m->link_image[l], m->link_point[l]), sizeof tgt[j]);
+                    break;
+                }
+            }
+            double M[16];
+            const bool ok = frog::similarity_fit(4, [&](size_t i, double a[3], double b[3]) {
+                for (int k = 0; k < 3; k++) { a[k] = src[i][k]; b[k] = tgt[i][k]; }
+            }, M);
+            const float determinant = (float)std::fabs(frog::det3_of_4x4(M));           // :787-788
+            usable.push_back(ok && !((determinant > o->max_scale) || ((double)determinant < 1.0 / (double)o->max_scale)));
+            cand.insert(cand.end(), M, M + 12);
+        }
+    }
+    const uint32_t nCand = (uint32_t)usable.size();
+    std::vector<unsigned int> counts(nCand, 0u);
+    const uint32_t lpb = pb - ctx->own_pt_begin, lpe = lpb + nPoints;
+    const uint64_t nLinks = m->row_ptr[pb + nPoints] - m->row_ptr[pb];
+    if (nCand) {
+        DevBuf<double> d_cand;
+        DevBuf<unsigned int> d_counts;
+        FROG_HIP_CHECK(d_cand.upload(cand, s));
+        FROG_HIP_CHECK(d_counts.alloc(nCand));
+        FROG_HIP_CHECK(hipMemsetAsync(d_counts.p, 0, d_counts.bytes(), s));
+        const unsigned blocks = div_up(nLinks, (size_t)256 * RANSAC_LINKS);
+        ransac_count_kernel<<<blocks, 256, 0, s>>>(ctx->pos.p, ctx->pos2.p, ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p,
+                                                  lpb, lpe, d_cand.p, nCand, maxDistance2, d_counts.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        FROG_HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts.p, d_counts.bytes(), hipMemcpyDeviceToHost, s));
+        FROG_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    // best of each batch (first strictly larger count, :790-795), then best batch (:651-664; upstream takes the
+    // batches in the order their threads finished -- here in batch order, so ties resolve the same way every run)
+    long long maxNumberOfInliers = 0;
+    int bestCand = -1;
+    for (int batch = 0; batch < o->batches; batch++) {
+        long long batchMax = 0;
+        int batchBest = -1;
+        for (int it = 0; it < perBatch; it++) {
+            const int c = batch * perBatch + it;
+            if (!usable[c]) continue;
+            if (batchMax < (long long)counts[c]) { batchMax = counts[c]; batchBest = c; }
+        }
+        if (batchMax > maxNumberOfInliers) { maxNumberOfInliers = batchMax; bestCand = batchBest; }
+    }
+    double best[16];
+    if (bestCand >= 0) {
+        std::memcpy(best, &cand[(size_t)bestCand * 12], 12 * sizeof(double));
+        best[12] = best[13] = best[14] = 0.0; best[15] = 1.0;
+    } else {
+        FROG_HIP_CHECK(hipMemcpyAsync(best, ctx->mat.p + (size_t)image * 16, sizeof best, hipMemcpyDeviceToHost, s));
+        FROG_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    // refit on every half-link the best candidate brings within the distance (:666-700)
+    std::vector<float> xyz2(3 * ctx->P);
+    int rc = download_points(ctx, ctx->pos2.p, xyz2.data());
+    if (rc) return rc;
+    std::vector<const float *> srcs, tgts;
+    for (uint32_t pt = 0; pt < nPoints; pt++) {
+        const float *in = m->xyz + 3 * ((size_t)pb + pt);
+        const float t[3] = { (float)(best[0] * in[0] + best[1] * in[1] + best[2] * in[2] + best[3]),
+                             (float)(best[4] * in[0] + best[5] * in[1] + best[6] * in[2] + best[7]),
+                             (float)(best[8] * in[0] + best[9] * in[1] + best[10] * in[2] + best[11]) };
+        for (uint64_t l = m->row_ptr[pb + pt]; l < m->row_ptr[pb + pt + 1]; l++) {
+            const float *pB = &xyz2[3 * ((size_t)m->point_offset[m->link_image[l]] + m->link_point[l])];
+            const float dx = t[0] - pB[0], dy = t[1] - pB[1], dz = t[2] - pB[2];
+            if (dx * dx + dy * dy + dz * dz < maxDistance2) { srcs.push_back(in); tgts.push_back(pB); }
+        }
+    }
+    double fit[16];
+    if (!frog::similarity_fit(srcs.size(), [&](size_t i, double a[3], double b[3]) {
+            for (int k = 0; k < 3; k++) { a[k] = srcs[i][k]; b[k] = tgts[i][k]; }
+        }, fit))
+        std::memcpy(fit, best, sizeof fit);      // rotation undetermined (collinear inliers): keep the candidate
+    FROG_HIP_CHECK(hipMemcpyAsync(ctx->mat.p + (size_t)image * 16, fit, sizeof fit, hipMemcpyHostToDevice, s));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_inliers) *n_inliers = maxNumberOfInliers;
+    return FROG_OK;
 }
 
 // ---- updateLinearTransforms (imageGroup.cxx:1063-1149) ----------------------------------

@@ -100,10 +100,6 @@ void ImageGroup::usePairs(frog_pairs *p)
 // the reference where setupStats runs inside run().
 void ImageGroup::createContext()
 {
-    if (numberOfFixedImages != 0 || fixedTransformsDirectory) {
-        cout << "Error : fixed images (-fi/-fd/-r) are not supported by this build" << endl;
-        exit(1);
-    }
     frog_options o;
     frog_options_default(&o);
     o.linear_alpha = linearAlpha;
@@ -116,6 +112,7 @@ void ImageGroup::createContext()
     o.stats_max_size = statsMaxSize;
     o.stats_max_iterations = statsMaxIterations;
     o.stats_epsilon = statsEpsilon;
+    o.n_fixed_images = numberOfFixedImages;
     frog_model m;
     frog_pairs_model(pairs, &m);
     check(frog_create(&m, &o, device, 0, m.n_images, &ctx), "frog_create");
@@ -131,11 +128,49 @@ void ImageGroup::createContext()
     counts.assign(m.n_images, frog_counts{});
 }
 
+// readAndApplyFixedImagesTransforms, imageGroup.cxx:1419-1456: the keypoints of the fixed images move to
+// their registered position (`xyz := T(xyz)`) before anything else; without -fd the transform is the identity.
+// T is evaluated on the device (frog_chain.h), one link at a time with the point rounded to float in
+// between, as vtkGeneralTransform's float TransformPoint does.
+void ImageGroup::readAndApplyFixedImagesTransforms()
+{
+    if (!fixedTransformsDirectory) return;
+    cout << "Reading transforms in directory " << fixedTransformsDirectory << endl;
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    for (int i = 0; i < numberOfFixedImages; i++) {
+        std::ostringstream file;
+        file << fixedTransformsDirectory << "/" << i << ".json";
+        int status = 0;
+        frog_transform_file *tf = frog_transform_read(file.str().c_str(), &status);
+        if (!tf) { cout << "Error : could not read " << file.str() << endl; exit(1); }
+        const uint32_t b = m.point_offset[i], n = m.point_offset[i + 1] - b;
+        std::vector<float> xyz(m.xyz + 3 * (size_t)b, m.xyz + 3 * (size_t)(b + n));
+        std::vector<double> in(3 * (size_t)n), out(3 * (size_t)n);
+        const frog_chain_link *links = frog_transform_links(tf);
+        for (uint32_t l = 0; l < frog_transform_num_links(tf) && n; l++) {
+            frog_chain *chain = nullptr;
+            check(frog_chain_create(links + l, 1, device, &chain), "frog_chain_create");
+            for (size_t k = 0; k < in.size(); k++) in[k] = xyz[k];
+            check(frog_chain_apply(chain, in.data(), out.data(), n), "frog_chain_apply");
+            for (size_t k = 0; k < in.size(); k++) xyz[k] = (float)out[k];
+            frog_chain_destroy(chain);
+        }
+        frog_transform_free(tf);
+        check(frog_pairs_set_points(pairs, i, xyz.data()), "frog_pairs_set_points");
+    }
+}
+
 // run, imageGroup.cxx:31-157
 void ImageGroup::run()
 {
     using clk = std::chrono::steady_clock;
     if (!pairs) { cout << "Error : no pairs" << endl; exit(1); }
+    if (numberOfFixedImages < 0 || numberOfFixedImages >= (int)frog_pairs_num_images(pairs)) {
+        cout << "Error : -fi must leave at least one image to register" << endl;
+        exit(1);
+    }
+    if (numberOfFixedImages) readAndApplyFixedImagesTransforms();       // :34
     createContext();                                                    // :36 setupStats
     check(frog_linear_init(ctx, linearInitializationAnchor), "frog_linear_init");   // :37
     check(frog_transform_points(ctx, 0), "frog_transform_points");      // :38
@@ -242,7 +277,7 @@ void ImageGroup::saveErrorMaps()
     check(frog_residual_sums(ctx), "frog_residual_sums");
     const uint32_t n = frog_num_images(ctx);
     std::vector<float> map;
-    for (uint32_t image = 0; image < n; image++) {
+    for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :481
         frog_grid_info info;
         check(frog_get_error_map(ctx, image, &info, nullptr, 0), "frog_get_error_map");
         map.resize((size_t)4 * info.dims[0] * info.dims[1] * info.dims[2]);
@@ -491,7 +526,7 @@ void ImageGroup::displayStats()
 void ImageGroup::displayLinearTransforms()
 {
     const uint32_t n = frog_num_images(ctx);
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = numberOfFixedImages; i < n; i++) {                           // :602
         double m[16];
         check(frog_get_linear(ctx, i, m), "frog_get_linear");
         cout << "Image " << i << ", translation=" << m[3] << " " << m[7] << " " << m[11] << endl;
@@ -559,7 +594,7 @@ void ImageGroup::saveTransforms()
     std::filesystem::create_directory(transformSubdirectory.c_str());
     const uint32_t n = frog_num_images(ctx);
     const int nGrids = frog_num_grids(ctx);
-    for (uint32_t image = 0; image < n; image++) {
+    for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :1464
         frogjson::Value transforms = frogjson::Value::array();
         {
             double m[16];
@@ -623,6 +658,7 @@ void ImageGroup::saveStatsJSON()
         long long nPairs = 0, nInliers = 0, nOutliers = 0;
         frogjson::Value images = frogjson::Value::array();
         for (uint32_t i = 0; i < n; i++) {
+            if ((int)i < numberOfFixedImages) { images.push(frogjson::Value::object()); continue; }   // :995-1000
             const frog_counts &c = counts[i];
             nPairs += c.pairs; nInliers += c.inliers; nOutliers += c.outliers;
             frogjson::Value s = frogjson::Value::object();

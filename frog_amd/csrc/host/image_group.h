@@ -72,6 +72,7 @@ protected:
     std::vector<frog_counts> counts;
 
     void createContext();
+    void readAndApplyFixedImagesTransforms();    // :1419
     void check(int rc, const char *what);
     void computeLandmarkDistances(float e);      // :1229
     bool saveTransformedLandmarks();             // :1284

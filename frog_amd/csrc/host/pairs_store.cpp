@@ -146,6 +146,14 @@ int frog_pairs_append_points(frog_pairs *p, uint32_t image, const float *xyz, ui
     return FROG_OK;
 }
 
+int frog_pairs_set_points(frog_pairs *p, uint32_t image, const float *xyz)
+{
+    if (!p || image >= p->n_images || !xyz) return FROG_E_INVALID;
+    const size_t at = 3 * (size_t)p->point_offset[image], n = 3 * (size_t)(p->point_offset[image + 1] - p->point_offset[image]);
+    std::copy(xyz, xyz + n, p->xyz.begin() + at);
+    return FROG_OK;
+}
+
 int frog_pairs_write(const frog_pairs *p, const char *path)
 {
     FILE *f = fopen(path, "wb");

@@ -92,6 +92,14 @@ class ImageGroup:
         check(self._lib.frog_linear_step(self._ctx, C.byref(e)), "frog_linear_step")
         return e.value
 
+    def RANSAC(self, image, iterations=5000, batches=None, inlier_distance=50.0, max_scale=10.0):
+        """ImageGroup::RANSAC (imageGroup.cxx:629-716); `batches` defaults to the host's core count as upstream."""
+        import os
+        o = _abi.FrogRansacOptions(iterations, batches or os.cpu_count() or 1, inlier_distance, max_scale)
+        n = C.c_int64()
+        check(self._lib.frog_ransac(self._ctx, C.byref(self.pairs.model), image, C.byref(o), C.byref(n)), "frog_ransac")
+        return n.value
+
     def setupDeformableTransforms(self, level):
         info = _abi.FrogGridInfo()
         check(self._lib.frog_deformable_setup(self._ctx, level, C.byref(info)), "frog_deformable_setup")

@@ -122,6 +122,15 @@ class Pairs:
     def link_point(self):
         return self._view(self.model.link_point, C.c_uint32, self.n_half_links)
 
+    def set_points(self, image, xyz):
+        """Move all keypoints of a (fixed) image to their registered position (imageGroup.cxx:1445-1450)."""
+        a = np.ascontiguousarray(xyz, np.float32)
+        if a.shape != (int(self.point_offset[image + 1]) - int(self.point_offset[image]), 3):
+            raise ValueError("one xyz triple per point of the image")
+        if self._lib.frog_pairs_set_points(self._h, image, a.ctypes.data_as(_abi.c_float_p)):
+            raise ValueError("frog_pairs_set_points")
+        self._lib.frog_pairs_model(self._h, C.byref(self.model))
+
     def append_points(self, image, xyz):
         """Extra link-less points at the end of `image` (how the reference stores landmarks,
         imageGroup.cxx:1185-1201); the model views are refreshed."""

@@ -68,6 +68,28 @@ int frog_transform_points(frog_ctx *ctx, int apply);
 int frog_update_stats(frog_ctx *ctx);
 /* updateLinearTransforms (imageGroup.cxx:1063-1149); *E = sqrt(sum w2 d2 / sum w2). */
 int frog_linear_step(frog_ctx *ctx, double *E);
+
+/* ImageGroup::RANSAC + RANSACBatch (imageGroup.cxx:629-804), the stage that replaces the linear
+ * iterations when fixed images are present (run(), :40-49, `-r 1`, the default with -fi).
+ * `iterations / batches` candidates per batch, batch b drawn from std::mt19937(b * 1000): four
+ * random (point, link) correspondences between the image's xyz and the partners' xyz, a
+ * least-squares similarity transform through them (vtkLandmarkTransform, similarity mode), its
+ * inlier count = half-links of the image with |T(xyz) - partner xyz2|^2 < inlier_distance^2.
+ * Candidates whose |determinant| is outside [1/max_scale, max_scale] are skipped.  The best
+ * candidate is refitted on all its inlier half-links and becomes the image's matrix
+ * (frog_get_linear); *n_inliers = the best candidate's count (before the refit, as upstream
+ * reports it).  All candidates are counted in one launch.  Upstream's `batches` is
+ * omp_get_num_procs(), i.e. a property of the machine: pass the value you want reproduced.
+ * `model` must be the model the context was created from (it is not retained by the context;
+ * the candidate draws need the link table in reference order). */
+typedef struct frog_ransac_options {
+    int32_t iterations;         /* -ri   5000   imageGroup.h:70 */
+    int32_t batches;            /*       omp_get_num_procs() upstream */
+    float   inlier_distance;    /* -rid  50     imageGroup.h:73 */
+    float   max_scale;          /* -rs   10     imageGroup.h:74 */
+} frog_ransac_options;
+int frog_ransac(frog_ctx *ctx, const frog_model *model, uint32_t image, const frog_ransac_options *options,
+                int64_t *n_inliers);
 /* setupDeformableTransforms(level) (imageGroup.cxx:159-218). */
 int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out);
 /* updateDeformableTransforms(alpha) (imageGroup.cxx:234-472); *E = -1 and no

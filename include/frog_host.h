@@ -84,6 +84,11 @@ frog_pairs *frog_synth_generate(const frog_synth_params *p);
  * the bounding boxes. */
 int frog_pairs_append_points(frog_pairs *p, uint32_t image, const float *xyz, uint32_t n);
 
+/* Overwrites the coordinates of all points of `image` (3 floats per point).  Used for fixed
+ * images, whose keypoints are moved to their registered position before the solve
+ * (readAndApplyFixedImagesTransforms, imageGroup.cxx:1419-1456: `xyz := T(xyz)`). */
+int frog_pairs_set_points(frog_pairs *p, uint32_t image, const float *xyz);
+
 /* ---- NIfTI-1 writer for lattice images ------------------------------------------
  * Replaces vtkNIFTIImageWriter at tools/transformIO.h:196-208 (B-spline coefficient
  * sidecars `<i>.json.<n>.nii.gz`, 3 components) and registration/imageGroup.cxx:559-563

@@ -837,6 +837,14 @@ int frogo_run(frogo_group *g, int linear_iterations, int deformable_levels,
 }
 
 uint64_t frogo_num_points(const frogo_group *g) { return g->P; }
+// raw views for the oracle's other translation units (ransac_oracle.cpp)
+const float *frogo_xyz_ptr(const frogo_group *g) { return g->xyz.data(); }
+const float *frogo_xyz2_ptr(const frogo_group *g) { return g->xyz2.data(); }
+const uint32_t *frogo_point_offset_ptr(const frogo_group *g) { return g->poff.data(); }
+const uint64_t *frogo_row_ptr(const frogo_group *g) { return g->rowp.data(); }
+const uint16_t *frogo_link_image_ptr(const frogo_group *g) { return g->limg.data(); }
+const uint32_t *frogo_link_point_ptr(const frogo_group *g) { return g->lpt.data(); }
+void frogo_set_matrix(frogo_group *g, uint32_t image, const double in16[16]) { std::memcpy(&g->matrix[(size_t)image * 16], in16, 16 * sizeof(double)); }
 void frogo_get_xyz(const frogo_group *g, float *out) { std::memcpy(out, g->xyz.data(), g->xyz.size() * sizeof(float)); }
 void frogo_get_xyz2(const frogo_group *g, float *out) { std::memcpy(out, g->xyz2.data(), g->xyz2.size() * sizeof(float)); }
 void frogo_set_xyz2(frogo_group *g, const float *in) { std::memcpy(g->xyz2.data(), in, g->xyz2.size() * sizeof(float)); }

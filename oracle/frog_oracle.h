@@ -74,6 +74,16 @@ int frogo_run(frogo_group *g, int linear_iterations, int deformable_levels,
               int stat_interval, const float anchor[3],
               double *E_out, int cap, int *n_grids_out);
 
+/* RANSAC + RANSACBatch (:629-804), ransac_oracle.cpp; returns the best candidate's inlier count */
+long frogo_ransac(frogo_group *g, uint32_t image, int iterations, int batches, float inlier_distance, float max_scale);
+const float *frogo_xyz_ptr(const frogo_group *g);
+const float *frogo_xyz2_ptr(const frogo_group *g);
+const uint32_t *frogo_point_offset_ptr(const frogo_group *g);
+const uint64_t *frogo_row_ptr(const frogo_group *g);
+const uint16_t *frogo_link_image_ptr(const frogo_group *g);
+const uint32_t *frogo_link_point_ptr(const frogo_group *g);
+void frogo_set_matrix(frogo_group *g, uint32_t image, const double in16[16]);
+
 /* state read-back */
 uint64_t frogo_num_points(const frogo_group *g);
 void frogo_get_xyz(const frogo_group *g, float *out3P);

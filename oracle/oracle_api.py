@@ -258,6 +258,11 @@ class OracleGroup:
     def phase_c(self):
         self.L.frogo_deformable_phase_c(self.h)
 
+    def ransac(self, image, iterations=5000, batches=8, inlier_distance=50.0, max_scale=10.0):
+        self.L.frogo_ransac.restype = C.c_long
+        self.L.frogo_ransac.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float]
+        return self.L.frogo_ransac(self.h, image, iterations, batches, inlier_distance, max_scale)
+
     def run(self, li=50, dl=3, di=200, da=0.02, si=10, anchor=(0.5, 0.5, 0.5)):
         cap = li + dl * di + 8
         E = (C.c_double * cap)()

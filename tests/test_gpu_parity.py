@@ -501,3 +501,39 @@ def test_fixed_images_match_oracle(small_pairs, n_fixed):
     assert _abi.hip_lib().frog_create(C.byref(small_pairs.model), C.byref(o), 0, 1, n, C.byref(ctx)) == _abi.FROG_E_INVALID
     o = _abi.FrogOptions.default(n_fixed_images=n)
     assert _abi.hip_lib().frog_create(C.byref(small_pairs.model), C.byref(o), 0, 0, n, C.byref(ctx)) == _abi.FROG_E_INVALID
+
+
+def test_ransac_stage_matches_oracle(small_pairs):
+    """run() with fixed images and -r 1 (imageGroup.cxx:40-49): RANSAC per moving image instead of the linear
+    iterations, then the deformable levels.  Candidates and the refit are f64 host arithmetic on both sides
+    (two independent eigen-solvers: agreement to rounding), the census is integer."""
+    n, nf = small_pairs.n_images, 2
+    g = ImageGroup(small_pairs, n_fixed_images=nf)
+    ref = OracleGroup(small_pairs.model, _abi.FrogOptions.default(n_fixed_images=nf))
+    ref.setup_stats()
+    start(g, ref)
+    for i in range(nf, n):
+        a = g.RANSAC(i, iterations=600, batches=4, inlier_distance=50.0, max_scale=10.0)
+        b = ref.ransac(i, iterations=600, batches=4, inlier_distance=50.0, max_scale=10.0)
+        assert a == b and a > 1000, f"best census of image {i}"
+        assert np.allclose(g.matrix(i), ref.matrix(i), rtol=1e-9, atol=1e-9), f"refitted matrix of image {i}"
+        m = g.matrix(i)[:3, :3]
+        s = np.cbrt(np.linalg.det(m))
+        assert np.allclose(m @ m.T, s * s * np.eye(3), atol=1e-9)        # a similarity: rotation times one scale
+    g.transformPoints(); ref.transform_points()
+    g.updateStats(); ref.update_stats()
+    assert relerr(g.points()[1], ref.xyz2()) < 1e-6
+    g.transformPoints(True); ref.transform_points(True)
+    info = g.setupDeformableTransforms(0); ref.deformable_setup(0, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    for it in range(10):
+        if it % 10 == 0:
+            g.updateStats(); ref.update_stats()
+        e, er = g.updateDeformableTransforms(0.02), ref.deformable_step(0.02)
+        assert abs(e - er) / er < REL
+        g.transformPoints(); ref.transform_points()
+    # degenerate requests are refused before any launch
+    with pytest.raises(Exception):
+        g2 = ImageGroup(small_pairs, n_fixed_images=nf)
+        g2.setupLinearTransforms(); g2.transformPoints()
+        g2.RANSAC(0)                                                     # a fixed image is not owned
