@@ -69,8 +69,14 @@ int main(int argc, char *argv[])
         cout << "-se number    : stats epsilon. Default : " << group.statsEpsilon << endl;
         cout << "-ss number    : stats maximal sample size. Default : " << group.statsMaxSize << endl;
         cout << "-t threshold  : inlier probability threshold. Default : " << group.inlierThreshold << endl;
-        cout << endl << "*Registration with fixed images: (not supported by this build)" << endl;
+        cout << endl << "*Registration with fixed images:" << endl;
+        cout << "-fd path      : fixed images transforms directory." << endl;
         cout << "-fi number    : number of fixed images. Default : " << group.numberOfFixedImages << endl;
+        cout << "-r 0/1        : use RANSAC instead of linear registration. Default : " << group.useRANSAC << endl;
+        cout << "-ri number    : number of RANSAC iterations. Default : " << group.numberOfRANSACIterations << endl;
+        cout << "-rs maxScale  : maximum allowed scale for RANSAC iterations. Default : " << group.RANSACMaxScale << endl;
+        cout << "-rid value    : RANSAC inlier distance. Default : " << group.RANSACInlierDistance << endl;
+        cout << "-rb number    : RANSAC candidate batches (seeds 0, 1000, ...). Default : number of cores, as upstream" << endl;
         cout << endl << "*Other parameters:" << endl;
         cout << "-nt number    : set number of host threads. Default : number of cores" << endl;
         cout << "-mf file      : path+name of measure.csv file." << endl;
@@ -113,6 +119,7 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-ri") == 0) group.numberOfRANSACIterations = atoi(value);
         if (strcmp(key, "-rs") == 0) group.RANSACMaxScale = atof(value);
         if (strcmp(key, "-rid") == 0) group.RANSACInlierDistance = atof(value);
+        if (strcmp(key, "-rb") == 0) group.RANSACBatches = atoi(value);
         if (strcmp(key, "-s") == 0) group.useScale = atoi(value);
         if (strcmp(key, "-se") == 0) group.statsEpsilon = atof(value);
         if (strcmp(key, "-si") == 0) group.statIntervalUpdate = atoi(value);

@@ -16,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <omp.h>
 #include <zlib.h>
 #include <sstream>
 
@@ -175,21 +176,46 @@ void ImageGroup::run()
     check(frog_linear_init(ctx, linearInitializationAnchor), "frog_linear_init");   // :37
     check(frog_transform_points(ctx, 0), "frog_transform_points");      // :38
 
-    cout << endl << "Linear registration" << endl;
     auto t0 = clk::now();
-    for (int iteration = 0; iteration < linearIterations; iteration++) {
-        if (!quiet) cout << "Linear registration, iteration " << iteration + 1 << "/" << linearIterations << endl;
-        if (!(iteration % statIntervalUpdate)) check(frog_update_stats(ctx), "frog_update_stats");
-        if (printStats) displayStats();
-        double E = 0;
-        check(frog_linear_step(ctx, &E), "frog_linear_step");
-        float e = (float)E;
-        if (printLinear) displayLinearTransforms();
+    if (useRANSAC && numberOfFixedImages) {                             // :40-49
+        frog_model m;
+        frog_pairs_model(pairs, &m);
+        frog_ransac_options ro;
+        ro.iterations = numberOfRANSACIterations;
+        ro.batches = RANSACBatches > 0 ? RANSACBatches : omp_get_num_procs();   // :635
+        ro.inlier_distance = RANSACInlierDistance;
+        ro.max_scale = RANSACMaxScale;
+        for (uint32_t i = numberOfFixedImages; i < m.n_images; i++) {
+            auto start = std::chrono::system_clock::now();
+            cout << "RANSAC registration for image " << i << ": " << std::flush;
+            int64_t inliers = 0;
+            check(frog_ransac(ctx, &m, i, &ro, &inliers), "frog_ransac");
+            auto end = std::chrono::system_clock::now();
+            cout << inliers << " inliers, computed in " << std::chrono::duration<float>(end - start).count() << "s" << endl;
+            ransacInliers.push_back({ (int)i, (long long)inliers });
+        }
         check(frog_transform_points(ctx, 0), "frog_transform_points");
-        computeLandmarkDistances(e);
+        check(frog_update_stats(ctx), "frog_update_stats");
+        if (printStats) displayStats();
+        if (printLinear) displayLinearTransforms();
+    } else {
+        cout << endl << "Linear registration" << endl;
+        t0 = clk::now();
+        for (int iteration = 0; iteration < linearIterations; iteration++) {
+            if (!quiet) cout << "Linear registration, iteration " << iteration + 1 << "/" << linearIterations << endl;
+            if (!(iteration % statIntervalUpdate)) check(frog_update_stats(ctx), "frog_update_stats");
+            if (printStats) displayStats();
+            double E = 0;
+            check(frog_linear_step(ctx, &E), "frog_linear_step");
+            float e = (float)E;
+            if (printLinear) displayLinearTransforms();
+            check(frog_transform_points(ctx, 0), "frog_transform_points");
+            computeLandmarkDistances(e);
+        }
+        loopSeconds += std::chrono::duration<double>(clk::now() - t0).count();
+        loopIterations += linearIterations;
+
     }
-    loopSeconds += std::chrono::duration<double>(clk::now() - t0).count();
-    loopIterations += linearIterations;
 
     check(frog_transform_points(ctx, 1), "frog_transform_points");      // :70
     saveDistanceHistograms("histograms_linear.csv");                    // :71
@@ -678,6 +704,17 @@ void ImageGroup::saveStatsJSON()
         stats["inliers"] = frogjson::Value((double)nInliers);
         stats["outliers"] = frogjson::Value((double)nOutliers);
         stats["outlierRatio"] = frogjson::Value((double)nOutliers / (double)nPairs);
+    }
+    if (!ransacInliers.empty()) {                                       // :707-714
+        frogjson::Value arr = frogjson::Value::array();
+        for (const auto &r : ransacInliers) {
+            frogjson::Value e = frogjson::Value::object();
+            e["image"] = frogjson::Value((double)r.first);
+            e["threshold"] = frogjson::Value((double)RANSACInlierDistance);
+            e["inliers"] = frogjson::Value((double)r.second);
+            arr.push(e);
+        }
+        stats["RANSAC"] = arr;
     }
     // bounding box of every image's xyz (getBoundingBox(box, true))
     const uint64_t P = frog_num_points(ctx);

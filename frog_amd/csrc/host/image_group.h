@@ -50,6 +50,8 @@ public:
     int statsMaxSize, statsMaxIterations;
     float statsEpsilon;
 
+    int RANSACBatches = 0;       // candidate batches (new: -rb; 0 = omp_get_num_procs() as upstream, imageGroup.cxx:635)
+    std::vector<std::pair<int, long long>> ransacInliers;   // (image, best census) for bbox.json
     int device = 0;              // HIP device ordinal (new: -dev)
     bool quiet = false;          // suppress per-iteration lines (new: -q)
 

@@ -304,3 +304,71 @@ def test_cli_validation_landmarks(tmp_path):
     lc = np.array([[float(v) for v in r_[2:5]] for r_ in list(csv.reader(open(tmp_path / "measures_lc.csv")))[1:]])
     assert np.allclose(lc[:12], got[:12], rtol=1e-5)          # the linear stage ignores hard links
     assert lc[-1, 0] < 0.95 * got[-1, 0]
+
+
+def test_cli_incremental_registration_with_fixed_images(tmp_path):
+    """The workflow of tools/register.py:88-94: register a group, then register an image against it with the
+    group's images fixed at their transforms (`-fi n -fd dir`, RANSAC by default)."""
+    from frog_amd.chain import Chain, read_transform
+    from frog_amd.pairs import Pairs
+    # images that differ by translations and smooth bumps only: a similarity + one lattice level can register them
+    small_pairs = Pairs.synthetic(6, 3000, 1500, seed=11, scale_min=1.0, scale_max=1.0)
+    n = small_pairs.n_images
+    first = tmp_path / "group"; second = tmp_path / "added"
+    first.mkdir(); second.mkdir()
+    small_pairs.write(first / "pairs.bin")
+    small_pairs.write(second / "pairs.bin")
+    exe = os.path.join(ROOT, "bin", "frog")
+    r = subprocess.run([exe, "pairs.bin", "-li", "30", "-dl", "1", "-di", "20", "-q", "1"], cwd=first, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([exe, "pairs.bin", "-j", "-fd", str(first / "transforms"), "-fi", str(n - 1), "-dl", "1", "-di", "20",
+                        "-ri", "800", "-rb", "4", "-q", "1"], cwd=second, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert f"RANSAC registration for image {n - 1}: " in r.stdout and "Reading transforms in directory" in r.stdout
+    assert "Linear registration, iteration" not in r.stdout                       # :40-49 replaces the linear loop
+    # only the moving image gets outputs (:481, :1464); bbox.json lists {} for the fixed ones (:995-1000)
+    assert sorted(os.listdir(second / "transforms")) == [f"{n - 1}.json"]
+    assert sorted(os.listdir(second / "errorMaps")) == [f"{n - 1}.nii.gz"]
+    bbox = json.load(open(second / "bbox.json"))
+    assert bbox["images"][:n - 1] == [{}] * (n - 1) and bbox["images"][n - 1]["pairs"] > 0
+    assert bbox["RANSAC"][0]["image"] == n - 1 and bbox["RANSAC"][0]["threshold"] == 50
+
+    # the oracle on the same inputs: fixed images moved by the first run's transforms
+    po = small_pairs.point_offset
+    xyz = np.array(small_pairs.xyz, np.float32)
+    for i in range(n - 1):
+        p = xyz[po[i]:po[i + 1]]
+        for link in read_transform(first / "transforms" / f"{i}.json"):           # float between links, as vtkGeneralTransform
+            p = Chain([link]).apply(p.astype(np.float64)).astype(np.float32)
+        xyz[po[i]:po[i + 1]] = p
+    blocks = [small_pairs.block(b) for b in range(small_pairs.n_blocks)]
+    moved = Pairs.from_arrays(po, xyz, blocks)
+    ref = OracleGroup(moved.model, _abi.FrogOptions.default(n_fixed_images=n - 1))
+    ref.setup_stats(); ref.linear_init(); ref.transform_points()
+    best = ref.ransac(n - 1, iterations=800, batches=4)
+    assert bbox["RANSAC"][0]["inliers"] == best
+    ref.transform_points(); ref.update_stats(); ref.transform_points(True)
+    ref.deformable_setup(0, _abi.FrogGridInfo()); ref.transform_points()
+    E = []
+    for it in range(20):
+        if it % 10 == 0:
+            ref.update_stats()
+        E.append(ref.deformable_step(0.02)); ref.transform_points()
+    rows = list(csv.reader(open(second / "measures.csv")))
+    got_e = np.array([float(x[1]) for x in rows[1:]])
+    assert len(got_e) == len(E) and np.max(np.abs(got_e - np.array(E)) / np.array(E)) < 1e-3
+    t = json.load(open(second / "transforms" / f"{n - 1}.json"))["transforms"]
+    m = np.array(t[0]["matrix"]).reshape(4, 4)
+    assert np.allclose(m, ref.matrix(n - 1), rtol=1e-6, atol=1e-6)
+    assert abs(np.linalg.det(m[:3, :3])) > 0 and not np.allclose(m[:3, :3], np.diag(np.diag(m[:3, :3])))   # a rotation, unlike the linear stage
+    info, c = ref.grid(n - 1, 0, _abi.FrogGridInfo())
+    assert relerr(np.array(t[1]["coeffs"]).reshape(-1, 3), c) < REL
+    # and the point of it all: the added image lands where the group registration had put it
+    rec = bbox["images"][n - 1]
+    print("inliers", rec["inliers"], "of", rec["pairs"], "E", got_e[0], got_e[-1])
+    assert rec["inliers"] > 0.5 * rec["pairs"] and got_e[-1] < got_e[0]
+    own = np.array(small_pairs.xyz[po[n - 1]:po[n]], np.float64)
+    a = Chain(read_transform(first / "transforms" / f"{n - 1}.json")).apply(own)
+    b = Chain(read_transform(second / "transforms" / f"{n - 1}.json")).apply(own)
+    print("median distance", np.median(np.linalg.norm(a - b, axis=1)), np.median(np.linalg.norm(a - own, axis=1)))
+    assert np.median(np.linalg.norm(a - b, axis=1)) < 5.0 < np.median(np.linalg.norm(a - own, axis=1))
