@@ -100,6 +100,15 @@ class FrogKeypoints(C.Structure):
                 ("laplacian", c_float_p), ("response", c_float_p), ("desc", c_float_p)]
 
 
+class FrogVolume(C.Structure):
+    """frog_volume (include/frog_chain.h)."""
+    _fields_ = [("dims", C.c_uint32 * 3), ("spacing", C.c_double * 3), ("origin", C.c_double * 3),
+                ("dtype", C.c_int), ("data", C.c_void_p)]
+
+
+FROG_V_DTYPES = ["uint8", "int8", "uint16", "int16", "uint32", "int32", "float32", "float64"]
+
+
 class FrogChainLink(C.Structure):
     """frog_chain_link (include/frog_chain.h)."""
     _fields_ = [("type", C.c_int), ("matrix", C.c_double * 16), ("dims", C.c_uint32 * 3), ("origin", C.c_double * 3),
@@ -155,6 +164,9 @@ HIP_SYMBOLS = {
     "frog_chain_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_size_t]),
     "frog_chain_check": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                    c_double_p]),
+    "frog_chain_invert_links": (C.c_int, [C.POINTER(FrogChainLink), C.c_uint32, C.POINTER(FrogChainLink)]),
+    "frog_volume_voxel_bytes": (C.c_size_t, [C.c_int]),
+    "frog_chain_reslice": (C.c_int, [C.c_void_p, C.POINTER(FrogVolume), C.POINTER(FrogVolume), C.c_int, C.c_double]),
     "frog_match_options_default": (None, [C.POINTER(FrogMatchOptions)]),
     "frog_matcher_create": (C.c_int, [C.POINTER(FrogKeypoints), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "frog_matcher_destroy": (None, [C.c_void_p]),

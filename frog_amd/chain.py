@@ -11,7 +11,7 @@ import numpy as np
 from . import _abi
 from ._abi import check
 
-LINEAR, BSPLINE = 0, 1
+LINEAR, BSPLINE, BSPLINE_INVERSE = 0, 1, 2
 
 
 class Link:
@@ -24,7 +24,7 @@ class Link:
         self.origin = None if origin is None else tuple(float(v) for v in origin)
         self.spacing = None if spacing is None else tuple(float(v) for v in spacing)
         self.coeffs = None if coeffs is None else np.ascontiguousarray(coeffs, np.float32).reshape(-1, 3)
-        if kind == BSPLINE and len(self.coeffs) != self.dims[0] * self.dims[1] * self.dims[2]:
+        if kind != LINEAR and len(self.coeffs) != self.dims[0] * self.dims[1] * self.dims[2]:
             raise ValueError("coefficient count does not match the lattice dimensions")
 
     @classmethod
@@ -44,6 +44,24 @@ class Link:
             v.dims[:] = self.dims; v.origin[:] = self.origin; v.spacing[:] = self.spacing
             v.coeffs = self.coeffs.ctypes.data_as(_abi.c_float_p)
         return v
+
+
+def invert(links):
+    """vtkGeneralTransform::Inverse() of a chain: reversed order, inverted matrices, lattices evaluated by
+    Newton's method (frog_chain_invert_links)."""
+    links = list(links)
+    n = len(links)
+    src = (_abi.FrogChainLink * max(1, n))(*[l.view() for l in links])
+    dst = (_abi.FrogChainLink * max(1, n))()
+    check(_abi.hip_lib().frog_chain_invert_links(src, n, dst), "frog_chain_invert_links")
+    out = []
+    for k in range(n):
+        o, v = links[n - 1 - k], dst[k]
+        if v.type == LINEAR:
+            out.append(Link.linear(np.array(v.matrix[:], np.float64).reshape(4, 4)))
+        else:
+            out.append(Link(v.type, dims=o.dims, origin=o.origin, spacing=o.spacing, coeffs=o.coeffs))
+    return out
 
 
 def read_nifti_lattice(path):
@@ -106,6 +124,21 @@ class Chain:
         out = np.empty_like(p)
         check(self._lib.frog_chain_apply(self._h, p.ctypes.data_as(_abi.c_double_p), out.ctypes.data_as(_abi.c_double_p), len(p)),
               "frog_chain_apply")
+        return out
+
+    def reslice(self, volume, origin, spacing, out_dims, out_origin, out_spacing, interpolation=1, background=0.0):
+        """vtkImageReslice as tools/VolumeTransform.cxx:119-136 uses it: `volume` is indexed [z, y, x]; the chain
+        maps the output grid's space to the volume's.  Returns an array of the same dtype, shape out_dims[::-1]."""
+        src = np.ascontiguousarray(volume)
+        if src.dtype.name not in _abi.FROG_V_DTYPES or src.ndim != 3:
+            raise ValueError("3-D scalar volume of a supported type expected")
+        out = np.empty(tuple(int(v) for v in out_dims[::-1]), src.dtype)
+        a, b = _abi.FrogVolume(), _abi.FrogVolume()
+        a.dims[:] = src.shape[::-1]; a.spacing[:] = spacing; a.origin[:] = origin
+        b.dims[:] = [int(v) for v in out_dims]; b.spacing[:] = out_spacing; b.origin[:] = out_origin
+        a.dtype = b.dtype = _abi.FROG_V_DTYPES.index(src.dtype.name)
+        a.data = src.ctypes.data; b.data = out.ctypes.data
+        check(self._lib.frog_chain_reslice(self._h, C.byref(a), C.byref(b), int(interpolation), float(background)), "frog_chain_reslice")
         return out
 
     def check(self, origin, spacing, dims):

@@ -17,7 +17,9 @@
  *              contribute zero (BorderModeZero), y = x + d(x)
  *   Jacobian : analytic, I + (basis derivative / spacing) products; the chain's Jacobian is
  *              the product of the links' Jacobians at the successive points.
- * Inverse transforms (-ti) are not built.
+ * Inverse of a B-spline link (FROG_T_BSPLINE_INVERSE): Newton's method with vtkWarpTransform's
+ *              defaults (tolerance 1e-3, 500 iterations, step shortening when the residual grows);
+ *              the inverse of a linear link is its inverted matrix (frog_chain_invert_links).
  */
 #ifndef FROG_CHAIN_H
 #define FROG_CHAIN_H
@@ -31,10 +33,10 @@
 extern "C" {
 #endif
 
-enum { FROG_T_LINEAR = 0, FROG_T_BSPLINE = 1 };
+enum { FROG_T_LINEAR = 0, FROG_T_BSPLINE = 1, FROG_T_BSPLINE_INVERSE = 2 };
 
 typedef struct frog_chain_link {
-    int type;                   /* FROG_T_LINEAR | FROG_T_BSPLINE                        */
+    int type;                   /* FROG_T_LINEAR | FROG_T_BSPLINE | FROG_T_BSPLINE_INVERSE */
     double matrix[16];          /* linear: row-major 4x4                                  */
     uint32_t dims[3];           /* B-spline: control points per axis                      */
     double origin[3], spacing[3];
@@ -56,6 +58,32 @@ int frog_chain_apply(frog_chain *c, const double *in3n, double *out3n, size_t n)
  * smallest determinant met. */
 int frog_chain_check(frog_chain *c, const double origin[3], const double spacing[3], const uint32_t dims[3],
                      uint64_t *n_negative, double *min_determinant);
+
+/* vtkGeneralTransform::Inverse() of a chain (tools/VolumeTransform.cxx:55-57, PointsTransform's -ti):
+ * the links in reverse order, matrices inverted, lattices switched between forward and inverse
+ * evaluation.  `out` receives n links (coefficient pointers are shared with `in`).  Returns
+ * FROG_E_INVALID for a singular matrix. */
+int frog_chain_invert_links(const frog_chain_link *in, uint32_t n, frog_chain_link *out);
+
+/* ---- volume reslicing (tools/VolumeTransform.cxx:119-136 = vtkImageReslice) ----------------------
+ * A scalar volume on a regular grid; `data` is x-fastest, one component. */
+enum { FROG_V_U8 = 0, FROG_V_I8, FROG_V_U16, FROG_V_I16, FROG_V_U32, FROG_V_I32, FROG_V_F32, FROG_V_F64 };
+typedef struct frog_volume {
+    uint32_t dims[3];
+    double   spacing[3], origin[3];
+    int      dtype;             /* FROG_V_*                                                     */
+    void    *data;
+} frog_volume;
+size_t frog_volume_voxel_bytes(int dtype);
+
+/* out(voxel) = source(chain(position of the voxel)): `chain` maps the output grid's space to the
+ * source's (for a registration transform T of the source that is T^-1: frog_chain_invert_links).
+ * `out` describes the output grid (VolumeTransform takes it from the reference volume); its
+ * dtype must be the source's and its data buffer is filled.  interpolation: 0 nearest, otherwise
+ * trilinear.  A sample more than half a voxel outside the source's voxel centres gives
+ * `background` (VTK's default border); integer outputs are rounded half up and clamped to the
+ * type's range, as vtkImageReslice does. */
+int frog_chain_reslice(frog_chain *c, const frog_volume *source, frog_volume *out, int interpolation, double background);
 
 #ifdef __cplusplus
 }

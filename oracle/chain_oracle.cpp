@@ -9,6 +9,7 @@
 // is an exact quadratic/linear function of position).
 #include "../include/frog_chain.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <omp.h>
@@ -73,13 +74,85 @@ void link_apply(const frog_chain_link &t, const double x[3], double y[3], double
     }
 }
 
+// 3x3 linear solve by Gaussian elimination with partial pivoting (the role of vtkMath::LinearSolve3x3)
+void solve3x3(const double A[3][3], const double b[3], double x[3])
+{
+    double M[3][4];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r][c] = A[r][c]; M[r][3] = b[r]; }
+    for (int col = 0; col < 3; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 3; r++) if (std::fabs(M[r][col]) > std::fabs(M[piv][col])) piv = r;
+        if (piv != col) for (int c = 0; c < 4; c++) std::swap(M[piv][c], M[col][c]);
+        for (int r = col + 1; r < 3; r++) {
+            const double f = M[r][col] / M[col][col];
+            for (int c = col; c < 4; c++) M[r][c] -= f * M[col][c];
+        }
+    }
+    for (int r = 2; r >= 0; r--) {
+        double v = M[r][3];
+        for (int c = r + 1; c < 3; c++) v -= M[r][c] * x[c];
+        x[r] = v / M[r][r];
+    }
+}
+
+// vtkWarpTransform's inverse (the scheme vtkBSplineTransform inherits): Newton iterations on
+// T(x) = p from the first guess x = p - (T(p) - p); when |T(x) - p|^2 grows, the last step is
+// shortened by the factor a parabola through the last two values suggests, clamped to [0.1, 0.5];
+// stops when step and residual are both under InverseTolerance (0.001) or after InverseIterations
+// (500), then keeps the last good point.  VTK absent: restated from its documented behaviour.
+void bspline_inverse(const frog_chain_link &t, const double point[3], double inverse[3], double Jinv[3][3])
+{
+    frog_chain_link fwd = t;
+    fwd.type = FROG_T_BSPLINE;
+    const double toleranceSquared = 1e-3 * 1e-3;
+    double deltaP[3], deltaI[3] = { 0, 0, 0 }, derivative[3][3], lastInverse[3];
+    double functionValue = 0, functionDerivative = 0, lastFunctionValue = 1e300, f = 1.0;
+    link_apply(fwd, point, inverse, derivative);
+    for (int k = 0; k < 3; k++) { inverse[k] = point[k] - (inverse[k] - point[k]); lastInverse[k] = inverse[k]; }
+    int i;
+    const int n = 500;
+    for (i = 0; i < n; i++) {
+        link_apply(fwd, inverse, deltaP, derivative);
+        for (int k = 0; k < 3; k++) deltaP[k] -= point[k];
+        functionValue = deltaP[0] * deltaP[0] + deltaP[1] * deltaP[1] + deltaP[2] * deltaP[2];
+        if (i == 0 || functionValue < lastFunctionValue) {
+            solve3x3(derivative, deltaP, deltaI);
+            const double errorSquared = deltaI[0] * deltaI[0] + deltaI[1] * deltaI[1] + deltaI[2] * deltaI[2];
+            if (errorSquared < toleranceSquared && functionValue < toleranceSquared) break;
+            for (int k = 0; k < 3; k++) lastInverse[k] = inverse[k];
+            lastFunctionValue = functionValue;
+            functionDerivative = 0;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) functionDerivative -= 2 * deltaP[r] * derivative[r][c] * deltaI[c];
+            for (int k = 0; k < 3; k++) inverse[k] -= deltaI[k];
+            f = 1.0;
+            continue;
+        }
+        double a = -functionDerivative / (2 * (functionValue - lastFunctionValue - functionDerivative));
+        if (a < 0.1) a = 0.1;
+        if (a > 0.5) a = 0.5;
+        f *= a;
+        for (int k = 0; k < 3; k++) inverse[k] = lastInverse[k] - f * deltaI[k];
+    }
+    if (i >= n) for (int k = 0; k < 3; k++) inverse[k] = lastInverse[k];
+    double out[3];
+    link_apply(fwd, inverse, out, derivative);
+    for (int c = 0; c < 3; c++) {
+        const double e[3] = { c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0 };
+        double col[3];
+        solve3x3(derivative, e, col);
+        for (int r = 0; r < 3; r++) Jinv[r][c] = col[r];
+    }
+}
+
 void chain_apply(const frog_chain_link *links, uint32_t n, const double x[3], double y[3], double J[3][3])
 {
     double p[3] = { x[0], x[1], x[2] };
     double A[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
     for (uint32_t l = 0; l < n; l++) {
         double q[3], Jl[3][3], B[3][3];
-        link_apply(links[l], p, q, Jl);
+        if (links[l].type == FROG_T_BSPLINE_INVERSE) bspline_inverse(links[l], p, q, Jl);
+        else link_apply(links[l], p, q, Jl);
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) B[r][c] = Jl[r][0] * A[0][c] + Jl[r][1] * A[1][c] + Jl[r][2] * A[2][c];
         std::memcpy(A, B, sizeof A);
@@ -128,6 +201,49 @@ void frogo_chain_check(const frog_chain_link *links, uint32_t n_links, const dou
             }
     *n_negative = neg;
     *min_det = mn;
+}
+
+
+// vtkImageReslice as tools/VolumeTransform.cxx:119-136 sets it up: every voxel of the output grid goes
+// through the chain into the source's frame; nearest or trilinear sampling; default border (half a voxel
+// beyond the outermost voxel centres still reads the edge), background elsewhere.  `src` and `out`
+// are doubles here (the product converts to and from the file's scalar type around the same arithmetic).
+void frogo_chain_reslice(const frog_chain_link *links, uint32_t n_links, const double *src, const uint32_t sdims[3],
+                         const double sorigin[3], const double sspacing[3], const uint32_t odims[3], const double oorigin[3],
+                         const double ospacing[3], int interpolation, double background, double *out)
+{
+    const long sx = sdims[0], sy = sdims[1], sz = sdims[2];
+    auto voxel = [&](long x, long y, long z) {
+        x = std::min(std::max(x, 0L), sx - 1); y = std::min(std::max(y, 0L), sy - 1); z = std::min(std::max(z, 0L), sz - 1);
+        return src[x + sx * (y + sy * z)];
+    };
+    #pragma omp parallel for
+    for (long k = 0; k < (long)odims[2]; k++)
+        for (uint32_t j = 0; j < odims[1]; j++)
+            for (uint32_t i = 0; i < odims[0]; i++) {
+                const double in[3] = { oorigin[0] + i * ospacing[0], oorigin[1] + j * ospacing[1], oorigin[2] + k * ospacing[2] };
+                double p[3], J[3][3];
+                chain_apply(links, n_links, in, p, J);
+                double c[3];
+                bool inside = true;
+                for (int a = 0; a < 3; a++) {
+                    c[a] = (p[a] - sorigin[a]) / sspacing[a];
+                    inside = inside && c[a] >= -0.5 && c[a] <= (double)sdims[a] - 0.5;
+                }
+                double v = background;
+                if (inside && !interpolation) {
+                    v = voxel((long)std::floor(c[0] + 0.5), (long)std::floor(c[1] + 0.5), (long)std::floor(c[2] + 0.5));
+                } else if (inside) {
+                    const long x0 = (long)std::floor(c[0]), y0 = (long)std::floor(c[1]), z0 = (long)std::floor(c[2]);
+                    const double fx = c[0] - x0, fy = c[1] - y0, fz = c[2] - z0;
+                    v = 0;
+                    for (int dz = 0; dz < 2; dz++)
+                        for (int dy = 0; dy < 2; dy++)
+                            for (int dx = 0; dx < 2; dx++)
+                                v += (dx ? fx : 1 - fx) * (dy ? fy : 1 - fy) * (dz ? fz : 1 - fz) * voxel(x0 + dx, y0 + dy, z0 + dz);
+                }
+                out[i + (size_t)odims[0] * (j + (size_t)odims[1] * k)] = v;
+            }
 }
 
 }

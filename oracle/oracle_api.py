@@ -391,3 +391,19 @@ def chain_check(links, origin, spacing, dims):
     n, m = C.c_uint64(), C.c_double()
     L.frogo_chain_check(views, len(links), o, s, d, C.byref(n), C.byref(m))
     return int(n.value), float(m.value)
+
+
+def chain_reslice(links, src, src_origin, src_spacing, out_dims, out_origin, out_spacing, interpolation=1, background=0.0):
+    """vtkImageReslice as VolumeTransform uses it, on the CPU.  `src` is indexed [z, y, x]; so is the result (f64)."""
+    from frog_amd import _abi
+    L = lib()
+    L.frogo_chain_reslice.restype = None
+    u3 = C.c_uint32 * 3
+    d3 = C.c_double * 3
+    L.frogo_chain_reslice.argtypes = [C.POINTER(_abi.FrogChainLink), C.c_uint32, dp, u3, d3, d3, u3, d3, d3, C.c_int, C.c_double, dp]
+    views = (_abi.FrogChainLink * max(1, len(links)))(*[l.view() for l in links])
+    s = np.ascontiguousarray(src, np.float64)
+    out = np.empty(tuple(int(v) for v in out_dims[::-1]), np.float64)
+    L.frogo_chain_reslice(views, len(links), s.ctypes.data_as(dp), u3(*s.shape[::-1]), d3(*src_origin), d3(*src_spacing),
+                          u3(*out_dims), d3(*out_origin), d3(*out_spacing), int(interpolation), float(background), out.ctypes.data_as(dp))
+    return out

@@ -119,3 +119,56 @@ def test_native_transform_reader_matches_python_reader(tmp_path):
     (tmp_path / "v.mhd").write_text("ObjectType = Image\nNDims = 3\nDimSize = 7 8 9\nElementSpacing = 0.5 0.75 2\nOffset = -1 2 3.5\n")
     assert lib.frog_volume_geometry(str(tmp_path / "v.mhd").encode(), dd, ss, oo) == 0
     assert tuple(dd) == (7, 8, 9) and list(ss) == [0.5, 0.75, 2.0] and list(oo) == [-1.0, 2.0, 3.5]
+
+
+def smooth_chain(seed=3, amplitude=2.0):
+    rng = np.random.default_rng(seed)
+    M = np.array([[1.05, 0.08, 0, 4], [-0.06, 0.95, 0.03, -3], [0.02, 0, 1.1, 2], [0, 0, 0, 1.0]])
+    dims = (9, 8, 10)
+    co = (amplitude * rng.normal(size=(dims[0] * dims[1] * dims[2], 3))).astype(np.float32)
+    return [Link.linear(M), Link.bspline(dims, (-25.0, -25.0, -25.0), (15.0, 15.0, 15.0), co)]
+
+
+def test_inverse_links_undo_the_chain():
+    """vtkGeneralTransform::Inverse (VolumeTransform.cxx:55-57): reversed order, inverted matrix, Newton on the
+    lattice to VTK's default tolerance of 1e-3."""
+    from frog_amd.chain import BSPLINE_INVERSE
+    links = smooth_chain()
+    inv = [Link(BSPLINE_INVERSE, dims=links[1].dims, origin=links[1].origin, spacing=links[1].spacing, coeffs=links[1].coeffs),
+           Link.linear(np.linalg.inv(links[0].matrix))]
+    pts = np.random.default_rng(1).uniform(-10, 90, (2000, 3))
+    fwd, J = chain_apply(links, pts, jacobian=True)
+    back, Ji = chain_apply(inv, fwd, jacobian=True)
+    assert np.abs(back - pts).max() < 2e-3                       # the tolerance VTK iterates to
+    assert np.abs(np.einsum("nij,njk->nik", Ji, J) - np.eye(3)).max() < 1e-4
+    # inverse then forward as well
+    assert np.abs(chain_apply(links, chain_apply(inv, pts)) - pts).max() < 2e-3
+
+
+def test_reslice_oracle_closed_forms():
+    """vtkImageReslice as VolumeTransform.cxx:119-136 sets it up."""
+    from oracle.oracle_api import chain_reslice
+    rng = np.random.default_rng(5)
+    vol = rng.uniform(0, 100, (6, 7, 8))                           # [z, y, x]
+    o, s = (10.0, -5.0, 3.0), (2.0, 1.5, 3.0)
+    # identity chain, same grid: the volume itself, in both modes
+    for mode in (0, 1):
+        assert np.array_equal(chain_reslice([], vol, o, s, (8, 7, 6), o, s, mode), vol)
+    # the chain maps output space to source space: +1 voxel in x reads the neighbour; beyond the half-voxel
+    # border the background
+    T = np.eye(4); T[0, 3] = s[0]
+    out = chain_reslice([Link.linear(T)], vol, o, s, (8, 7, 6), o, s, 1, background=-7.0)
+    assert np.allclose(out[:, :, :7], vol[:, :, 1:]) and np.all(out[:, :, 7] == -7.0)
+    T[0, 3] = 0.4 * s[0]                                           # 0.4 voxel: the last column is inside the border
+    out = chain_reslice([Link.linear(T)], vol, o, s, (8, 7, 6), o, s, 1, background=-7.0)
+    assert np.allclose(out[:, :, :7], 0.6 * vol[:, :, :7] + 0.4 * vol[:, :, 1:]) and np.allclose(out[:, :, 7], vol[:, :, 7])
+    assert np.array_equal(chain_reslice([Link.linear(T)], vol, o, s, (8, 7, 6), o, s, 0), vol)      # nearest: 0.4 rounds back
+    # a linear ramp is reproduced exactly by trilinear interpolation under any affine map (inside the volume)
+    z, y, x = np.meshgrid(np.arange(6), np.arange(7), np.arange(8), indexing="ij")
+    ramp = 2.0 * (o[0] + s[0] * x) - 1.0 * (o[1] + s[1] * y) + 0.5 * (o[2] + s[2] * z)
+    A = np.array([[0.9, 0.1, 0, 1.0], [0, 1.05, 0.05, 0.2], [0.02, 0, 0.95, 0.5], [0, 0, 0, 1]])
+    oo, os_, od = (13.0, -3.0, 6.0), (1.0, 1.0, 2.0), (5, 4, 3)
+    out = chain_reslice([Link.linear(A)], ramp, o, s, od, oo, os_, 1, background=np.nan)
+    zz, yy, xx = np.meshgrid(np.arange(3), np.arange(4), np.arange(5), indexing="ij")
+    P = np.stack([oo[0] + os_[0] * xx, oo[1] + os_[1] * yy, oo[2] + os_[2] * zz, np.ones_like(xx)], -1) @ A.T
+    assert not np.isnan(out).any() and np.allclose(out, 2.0 * P[..., 0] - P[..., 1] + 0.5 * P[..., 2])

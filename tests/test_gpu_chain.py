@@ -115,3 +115,37 @@ def test_tools_points_transform_and_check_diffeomorphism(tmp_path):
     assert r.returncode == 0 and "0 negative jacobian determinant values (0%)" in r.stdout
     assert subprocess.run([os.path.join(ROOT, "bin", "PointsTransform"), "-p", "1", "1", "1", "-ti", "t.json"], cwd=tmp_path,
                           capture_output=True).returncode == 1
+
+
+def test_inverse_and_reslice_match_oracle():
+    """The inverse chain (VolumeTransform's -t) and vtkImageReslice's sampling: device against the oracle."""
+    from frog_amd.chain import invert
+    from oracle.oracle_api import chain_reslice
+    from test_chain import smooth_chain
+    links = smooth_chain()
+    inv = invert(links)
+    assert [l.kind for l in inv] == [2, 0] and np.allclose(inv[1].matrix @ links[0].matrix, np.eye(4), atol=1e-12)
+    pts = np.random.default_rng(4).uniform(-10, 90, (4000, 3))
+    c = Chain(inv)
+    got, want = c.apply(pts), chain_apply(inv, pts)
+    assert np.abs(got - want).max() < 1e-6                        # two Newton iterations with different 3x3 solvers
+    assert np.abs(Chain(links).apply(got) - pts).max() < 2e-3
+    n, m = c.check((0.0, 0.0, 0.0), (4.0, 4.0, 4.0), (20, 20, 20))
+    rn, rm = chain_check(inv, (0.0, 0.0, 0.0), (4.0, 4.0, 4.0), (20, 20, 20))
+    assert n == rn == 0 and abs(m - rm) < 1e-6
+    rng = np.random.default_rng(8)
+    o, s = (-5.0, 0.0, 2.0), (1.5, 2.0, 1.0)
+    for dtype, bg in (("float32", -1.0), ("int16", -1000.0), ("uint8", 0.0), ("float64", 3.5), ("int32", 7.0)):
+        vol = rng.uniform(0, 200, (40, 30, 50)).astype(dtype)
+        for mode in (0, 1):
+            got = c.reslice(vol, o, s, (33, 35, 31), (0.0, 2.0, 4.0), (2.0, 1.5, 1.2), mode, bg)
+            want = chain_reslice(inv, vol, o, s, (33, 35, 31), (0.0, 2.0, 4.0), (2.0, 1.5, 1.2), mode, bg)
+            assert got.dtype == vol.dtype and got.shape == (31, 35, 33)
+            if vol.dtype.kind == "f":
+                assert np.allclose(got, want, rtol=0, atol=2e-3 if mode else 0)       # 1e-6 mm x gradient <= 200 / mm
+                if mode == 0:
+                    assert (got != want).mean() < 1e-3                                  # a sample on a voxel boundary
+            else:
+                r = np.clip(np.floor(want + 0.5), np.iinfo(vol.dtype).min, np.iinfo(vol.dtype).max)
+                assert np.abs(got.astype(np.float64) - r).max() <= 1 and (got != r).mean() < 1e-3
+            assert (got == np.array(bg).astype(vol.dtype)).any() and (got != np.array(bg).astype(vol.dtype)).any()
