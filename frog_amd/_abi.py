@@ -213,6 +213,11 @@ HOST_SYMBOLS = {
     "frog_synth_generate": (C.c_void_p, [C.POINTER(FrogSynthParams)]),
     "frog_pairs_append_points": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_uint32]),
     "frog_pairs_set_points": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
+    "frog_volume_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "frog_volume_free": (None, [C.c_void_p]),
+    "frog_volume_view": (None, [C.c_void_p, C.POINTER(FrogVolume)]),
+    "frog_volume_range": (C.c_int, [C.POINTER(FrogVolume), c_double_p, c_double_p]),
+    "frog_volume_write": (C.c_int, [C.c_char_p, C.POINTER(FrogVolume)]),
     "frog_keypoints_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
     "frog_keypoints_free": (None, [C.c_void_p]),
     "frog_keypoints_count": (C.c_uint32, [C.c_void_p]),

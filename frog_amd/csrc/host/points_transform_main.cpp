@@ -1,7 +1,8 @@
 // PointsTransform: a point through a FROG transform chain, on the GPU (tools/PointsTransform.cxx).
 //   PointsTransform [-p x y z] [-t transform] [-ti inverse_transform] [-o outputFileName]
-// Several -t are concatenated in the order given (vtkGeneralTransform::Concatenate, :31-33).
-// Not built: -ti (VTK inverts B-spline transforms iteratively); exits 1.
+// -t concatenates a transform file, -ti its inverse (reversed links, inverted matrices, Newton on the
+// lattices: frog_chain_invert_links).  The outer vtkGeneralTransform is in VTK's default PreMultiply mode
+// (:25-26), so of several -t/-ti the one given LAST is applied to the point FIRST.
 #include "frog_chain.h"
 #include "frog_host.h"
 
@@ -32,9 +33,20 @@ int main(int argc, char *argv[])
             frog_transform_file *f = frog_transform_read(value, &status);
             if (!f) { cout << "Error : cannot read transform " << value << endl; exit(1); }
             files.push_back(f);
-            for (uint32_t k = 0; k < frog_transform_num_links(f); k++) links.push_back(frog_transform_links(f)[k]);
+            const uint32_t n = frog_transform_num_links(f);
+            std::vector<frog_chain_link> group(frog_transform_links(f), frog_transform_links(f) + n);
+            links.insert(links.begin(), group.begin(), group.end());              // PreMultiply: applied before what is there
         }
-        if (strcmp(key, "-ti") == 0) { cout << "Error : inverse transforms (-ti) are not supported by this build" << endl; exit(1); }
+        if (strcmp(key, "-ti") == 0) {
+            int status = 0;
+            frog_transform_file *f = frog_transform_read(value, &status);
+            if (!f) { cout << "Error : cannot read transform " << value << endl; exit(1); }
+            files.push_back(f);
+            const uint32_t n = frog_transform_num_links(f);
+            std::vector<frog_chain_link> group(n);
+            if (frog_chain_invert_links(frog_transform_links(f), n, group.data())) { cout << "Error : " << frog_last_error() << endl; exit(1); }
+            links.insert(links.begin(), group.begin(), group.end());
+        }
         if (strcmp(key, "-p") == 0) {
             if (argumentsIndex + 3 >= argc) { cout << "Error : -p needs three values" << endl; exit(1); }
             point = new double[3];

@@ -128,6 +128,18 @@ uint32_t frog_transform_num_links(const frog_transform_file *f);
 const frog_chain_link *frog_transform_links(const frog_transform_file *f);
 int frog_volume_geometry(const char *path, uint32_t dims[3], double spacing[3], double origin[3]);
 
+/* ---- scalar volumes (tools/VolumeTransform.cxx:86-101 reader, :146-202 writers) ----------------
+ * NIfTI-1 single files (.nii, .nii.gz) and MetaImage (.mhd + .raw/.zraw, .mha); little-endian,
+ * one component.  frog_volume (frog_chain.h) views the file's own buffer until frog_volume_free.
+ * frog_volume_write picks the format from the suffix: .mhd (header + zlib-compressed .zraw beside
+ * it, vtkMetaImageWriter's default) or .nii / .nii.gz. */
+typedef struct frog_volume_file frog_volume_file;
+frog_volume_file *frog_volume_read(const char *path, int *status);
+void frog_volume_free(frog_volume_file *f);
+void frog_volume_view(const frog_volume_file *f, frog_volume *out);
+int frog_volume_range(const frog_volume *v, double *lo, double *hi);
+int frog_volume_write(const char *path, const frog_volume *v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,46 @@ def test_pairs_reader_rejects_counts_larger_than_the_file(tmp_path):
     status = C.c_int()
     assert not _abi.host_lib().frog_pairs_read(str(tmp_path / "bad.bin").encode(), C.byref(status))
     assert status.value == _abi.FROG_E_INVALID
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int16", "uint16", "int32", "float32", "float64"])
+def test_volume_files_round_trip_and_independent_readers(tmp_path, dtype):
+    """Volumes for VolumeTransform (VolumeTransform.cxx:86-101, :146-202): written by the host library, read back by
+    it and by readers that share no code with it (struct/zlib here)."""
+    import gzip
+    import struct
+    import zlib
+    from frog_amd.volume import read_volume, write_volume
+    vol = np.random.default_rng(3).uniform(0, 250, (4, 5, 6)).astype(dtype)          # [z, y, x]
+    origin, spacing = (1.5, -2.0, 3.25), (0.5, 1.25, 2.0)
+    # MetaImage: text header + zlib-compressed .zraw beside it (vtkMetaImageWriter's default)
+    write_volume(tmp_path / "v.mhd", vol, origin, spacing)
+    hdr = dict(l.split(" = ", 1) for l in open(tmp_path / "v.mhd").read().splitlines())
+    assert hdr["DimSize"] == "6 5 4" and hdr["ElementDataFile"] == "v.zraw" and hdr["CompressedData"] == "True"
+    assert [float(v) for v in hdr["ElementSpacing"].split()] == list(spacing) and [float(v) for v in hdr["Offset"].split()] == list(origin)
+    raw = zlib.decompress(open(tmp_path / "v.zraw", "rb").read())
+    assert np.array_equal(np.frombuffer(raw, dtype).reshape(vol.shape), vol)
+    # an uncompressed .mhd/.raw pair written by hand is read too
+    open(tmp_path / "u.raw", "wb").write(vol.tobytes())
+    met = {"uint8": "MET_UCHAR", "int16": "MET_SHORT", "uint16": "MET_USHORT", "int32": "MET_INT", "float32": "MET_FLOAT", "float64": "MET_DOUBLE"}[dtype]
+    open(tmp_path / "u.mhd", "w").write(f"ObjectType = Image\nNDims = 3\nDimSize = 6 5 4\nElementSpacing = 0.5 1.25 2\nOffset = 1.5 -2 3.25\n"
+                                        f"ElementType = {met}\nElementDataFile = u.raw\n")
+    for name in ("v.mhd", "u.mhd"):
+        got, o, s = read_volume(tmp_path / name)
+        assert got.dtype == vol.dtype and np.array_equal(got, vol) and o == origin and s == spacing
+    # NIfTI-1
+    write_volume(tmp_path / "v.nii.gz", vol, origin, spacing)
+    raw = gzip.decompress(open(tmp_path / "v.nii.gz", "rb").read())
+    assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:348] == b"n+1\0"
+    assert struct.unpack_from("<4h", raw, 40) == (3, 6, 5, 4)
+    code = {"uint8": 2, "int16": 4, "uint16": 512, "int32": 8, "float32": 16, "float64": 64}[dtype]
+    assert struct.unpack_from("<2h", raw, 70) == (code, 8 * vol.itemsize)
+    assert struct.unpack_from("<3f", raw, 80) == spacing and struct.unpack_from("<3f", raw, 268) == origin
+    assert np.array_equal(np.frombuffer(raw, dtype, offset=352).reshape(vol.shape), vol)
+    got, o, s = read_volume(tmp_path / "v.nii.gz")
+    assert np.array_equal(got, vol) and o == origin and s == spacing
+    with pytest.raises(OSError):
+        read_volume(tmp_path / "missing.nii.gz")
+    open(tmp_path / "bad.nii", "wb").write(b"\0" * 400)
+    with pytest.raises(OSError):
+        read_volume(tmp_path / "bad.nii")
