@@ -17,7 +17,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/sq -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/sq.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -d $O/ta -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/ta.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum -d $O/lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/lat.log
-python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat > /dev/null
+python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat $(python3 -c "import json; print(json.load(open('$O/bench.json'))['roofline']['half_links_per_launch'])") > /dev/null
 cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
 cp $O/under_rocprof.json gpurun_out/${TAG}_bench_n1_under_rocprof.json
 head -12 gpurun_out/${TAG}_bench_n1.txt
