@@ -165,7 +165,6 @@ HIP_SYMBOLS = {
     "frog_chain_check": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                    c_double_p]),
     "frog_chain_invert_links": (C.c_int, [C.POINTER(FrogChainLink), C.c_uint32, C.POINTER(FrogChainLink)]),
-    "frog_volume_voxel_bytes": (C.c_size_t, [C.c_int]),
     "frog_chain_reslice": (C.c_int, [C.c_void_p, C.POINTER(FrogVolume), C.POINTER(FrogVolume), C.c_int, C.c_double]),
     "frog_match_options_default": (None, [C.POINTER(FrogMatchOptions)]),
     "frog_matcher_create": (C.c_int, [C.POINTER(FrogKeypoints), C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),

@@ -386,17 +386,6 @@ int frog_chain_check(frog_chain *c, const double origin[3], const double spacing
 }
 
 
-size_t frog_volume_voxel_bytes(int dtype)
-{
-    switch (dtype) {
-    case FROG_V_U8: case FROG_V_I8: return 1;
-    case FROG_V_U16: case FROG_V_I16: return 2;
-    case FROG_V_U32: case FROG_V_I32: case FROG_V_F32: return 4;
-    case FROG_V_F64: return 8;
-    default: return 0;
-    }
-}
-
 int frog_chain_invert_links(const frog_chain_link *in, uint32_t n, frog_chain_link *out)
 {
     if (n && (!in || !out)) return fail(FROG_E_INVALID, "bad arguments to frog_chain_invert_links");

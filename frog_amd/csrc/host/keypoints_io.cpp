@@ -99,7 +99,7 @@ frog_keypoint_file *frog_keypoints_read(const char *path, int *status)
         char buf[65536];
         while (std::fgets(buf, sizeof buf, in)) {
             line += buf;
-            if (line.back() != '\n' && !std::feof(in)) continue;
+            if ((line.empty() || line.back() != '\n') && !std::feof(in)) continue;   // a NUL byte yields an empty piece
             parse_line(line.c_str(), vals);
             push_row(*f, vals);
             line.clear();

@@ -122,6 +122,7 @@ frog_volume_file *frog_volume_read(const char *path, int *status)
         }
         if (header_size > 0 && (size_t)header_size <= raw.size()) raw.erase(raw.begin(), raw.begin() + header_size);
         if (compressed) {
+            if (want / 1100 > raw.size() + 1) return bad(FROG_E_INVALID);   // deflate cannot expand more than ~1032:1
             f->bytes.resize(want);
             uLongf got = (uLongf)want;
             if (uncompress(f->bytes.data(), &got, raw.data(), (uLong)raw.size()) != Z_OK || got != want) return bad(FROG_E_INVALID);

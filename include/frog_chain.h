@@ -74,7 +74,16 @@ typedef struct frog_volume {
     int      dtype;             /* FROG_V_*                                                     */
     void    *data;
 } frog_volume;
-size_t frog_volume_voxel_bytes(int dtype);
+static inline size_t frog_volume_voxel_bytes(int dtype)
+{
+    switch (dtype) {
+    case FROG_V_U8: case FROG_V_I8: return 1;
+    case FROG_V_U16: case FROG_V_I16: return 2;
+    case FROG_V_U32: case FROG_V_I32: case FROG_V_F32: return 4;
+    case FROG_V_F64: return 8;
+    default: return 0;
+    }
+}
 
 /* out(voxel) = source(chain(position of the voxel)): `chain` maps the output grid's space to the
  * source's (for a registration transform T of the source that is T^-1: frog_chain_invert_links).

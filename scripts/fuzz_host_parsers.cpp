@@ -1,7 +1,7 @@
 // fuzz_host_parsers.cpp -- the host-side file parsers (pairs.bin, keypoint files, transform JSON,
 // NIfTI headers) on mutated and truncated inputs, to be built with -fsanitize=address,undefined:
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fopenmp -Iinclude scripts/fuzz_host_parsers.cpp \
-//       frog_amd/csrc/host/{pairs_store,keypoints_io,transform_io,nifti_out,synth}.cpp -lz -o /tmp/fuzz_host
+//       frog_amd/csrc/host/{pairs_store,keypoints_io,transform_io,nifti_out,synth,volume_io}.cpp -lz -o /tmp/fuzz_host
 //   /tmp/fuzz_host /tmp/fuzzdir 3000
 // Every parser must either succeed or fail with a status; no crash, no out-of-bounds access.
 #include "frog_host.h"
@@ -56,11 +56,20 @@ int main(int argc, char **argv)
               "{\"type\":\"vtkBSplineTransform\",\"dimensions\":[2,2,2],\"origin\":[0,0,0],\"spacing\":[1,1,1],\"coeffs\":["
               "0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0]}]}";
     }
+    {
+        std::vector<int16_t> vox(6 * 5 * 4, 7);
+        frog_volume v{ { 6, 5, 4 }, { 1, 2, 3 }, { -1, 0, 1 }, FROG_V_I16, vox.data() };
+        frog_volume_write((dir + "/vol.nii.gz").c_str(), &v);
+        frog_volume_write((dir + "/vol.nii").c_str(), &v);
+        frog_volume_write((dir + "/vol.mhd").c_str(), &v);
+    }
     struct Target { std::string seed, out; int kind; };
     const std::vector<Target> targets = {
         { dir + "/seed.bin", dir + "/m.bin", 0 }, { dir + "/seed.csv", dir + "/m.csv", 1 }, { dir + "/seed.csv.gz", dir + "/m.csv.gz", 1 },
         { dir + "/seed.bin2.bin", dir + "/m2.bin", 1 }, { dir + "/seed.json", dir + "/m.json", 2 }, { dir + "/seed.nii", dir + "/m.nii", 3 },
         { dir + "/seed.json.0.nii.gz", dir + "/m.json.0.nii.gz", 4 },
+        { dir + "/vol.nii.gz", dir + "/mv.nii.gz", 5 }, { dir + "/vol.mhd", dir + "/mv.mhd", 5 }, { dir + "/vol.zraw", dir + "/mv.zraw", 6 },
+        { dir + "/vol.nii", dir + "/mv.nii", 5 },
     };
     long ok = 0, rejected = 0;
     for (int it = 0; it < iters; it++) {
@@ -83,6 +92,20 @@ int main(int argc, char **argv)
             if (t.kind == 4) spit(dir + "/m.json", slurp(dir + "/seed.json"));           // valid JSON, mutated sidecar
             frog_transform_file *f = frog_transform_read((dir + "/m.json").c_str(), &status);
             if (f) { (void)frog_transform_links(f); frog_transform_free(f); ok++; } else rejected++;
+        } else if (t.kind == 5 || t.kind == 6) {
+            // a mutated header with the intact data file beside it, or the intact header with mutated data
+            std::string header = t.out;
+            if (t.kind == 6) { header = dir + "/mv.mhd"; }
+            if (t.kind == 6 || t.out == dir + "/mv.mhd") {
+                std::vector<unsigned char> h = slurp(t.kind == 6 ? dir + "/vol.mhd" : t.out);
+                std::string text(h.begin(), h.end());
+                const size_t at = text.find("vol.zraw");
+                if (at != std::string::npos) text.replace(at, 8, "mv.zraw");
+                spit(header, std::vector<unsigned char>(text.begin(), text.end()));
+                if (t.kind == 5) spit(dir + "/mv.zraw", slurp(dir + "/vol.zraw"));
+            }
+            frog_volume_file *f = frog_volume_read(header.c_str(), &status);
+            if (f) { frog_volume v; frog_volume_view(f, &v); double lo, hi; (void)frog_volume_range(&v, &lo, &hi); frog_volume_free(f); ok++; } else rejected++;
         } else {
             uint32_t dims[3]; double s3[3], o3[3];
             if (frog_volume_geometry(t.out.c_str(), dims, s3, o3) == 0) ok++; else rejected++;
