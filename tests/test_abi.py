@@ -14,7 +14,7 @@ INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 def declared(header):
     text = open(os.path.join(INC, header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(frog_[a-z0-9_]+)\s*\(", text)) - {"frog_options_default"})
+    return sorted(set(re.findall(r"\b(frog_[a-z0-9_]+)\s*\(", text)) - {"frog_options_default", "frog_volume_voxel_bytes"})    # static inline helpers
 
 
 def test_device_library_exports_every_declared_symbol():
