@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -169,17 +170,31 @@ __device__ void chain_point(const DevLink *links, int n_links, double p[3], doub
 
 // ---- vtkImageReslice as tools/VolumeTransform.cxx:119-136 configures it ------------------------------------
 // One thread per output voxel: its position in the reference volume's frame goes through the chain (which
-// maps output space to source space), the source is sampled there.  Source voxels are stored as float
-// (double for 32-bit integer and f64 volumes, which a float cannot hold).  Inside test with VTK's default
+// maps output space to source space), the source is sampled there in its own scalar type, the arithmetic is
+// f64, the result goes back to that type (integers: rounded half up and clamped, as vtkImageReslice does).
+// Inside test with VTK's default
 // half-voxel border: a sample up to half a voxel outside the first/last voxel centre still reads the
 // edge value (indices clamped); further out it is `background`.
+template <class S>
+__device__ __forceinline__ S to_voxel(double v)
+{
+    if constexpr (std::is_integral<S>::value) {
+        const double lo = (double)std::numeric_limits<S>::lowest(), hi = (double)std::numeric_limits<S>::max();
+        double x = floor(v + 0.5);
+        x = x < lo ? lo : (x > hi ? hi : x);
+        return (S)x;
+    } else {
+        return (S)v;
+    }
+}
+
 template <class S>
 __global__ __launch_bounds__(256) void reslice_kernel(const DevLink *links, int n_links, const S *__restrict__ src,
                                                       int sx, int sy, int sz, double so0, double so1, double so2,
                                                       double ss0, double ss1, double ss2,
                                                       uint32_t nx, uint32_t ny, uint32_t nz, double oo0, double oo1, double oo2,
                                                       double os0, double os1, double os2, int linear, double background,
-                                                      double *__restrict__ out)
+                                                      S *__restrict__ out)
 {
     const size_t total = (size_t)nx * ny * nz;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256) void reslice_kernel(const DevLink *links, int 
               + fz * (ry * (rx * at(x0, y0, z0 + 1) + fx * at(x0 + 1, y0, z0 + 1)) + fy * (rx * at(x0, y0 + 1, z0 + 1) + fx * at(x0 + 1, y0 + 1, z0 + 1)));
         }
     }
-    out[idx] = v;
+    out[idx] = to_voxel<S>(v);
 }
 
 __global__ __launch_bounds__(256) void chain_apply_kernel(const DevLink *links, int n_links, const double *in, double *out, size_t n)
@@ -420,35 +435,14 @@ int frog_chain_invert_links(const frog_chain_link *in, uint32_t n, frog_chain_li
 extern "C++" {
 namespace {
 
-template <class T, class S> void widen(const void *src, size_t n, std::vector<S> &dst)
-{
-    const T *p = static_cast<const T *>(src);
-    dst.resize(n);
-    for (size_t i = 0; i < n; i++) dst[i] = (S)p[i];
-}
-
-// vtkImageReslice's conversion of an interpolated value to the output scalar type
-template <class T> void narrow_int(const std::vector<double> &v, void *dst)
-{
-    T *p = static_cast<T *>(dst);
-    const double lo = (double)std::numeric_limits<T>::lowest(), hi = (double)std::numeric_limits<T>::max();
-    for (size_t i = 0; i < v.size(); i++) {
-        double x = std::floor(v[i] + 0.5);
-        x = x < lo ? lo : (x > hi ? hi : x);
-        p[i] = (T)x;
-    }
-}
-
 template <class S>
-int reslice_typed(frog_chain *c, const std::vector<S> &host_src, const frog_volume *src, frog_volume *out, int interpolation,
-                  double background, std::vector<double> &result)
+int reslice_typed(frog_chain *c, const frog_volume *src, frog_volume *out, int interpolation, double background)
 {
-    const size_t n_out = (size_t)out->dims[0] * out->dims[1] * out->dims[2];
-    S *d_src = nullptr;
-    double *d_out = nullptr;
-    KCHECK(hipMalloc((void **)&d_src, host_src.size() * sizeof(S)));
-    if (hipMalloc((void **)&d_out, n_out * sizeof(double)) != hipSuccess) { (void)hipFree(d_src); return fail(FROG_E_NOMEM, "hipMalloc (output volume)"); }
-    hipError_t e = hipMemcpy(d_src, host_src.data(), host_src.size() * sizeof(S), hipMemcpyHostToDevice);
+    const size_t n_src = (size_t)src->dims[0] * src->dims[1] * src->dims[2], n_out = (size_t)out->dims[0] * out->dims[1] * out->dims[2];
+    S *d_src = nullptr, *d_out = nullptr;
+    KCHECK(hipMalloc((void **)&d_src, n_src * sizeof(S)));
+    if (hipMalloc((void **)&d_out, n_out * sizeof(S)) != hipSuccess) { (void)hipFree(d_src); return fail(FROG_E_NOMEM, "hipMalloc (output volume)"); }
+    hipError_t e = hipMemcpy(d_src, src->data, n_src * sizeof(S), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         reslice_kernel<S><<<(unsigned)((n_out + 255) / 256), 256>>>(
             c->d_links, (int)c->h_links.size(), d_src, (int)src->dims[0], (int)src->dims[1], (int)src->dims[2],
@@ -457,8 +451,7 @@ int reslice_typed(frog_chain *c, const std::vector<S> &host_src, const frog_volu
             out->spacing[0], out->spacing[1], out->spacing[2], interpolation != 0, background, d_out);
         e = hipGetLastError();
     }
-    result.resize(n_out);
-    if (e == hipSuccess) e = hipMemcpy(result.data(), d_out, n_out * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out->data, d_out, n_out * sizeof(S), hipMemcpyDeviceToHost);
     (void)hipFree(d_src); (void)hipFree(d_out);
     if (e != hipSuccess) return fail(FROG_E_HIP, std::string("frog_chain_reslice: ") + hipGetErrorString(e));
     return FROG_OK;
@@ -476,38 +469,16 @@ int frog_chain_reslice(frog_chain *c, const frog_volume *src, frog_volume *out, 
     for (int k = 0; k < 3; k++)
         if (src->dims[k] > 0x7FFFFFFFu || !(src->spacing[k] != 0.0)) return fail(FROG_E_INVALID, "bad source geometry");
     KCHECK(hipSetDevice(c->device));
-    std::vector<double> v;
-    int rc;
-    const bool wide = src->dtype == FROG_V_U32 || src->dtype == FROG_V_I32 || src->dtype == FROG_V_F64;
-    if (wide) {
-        std::vector<double> h;
-        if (src->dtype == FROG_V_U32) widen<uint32_t>(src->data, n_src, h);
-        else if (src->dtype == FROG_V_I32) widen<int32_t>(src->data, n_src, h);
-        else widen<double>(src->data, n_src, h);
-        rc = reslice_typed(c, h, src, out, interpolation, background, v);
-    } else {
-        std::vector<float> h;
-        switch (src->dtype) {
-        case FROG_V_U8: widen<uint8_t>(src->data, n_src, h); break;
-        case FROG_V_I8: widen<int8_t>(src->data, n_src, h); break;
-        case FROG_V_U16: widen<uint16_t>(src->data, n_src, h); break;
-        case FROG_V_I16: widen<int16_t>(src->data, n_src, h); break;
-        default: widen<float>(src->data, n_src, h); break;
-        }
-        rc = reslice_typed(c, h, src, out, interpolation, background, v);
-    }
-    if (rc) return rc;
     switch (src->dtype) {
-    case FROG_V_U8: narrow_int<uint8_t>(v, out->data); break;
-    case FROG_V_I8: narrow_int<int8_t>(v, out->data); break;
-    case FROG_V_U16: narrow_int<uint16_t>(v, out->data); break;
-    case FROG_V_I16: narrow_int<int16_t>(v, out->data); break;
-    case FROG_V_U32: narrow_int<uint32_t>(v, out->data); break;
-    case FROG_V_I32: narrow_int<int32_t>(v, out->data); break;
-    case FROG_V_F32: { float *p = static_cast<float *>(out->data); for (size_t i = 0; i < v.size(); i++) p[i] = (float)v[i]; break; }
-    default: std::memcpy(out->data, v.data(), v.size() * sizeof(double)); break;
+    case FROG_V_U8: return reslice_typed<uint8_t>(c, src, out, interpolation, background);
+    case FROG_V_I8: return reslice_typed<int8_t>(c, src, out, interpolation, background);
+    case FROG_V_U16: return reslice_typed<uint16_t>(c, src, out, interpolation, background);
+    case FROG_V_I16: return reslice_typed<int16_t>(c, src, out, interpolation, background);
+    case FROG_V_U32: return reslice_typed<uint32_t>(c, src, out, interpolation, background);
+    case FROG_V_I32: return reslice_typed<int32_t>(c, src, out, interpolation, background);
+    case FROG_V_F32: return reslice_typed<float>(c, src, out, interpolation, background);
+    default: return reslice_typed<double>(c, src, out, interpolation, background);
     }
-    return FROG_OK;
 }
 
 }

@@ -477,9 +477,10 @@ int frog_ransac(frog_ctx *ctx, const frog_model *m, uint32_t image, const frog_r
     // candidates: 4 random correspondences each (:743-760).  A draw that lands on a point without
     // links is repeated, so an image without any link would never return: refuse it.
     if (nPoints == 0 || m->row_ptr[pb + nPoints] == m->row_ptr[pb]) return fail(FROG_E_INVALID, "image has no link");
-    std::vector<double> cand;                    // 12 doubles per candidate (rows 0..2)
-    std::vector<uint8_t> usable;                 // determinant inside [1/maxScale, maxScale] and a defined rotation
-    cand.reserve((size_t)perBatch * o->batches * 12);
+    const uint32_t nCand = (uint32_t)perBatch * (uint32_t)o->batches;
+    std::vector<double> cand((size_t)nCand * 12);   // 12 doubles per candidate (rows 0..2)
+    std::vector<uint8_t> usable(nCand, 0);        // determinant inside [1/maxScale, maxScale] and a defined rotation
+    #pragma omp parallel for schedule(dynamic, 1)    // batches are independent streams, as upstream's threads (:639-647)
     for (int batch = 0; batch < o->batches; batch++) {
         std::mt19937 rng((uint32_t)(batch * 1000));
         for (int it = 0; it < perBatch; it++) {
@@ -500,11 +501,11 @@ int frog_ransac(frog_ctx *ctx, const frog_model *m, uint32_t image, const frog_r
                 for (int k = 0; k < 3; k++) { a[k] = src[i][k]; b[k] = tgt[i][k]; }
             }, M);
             const float determinant = (float)std::fabs(frog::det3_of_4x4(M));           // :787-788
-            usable.push_back(ok && !((determinant > o->max_scale) || ((double)determinant < 1.0 / (double)o->max_scale)));
-            cand.insert(cand.end(), M, M + 12);
+            const size_t c = (size_t)batch * perBatch + it;
+            usable[c] = ok && !((determinant > o->max_scale) || ((double)determinant < 1.0 / (double)o->max_scale));
+            std::memcpy(&cand[c * 12], M, 12 * sizeof(double));
         }
     }
-    const uint32_t nCand = (uint32_t)usable.size();
     std::vector<unsigned int> counts(nCand, 0u);
     const uint32_t lpb = pb - ctx->own_pt_begin, lpe = lpb + nPoints;
     const uint64_t nLinks = m->row_ptr[pb + nPoints] - m->row_ptr[pb];

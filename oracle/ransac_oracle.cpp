@@ -179,6 +179,9 @@ extern "C" long frogo_ransac(frogo_group *g, uint32_t image, int iterations, int
     long maxNumberOfInliers = 0;
     double best[4][4];
     frogo_get_matrix(g, image, &best[0][0]);
+    std::vector<long> batchMaxima(batches, 0);
+    std::vector<double> batchMatrices((size_t)batches * 16, 0.0);
+    #pragma omp parallel for schedule(dynamic, 1)                         // :639-647, one batch per thread
     for (int batch = 0; batch < batches; batch++) {                       // RANSACBatch, :718-804
         std::mt19937 rng(batch * 1000);
         long batchMax = 0;
@@ -211,8 +214,14 @@ extern "C" long frogo_ransac(frogo_group *g, uint32_t image, int iterations, int
             if ((determinant > max_scale) || (determinant < 1.0 / max_scale)) continue;
             if (batchMax < nInliers) { batchMax = nInliers; std::memcpy(batchMatrix, matrix2, sizeof batchMatrix); }
         }
-        if (batchMax > maxNumberOfInliers) { maxNumberOfInliers = batchMax; std::memcpy(best, batchMatrix, sizeof best); }
+        batchMaxima[batch] = batchMax;
+        std::memcpy(&batchMatrices[(size_t)batch * 16], batchMatrix, sizeof batchMatrix);
     }
+    for (int batch = 0; batch < batches; batch++)                         // :651-664, in batch order (see header)
+        if (batchMaxima[batch] > maxNumberOfInliers) {
+            maxNumberOfInliers = batchMaxima[batch];
+            std::memcpy(best, &batchMatrices[(size_t)batch * 16], sizeof best);
+        }
     // refit on the inlier half-links of the best candidate, :666-700
     Correspondences all;
     float transformed[3];
