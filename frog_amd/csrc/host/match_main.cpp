@@ -3,7 +3,7 @@
 //   match pointFiles.txt|directory [options]
 //
 // Same flags (-n -sp -np -nt -d -d2 -zmin -zmax -o -p -anat -sym -targ), same input files, same
-// pairs.bin.  Not built: -all (every pair below the threshold) and -transformPrefix; both exit 1.
+// pairs.bin, plus -transformPrefix (positions for the -anat test).  Not built: -all (exits 1).
 // A directory is read in sorted name order (upstream: the file system's order).
 #include "frog_host.h"
 #include "frog_match.h"
@@ -41,6 +41,7 @@ int main(int argc, char *argv[])
     bool writePoints = false, symFlag = false;
     char *outputFileName = 0;
     int target = -1, device = 0;
+    char *transformPrefix = 0;
     int argumentsIndex = 2;
     while (argumentsIndex < argc) {                                         // match.cpp:367-435
         char *key = argv[argumentsIndex];
@@ -60,7 +61,7 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-anat") == 0) anatVal = atof(value);
         if (strcmp(key, "-sym") == 0) { symFlag = true; argumentsIndex -= 1; }
         if (strcmp(key, "-targ") == 0) target = atoi(value);
-        if (strcmp(key, "-transformPrefix") == 0) { cout << "Error : -transformPrefix is not supported by this build" << endl; return 1; }
+        if (strcmp(key, "-transformPrefix") == 0) transformPrefix = value;
         argumentsIndex += 2;
     }
 
@@ -174,8 +175,37 @@ int main(int argc, char *argv[])
     cout << "Pairing... " << endl;
     std::vector<frog_keypoints> views(nb);
     for (int it = 0; it < nb; ++it) frog_keypoints_view(allPoints[it], &views[it]);
+    // -transformPrefix (:517-558): the -anat test compares keypoint positions moved by <prefix><image>.json.
+    // (Upstream transforms a COPY of every point -- `for ( auto point : *points )` -- so its test reads
+    // transformedCoordinates that were never written; this does what the option is for.)  The chain is
+    // applied link by link in float, as vtkGeneralTransform's float TransformPoint; pairs.bin keeps the
+    // original coordinates.
+    std::vector<frog_keypoints> matchViews(views);
+    std::vector<std::vector<float>> moved(nb);
+    if (transformPrefix) {
+        for (int it = 0; it < nb; ++it) {
+            const std::string transformFile = std::string(transformPrefix) + std::to_string(it) + ".json";
+            cout << "Reading transform " << transformFile << endl;
+            int status = 0;
+            frog_transform_file *tf = frog_transform_read(transformFile.c_str(), &status);
+            if (!tf) { cout << "Error : cannot read transform " << transformFile << endl; return 1; }
+            const size_t n = views[it].n;
+            moved[it].assign(views[it].xyz, views[it].xyz + 3 * n);
+            std::vector<double> in(3 * n), out(3 * n);
+            for (uint32_t l = 0; l < frog_transform_num_links(tf) && n; l++) {
+                frog_chain *chain = nullptr;
+                if (frog_chain_create(frog_transform_links(tf) + l, 1, device, &chain)) { cout << "Error : " << frog_last_error() << endl; return 1; }
+                for (size_t k = 0; k < in.size(); k++) in[k] = moved[it][k];
+                if (frog_chain_apply(chain, in.data(), out.data(), n)) { cout << "Error : " << frog_last_error() << endl; return 1; }
+                for (size_t k = 0; k < in.size(); k++) moved[it][k] = (float)out[k];
+                frog_chain_destroy(chain);
+            }
+            frog_transform_free(tf);
+            matchViews[it].xyz = moved[it].data();
+        }
+    }
     frog_matcher *m = nullptr;
-    if (frog_matcher_create(views.data(), (uint32_t)nb, device, &m)) { cout << "Error : " << frog_last_error() << endl; return 1; }
+    if (frog_matcher_create(matchViews.data(), (uint32_t)nb, device, &m)) { cout << "Error : " << frog_last_error() << endl; return 1; }
     frog_match_options o;
     frog_match_options_default(&o);
     o.threshold = dist; o.dist2second = dist2second; o.anat = anatVal; o.sym = symFlag ? 1 : 0;

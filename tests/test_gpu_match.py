@@ -173,6 +173,28 @@ def test_match_cli_end_to_end(tmp_path):
     r = subprocess.run([os.path.join(root, "bin", "frog"), "pairs.bin", "-li", "3", "-dl", "0", "-q", "1"], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "pairs read" in r.stdout, r.stdout[-1500:]
-    for flag in (["-all", "1"], ["-transformPrefix", "x"]):
-        assert subprocess.run([exe, "list.txt"] + flag, cwd=tmp_path, capture_output=True).returncode == 1
+    assert subprocess.run([exe, "list.txt", "-all", "1"], cwd=tmp_path, capture_output=True).returncode == 1
+    # -anat with -transformPrefix (match.cpp:517-558, :278-290): the anatomical-distance test is taken on positions
+    # moved by <prefix><image>.json.  Image 1 is written 150 mm off; its transform brings it back.
+    import json
+    two = [imgs[0], Keypoints(imgs[1].xyz + np.float32([150, 0, 0]), imgs[1].scale, imgs[1].laplacian, imgs[1].response, imgs[1].desc)]
+    sub = tmp_path / "anat"; sub.mkdir()
+    for i, kp in enumerate(two):
+        write_keypoints(sub / f"points{i}.csv.gz", kp)
+    (sub / "list.txt").write_text("".join(f"{sub}/points{i}.csv.gz\n" for i in range(2)))
+    for i, tx in enumerate((0.0, -150.0)):
+        M = np.eye(4); M[0, 3] = tx
+        (sub / f"t{i}.json").write_text(json.dumps({"transforms": [{"type": "vtkMatrixToLinearTransform", "matrix": M.ravel().tolist()}]}))
+    want = match_run(imgs[:2], [(0, 1)], threshold=1.0, anat=20.0)[0]
+    r = subprocess.run([exe, "list.txt", "-o", "far.bin", "-d", "1", "-anat", "20"], cwd=sub, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    far = _read_pairs_bin(sub / "far.bin")[1][0][2]
+    r = subprocess.run([exe, "list.txt", "-o", "near.bin", "-d", "1", "-anat", "20", "-transformPrefix", str(sub / "t")], cwd=sub,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Reading transform" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    images, blocks = _read_pairs_bin(sub / "near.bin")
+    assert np.array_equal(blocks[0][2][:, 0], want[0]) and np.array_equal(blocks[0][2][:, 1], want[1])
+    assert len(want[0]) > 300 and len(far) < len(want[0]) // 10
+    assert np.array_equal(images[1][2][:, :3], two[1].xyz)                      # pairs.bin keeps the original coordinates
+    assert subprocess.run([exe, "list.txt", "-transformPrefix", "missing"], cwd=sub, capture_output=True).returncode == 1
     assert subprocess.run([exe], capture_output=True, text=True).stdout.startswith("Usage : match pointFiles.txt")
