@@ -532,6 +532,14 @@ def test_ransac_stage_matches_oracle(small_pairs):
         e, er = g.updateDeformableTransforms(0.02), ref.deformable_step(0.02)
         assert abs(e - er) / er < REL
         g.transformPoints(); ref.transform_points()
+    # no candidate at all (iterations / batches rounds down to 0, :636): the census is 0 and the matrix is the refit of
+    # what the CURRENT matrix brings within the distance -- on both sides
+    g3 = ImageGroup(small_pairs, n_fixed_images=nf)
+    ref3 = OracleGroup(small_pairs.model, _abi.FrogOptions.default(n_fixed_images=nf))
+    ref3.setup_stats()
+    start(g3, ref3)
+    assert g3.RANSAC(nf, iterations=3, batches=4, inlier_distance=80.0) == ref3.ransac(nf, iterations=3, batches=4, inlier_distance=80.0) == 0
+    assert np.allclose(g3.matrix(nf), ref3.matrix(nf), rtol=1e-9, atol=1e-9)
     # degenerate requests are refused before any launch
     with pytest.raises(Exception):
         g2 = ImageGroup(small_pairs, n_fixed_images=nf)
