@@ -250,7 +250,7 @@ struct frog_ctx {
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 
     // live timing
-    bool profiling = false;
+    int profiling = 0;                         // 0 off, 1 every kernel group, 2 the two half-link sweeps only
     struct TimedSpan { hipEvent_t a, b; int slot; };
     std::vector<TimedSpan> spans;             // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;

@@ -37,7 +37,7 @@ struct Span {
     frog_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
     Span(frog_ctx *ctx, int s) : c(ctx), slot(s)
     {
-        if (!c->profiling) return;
+        if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE)) return;
         if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, c->stream);
@@ -1181,7 +1181,7 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
 int frog_profile_enable(frog_ctx *ctx, int on)
 {
     CTX_GUARD(ctx);
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 2 ? 2 : (on != 0);
     return FROG_OK;
 }
 

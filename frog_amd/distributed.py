@@ -189,6 +189,7 @@ class HipEngine:
         return xyz, xyz2
 
     def profile_enable(self, on=True):
+        """True/1: every kernel group; 2: the half-link sweeps only (cheap); False/0: off."""
         check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")
 
     def profile_read(self, reset=True):

@@ -203,8 +203,10 @@ typedef struct frog_kernel_time {
     double   ms_total;      /* sum of hipEventElapsedTime over the launches */
     uint64_t launches;
 } frog_kernel_time;
-/* While enabled every launch of the kernels above is bracketed by a pair of
- * hipEvents recorded on the context's stream. */
+/* on = 1: every launch of the kernels above is bracketed by a pair of hipEvents recorded on the
+ * context's stream.  The markers keep consecutive kernels from overlapping their tails and
+ * ramp-ups: measured 6 % of the iteration rate with all seven groups bracketed.  on = 2 brackets
+ * the two half-link sweeps only (the kernels a roofline is quoted for): < 1 %.  on = 0: off. */
 int frog_profile_enable(frog_ctx *ctx, int on);
 /* Waits for the stream, adds up the recorded pairs into out[FROG_K_COUNT_];
  * reset != 0 clears the accumulators afterwards. */

@@ -8,7 +8,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/$TAG
 mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-ARGS="bench.py --steps 65 --warmup 10 --no-cpu-baseline"
+python3 bench.py --no-cpu-baseline --kernel-times > $O/bench_kernel_times.json 2>> $O/bench.err
+ARGS="bench.py --steps 65 --warmup 10 --no-cpu-baseline --kernel-times"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python3 $ARGS > $O/under_rocprof.json 2> $O/trace.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/fetch.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/write.log
@@ -19,6 +20,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum -d $O/lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/lat.log
 python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat $(python3 -c "import json; print(json.load(open('$O/bench.json'))['roofline']['half_links_per_launch'])") > /dev/null
 cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
+cp $O/bench_kernel_times.json gpurun_out/${TAG}_bench_n1_kernel_times.json
 cp $O/under_rocprof.json gpurun_out/${TAG}_bench_n1_under_rocprof.json
 head -12 gpurun_out/${TAG}_bench_n1.txt
 python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_n1.json')); print(d['value'], d['roofline'], d['cpu_baseline']['value'])"
