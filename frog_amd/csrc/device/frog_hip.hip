@@ -480,7 +480,7 @@ int frog_ransac(frog_ctx *ctx, const frog_model *m, uint32_t image, const frog_r
     const uint32_t nCand = (uint32_t)perBatch * (uint32_t)o->batches;
     std::vector<double> cand((size_t)nCand * 12);   // 12 doubles per candidate (rows 0..2)
     std::vector<uint8_t> usable(nCand, 0);        // determinant inside [1/maxScale, maxScale] and a defined rotation
-    #pragma omp parallel for schedule(dynamic, 1)    // batches are independent streams, as upstream's threads (:639-647)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())    // batches are independent streams, as upstream's threads (:639-647)
     for (int batch = 0; batch < o->batches; batch++) {
         std::mt19937 rng((uint32_t)(batch * 1000));
         for (int it = 0; it < perBatch; it++) {

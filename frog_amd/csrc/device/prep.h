@@ -21,6 +21,10 @@
 #include <algorithm>
 #include <omp.h>
 
+// Host threads of the layout build: what OpenMP offers, but at most 64 -- on a 256-thread host, with one
+// process per GPU, eight uncapped pools would be 2048 threads for a job that takes half a second.
+inline int host_threads() { const int n = omp_get_max_threads(); return n < 1 ? 1 : (n > 64 ? 64 : n); }
+
 namespace frog {
 
 struct Layout {
@@ -70,7 +74,7 @@ inline void build_numbering(const frog_model &m, Layout &out)
     // (1.15 s -> 0.49 s for 100 images, measured), so they go to sleep at once
     kmp_set_blocktime(0);
 #endif
-    #pragma omp parallel for schedule(dynamic)
+    #pragma omp parallel for schedule(dynamic) num_threads(host_threads())
     for (int i = 0; i < (int)nI; i++) {
         const uint32_t b = poff[i], e = poff[i + 1];
         float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
@@ -113,7 +117,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     for (uint32_t p = p0; p <= p1; p++) out.ref_rowptr[p - p0] = m.row_ptr[p] - l0;
     out.ref_link.resize(L);
     int bad = 0;
-    #pragma omp parallel for reduction(| : bad)
+    #pragma omp parallel for reduction(| : bad) num_threads(host_threads())
     for (long long l = 0; l < (long long)L; l++) {
         const uint16_t im = m.link_image[l0 + l];
         const uint32_t pt = m.link_point[l0 + l];
@@ -162,7 +166,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
 
     // records per (tile, group), then the padded offsets
     const long long nT = (long long)out.tiles.size();
-    #pragma omp parallel for schedule(dynamic, 64)
+    #pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads())
     for (long long t = 0; t < nT; t++) {
         Tile &tl = out.tiles[t];
         for (uint32_t n = tl.pt_begin; n < tl.pt_begin + tl.pt_count; n++) {
@@ -200,7 +204,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     // partner-major records, stable counting sort per tile
     if (narrow) out.recs32.assign(rec_total, 0u);
     else out.recs.assign(rec_total, LinkRec{ 0u, 0u });
-    #pragma omp parallel
+    #pragma omp parallel num_threads(host_threads())
     {
         std::vector<uint32_t> cnt(nI + 1);
         std::vector<LinkRec> logical;
