@@ -18,8 +18,9 @@
  * USE_SSE_FOR_MATCHING build sums the dimensions in another order; it is a different
  * reference.)
  *
- * Not built: matchAll (`-all`, variable-length output) and `-transformPrefix` (the
- * anatomical test then uses the untransformed coordinates, as upstream without it).
+ * The anatomical test (`-anat`) compares frog_keypoints.xyz: pass the positions it is meant for
+ * (bin/match -transformPrefix hands over the transformed ones, match.cpp:517-558).
+ * Not built: matchAll (`-all`; upstream's branch emits the running best index, not the candidate).
  */
 #ifndef FROG_MATCH_H
 #define FROG_MATCH_H
