@@ -213,6 +213,7 @@ struct frog_ctx {
     // energy / counters
     frog::DevBuf<double> energy;              // [4]
     frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
+    frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel, [1] in cp_center_kernel
     double *h_energy = nullptr;               // pinned [4]
 
     // deformable

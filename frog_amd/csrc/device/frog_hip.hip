@@ -291,6 +291,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->mat.upload(hm, s));
     CREATE_CHECK(c->energy.alloc(4));
     CREATE_CHECK(c->energy_blocks.alloc(2 * ENERGY_BLOCKS));
+    CREATE_CHECK(c->energy_ticket.alloc(2));
+    CREATE_CHECK(hipMemsetAsync(c->energy_ticket.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
     CREATE_CHECK(c->n_big.alloc(1));
     CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
@@ -586,8 +588,8 @@ int frog_linear_step_local(frog_ctx *ctx)
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
     FROG_HIP_CHECK(hipGetLastError());
-    energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, LINEAR_SUMS, 16, ctx->energy_blocks.p);
-    energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
+    energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, LINEAR_SUMS, 16, ctx->energy_blocks.p,
+                                                       ctx->energy_ticket.p, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -806,8 +808,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         Span span(ctx, FROG_K_COMBINE);
         combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
             ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
-        energy_partial_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p);
-        energy_final_kernel<<<1, 64, 0, s>>>(ctx->energy_blocks.p, ENERGY_BLOCKS, ctx->energy.p);
+        energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
+                                                           ctx->energy_ticket.p, ctx->energy.p);
         if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
             hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
                                                                     ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, ctx->hl_partial.p);
@@ -846,9 +848,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     // :398: the group mean is removed only when no image is fixed
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
-                                                        (double)maxD * g.spacing[2], ctx->n_big.p);
-    FROG_HIP_CHECK(hipGetLastError());
-    nbig_publish_kernel<<<1, 1, 0, s>>>(ctx->n_big.p, ctx->energy.p);
+                                                        (double)maxD * g.spacing[2], ctx->n_big.p, ctx->energy_ticket.p + 1, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->phase = 2;
     return FROG_OK;

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *__restric
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
-                                                        unsigned long long *n_big)
+                                                        unsigned long long *n_big, unsigned int *ticket, double *energy)
 {
     __shared__ unsigned int sh[256];
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,13 +662,17 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
         if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && sh[0]) atomicAdd(n_big, (unsigned long long)sh[0]);
-}
-
-// counter -> double slot of the energy buffer (so one f64 all-reduce carries it)
-__global__ void nbig_publish_kernel(const unsigned long long *n_big, double *energy)
-{
-    energy[2] = (double)*n_big;
+    if (threadIdx.x == 0) {
+        if (sh[0]) atomicAdd(n_big, (unsigned long long)sh[0]);
+        // the block that finishes last publishes the count as a double in the energy buffer (so that one f64
+        // all-reduce carries it); an integer sum: the order of the blocks does not matter
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            energy[2] = (double)atomicAdd(n_big, 0ull);
+            *ticket = 0u;
+        }
+    }
 }
 
 // ---- K10: commit (imageGroup.cxx:441-468) -------------------------------------------

@@ -425,10 +425,14 @@ __global__ void hard_energy_kernel(const double *partial, uint32_t n_hard, doubl
 // block adds their results in order.
 constexpr int ENERGY_BLOCKS = 64;
 
-__global__ __launch_bounds__(256) void energy_partial_kernel(const double *partial, uint32_t n, int stride, int off,
-                                                             double *block_sums /*[ENERGY_BLOCKS][2]*/)
+// One launch: the block that finishes last (a ticket counter in memory) adds the block sums in block
+// order, so the result does not depend on which block that is.
+__global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partial, uint32_t n, int stride, int off,
+                                                            double *block_sums /*[ENERGY_BLOCKS][2]*/, unsigned int *ticket,
+                                                            double *energy)
 {
     __shared__ double sh[2][256];
+    __shared__ bool last;
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t b = min(n, blockIdx.x * per), e = min(n, b + per);
     double a0 = 0, a1 = 0;
@@ -442,15 +446,22 @@ __global__ __launch_bounds__(256) void energy_partial_kernel(const double *parti
         if ((int)threadIdx.x < h) { sh[0][threadIdx.x] += sh[0][threadIdx.x + h]; sh[1][threadIdx.x] += sh[1][threadIdx.x + h]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { block_sums[2 * blockIdx.x] = sh[0][0]; block_sums[2 * blockIdx.x + 1] = sh[1][0]; }
-}
-
-__global__ __launch_bounds__(64) void energy_final_kernel(const double *block_sums, int n_blocks, double *energy)
-{
     if (threadIdx.x == 0) {
-        double a0 = 0, a1 = 0;
-        for (int b = 0; b < n_blocks; b++) { a0 += block_sums[2 * b]; a1 += block_sums[2 * b + 1]; }
-        energy[0] = a0; energy[1] = a1; energy[2] = 0.0; energy[3] = 0.0;
+        __hip_atomic_store(&block_sums[2 * blockIdx.x], sh[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&block_sums[2 * blockIdx.x + 1], sh[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double s0 = 0, s1 = 0;
+        for (unsigned int k = 0; k < gridDim.x; k++) {
+            s0 += __hip_atomic_load(&block_sums[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(&block_sums[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        energy[0] = s0; energy[1] = s1; energy[2] = 0.0; energy[3] = 0.0;
+        *ticket = 0u;                                       // ready for the next launch (same stream: ordered)
     }
 }
 
