@@ -48,6 +48,10 @@ struct DevImage {
     float *desc = nullptr;              // [n][dp], zero padded
     float *sign = nullptr, *scale = nullptr, *lo = nullptr, *hi = nullptr;
     float *xyz = nullptr;               // [n][3]
+    float *norm = nullptr;              // |descriptor|^2 (f64 sum rounded to f32), for the MFMA filter
+    float *mf = nullptr;                // extended vectors in MFMA operand order: [ceil(n/32)][(dp+2)/2][64]
+    float norm_max = 0.f;
+    bool finite = true;                 // every descriptor value is finite
     uint32_t *orig = nullptr;           // sorted position -> index in the caller's order
     std::vector<uint32_t> h_orig;
 };
@@ -229,6 +233,303 @@ __global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_
     out[qi] = ok ? (match >= 0 ? match : -2) : (match >= 0 ? -(match + 3) : -1);
 }
 
+
+// ---- the same result through the matrix cores ---------------------------------------------------
+// The distances that decide a query's outcome are its two smallest; everything else only has to be
+// known to be larger.  Every keypoint is also stored as an EXTENDED vector (p, -|p|^2/2, 1): the
+// product of two of them is q.c - |q|^2/2 - |c|^2/2 = -d^2/2, so ONE f32 MFMA chain
+// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, error bounded, MF_EPS below) yields an approximate
+// -d^2/2 for 32 x 32 (candidate, query) pairs, and the same array serves an image as query and as
+// candidate: it is kept in the operand's own lane order ([group of 32 points][step][lane]), so both
+// operands are plain coalesced loads -- no LDS, no barrier, a wavefront is on its own.
+//   pass 1: the two largest products per query (a max and a med3 per candidate);
+//   pass 2: the products again; the few candidates within the error bound of the second largest get the
+//           reference's own arithmetic (sequential sum of (q_k - c_k)^2, strict-< bookkeeping).
+// Candidates outside the bound provably cannot be one of the two nearest, so the pair lists are those of
+// the exact kernel above, bit for bit; its 3 vector instructions per (query, candidate, dimension) become
+// 2/32 of a matrix instruction plus ~9 vector instructions per (query, candidate).
+// The sign / scale filters of a query select ONE contiguous range of the sorted candidates (see the header),
+// found per query by binary search (match_qrange_kernel): the test is two integer compares.
+constexpr int MF_TILE = 32;             // points per MFMA operand group
+// |(-2 x product) - reference distance| <= MF_EPS * (|q|^2 + |c|^2): D + 2 products and sums in f32 in the chain,
+// D sums in the reference's own chain, the rounded norms: under 2^-24 * 512 (D <= 64) in all
+constexpr float MF_EPS = 1.0f / 32768.0f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct QRange { uint32_t first, last; };        // candidates [first, last) pass the query's sign and scale tests
+
+// per query: the exact set {c : sign == qsign, lo[c] < qscale < hi[c]} as a range of the sorted candidates
+__global__ void match_qrange_kernel(const MatchArgs a, QRange *qr)
+{
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.nq) return;
+    const float sg = a.q_sign[qi], sc = a.q_scale[qi];
+    uint32_t lo = 0, hi = a.nc;                    // sign segment [sb, se)
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_sign[mid] < sg) lo = mid + 1; else hi = mid; }
+    const uint32_t sb = lo;
+    hi = a.nc;
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_sign[mid] <= sg) lo = mid + 1; else hi = mid; }
+    const uint32_t se = lo;
+    lo = sb; hi = se;                              // first candidate with hi[c] > sc (hi grows with the scale)
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (!(a.c_hi[mid] > sc)) lo = mid + 1; else hi = mid; }
+    const uint32_t first = lo;
+    hi = se;                                       // first candidate with lo[c] >= sc (lo grows with the scale)
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_lo[mid] < sc) lo = mid + 1; else hi = mid; }
+    qr[qi] = QRange{ first, lo };
+}
+
+struct Top2 { float m1, m2; };
+
+// the reference's distance (norm, match.cpp:242-251): sequential f32 sum of squared differences.  Out of line:
+// it runs for a handful of candidates per query and must not cost the matrix loop its registers.
+template <int D>
+__device__ __noinline__ float exact_distance(const float *qrow, const float *crow)
+{
+    float dist = 0.f;
+    #pragma unroll 8
+    for (int k = 0; k < D; k++) { const float t = qrow[k] - crow[k]; dist += t * t; }
+    return dist;
+}
+
+// PASS 1: top2[split][query] = the two largest products.  PASS 2: partial[split][query] = exact (d1, d2, match) over
+// the candidates whose product reaches thr[query].
+template <int D, bool ANAT, int PASS>
+__global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
+                                                                 const float *q_mf, const float *c_mf,
+                                                                 Top2 *top2, const float *thr, float *hmax)
+{
+    constexpr int STEPS = (D + 2) / 2;              // MFMA instructions per 32 x 32 tile (K = 2 each)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t g0 = (blockIdx.x * MATCH_BLOCK + wave * 64) / MF_TILE;       // the wave's two query groups: g0, g0 + 1
+    const uint32_t n_qgroups = (a.nq + MF_TILE - 1) / MF_TILE;
+    if (g0 >= n_qgroups) return;
+
+    float b[2][STEPS], qthr[2], qx[2], qy[2], qz[2];
+    uint32_t qfirst[2], qcount[2], qidx[2];
+    #pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const uint32_t grp = min(g0 + g, n_qgroups - 1);
+        const float *src = q_mf + (size_t)grp * STEPS * 64 + lane;
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS - 1; s2++) b[g][s2] = src[s2 * 64];
+        // the last step holds (-|p|^2/2, 1): as the B operand its two dimensions trade places, so that the product is
+        // (c, -|c|^2/2, 1) . (q, 1, -|q|^2/2) = c.q - |c|^2/2 - |q|^2/2
+        b[g][STEPS - 1] = q_mf[((size_t)grp * STEPS + STEPS - 1) * 64 + (lane ^ 32)];
+        const uint32_t qi = (g0 + g) * MF_TILE + j;
+        qidx[g] = qi;
+        const bool valid = (g0 + g) < n_qgroups && qi < a.nq;
+        const QRange r = valid ? qr[qi] : QRange{ 0, 0 };
+        qfirst[g] = r.first; qcount[g] = r.last - r.first;                      // 0 for an invalid query: nothing passes
+        qthr[g] = (PASS == 2 && valid) ? thr[qi] : 0.f;
+        qx[g] = qy[g] = qz[g] = 0.f;
+        if (ANAT && valid) { qx[g] = a.q_xyz[3 * (size_t)qi]; qy[g] = a.q_xyz[3 * (size_t)qi + 1]; qz[g] = a.q_xyz[3 * (size_t)qi + 2]; }
+    }
+    float m1[2] = { -INFINITY, -INFINITY }, m2[2] = { -INFINITY, -INFINITY };   // pass 1
+    float d1[2] = { FLT_MAX, FLT_MAX }, d2[2] = { FLT_MAX, FLT_MAX };           // pass 2
+    int match[2] = { -1, -1 };
+    unsigned int evaluated = 0;
+
+    // this block's share of the candidate tiles its queries can pass
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t t_first = rg.x / MF_TILE, t_last = (rg.y + MF_TILE - 1) / MF_TILE;      // tiles [t_first, t_last)
+    const uint32_t per = (t_last - t_first + a.splits - 1) / a.splits;
+    const uint32_t t_begin = min(t_last, t_first + blockIdx.y * per), t_end = min(t_last, t_begin + per);
+
+    // the candidate operand of the NEXT tile is loaded while the current one is multiplied (a tile is 25 coalesced
+    // loads that the 50 matrix instructions would otherwise wait for)
+    float nx[STEPS];
+    {
+        const float *src = c_mf + (size_t)min(t_begin, t_last - 1) * STEPS * 64 + lane;
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) nx[s2] = src[s2 * 64];
+    }
+    for (uint32_t t = t_begin; t < t_end; t++) {
+        float av[STEPS];
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) av[s2] = nx[s2];
+        {
+            const float *src = c_mf + (size_t)min(t + 1, t_last - 1) * STEPS * 64 + lane;
+            #pragma unroll
+            for (int s2 = 0; s2 < STEPS; s2++) nx[s2] = src[s2 * 64];
+        }
+        f32x16 acc0, acc1;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b[0][s2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b[1][s2], acc1, 0, 0, 0);
+        }
+        const uint32_t base = t * MF_TILE + 4 * h;
+        #pragma unroll
+        for (int g = 0; g < 2; g++) {
+            float hm = -INFINITY;                   // largest product of this lane's 16 rows: pass 2 looks only where it is large
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t c = base + (uint32_t)((r & 3) + 8 * (r >> 2));   // row of the product = candidate
+                const float dot = g == 0 ? acc0[r] : acc1[r];
+                bool pass = (c - qfirst[g]) < qcount[g];                        // sign and scale tests, match.cpp:270-275
+
+                if (ANAT) {                                                     // :278-291
+                    const uint32_t cc = min(c, a.nc - 1);
+                    const float ex = qx[g] - a.c_xyz[3 * (size_t)cc], ey = qy[g] - a.c_xyz[3 * (size_t)cc + 1], ez = qz[g] - a.c_xyz[3 * (size_t)cc + 2];
+                    pass = pass && !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
+                }
+                if (PASS == 1) {
+                    const float v = pass ? dot : -INFINITY;
+                    m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], v);           // second largest of {m1 >= m2, v}
+                    m1[g] = fmaxf(m1[g], v);
+                    hm = fmaxf(hm, v);
+                    evaluated += pass ? 1u : 0u;
+                } else {
+                    const bool near = pass && dot >= qthr[g];
+                    if (near) {                                                 // rare: the reference's own arithmetic
+                        const float dist = exact_distance<D>(a.q_desc + (size_t)qidx[g] * D, a.c_desc + (size_t)c * D);
+                        const int orig = (int)a.c_orig[c];
+                        const bool better = dist < d1[g];                       // :303-313, in any scan order (see match_kernel)
+                        const bool second = !better && dist < d2[g];
+                        const bool tie = !better && dist == d1[g] && orig < match[g];
+                        d2[g] = better ? d1[g] : (second ? dist : d2[g]);
+                        d1[g] = better ? dist : d1[g];
+                        match[g] = (better || tie) ? orig : match[g];
+                        evaluated++;
+                    }
+                }
+            }
+            if (PASS == 1 && hmax && qidx[g] < a.nq && (g0 + g) < n_qgroups)
+                hmax[((size_t)t * 2 + h) * a.nq + qidx[g]] = hm;
+        }
+    }
+    // lanes j and j + 32 saw different rows of the same queries: merge, lane j writes
+    #pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const bool valid = (g0 + g) < n_qgroups && qidx[g] < a.nq;
+        if (PASS == 1) {
+            const float o1 = __shfl_xor(m1[g], 32, 64), o2 = __shfl_xor(m2[g], 32, 64);
+            const float hi1 = fmaxf(m1[g], o1), lo1 = fminf(m1[g], o1);
+            const float second = fmaxf(lo1, fmaxf(m2[g], o2));
+            if (h == 0 && valid) top2[(size_t)blockIdx.y * a.nq + qidx[g]] = Top2{ hi1, second };
+        } else {
+            const float od1 = __shfl_xor(d1[g], 32, 64), od2 = __shfl_xor(d2[g], 32, 64);
+            const int om = __shfl_xor(match[g], 32, 64);
+            float r1 = d1[g], r2 = d2[g];
+            int rm = match[g];
+            // the other lane's values enter as a sequential scan would see them (as match_decide_kernel)
+            if (od1 < r1) { r2 = r1; r1 = od1; rm = om; }
+            else {
+                if (od1 < r2) r2 = od1;
+                if (od1 == r1 && om >= 0 && om < rm) rm = om;
+            }
+            if (od2 < r2) r2 = od2;
+            if (h == 0 && valid) a.partial[(size_t)blockIdx.y * a.nq + qidx[g]] = Partial{ r1, r2, rm };
+        }
+    }
+    unsigned int total = evaluated;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if (lane == 0 && total) atomicAdd(a.n_dist + (PASS == 1 ? 0 : 2), (unsigned long long)total);
+    if (PASS == 1 && lane == 0 && t_end > t_begin) atomicAdd(a.n_dist + 1, 64ull * MF_TILE * (t_end - t_begin));
+}
+
+// threshold of pass 2: a candidate whose product is below it cannot be one of the two nearest.
+// -2 x product approximates the distance to MF_EPS * (|q|^2 + |c|^2); with M2 the second largest product, every
+// candidate with exact distance <= (second smallest exact distance) has product >= M2 - MF_EPS * (|q|^2 + max|c|^2).
+__global__ void match_threshold_kernel(const Top2 *top2, uint32_t nq, uint32_t splits, const float *q_norm, float c_norm_max, float *thr)
+{
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (uint32_t s = 0; s < splits; s++) {
+        const Top2 t = top2[(size_t)s * nq + qi];
+        const float lo1 = fminf(m1, t.m1);
+        m1 = fmaxf(m1, t.m1);
+        m2 = fmaxf(lo1, fmaxf(m2, t.m2));
+    }
+    thr[qi] = m2 - MF_EPS * (q_norm[qi] + c_norm_max);      // -inf when fewer than two candidates pass: all of them are verified
+}
+
+
+// Pass 2 without the matrix cores: a team of 16 lanes per query walks the half-tile maxima pass 1 left behind; for
+// every half tile whose maximum reaches the query's threshold (a few per query) each lane of the team gives ONE of
+// its 16 candidates the reference's arithmetic; the team's (d1, d2, match) partials are merged as a sequential scan
+// would see them and lane 0 applies the acceptance test.  Replaces threshold + second MFMA pass + decide.
+template <int D, bool ANAT>
+__global__ __launch_bounds__(256) void match_scan_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr, const Top2 *top2,
+                                                         const float *q_norm, float c_norm_max, const float *hmax,
+                                                         float threshold, float dist2second, int *out)
+{
+    const int lane = threadIdx.x & 63, tl = lane & 15, team_shift = lane & 48;   // team = 16 consecutive lanes
+    const uint32_t qi = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = qi < a.nq;
+    const uint32_t qc = min(qi, a.nq - 1);
+    float t1 = -INFINITY, t2 = -INFINITY;
+    for (uint32_t s = 0; s < a.splits; s++) {
+        const Top2 t = top2[(size_t)s * a.nq + qc];
+        const float lo1 = fminf(t1, t.m1);
+        t1 = fmaxf(t1, t.m1);
+        t2 = fmaxf(lo1, fmaxf(t2, t.m2));
+    }
+    const float thr = t2 - MF_EPS * (q_norm[qc] + c_norm_max);  // see match_threshold_kernel
+    const QRange r = valid ? qr[qc] : QRange{ 0, 0 };
+    const uint2 rg = ranges[qc / MATCH_BLOCK];
+    const uint32_t t_first = rg.x / MF_TILE, t_last = (rg.y + MF_TILE - 1) / MF_TILE;
+    const uint32_t n_entries = valid ? (t_last - t_first) * 2 : 0;
+    const float *qrow = a.q_desc + (size_t)qc * D;
+    float d1 = FLT_MAX, d2 = FLT_MAX;
+    int match = -1;
+    unsigned int verified = 0;
+    // every team of the wavefront runs the same number of rounds (ballots need all lanes)
+    uint32_t rounds = (n_entries + 15) / 16;
+    #pragma unroll
+    for (int off = 16; off < 64; off <<= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, off, 64));
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+        const uint32_t e = rd * 16 + tl;
+        const bool hit = e < n_entries && hmax[((size_t)(t_first + e / 2) * 2 + (e & 1)) * a.nq + qc] >= thr;
+        unsigned int mask = (unsigned int)((__ballot(hit) >> team_shift) & 0xFFFFull);
+        while (mask) {                                                  // uniform inside a team
+            const uint32_t eh = rd * 16 + (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1;
+            const uint32_t c = (t_first + eh / 2) * MF_TILE + 4 * (eh & 1) + (uint32_t)((tl & 3) + 8 * (tl >> 2));
+            bool pass = (c - r.first) < (r.last - r.first);
+            if (ANAT && pass) {
+                const float ex = a.q_xyz[3 * (size_t)qc] - a.c_xyz[3 * (size_t)c], ey = a.q_xyz[3 * (size_t)qc + 1] - a.c_xyz[3 * (size_t)c + 1],
+                            ez = a.q_xyz[3 * (size_t)qc + 2] - a.c_xyz[3 * (size_t)c + 2];
+                pass = !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
+            }
+            if (pass) {
+                const float dist = exact_distance<D>(qrow, a.c_desc + (size_t)c * D);
+                const int orig = (int)a.c_orig[c];
+                const bool better = dist < d1;                          // match.cpp:303-313, in any scan order
+                const bool second = !better && dist < d2;
+                const bool tie = !better && dist == d1 && orig < match;
+                d2 = better ? d1 : (second ? dist : d2);
+                d1 = better ? dist : d1;
+                match = (better || tie) ? orig : match;
+                verified++;
+            }
+        }
+    }
+    #pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {                             // merge the team's partials (as match_decide_kernel)
+        const float od1 = __shfl_xor(d1, off, 64), od2 = __shfl_xor(d2, off, 64);
+        const int om = __shfl_xor(match, off, 64);
+        if (od1 < d1) { d2 = d1; d1 = od1; match = om; }
+        else {
+            if (od1 < d2) d2 = od1;
+            if (od1 == d1 && om >= 0 && (match < 0 || om < match)) match = om;
+        }
+        if (od2 < d2) d2 = od2;
+        verified += (unsigned int)__shfl_xor((int)verified, off, 64);
+    }
+    if (tl == 0 && valid) {
+        if (verified) atomicAdd(a.n_dist + 2, (unsigned long long)verified);
+        const bool ok = (sqrtf(d1 / d2) < dist2second || d2 == FLT_MAX) && (sqrtf(d1) < threshold);   // :320-321
+        out[qi] = ok ? (match >= 0 ? match : -2) : (match >= 0 ? -(match + 3) : -1);
+    }
+}
+
 #define MCHECK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -272,7 +573,7 @@ struct frog_matcher {
     std::vector<DevImage> img;
     hipStream_t stream = nullptr;
     unsigned long long *n_dist = nullptr;
-    double last_ms = 0, last_dist = 0, last_computed = 0;
+    double last_ms = 0, last_dist = 0, last_computed = 0, last_fallback = 0;
 };
 
 extern "C" {
@@ -297,6 +598,8 @@ void frog_matcher_destroy(frog_matcher *m)
         if (d.hi) (void)hipFree(d.hi);
         if (d.xyz) (void)hipFree(d.xyz);
         if (d.orig) (void)hipFree(d.orig);
+        if (d.norm) (void)hipFree(d.norm);
+        if (d.mf) (void)hipFree(d.mf);
     }
     if (m->n_dist) (void)hipFree(m->n_dist);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -331,8 +634,8 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     m->img.resize(n_images);
 #define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
     CCHECK(hipStreamCreate(&m->stream));
-    CCHECK(hipMalloc((void **)&m->n_dist, 2 * sizeof(unsigned long long)));
-    std::vector<float> pad, lo, hi, sg, sc, xyz;
+    CCHECK(hipMalloc((void **)&m->n_dist, 3 * sizeof(unsigned long long)));
+    std::vector<float> pad, lo, hi, sg, sc, xyz, nrm, mfv;
     for (uint32_t i = 0; i < n_images; i++) {
         const frog_keypoints &k = images[i];
         DevImage &d = m->img[i];
@@ -354,6 +657,29 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
             lo[p] = scale_lo(k.scale[o]); hi[p] = scale_hi(k.scale[o]);
             sg[p] = k.laplacian[o]; sc[p] = k.scale[o];
             for (int c = 0; c < 3; c++) xyz[3 * (size_t)p + c] = k.xyz[3 * (size_t)o + c];
+        }
+        nrm.assign(n, 0.f);
+        for (uint32_t p = 0; p < k.n; p++) {
+            double sum = 0;
+            for (uint32_t c = 0; c < m->dp; c++) { const double v = pad[(size_t)p * m->dp + c]; sum += v * v; }
+            nrm[p] = (float)sum;
+            if (!std::isfinite(nrm[p])) d.finite = false;
+            d.norm_max = std::max(d.norm_max, nrm[p]);
+        }
+        CCHECK(hipMalloc((void **)&d.norm, n * sizeof(float)));
+        CCHECK(hipMemcpy(d.norm, nrm.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        {
+            // (p, -|p|^2/2, 1) by groups of 32 points in the lane order of v_mfma_f32_32x32x2_f32's operands:
+            // lane l of step s holds dimension 2s + (l >> 5) of point l & 31 -- the same for A and for B
+            const uint32_t steps = (m->dp + 2) / 2, groups = (uint32_t)((n + 31) / 32);
+            mfv.assign((size_t)groups * steps * 64, 0.f);
+            for (uint32_t p = 0; p < k.n; p++)
+                for (uint32_t dim2 = 0; dim2 < m->dp + 2; dim2++) {
+                    const float v = dim2 < m->dp ? pad[(size_t)p * m->dp + dim2] : (dim2 == m->dp ? -0.5f * nrm[p] : 1.0f);
+                    mfv[((size_t)(p / 32) * steps + dim2 / 2) * 64 + (dim2 & 1) * 32 + (p & 31)] = v;
+                }
+            CCHECK(hipMalloc((void **)&d.mf, mfv.size() * sizeof(float)));
+            CCHECK(hipMemcpy(d.mf, mfv.data(), mfv.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         CCHECK(hipMalloc((void **)&d.desc, n * m->dp * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.sign, n * sizeof(float)));
@@ -411,6 +737,13 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     const uint32_t splits_max = 64;
     const uint32_t q_blocks_max = (max_n + MATCH_BLOCK - 1) / MATCH_BLOCK;
     Partial *partial = nullptr;
+    Top2 *top2 = nullptr;
+    float *thr = nullptr;
+    QRange *qrange = nullptr;
+    float *hmax = nullptr;                      // [tiles of the largest image][2][max_n] per ring slot
+    // FROG_MATCH_VALU=1 keeps every pass on the exact vector-ALU kernel (test hook; also taken for descriptors
+    // longer than 64 values or with non-finite entries, where the MFMA filter's error bound means nothing)
+    const bool force_valu = getenv("FROG_MATCH_VALU") != nullptr;
     uint2 *ranges = nullptr;
     int *d_out = nullptr, *h_out = nullptr;
     hipEvent_t done[RING] = {}, t0 = nullptr, t1 = nullptr;
@@ -418,6 +751,10 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     int rc = FROG_OK;
     auto cleanup = [&]() {
         if (partial) (void)hipFree(partial);
+        if (top2) (void)hipFree(top2);
+        if (thr) (void)hipFree(thr);
+        if (qrange) (void)hipFree(qrange);
+        if (hmax) (void)hipFree(hmax);
         if (ranges) (void)hipFree(ranges);
         if (d_out) (void)hipFree(d_out);
         if (h_out) (void)hipHostFree(h_out);
@@ -427,13 +764,18 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     };
 #define RCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return FROG_E_HIP; } } while (0)
     RCHECK(hipMalloc((void **)&partial, (size_t)RING * splits_max * max_n * sizeof(Partial)));
+    RCHECK(hipMalloc((void **)&top2, (size_t)RING * splits_max * max_n * sizeof(Top2)));
+    RCHECK(hipMalloc((void **)&thr, (size_t)RING * max_n * sizeof(float)));
+    RCHECK(hipMalloc((void **)&qrange, (size_t)RING * max_n * sizeof(QRange)));
+    const size_t hmax_slot = (size_t)((max_n + MF_TILE - 1) / MF_TILE) * 2 * max_n;
+    if (!force_valu && m->dp <= 64) RCHECK(hipMalloc((void **)&hmax, (size_t)RING * hmax_slot * sizeof(float)));
     RCHECK(hipMalloc((void **)&ranges, (size_t)RING * q_blocks_max * sizeof(uint2)));
     RCHECK(hipMalloc((void **)&d_out, (size_t)RING * max_n * sizeof(int)));
     RCHECK(hipHostMalloc((void **)&h_out, (size_t)RING * max_n * sizeof(int)));
     for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
     RCHECK(hipEventCreate(&t0));
     RCHECK(hipEventCreate(&t1));
-    RCHECK(hipMemsetAsync(m->n_dist, 0, 2 * sizeof(unsigned long long), m->stream));
+    RCHECK(hipMemsetAsync(m->n_dist, 0, 3 * sizeof(unsigned long long), m->stream));
     RCHECK(hipEventRecord(t0, m->stream));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
@@ -477,9 +819,36 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
             a.nq = nq; a.nc = C.n; a.splits = splits; a.anat = o->anat;
             a.partial = partial + (size_t)slot * splits_max * max_n;
             a.n_dist = m->n_dist;
-            const dim3 grid(q_blocks, splits);
             uint2 *rg = ranges + (size_t)slot * q_blocks_max;
             match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, m->stream>>>(a, q_blocks, rg);
+            const bool mfma = !force_valu && m->dp <= 64 && Q.finite && C.finite && C.n > 0;
+            if (mfma) {
+                // about 4 candidate tiles per block: the ranges of the query blocks differ a lot in length, small
+                // units keep the 256 CUs evenly loaded (measured: 8 tiles per block left them idle 40 % of the time)
+                a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + 3) / 4));
+                Top2 *t2 = top2 + (size_t)slot * splits_max * max_n;
+                float *th = thr + (size_t)slot * max_n;
+                QRange *qr = qrange + (size_t)slot * max_n;
+                float *hm = hmax + (size_t)slot * hmax_slot;
+                const dim3 mgrid(q_blocks, a.splits);
+                int *dst = d_out + (size_t)slot * max_n;
+                const bool anat = o->anat != 0.f;
+                match_qrange_kernel<<<(nq + 255) / 256, 256, 0, m->stream>>>(a, qr);
+#define MF_LAUNCH(DD, AA)                                                                                               \
+                do {                                                                                                    \
+                    match_mfma_kernel<DD, AA, 1><<<mgrid, MATCH_BLOCK, 0, m->stream>>>(a, rg, qr, Q.mf, C.mf, t2, th, hm); \
+                    match_scan_kernel<DD, AA><<<(nq + 15) / 16, 256, 0, m->stream>>>(a, rg, qr, t2, Q.norm, C.norm_max, hm, \
+                                                                                       o->threshold, o->dist2second, dst); \
+                } while (0)
+                if (m->dp == 48) { if (anat) MF_LAUNCH(48, true); else MF_LAUNCH(48, false); }
+                else { if (anat) MF_LAUNCH(64, true); else MF_LAUNCH(64, false); }
+#undef MF_LAUNCH
+                RCHECK(hipGetLastError());
+                RCHECK(hipMemcpyAsync(h_out + (size_t)slot * max_n, dst, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+                RCHECK(hipEventRecord(done[slot], m->stream));
+                continue;
+            }
+            const dim3 grid(q_blocks, splits);
             switch (m->dp) {
             case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
             case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
@@ -499,9 +868,9 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
     float ms = 0;
     RCHECK(hipEventElapsedTime(&ms, t0, t1));
-    unsigned long long nd[2] = { 0, 0 };
+    unsigned long long nd[3] = { 0, 0, 0 };
     RCHECK(hipMemcpy(nd, m->n_dist, sizeof nd, hipMemcpyDeviceToHost));
-    m->last_ms = ms; m->last_dist = (double)nd[0]; m->last_computed = (double)nd[1];
+    m->last_ms = ms; m->last_dist = (double)nd[0]; m->last_computed = (double)nd[1]; m->last_fallback = (double)nd[2];
 #undef RCHECK
     cleanup();
 
