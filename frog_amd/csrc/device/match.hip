@@ -63,6 +63,7 @@ struct MatchArgs {
     const float *c_desc, *c_sign, *c_lo, *c_hi, *c_xyz;
     const uint32_t *c_orig;
     uint32_t nq, nc, splits;
+    uint32_t hmax_stride;               // entries per query of the half-tile maxima: 2 * tiles of the candidate image
     float anat;
     Partial *partial;                   // [splits][nq]
     unsigned long long *n_dist;         // distances evaluated (statistics)
@@ -251,6 +252,7 @@ __global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_
 // The sign / scale filters of a query select ONE contiguous range of the sorted candidates (see the header),
 // found per query by binary search (match_qrange_kernel): the test is two integer compares.
 constexpr int MF_TILE = 32;             // points per MFMA operand group
+constexpr int STAT_BASE = 4, STAT_SLOTS = 256;      // n_dist[STAT_BASE + k]: exact distances, then product pairs, spread over slots
 // |(-2 x product) - reference distance| <= MF_EPS * (|q|^2 + |c|^2): D + 2 products and sums in f32 in the chain,
 // D sums in the reference's own chain, the rounded norms: under 2^-24 * 512 (D <= 64) in all
 constexpr float MF_EPS = 1.0f / 32768.0f;
@@ -259,11 +261,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct QRange { uint32_t first, last; };        // candidates [first, last) pass the query's sign and scale tests
 
-// per query: the exact set {c : sign == qsign, lo[c] < qscale < hi[c]} as a range of the sorted candidates
-__global__ void match_qrange_kernel(const MatchArgs a, QRange *qr)
+// per query: the exact set {c : sign == qsign, lo[c] < qscale < hi[c]} as a range of the sorted candidates;
+// per block of MATCH_BLOCK queries: the union of their ranges (what match_range_kernel estimates for the vector kernel)
+__global__ __launch_bounds__(MATCH_BLOCK) void match_qrange_kernel(const MatchArgs a, QRange *qr, uint2 *ranges)
 {
+    __shared__ uint32_t lo_s, hi_s, n_s;
+    if (threadIdx.x == 0) { lo_s = 0xFFFFFFFFu; hi_s = 0u; n_s = 0u; }
+    __syncthreads();
     const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= a.nq) return;
+    if (qi < a.nq) {
     const float sg = a.q_sign[qi], sc = a.q_scale[qi];
     uint32_t lo = 0, hi = a.nc;                    // sign segment [sb, se)
     while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_sign[mid] < sg) lo = mid + 1; else hi = mid; }
@@ -277,6 +283,13 @@ __global__ void match_qrange_kernel(const MatchArgs a, QRange *qr)
     hi = se;                                       // first candidate with lo[c] >= sc (lo grows with the scale)
     while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a.c_lo[mid] < sc) lo = mid + 1; else hi = mid; }
     qr[qi] = QRange{ first, lo };
+    if (lo > first) { atomicMin(&lo_s, first); atomicMax(&hi_s, lo); atomicAdd(&n_s, lo - first); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ranges[blockIdx.x] = lo_s <= hi_s ? make_uint2(lo_s, hi_s) : make_uint2(0u, 0u);
+        if (n_s) atomicAdd(a.n_dist, (unsigned long long)n_s);      // (query, candidate) pairs that pass the sign and scale tests
+    }
 }
 
 struct Top2 { float m1, m2; };
@@ -286,9 +299,18 @@ struct Top2 { float m1, m2; };
 template <int D>
 __device__ __noinline__ float exact_distance(const float *qrow, const float *crow)
 {
+    // rows are 16-byte aligned (D is a multiple of 4): 2 x D/4 loads, the sum stays in dimension order
+    const float4 *q4 = reinterpret_cast<const float4 *>(qrow), *c4 = reinterpret_cast<const float4 *>(crow);
     float dist = 0.f;
-    #pragma unroll 8
-    for (int k = 0; k < D; k++) { const float t = qrow[k] - crow[k]; dist += t * t; }
+    #pragma unroll
+    for (int k = 0; k < D / 4; k++) {
+        const float4 x = q4[k], y = c4[k];
+        float t;
+        t = x.x - y.x; dist += t * t;
+        t = x.y - y.y; dist += t * t;
+        t = x.z - y.z; dist += t * t;
+        t = x.w - y.w; dist += t * t;
+    }
     return dist;
 }
 
@@ -378,11 +400,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
                     pass = pass && !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
                 }
                 if (PASS == 1) {
-                    const float v = pass ? dot : -INFINITY;
-                    m2[g] = __builtin_amdgcn_fmed3f(m1[g], m2[g], v);           // second largest of {m1 >= m2, v}
-                    m1[g] = fmaxf(m1[g], v);
-                    hm = fmaxf(hm, v);
-                    evaluated += pass ? 1u : 0u;
+                    hm = fmaxf(hm, pass ? dot : -INFINITY);
                 } else {
                     const bool near = pass && dot >= qthr[g];
                     if (near) {                                                 // rare: the reference's own arithmetic
@@ -398,20 +416,17 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
                     }
                 }
             }
-            if (PASS == 1 && hmax && qidx[g] < a.nq && (g0 + g) < n_qgroups)
-                hmax[((size_t)t * 2 + h) * a.nq + qidx[g]] = hm;
+            if (PASS == 1) {
+                if (hmax && qidx[g] < a.nq && (g0 + g) < n_qgroups)
+                    hmax[(size_t)qidx[g] * a.hmax_stride + t * 2 + h] = hm;   // read back 16 entries at a time by the query's team
+            }
         }
     }
     // lanes j and j + 32 saw different rows of the same queries: merge, lane j writes
     #pragma unroll
     for (int g = 0; g < 2; g++) {
         const bool valid = (g0 + g) < n_qgroups && qidx[g] < a.nq;
-        if (PASS == 1) {
-            const float o1 = __shfl_xor(m1[g], 32, 64), o2 = __shfl_xor(m2[g], 32, 64);
-            const float hi1 = fmaxf(m1[g], o1), lo1 = fminf(m1[g], o1);
-            const float second = fmaxf(lo1, fmaxf(m2[g], o2));
-            if (h == 0 && valid) top2[(size_t)blockIdx.y * a.nq + qidx[g]] = Top2{ hi1, second };
-        } else {
+        if (PASS == 2) {
             const float od1 = __shfl_xor(d1[g], 32, 64), od2 = __shfl_xor(d2[g], 32, 64);
             const int om = __shfl_xor(match[g], 32, 64);
             float r1 = d1[g], r2 = d2[g];
@@ -429,8 +444,11 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
     unsigned int total = evaluated;
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if (lane == 0 && total) atomicAdd(a.n_dist + (PASS == 1 ? 0 : 2), (unsigned long long)total);
-    if (PASS == 1 && lane == 0 && t_end > t_begin) atomicAdd(a.n_dist + 1, 64ull * MF_TILE * (t_end - t_begin));
+    if (PASS == 2 && lane == 0 && total) atomicAdd(a.n_dist + 2, (unsigned long long)total);
+    // statistics go to one of STAT_SLOTS counters: thousands of atomics on ONE address serialise in L2 (20 000 of
+    // them, one per query, cost the scan kernel 60 of its 70 us)
+    if (PASS == 1 && lane == 0 && t_end > t_begin)
+        atomicAdd(a.n_dist + STAT_BASE + STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, 64ull * MF_TILE * (t_end - t_begin));
 }
 
 // threshold of pass 2: a candidate whose product is below it cannot be one of the two nearest.
@@ -451,66 +469,142 @@ __global__ void match_threshold_kernel(const Top2 *top2, uint32_t nq, uint32_t s
 }
 
 
+constexpr int SCAN_BLOCK = 64;          // one wavefront = 4 query teams
+constexpr int SCAN_HITS = 64;           // half tiles listed per query before the slow path
+
 // Pass 2 without the matrix cores: a team of 16 lanes per query walks the half-tile maxima pass 1 left behind; for
 // every half tile whose maximum reaches the query's threshold (a few per query) each lane of the team gives ONE of
 // its 16 candidates the reference's arithmetic; the team's (d1, d2, match) partials are merged as a sequential scan
 // would see them and lane 0 applies the acceptance test.  Replaces threshold + second MFMA pass + decide.
 template <int D, bool ANAT>
-__global__ __launch_bounds__(256) void match_scan_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr, const Top2 *top2,
+__global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
                                                          const float *q_norm, float c_norm_max, const float *hmax,
                                                          float threshold, float dist2second, int *out)
 {
     const int lane = threadIdx.x & 63, tl = lane & 15, team_shift = lane & 48;   // team = 16 consecutive lanes
-    const uint32_t qi = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const uint32_t qi = blockIdx.x * (SCAN_BLOCK / 16) + (threadIdx.x >> 4);
     const bool valid = qi < a.nq;
     const uint32_t qc = min(qi, a.nq - 1);
-    float t1 = -INFINITY, t2 = -INFINITY;
-    for (uint32_t s = 0; s < a.splits; s++) {
-        const Top2 t = top2[(size_t)s * a.nq + qc];
-        const float lo1 = fminf(t1, t.m1);
-        t1 = fmaxf(t1, t.m1);
-        t2 = fmaxf(lo1, fmaxf(t2, t.m2));
-    }
-    const float thr = t2 - MF_EPS * (q_norm[qc] + c_norm_max);  // see match_threshold_kernel
     const QRange r = valid ? qr[qc] : QRange{ 0, 0 };
     const uint2 rg = ranges[qc / MATCH_BLOCK];
     const uint32_t t_first = rg.x / MF_TILE, t_last = (rg.y + MF_TILE - 1) / MF_TILE;
     const uint32_t n_entries = valid ? (t_last - t_first) * 2 : 0;
-    const float *qrow = a.q_desc + (size_t)qc * D;
+    const float *hrow = hmax + (size_t)qc * a.hmax_stride + t_first * 2;
+    // the two largest half-tile maxima (the second can only be smaller than the true second largest product, when both
+    // sit in one half tile: a lower threshold, more candidates verified, never fewer)
+    float t1 = -INFINITY, t2 = -INFINITY;
+    for (uint32_t e0 = 0; e0 < n_entries; e0 += 64) {
+        float v[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t e = e0 + 16 * k + tl; v[k] = e < n_entries ? hrow[e] : -INFINITY; }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { t2 = __builtin_amdgcn_fmed3f(t1, t2, v[k]); t1 = fmaxf(t1, v[k]); }
+    }
+    #pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const float o1 = __shfl_xor(t1, off, 64), o2 = __shfl_xor(t2, off, 64);
+        const float lo1 = fminf(t1, o1);
+        t1 = fmaxf(t1, o1);
+        t2 = fmaxf(lo1, fmaxf(t2, o2));
+    }
+    // -2 x product approximates the distance to MF_EPS * (|q|^2 + |c|^2): every candidate whose exact distance is at most
+    // the second smallest exact distance has a product >= (second largest product) - MF_EPS * (|q|^2 + max |c|^2)
+    const float thr = t2 - MF_EPS * (q_norm[qc] + c_norm_max);      // -inf when fewer than two half tiles hold a candidate
+    // per team: its 16 candidate rows, D/4 + 1 float4 apart: the odd stride spreads the rows over all banks (with
+    // D/4 = 12 the four runs of rows collided 16 ways and the kernel spent its time in LDS: 71 us against 25 us)
+    constexpr int ROW4 = D / 4 + 1;
+    __shared__ float4 rows[SCAN_BLOCK / 16][16 * ROW4];
+    const int team = threadIdx.x >> 4;
+    float4 q4[D / 4];                                               // the query's descriptor, kept for all its hits
+    {
+        const float4 *qrow = reinterpret_cast<const float4 *>(a.q_desc + (size_t)qc * D);
+        #pragma unroll
+        for (int k = 0; k < D / 4; k++) q4[k] = qrow[k];
+    }
     float d1 = FLT_MAX, d2 = FLT_MAX;
     int match = -1;
     unsigned int verified = 0;
-    // every team of the wavefront runs the same number of rounds (ballots need all lanes)
-    uint32_t rounds = (n_entries + 15) / 16;
-    #pragma unroll
-    for (int off = 16; off < 64; off <<= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, off, 64));
-    for (uint32_t rd = 0; rd < rounds; rd++) {
-        const uint32_t e = rd * 16 + tl;
-        const bool hit = e < n_entries && hmax[((size_t)(t_first + e / 2) * 2 + (e & 1)) * a.nq + qc] >= thr;
-        unsigned int mask = (unsigned int)((__ballot(hit) >> team_shift) & 0xFFFFull);
-        while (mask) {                                                  // uniform inside a team
-            const uint32_t eh = rd * 16 + (uint32_t)__builtin_ctz(mask);
-            mask &= mask - 1;
-            const uint32_t c = (t_first + eh / 2) * MF_TILE + 4 * (eh & 1) + (uint32_t)((tl & 3) + 8 * (tl >> 2));
-            bool pass = (c - r.first) < (r.last - r.first);
-            if (ANAT && pass) {
-                const float ex = a.q_xyz[3 * (size_t)qc] - a.c_xyz[3 * (size_t)c], ey = a.q_xyz[3 * (size_t)qc + 1] - a.c_xyz[3 * (size_t)c + 1],
-                            ez = a.q_xyz[3 * (size_t)qc + 2] - a.c_xyz[3 * (size_t)c + 2];
-                pass = !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
+    // one verification: the half tile `eh` of this team's query -- 16 candidates, one per lane
+    auto verify = [&](uint32_t eh) {
+        const uint32_t row0 = (t_first + eh / 2) * MF_TILE + 4 * (eh & 1);      // the half tile: rows row0 + {0..3} + 8 * {0..3}
+        const uint32_t c = row0 + (uint32_t)((tl & 3) + 8 * (tl >> 2));
+        // the team fetches its 16 candidate rows together: 4 runs of 4 consecutive rows, 16 lanes x 16 bytes per load
+        #pragma unroll
+        for (int k = 0; k < D / 4; k++) {
+            const int idx = k * 16 + tl, run = idx / (D), off = idx % (D);          // float4 units: D per run of 4 rows
+            const uint32_t src_row = min(row0 + 8u * (uint32_t)run, a.nc - 1);
+            const float4 *src = reinterpret_cast<const float4 *>(a.c_desc + (size_t)src_row * D);
+            // a run of 4 rows is contiguous only while it stays inside the array: the last tile is read row by row
+            const uint32_t rr = min(row0 + 8u * (uint32_t)run + (uint32_t)(off / (D / 4)), a.nc - 1);
+            rows[team][(run * 4 + off / (D / 4)) * ROW4 + off % (D / 4)] =
+                (row0 + 8u * (uint32_t)run + 3u < a.nc) ? src[off] : reinterpret_cast<const float4 *>(a.c_desc + (size_t)rr * D)[off % (D / 4)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool pass = (c - r.first) < (r.last - r.first);
+        if (ANAT && pass) {
+            const float ex = a.q_xyz[3 * (size_t)qc] - a.c_xyz[3 * (size_t)c], ey = a.q_xyz[3 * (size_t)qc + 1] - a.c_xyz[3 * (size_t)c + 1],
+                        ez = a.q_xyz[3 * (size_t)qc + 2] - a.c_xyz[3 * (size_t)c + 2];
+            pass = !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
+        }
+        float dist = 0.f;                                               // norm, match.cpp:242-251: sequential f32 sum
+        {
+            const float4 *mine = &rows[team][((tl >> 2) * 4 + (tl & 3)) * ROW4];
+            #pragma unroll
+            for (int k = 0; k < D / 4; k++) {
+                const float4 y = mine[k];
+                float t;
+                t = q4[k].x - y.x; dist += t * t;
+                t = q4[k].y - y.y; dist += t * t;
+                t = q4[k].z - y.z; dist += t * t;
+                t = q4[k].w - y.w; dist += t * t;
             }
-            if (pass) {
-                const float dist = exact_distance<D>(qrow, a.c_desc + (size_t)c * D);
-                const int orig = (int)a.c_orig[c];
-                const bool better = dist < d1;                          // match.cpp:303-313, in any scan order
-                const bool second = !better && dist < d2;
-                const bool tie = !better && dist == d1 && orig < match;
-                d2 = better ? d1 : (second ? dist : d2);
-                d1 = better ? dist : d1;
-                match = (better || tie) ? orig : match;
-                verified++;
+        }
+        __builtin_amdgcn_wave_barrier();                                // the rows are overwritten by the next verification
+        if (pass) {
+            const int orig = (int)a.c_orig[c];
+            const bool better = dist < d1;                              // match.cpp:303-313, in any scan order
+            const bool second = !better && dist < d2;
+            const bool tie = !better && dist == d1 && orig < match;
+            d2 = better ? d1 : (second ? dist : d2);
+            d1 = better ? dist : d1;
+            match = (better || tie) ? orig : match;
+            verified++;
+        }
+    };
+    // The half tiles to verify are first LISTED per team, then verification k of all four teams runs together: a
+    // team's hits sit in different rounds of its walk, and verifying them where they are found would run the
+    // wavefront once per hit of any team with three quarters of its lanes idle (measured: 80 us against 20 us).
+    __shared__ unsigned short hits[SCAN_BLOCK / 16][SCAN_HITS];
+    __shared__ unsigned int n_hits[SCAN_BLOCK / 16];
+    if (tl == 0) n_hits[team] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e0 = 0; e0 < n_entries; e0 += 64) {
+        float v[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t e = e0 + 16 * k + tl; v[k] = e < n_entries ? hrow[e] : -INFINITY; }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t e = e0 + 16 * k + tl;
+            if (e < n_entries && v[k] >= thr) {
+                const unsigned int p = atomicAdd(&n_hits[team], 1u);
+                if (p < (unsigned int)SCAN_HITS) hits[team][p] = (unsigned short)e;
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned int listed = n_hits[team];
+    const bool overflow = listed > (unsigned int)SCAN_HITS || n_entries > 65535u;   // more hits than the list holds: walk again
+    uint32_t n_mine = overflow ? 0u : listed, n_max = n_mine;
+    #pragma unroll
+    for (int off = 16; off < 64; off <<= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off, 64));
+    for (uint32_t k = 0; k < n_max; k++)
+        if (k < n_mine) verify(hits[team][k]);
+    if (overflow)
+        for (uint32_t e = 0; e < n_entries; e++)
+            if (hrow[e] >= thr) verify(e);
     #pragma unroll
     for (int off = 8; off > 0; off >>= 1) {                             // merge the team's partials (as match_decide_kernel)
         const float od1 = __shfl_xor(d1, off, 64), od2 = __shfl_xor(d2, off, 64);
@@ -523,8 +617,13 @@ __global__ __launch_bounds__(256) void match_scan_kernel(const MatchArgs a, cons
         if (od2 < d2) d2 = od2;
         verified += (unsigned int)__shfl_xor((int)verified, off, 64);
     }
+    {
+        unsigned int wave_total = tl == 0 ? verified : 0u;
+        #pragma unroll
+        for (int off = 16; off < 64; off <<= 1) wave_total += (unsigned int)__shfl_xor((int)wave_total, off, 64);
+        if (lane == 0 && wave_total) atomicAdd(a.n_dist + STAT_BASE + blockIdx.x % STAT_SLOTS, (unsigned long long)wave_total);
+    }
     if (tl == 0 && valid) {
-        if (verified) atomicAdd(a.n_dist + 2, (unsigned long long)verified);
         const bool ok = (sqrtf(d1 / d2) < dist2second || d2 == FLT_MAX) && (sqrtf(d1) < threshold);   // :320-321
         out[qi] = ok ? (match >= 0 ? match : -2) : (match >= 0 ? -(match + 3) : -1);
     }
@@ -634,7 +733,7 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     m->img.resize(n_images);
 #define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
     CCHECK(hipStreamCreate(&m->stream));
-    CCHECK(hipMalloc((void **)&m->n_dist, 3 * sizeof(unsigned long long)));
+    CCHECK(hipMalloc((void **)&m->n_dist, (STAT_BASE + 2 * STAT_SLOTS) * sizeof(unsigned long long)));
     std::vector<float> pad, lo, hi, sg, sc, xyz, nrm, mfv;
     for (uint32_t i = 0; i < n_images; i++) {
         const frog_keypoints &k = images[i];
@@ -775,7 +874,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
     RCHECK(hipEventCreate(&t0));
     RCHECK(hipEventCreate(&t1));
-    RCHECK(hipMemsetAsync(m->n_dist, 0, 3 * sizeof(unsigned long long), m->stream));
+    RCHECK(hipMemsetAsync(m->n_dist, 0, (STAT_BASE + 2 * STAT_SLOTS) * sizeof(unsigned long long), m->stream));
     RCHECK(hipEventRecord(t0, m->stream));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
@@ -820,24 +919,27 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
             a.partial = partial + (size_t)slot * splits_max * max_n;
             a.n_dist = m->n_dist;
             uint2 *rg = ranges + (size_t)slot * q_blocks_max;
-            match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, m->stream>>>(a, q_blocks, rg);
             const bool mfma = !force_valu && m->dp <= 64 && Q.finite && C.finite && C.n > 0;
             if (mfma) {
-                // about 4 candidate tiles per block: the ranges of the query blocks differ a lot in length, small
-                // units keep the 256 CUs evenly loaded (measured: 8 tiles per block left them idle 40 % of the time)
-                a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + 3) / 4));
+                // candidate tiles per block: few = even load over the 256 CUs (the query blocks' ranges differ a lot in
+                // length), many = the block's 256 queries are loaded as operands less often.  Measured, image pairs/s
+                // at 20 000 x 20 000: 2 tiles 1584, 4: 2059, 8: 2249, 16: 2110
+                static const uint32_t tiles_per_block = getenv("FROG_MATCH_TILES") ? (uint32_t)std::max(1, atoi(getenv("FROG_MATCH_TILES"))) : 8u;
+                a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + tiles_per_block - 1) / tiles_per_block));
                 Top2 *t2 = top2 + (size_t)slot * splits_max * max_n;
                 float *th = thr + (size_t)slot * max_n;
                 QRange *qr = qrange + (size_t)slot * max_n;
                 float *hm = hmax + (size_t)slot * hmax_slot;
+                a.hmax_stride = 2 * ((C.n + MF_TILE - 1) / MF_TILE);
                 const dim3 mgrid(q_blocks, a.splits);
                 int *dst = d_out + (size_t)slot * max_n;
                 const bool anat = o->anat != 0.f;
-                match_qrange_kernel<<<(nq + 255) / 256, 256, 0, m->stream>>>(a, qr);
+                static const uint32_t scan_div = getenv("FROG_SCAN_DIV") ? (uint32_t)atoi(getenv("FROG_SCAN_DIV")) : 1u;   // timing experiment only
+                match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, m->stream>>>(a, qr, rg);
 #define MF_LAUNCH(DD, AA)                                                                                               \
                 do {                                                                                                    \
                     match_mfma_kernel<DD, AA, 1><<<mgrid, MATCH_BLOCK, 0, m->stream>>>(a, rg, qr, Q.mf, C.mf, t2, th, hm); \
-                    match_scan_kernel<DD, AA><<<(nq + 15) / 16, 256, 0, m->stream>>>(a, rg, qr, t2, Q.norm, C.norm_max, hm, \
+                    match_scan_kernel<DD, AA><<<((nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16) + scan_div - 1) / scan_div, SCAN_BLOCK, 0, m->stream>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
                                                                                        o->threshold, o->dist2second, dst); \
                 } while (0)
                 if (m->dp == 48) { if (anat) MF_LAUNCH(48, true); else MF_LAUNCH(48, false); }
@@ -849,6 +951,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 continue;
             }
             const dim3 grid(q_blocks, splits);
+            match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, m->stream>>>(a, q_blocks, rg);
             switch (m->dp) {
             case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
             case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
@@ -868,9 +971,12 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
     float ms = 0;
     RCHECK(hipEventElapsedTime(&ms, t0, t1));
-    unsigned long long nd[3] = { 0, 0, 0 };
-    RCHECK(hipMemcpy(nd, m->n_dist, sizeof nd, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> stat(STAT_BASE + 2 * STAT_SLOTS, 0ull);
+    RCHECK(hipMemcpy(stat.data(), m->n_dist, stat.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long nd[3] = { stat[0], stat[1], stat[2] };
+    for (int k = 0; k < STAT_SLOTS; k++) { nd[2] += stat[STAT_BASE + k]; nd[1] += stat[STAT_BASE + STAT_SLOTS + k]; }
     m->last_ms = ms; m->last_dist = (double)nd[0]; m->last_computed = (double)nd[1]; m->last_fallback = (double)nd[2];
+    if (getenv("FROG_MATCH_DEBUG")) std::fprintf(stderr, "matcher: %.3f ms, %.4g pairs pass the filters, %.4g exact distances, counter[1] = %.4g\n", ms, (double)nd[0], (double)nd[2], (double)nd[1]);
 #undef RCHECK
     cleanup();
 
