@@ -8,10 +8,10 @@ default flags of run.sh (-d 1, -d2 1).  Keypoints are resident in HBM before the
 the timed region covers all pairing kernels, the per-query decisions and the return of the
 pair lists to the host.
 
-Prints ONE JSON line.  `roofline` here is the f32 vector-ALU roofline (the kernel is pure
-sub/mul/add in dimension order, no MFMA: see frog_amd/csrc/device/match.hip): 3 lane-operations
-per descriptor dimension per evaluated (query, candidate) pair against 256 CUs x 64 lanes x
-2.4 GHz.
+Prints ONE JSON line.  `roofline` here is the f32-input MFMA roofline: the dominant kernel is the
+matrix-core filter of frog_amd/csrc/device/match.hip (one (D + 2)-term product per (query,
+candidate) pair that passes the sign and scale tests, 2 FLOP per term) against 256 CUs x 4 SIMDs x
+64 FLOP/clk x 2.4 GHz.
 """
 import argparse
 import json
@@ -51,8 +51,11 @@ def main():
     elapsed = time.perf_counter() - t0
     ms, nd = m.last_stats()
     n_pairs = int(sum(len(a) for a, _ in res))
-    lane_ops = 3.0 * args.dim * nd
-    peak = 256 * 64 * 2.4e9
+    # roofline of the dominant kernel (match_mfma_kernel): f32-input MFMA, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md) =
+    # 256 CUs x 4 SIMDs x 64 x 2.4 GHz = 157.3 TFLOP/s.  Algorithmic FLOPs: one (D + 2)-term product (2 FLOP per term)
+    # per (query, candidate) pair that passes the sign and scale tests.
+    flops = 2.0 * (args.dim + 2) * nd
+    peak = 256 * 4 * 64 * 2.4e9
     out = {
         "metric": "image pairs matched/sec (20 000 x 20 000 keypoints, 48-D)",
         "value": len(jobs) / elapsed, "unit": "image pairs/s", "n_gpus": 1, "higher_is_better": True,
@@ -60,8 +63,9 @@ def main():
         "config": {"workload": f"{args.images} images x {args.points} keypoints x {args.dim} floats, {len(jobs)} image pairs, "
                                f"-d {args.threshold} -d2 1", "matches": n_pairs,
                    "candidate_pairs": float(sum(imgs[a].n * imgs[b].n for a, b in jobs)), "distances_evaluated": nd},
-        "roofline": {"bound": "valu", "kernel": "match_kernel", "achieved": lane_ops / (ms * 1e-3) / 1e12,
-                     "peak": peak / 1e12, "unit": "T lane-op/s", "frac": lane_ops / (ms * 1e-3) / peak},
+        "roofline": {"bound": "mfma", "kernel": "match_mfma_kernel", "achieved": flops / (ms * 1e-3) / 1e12,
+                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak, "traffic": None,
+                     "note": "ms = all kernels of the run (range search, MFMA filter, exact verification)"},
         "setup_seconds": {"generate": t_gen, "upload": t_upload},
     }
     if args.cpu_jobs:
