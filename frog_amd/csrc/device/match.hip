@@ -42,6 +42,9 @@ namespace frog { void set_last_error(const std::string &s); }
 namespace {
 
 constexpr int MATCH_BLOCK = 256;        // queries per block
+// statistics: n_dist[0] pairs passing the filters (MFMA path: one add per query block); spread counters from STAT_BASE:
+// [0, S) exact distances of the scan kernel, [S, 2S) pairs computed (tiles), [2S, 3S) distances evaluated by the vector kernel
+constexpr int STAT_BASE = 4, STAT_SLOTS = 256;
 
 struct DevImage {
     uint32_t n = 0;
@@ -203,8 +206,9 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_kernel(const MatchArgs a, c
     unsigned int total = evaluated;
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.n_dist, (unsigned long long)total);
-    if ((threadIdx.x & 63) == 0 && computed) atomicAdd(a.n_dist + 1, 64ull * computed);
+    // spread over STAT_SLOTS counters: atomics on one address serialise in L2
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.n_dist + STAT_BASE + 2 * STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, (unsigned long long)total);
+    if ((threadIdx.x & 63) == 0 && computed) atomicAdd(a.n_dist + STAT_BASE + STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, 64ull * computed);
 }
 
 // merge the candidate ranges in order, then the acceptance test (match.cpp:320-321).
@@ -237,22 +241,25 @@ __global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_
 
 // ---- the same result through the matrix cores ---------------------------------------------------
 // The distances that decide a query's outcome are its two smallest; everything else only has to be
-// known to be larger.  Every keypoint is also stored as an EXTENDED vector (p, -|p|^2/2, 1): the
-// product of two of them is q.c - |q|^2/2 - |c|^2/2 = -d^2/2, so ONE f32 MFMA chain
-// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, error bounded, MF_EPS below) yields an approximate
+// known to be larger.  Every keypoint is also stored as an EXTENDED vector (p, -|p|^2/2, 1): with the last two
+// entries of one side swapped the product of two of them is q.c - |q|^2/2 - |c|^2/2 = -d^2/2, so ONE f32 MFMA
+// chain (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, error bounded, MF_EPS below) yields an approximate
 // -d^2/2 for 32 x 32 (candidate, query) pairs, and the same array serves an image as query and as
 // candidate: it is kept in the operand's own lane order ([group of 32 points][step][lane]), so both
 // operands are plain coalesced loads -- no LDS, no barrier, a wavefront is on its own.
-//   pass 1: the two largest products per query (a max and a med3 per candidate);
-//   pass 2: the products again; the few candidates within the error bound of the second largest get the
-//           reference's own arithmetic (sequential sum of (q_k - c_k)^2, strict-< bookkeeping).
+//   match_mfma_kernel: the products; per query and HALF TILE (the 16 candidates a lane holds of a 32 x 32 product)
+//                      the largest product of a candidate that passes the query's filters -- one max per candidate;
+//   match_scan_kernel: per query, the second largest half-tile maximum minus the error bound is a threshold no
+//                      candidate among the two nearest can be below; the few half tiles that reach it (two per
+//                      query, typically) get the reference's own arithmetic (sequential sum of (q_k - c_k)^2,
+//                      strict-< bookkeeping) on their 16 candidates, then the acceptance test.
 // Candidates outside the bound provably cannot be one of the two nearest, so the pair lists are those of
 // the exact kernel above, bit for bit; its 3 vector instructions per (query, candidate, dimension) become
-// 2/32 of a matrix instruction plus ~9 vector instructions per (query, candidate).
+// 1/32 of a matrix instruction plus 4 vector instructions per (query, candidate), and 32 exact distances
+// per query remain of the ~3 400 the vector kernel evaluates.
 // The sign / scale filters of a query select ONE contiguous range of the sorted candidates (see the header),
 // found per query by binary search (match_qrange_kernel): the test is two integer compares.
 constexpr int MF_TILE = 32;             // points per MFMA operand group
-constexpr int STAT_BASE = 4, STAT_SLOTS = 256;      // n_dist[STAT_BASE + k]: exact distances, then product pairs, spread over slots
 // |(-2 x product) - reference distance| <= MF_EPS * (|q|^2 + |c|^2): D + 2 products and sums in f32 in the chain,
 // D sums in the reference's own chain, the rounded norms: under 2^-24 * 512 (D <= 64) in all
 constexpr float MF_EPS = 1.0f / 32768.0f;
@@ -292,34 +299,12 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_qrange_kernel(const MatchAr
     }
 }
 
-struct Top2 { float m1, m2; };
 
-// the reference's distance (norm, match.cpp:242-251): sequential f32 sum of squared differences.  Out of line:
-// it runs for a handful of candidates per query and must not cost the matrix loop its registers.
-template <int D>
-__device__ __noinline__ float exact_distance(const float *qrow, const float *crow)
-{
-    // rows are 16-byte aligned (D is a multiple of 4): 2 x D/4 loads, the sum stays in dimension order
-    const float4 *q4 = reinterpret_cast<const float4 *>(qrow), *c4 = reinterpret_cast<const float4 *>(crow);
-    float dist = 0.f;
-    #pragma unroll
-    for (int k = 0; k < D / 4; k++) {
-        const float4 x = q4[k], y = c4[k];
-        float t;
-        t = x.x - y.x; dist += t * t;
-        t = x.y - y.y; dist += t * t;
-        t = x.z - y.z; dist += t * t;
-        t = x.w - y.w; dist += t * t;
-    }
-    return dist;
-}
-
-// PASS 1: top2[split][query] = the two largest products.  PASS 2: partial[split][query] = exact (d1, d2, match) over
-// the candidates whose product reaches thr[query].
-template <int D, bool ANAT, int PASS>
+// hmax[query][2 * tile + half] = the largest product among the 16 candidates of that half tile that pass the query's
+// filters (-inf if none); blockIdx.y splits the candidate tiles of the query block's range.
+template <int D, bool ANAT>
 __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
-                                                                 const float *q_mf, const float *c_mf,
-                                                                 Top2 *top2, const float *thr, float *hmax)
+                                                                 const float *q_mf, const float *c_mf, float *hmax)
 {
     constexpr int STEPS = (D + 2) / 2;              // MFMA instructions per 32 x 32 tile (K = 2 each)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -328,8 +313,9 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
     const uint32_t n_qgroups = (a.nq + MF_TILE - 1) / MF_TILE;
     if (g0 >= n_qgroups) return;
 
-    float b[2][STEPS], qthr[2], qx[2], qy[2], qz[2];
+    float b[2][STEPS], qx[2], qy[2], qz[2];
     uint32_t qfirst[2], qcount[2], qidx[2];
+    bool qvalid[2];
     #pragma unroll
     for (int g = 0; g < 2; g++) {
         const uint32_t grp = min(g0 + g, n_qgroups - 1);
@@ -341,29 +327,25 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
         b[g][STEPS - 1] = q_mf[((size_t)grp * STEPS + STEPS - 1) * 64 + (lane ^ 32)];
         const uint32_t qi = (g0 + g) * MF_TILE + j;
         qidx[g] = qi;
-        const bool valid = (g0 + g) < n_qgroups && qi < a.nq;
-        const QRange r = valid ? qr[qi] : QRange{ 0, 0 };
+        qvalid[g] = (g0 + g) < n_qgroups && qi < a.nq;
+        const QRange r = qvalid[g] ? qr[qi] : QRange{ 0, 0 };
         qfirst[g] = r.first; qcount[g] = r.last - r.first;                      // 0 for an invalid query: nothing passes
-        qthr[g] = (PASS == 2 && valid) ? thr[qi] : 0.f;
         qx[g] = qy[g] = qz[g] = 0.f;
-        if (ANAT && valid) { qx[g] = a.q_xyz[3 * (size_t)qi]; qy[g] = a.q_xyz[3 * (size_t)qi + 1]; qz[g] = a.q_xyz[3 * (size_t)qi + 2]; }
+        if (ANAT && qvalid[g]) { qx[g] = a.q_xyz[3 * (size_t)qi]; qy[g] = a.q_xyz[3 * (size_t)qi + 1]; qz[g] = a.q_xyz[3 * (size_t)qi + 2]; }
     }
-    float m1[2] = { -INFINITY, -INFINITY }, m2[2] = { -INFINITY, -INFINITY };   // pass 1
-    float d1[2] = { FLT_MAX, FLT_MAX }, d2[2] = { FLT_MAX, FLT_MAX };           // pass 2
-    int match[2] = { -1, -1 };
-    unsigned int evaluated = 0;
 
     // this block's share of the candidate tiles its queries can pass
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t t_first = rg.x / MF_TILE, t_last = (rg.y + MF_TILE - 1) / MF_TILE;      // tiles [t_first, t_last)
     const uint32_t per = (t_last - t_first + a.splits - 1) / a.splits;
     const uint32_t t_begin = min(t_last, t_first + blockIdx.y * per), t_end = min(t_last, t_begin + per);
+    if (t_begin >= t_end) return;
 
     // the candidate operand of the NEXT tile is loaded while the current one is multiplied (a tile is 25 coalesced
     // loads that the 50 matrix instructions would otherwise wait for)
     float nx[STEPS];
     {
-        const float *src = c_mf + (size_t)min(t_begin, t_last - 1) * STEPS * 64 + lane;
+        const float *src = c_mf + (size_t)t_begin * STEPS * 64 + lane;
         #pragma unroll
         for (int s2 = 0; s2 < STEPS; s2++) nx[s2] = src[s2 * 64];
     }
@@ -387,87 +369,26 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
         const uint32_t base = t * MF_TILE + 4 * h;
         #pragma unroll
         for (int g = 0; g < 2; g++) {
-            float hm = -INFINITY;                   // largest product of this lane's 16 rows: pass 2 looks only where it is large
+            float hm = -INFINITY;
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const uint32_t c = base + (uint32_t)((r & 3) + 8 * (r >> 2));   // row of the product = candidate
-                const float dot = g == 0 ? acc0[r] : acc1[r];
                 bool pass = (c - qfirst[g]) < qcount[g];                        // sign and scale tests, match.cpp:270-275
-
                 if (ANAT) {                                                     // :278-291
                     const uint32_t cc = min(c, a.nc - 1);
                     const float ex = qx[g] - a.c_xyz[3 * (size_t)cc], ey = qy[g] - a.c_xyz[3 * (size_t)cc + 1], ez = qz[g] - a.c_xyz[3 * (size_t)cc + 2];
                     pass = pass && !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
                 }
-                if (PASS == 1) {
-                    hm = fmaxf(hm, pass ? dot : -INFINITY);
-                } else {
-                    const bool near = pass && dot >= qthr[g];
-                    if (near) {                                                 // rare: the reference's own arithmetic
-                        const float dist = exact_distance<D>(a.q_desc + (size_t)qidx[g] * D, a.c_desc + (size_t)c * D);
-                        const int orig = (int)a.c_orig[c];
-                        const bool better = dist < d1[g];                       // :303-313, in any scan order (see match_kernel)
-                        const bool second = !better && dist < d2[g];
-                        const bool tie = !better && dist == d1[g] && orig < match[g];
-                        d2[g] = better ? d1[g] : (second ? dist : d2[g]);
-                        d1[g] = better ? dist : d1[g];
-                        match[g] = (better || tie) ? orig : match[g];
-                        evaluated++;
-                    }
-                }
+                hm = fmaxf(hm, pass ? (g == 0 ? acc0[r] : acc1[r]) : -INFINITY);
             }
-            if (PASS == 1) {
-                if (hmax && qidx[g] < a.nq && (g0 + g) < n_qgroups)
-                    hmax[(size_t)qidx[g] * a.hmax_stride + t * 2 + h] = hm;   // read back 16 entries at a time by the query's team
-            }
+            if (qvalid[g]) hmax[(size_t)qidx[g] * a.hmax_stride + t * 2 + h] = hm;  // read back 16 entries at a time by the query's team
         }
     }
-    // lanes j and j + 32 saw different rows of the same queries: merge, lane j writes
-    #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        const bool valid = (g0 + g) < n_qgroups && qidx[g] < a.nq;
-        if (PASS == 2) {
-            const float od1 = __shfl_xor(d1[g], 32, 64), od2 = __shfl_xor(d2[g], 32, 64);
-            const int om = __shfl_xor(match[g], 32, 64);
-            float r1 = d1[g], r2 = d2[g];
-            int rm = match[g];
-            // the other lane's values enter as a sequential scan would see them (as match_decide_kernel)
-            if (od1 < r1) { r2 = r1; r1 = od1; rm = om; }
-            else {
-                if (od1 < r2) r2 = od1;
-                if (od1 == r1 && om >= 0 && om < rm) rm = om;
-            }
-            if (od2 < r2) r2 = od2;
-            if (h == 0 && valid) a.partial[(size_t)blockIdx.y * a.nq + qidx[g]] = Partial{ r1, r2, rm };
-        }
-    }
-    unsigned int total = evaluated;
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if (PASS == 2 && lane == 0 && total) atomicAdd(a.n_dist + 2, (unsigned long long)total);
     // statistics go to one of STAT_SLOTS counters: thousands of atomics on ONE address serialise in L2 (20 000 of
     // them, one per query, cost the scan kernel 60 of its 70 us)
-    if (PASS == 1 && lane == 0 && t_end > t_begin)
+    if (lane == 0)
         atomicAdd(a.n_dist + STAT_BASE + STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, 64ull * MF_TILE * (t_end - t_begin));
 }
-
-// threshold of pass 2: a candidate whose product is below it cannot be one of the two nearest.
-// -2 x product approximates the distance to MF_EPS * (|q|^2 + |c|^2); with M2 the second largest product, every
-// candidate with exact distance <= (second smallest exact distance) has product >= M2 - MF_EPS * (|q|^2 + max|c|^2).
-__global__ void match_threshold_kernel(const Top2 *top2, uint32_t nq, uint32_t splits, const float *q_norm, float c_norm_max, float *thr)
-{
-    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    float m1 = -INFINITY, m2 = -INFINITY;
-    for (uint32_t s = 0; s < splits; s++) {
-        const Top2 t = top2[(size_t)s * nq + qi];
-        const float lo1 = fminf(m1, t.m1);
-        m1 = fmaxf(m1, t.m1);
-        m2 = fmaxf(lo1, fmaxf(m2, t.m2));
-    }
-    thr[qi] = m2 - MF_EPS * (q_norm[qi] + c_norm_max);      // -inf when fewer than two candidates pass: all of them are verified
-}
-
 
 constexpr int SCAN_BLOCK = 64;          // one wavefront = 4 query teams
 constexpr int SCAN_HITS = 64;           // half tiles listed per query before the slow path
@@ -481,7 +402,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
                                                          const float *q_norm, float c_norm_max, const float *hmax,
                                                          float threshold, float dist2second, int *out)
 {
-    const int lane = threadIdx.x & 63, tl = lane & 15, team_shift = lane & 48;   // team = 16 consecutive lanes
+    const int lane = threadIdx.x & 63, tl = lane & 15;              // team = 16 consecutive lanes
     const uint32_t qi = blockIdx.x * (SCAN_BLOCK / 16) + (threadIdx.x >> 4);
     const bool valid = qi < a.nq;
     const uint32_t qc = min(qi, a.nq - 1);
@@ -510,8 +431,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
     // -2 x product approximates the distance to MF_EPS * (|q|^2 + |c|^2): every candidate whose exact distance is at most
     // the second smallest exact distance has a product >= (second largest product) - MF_EPS * (|q|^2 + max |c|^2)
     const float thr = t2 - MF_EPS * (q_norm[qc] + c_norm_max);      // -inf when fewer than two half tiles hold a candidate
-    // per team: its 16 candidate rows, D/4 + 1 float4 apart: the odd stride spreads the rows over all banks (with
-    // D/4 = 12 the four runs of rows collided 16 ways and the kernel spent its time in LDS: 71 us against 25 us)
+    // per team: its 16 candidate rows, D/4 + 1 float4 apart: the odd stride spreads the rows over all banks
     constexpr int ROW4 = D / 4 + 1;
     __shared__ float4 rows[SCAN_BLOCK / 16][16 * ROW4];
     const int team = threadIdx.x >> 4;
@@ -574,7 +494,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
     };
     // The half tiles to verify are first LISTED per team, then verification k of all four teams runs together: a
     // team's hits sit in different rounds of its walk, and verifying them where they are found would run the
-    // wavefront once per hit of any team with three quarters of its lanes idle (measured: 80 us against 20 us).
+    // wavefront once per hit of any team with three quarters of its lanes idle.
     __shared__ unsigned short hits[SCAN_BLOCK / 16][SCAN_HITS];
     __shared__ unsigned int n_hits[SCAN_BLOCK / 16];
     if (tl == 0) n_hits[team] = 0;
@@ -733,7 +653,7 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     m->img.resize(n_images);
 #define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
     CCHECK(hipStreamCreate(&m->stream));
-    CCHECK(hipMalloc((void **)&m->n_dist, (STAT_BASE + 2 * STAT_SLOTS) * sizeof(unsigned long long)));
+    CCHECK(hipMalloc((void **)&m->n_dist, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long)));
     std::vector<float> pad, lo, hi, sg, sc, xyz, nrm, mfv;
     for (uint32_t i = 0; i < n_images; i++) {
         const frog_keypoints &k = images[i];
@@ -836,8 +756,6 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     const uint32_t splits_max = 64;
     const uint32_t q_blocks_max = (max_n + MATCH_BLOCK - 1) / MATCH_BLOCK;
     Partial *partial = nullptr;
-    Top2 *top2 = nullptr;
-    float *thr = nullptr;
     QRange *qrange = nullptr;
     float *hmax = nullptr;                      // [tiles of the largest image][2][max_n] per ring slot
     // FROG_MATCH_VALU=1 keeps every pass on the exact vector-ALU kernel (test hook; also taken for descriptors
@@ -850,8 +768,6 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     int rc = FROG_OK;
     auto cleanup = [&]() {
         if (partial) (void)hipFree(partial);
-        if (top2) (void)hipFree(top2);
-        if (thr) (void)hipFree(thr);
         if (qrange) (void)hipFree(qrange);
         if (hmax) (void)hipFree(hmax);
         if (ranges) (void)hipFree(ranges);
@@ -863,8 +779,6 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     };
 #define RCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return FROG_E_HIP; } } while (0)
     RCHECK(hipMalloc((void **)&partial, (size_t)RING * splits_max * max_n * sizeof(Partial)));
-    RCHECK(hipMalloc((void **)&top2, (size_t)RING * splits_max * max_n * sizeof(Top2)));
-    RCHECK(hipMalloc((void **)&thr, (size_t)RING * max_n * sizeof(float)));
     RCHECK(hipMalloc((void **)&qrange, (size_t)RING * max_n * sizeof(QRange)));
     const size_t hmax_slot = (size_t)((max_n + MF_TILE - 1) / MF_TILE) * 2 * max_n;
     if (!force_valu && m->dp <= 64) RCHECK(hipMalloc((void **)&hmax, (size_t)RING * hmax_slot * sizeof(float)));
@@ -874,7 +788,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
     RCHECK(hipEventCreate(&t0));
     RCHECK(hipEventCreate(&t1));
-    RCHECK(hipMemsetAsync(m->n_dist, 0, (STAT_BASE + 2 * STAT_SLOTS) * sizeof(unsigned long long), m->stream));
+    RCHECK(hipMemsetAsync(m->n_dist, 0, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long), m->stream));
     RCHECK(hipEventRecord(t0, m->stream));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
@@ -926,20 +840,17 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 // at 20 000 x 20 000: 2 tiles 1584, 4: 2059, 8: 2249, 16: 2110
                 static const uint32_t tiles_per_block = getenv("FROG_MATCH_TILES") ? (uint32_t)std::max(1, atoi(getenv("FROG_MATCH_TILES"))) : 8u;
                 a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + tiles_per_block - 1) / tiles_per_block));
-                Top2 *t2 = top2 + (size_t)slot * splits_max * max_n;
-                float *th = thr + (size_t)slot * max_n;
                 QRange *qr = qrange + (size_t)slot * max_n;
                 float *hm = hmax + (size_t)slot * hmax_slot;
                 a.hmax_stride = 2 * ((C.n + MF_TILE - 1) / MF_TILE);
                 const dim3 mgrid(q_blocks, a.splits);
                 int *dst = d_out + (size_t)slot * max_n;
                 const bool anat = o->anat != 0.f;
-                static const uint32_t scan_div = getenv("FROG_SCAN_DIV") ? (uint32_t)atoi(getenv("FROG_SCAN_DIV")) : 1u;   // timing experiment only
                 match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, m->stream>>>(a, qr, rg);
 #define MF_LAUNCH(DD, AA)                                                                                               \
                 do {                                                                                                    \
-                    match_mfma_kernel<DD, AA, 1><<<mgrid, MATCH_BLOCK, 0, m->stream>>>(a, rg, qr, Q.mf, C.mf, t2, th, hm); \
-                    match_scan_kernel<DD, AA><<<((nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16) + scan_div - 1) / scan_div, SCAN_BLOCK, 0, m->stream>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
+                    match_mfma_kernel<DD, AA><<<mgrid, MATCH_BLOCK, 0, m->stream>>>(a, rg, qr, Q.mf, C.mf, hm);           \
+                    match_scan_kernel<DD, AA><<<(nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16), SCAN_BLOCK, 0, m->stream>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
                                                                                        o->threshold, o->dist2second, dst); \
                 } while (0)
                 if (m->dp == 48) { if (anat) MF_LAUNCH(48, true); else MF_LAUNCH(48, false); }
@@ -971,12 +882,12 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
     float ms = 0;
     RCHECK(hipEventElapsedTime(&ms, t0, t1));
-    std::vector<unsigned long long> stat(STAT_BASE + 2 * STAT_SLOTS, 0ull);
+    std::vector<unsigned long long> stat(STAT_BASE + 3 * STAT_SLOTS, 0ull);
     RCHECK(hipMemcpy(stat.data(), m->n_dist, stat.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long nd[3] = { stat[0], stat[1], stat[2] };
-    for (int k = 0; k < STAT_SLOTS; k++) { nd[2] += stat[STAT_BASE + k]; nd[1] += stat[STAT_BASE + STAT_SLOTS + k]; }
+    for (int k = 0; k < STAT_SLOTS; k++) { nd[2] += stat[STAT_BASE + k]; nd[1] += stat[STAT_BASE + STAT_SLOTS + k]; nd[0] += stat[STAT_BASE + 2 * STAT_SLOTS + k]; }
     m->last_ms = ms; m->last_dist = (double)nd[0]; m->last_computed = (double)nd[1]; m->last_fallback = (double)nd[2];
-    if (getenv("FROG_MATCH_DEBUG")) std::fprintf(stderr, "matcher: %.3f ms, %.4g pairs pass the filters, %.4g exact distances, counter[1] = %.4g\n", ms, (double)nd[0], (double)nd[2], (double)nd[1]);
+    if (getenv("FROG_MATCH_DEBUG")) std::fprintf(stderr, "matcher: %.3f ms, %.4g pairs pass the filters, %.4g computed, %.4g exact distances after the filter\n", ms, (double)nd[0], (double)nd[1], (double)nd[2]);
 #undef RCHECK
     cleanup();
 
