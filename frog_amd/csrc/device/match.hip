@@ -1,12 +1,13 @@
 // match.hip -- keypoint pairing on MI355X (include/frog_match.h).
 //
-// One thread = one query keypoint, its descriptor in registers; every lane of a wavefront meets
-// the SAME candidate at the same time, so the candidate's descriptor is wave-uniform and comes
-// through the scalar path (s_load_dwordx16 into SGPRs that feed the vector instructions directly):
-// a (query, candidate) distance costs 3 vector instructions per dimension and nothing else.
-// The kernel is f32 vector-ALU work with scalar-load latency to hide (no MFMA: the pair lists
-// must be those of the reference's scalar sum, term by term in dimension order, and a
-// |a|^2 - 2ab + |b|^2 formulation on the matrix cores rounds differently).
+// Two ways to the same pair lists.  (1) The exact vector kernel, match_kernel: one thread = one query
+// keypoint, its descriptor in registers; every lane of a wavefront meets the SAME candidate at the same
+// time; a (query, candidate) distance costs 3 vector instructions per dimension, formed exactly as the
+// reference's scalar sum, term by term in dimension order.  (2) The matrix cores as a FILTER with a proven
+// error bound (match_mfma_kernel / match_scan_kernel, further down): a |q|^2 - 2qc + |c|^2 product rounds
+// differently, so it never decides a pair -- it only tells which 32 of a query's ~3 400 candidates can be
+// among its two nearest, and those get the arithmetic of (1).  (2) is the default for descriptors of up
+// to 64 finite values; (1) runs otherwise and under FROG_MATCH_VALU=1.
 //
 // Exactness (index work, bit-exact): sub / mul / add in dimension order without contraction;
 // (d1, d2, match) updated per candidate; candidates are split into contiguous ranges over

@@ -56,6 +56,39 @@ def test_ties_duplicates_and_range_boundaries():
         same(Matcher(imgs).run([(0, 1)], **opts), match_run(imgs, [(0, 1)], **opts))
 
 
+def test_matrix_core_filter_corner_cases(monkeypatch):
+    """The MFMA filter (match.hip) must leave the pair lists of the exact vector kernel untouched: descriptor norms far
+    from 1 (the bound scales with |q|^2 + |c|^2), hundreds of identical candidates (more half tiles inside the bound
+    than the scan kernel lists: its slow path), near-ties closer than the bound, and the two paths against each other."""
+    rng = np.random.default_rng(11)
+    f = np.float32
+    base = synthetic_keypoints(2, 2500, seed=13)
+    cases = []
+    for scale in (f(1e-3), f(37.0)):                                  # tiny and large norms
+        cases.append([Keypoints(k.xyz, k.scale, k.laplacian, k.response, k.desc * scale) for k in base])
+    rows_c, rows_q = base[0].rows(), base[1].rows()
+    rows_c[:, 3] = 1.0; rows_q[:, 3] = 1.0; rows_c[:, 4] = 1.0; rows_q[:, 4] = 1.0
+    rows_c[rng.permutation(2500)[:1500], 6:] = rows_c[7, 6:]           # 1 500 identical candidates, spread over every tile
+    rows_q[:300, 6:] = rows_c[7, 6:] + f(1e-4) * rng.normal(size=(300, 48)).astype(f)
+    cases.append([Keypoints.from_rows(rows_c), Keypoints.from_rows(rows_q)])
+    rows_c, rows_q = base[0].rows(), base[1].rows()
+    rows_c[:, 3] = 1.0; rows_q[:, 3] = 1.0; rows_c[:, 4] = 1.0; rows_q[:, 4] = 1.0
+    for k in range(400):                                               # candidates 1e-6 apart: far inside the bound of 6e-5
+        rows_c[(5 * k + 1) % 2500, 6:] = rows_c[(5 * k) % 2500, 6:] + f(1e-6) * rng.normal(size=48).astype(f)
+    rows_q[:400, 6:] = rows_c[(5 * np.arange(400)) % 2500, 6:] + f(3e-4) * rng.normal(size=(400, 48)).astype(f)
+    cases.append([Keypoints.from_rows(rows_c), Keypoints.from_rows(rows_q)])
+    for imgs in cases:
+        for opts in (dict(threshold=1e9, dist2second=1.0), dict(threshold=1e9, dist2second=0.9, sym=1)):
+            want = match_run(imgs, [(0, 1)], **opts)
+            monkeypatch.delenv("FROG_MATCH_VALU", raising=False)
+            got = Matcher(imgs).run([(0, 1)], **opts)
+            monkeypatch.setenv("FROG_MATCH_VALU", "1")
+            vec = Matcher(imgs).run([(0, 1)], **opts)
+            monkeypatch.delenv("FROG_MATCH_VALU")
+            same(got, want); same(vec, want)
+            assert len(want[0][0]) > 100
+
+
 def test_scale_ratio_boundary_and_filters():
     # scales straddling the 1.3 ratio by single ulps on both sides, both signs
     n = 512
