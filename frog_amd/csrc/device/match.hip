@@ -592,6 +592,7 @@ struct frog_matcher {
     uint32_t dim = 0, dp = 0;
     std::vector<DevImage> img;
     hipStream_t stream = nullptr;
+    hipStream_t extra[3] = { nullptr, nullptr, nullptr };   // image pairs rotate over stream + extra[]: one pair's tail overlaps the next pairs' start
     unsigned long long *n_dist = nullptr;
     double last_ms = 0, last_dist = 0, last_computed = 0, last_fallback = 0;
 };
@@ -623,6 +624,7 @@ void frog_matcher_destroy(frog_matcher *m)
     }
     if (m->n_dist) (void)hipFree(m->n_dist);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (hipStream_t e : m->extra) if (e) (void)hipStreamDestroy(e);
     delete m;
 }
 
@@ -654,6 +656,7 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     m->img.resize(n_images);
 #define CCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); frog_matcher_destroy(m); return FROG_E_HIP; } } while (0)
     CCHECK(hipStreamCreate(&m->stream));
+    for (hipStream_t &e : m->extra) CCHECK(hipStreamCreate(&e));
     CCHECK(hipMalloc((void **)&m->n_dist, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long)));
     std::vector<float> pad, lo, hi, sg, sc, xyz, nrm, mfv;
     for (uint32_t i = 0; i < n_images; i++) {
@@ -791,6 +794,8 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     RCHECK(hipEventCreate(&t1));
     RCHECK(hipMemsetAsync(m->n_dist, 0, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long), m->stream));
     RCHECK(hipEventRecord(t0, m->stream));
+    static const int n_streams = getenv("FROG_MATCH_STREAMS") ? std::min(4, std::max(1, atoi(getenv("FROG_MATCH_STREAMS")))) : 4;   // measured, image pairs/s: 1 stream 4537, 2: 5832, 3: 6345, 4: 6652 (a slot is reused only after the host has waited for it)
+    for (int k = 1; k < n_streams; k++) RCHECK(hipStreamWaitEvent(m->extra[k - 1], t0, 0));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
     std::vector<int> by_query;
@@ -821,6 +826,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
         const Pass &ps = passes[pi];
         const DevImage &Q = m->img[ps.query], &C = m->img[ps.cand];
         const uint32_t nq = Q.n;
+        hipStream_t st = (pi % n_streams) ? m->extra[pi % n_streams - 1] : m->stream;
         if (nq) {
             const uint32_t q_blocks = (nq + MATCH_BLOCK - 1) / MATCH_BLOCK;
             // every query block splits ITS candidate range over `splits` blocks (whole tiles)
@@ -847,36 +853,45 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 const dim3 mgrid(q_blocks, a.splits);
                 int *dst = d_out + (size_t)slot * max_n;
                 const bool anat = o->anat != 0.f;
-                match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, m->stream>>>(a, qr, rg);
+                match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, st>>>(a, qr, rg);
 #define MF_LAUNCH(DD, AA)                                                                                               \
                 do {                                                                                                    \
-                    match_mfma_kernel<DD, AA><<<mgrid, MATCH_BLOCK, 0, m->stream>>>(a, rg, qr, Q.mf, C.mf, hm);           \
-                    match_scan_kernel<DD, AA><<<(nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16), SCAN_BLOCK, 0, m->stream>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
+                    match_mfma_kernel<DD, AA><<<mgrid, MATCH_BLOCK, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm);           \
+                    match_scan_kernel<DD, AA><<<(nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16), SCAN_BLOCK, 0, st>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
                                                                                        o->threshold, o->dist2second, dst); \
                 } while (0)
                 if (m->dp == 48) { if (anat) MF_LAUNCH(48, true); else MF_LAUNCH(48, false); }
                 else { if (anat) MF_LAUNCH(64, true); else MF_LAUNCH(64, false); }
 #undef MF_LAUNCH
                 RCHECK(hipGetLastError());
-                RCHECK(hipMemcpyAsync(h_out + (size_t)slot * max_n, dst, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-                RCHECK(hipEventRecord(done[slot], m->stream));
+                RCHECK(hipMemcpyAsync(h_out + (size_t)slot * max_n, dst, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+                RCHECK(hipEventRecord(done[slot], st));
                 continue;
             }
             const dim3 grid(q_blocks, splits);
-            match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, m->stream>>>(a, q_blocks, rg);
+            match_range_kernel<<<(q_blocks + 63) / 64, 64, 0, st>>>(a, q_blocks, rg);
             switch (m->dp) {
-            case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
-            case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
-            case 96: match_kernel<96><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
-            default: match_kernel<128><<<grid, MATCH_BLOCK, 0, m->stream>>>(a, rg); break;
+            case 48: match_kernel<48><<<grid, MATCH_BLOCK, 0, st>>>(a, rg); break;
+            case 64: match_kernel<64><<<grid, MATCH_BLOCK, 0, st>>>(a, rg); break;
+            case 96: match_kernel<96><<<grid, MATCH_BLOCK, 0, st>>>(a, rg); break;
+            default: match_kernel<128><<<grid, MATCH_BLOCK, 0, st>>>(a, rg); break;
             }
-            match_decide_kernel<<<(nq + 255) / 256, 256, 0, m->stream>>>(a.partial, nq, splits, o->threshold, o->dist2second,
+            match_decide_kernel<<<(nq + 255) / 256, 256, 0, st>>>(a.partial, nq, splits, o->threshold, o->dist2second,
                                                                          d_out + (size_t)slot * max_n);
             RCHECK(hipGetLastError());
             RCHECK(hipMemcpyAsync(h_out + (size_t)slot * max_n, d_out + (size_t)slot * max_n, (size_t)nq * sizeof(int),
-                                  hipMemcpyDeviceToHost, m->stream));
+                                  hipMemcpyDeviceToHost, st));
         }
-        RCHECK(hipEventRecord(done[slot], m->stream));
+        RCHECK(hipEventRecord(done[slot], st));
+    }
+    {
+        for (int k = 1; k < n_streams; k++) {
+            hipEvent_t joined = nullptr;
+            RCHECK(hipEventCreateWithFlags(&joined, hipEventDisableTiming));
+            hipError_t e1 = hipEventRecord(joined, m->extra[k - 1]), e2 = hipStreamWaitEvent(m->stream, joined, 0);
+            (void)hipEventDestroy(joined);
+            RCHECK(e1); RCHECK(e2);
+        }
     }
     RCHECK(hipEventRecord(t1, m->stream));
     RCHECK(hipStreamSynchronize(m->stream));
