@@ -303,22 +303,24 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_qrange_kernel(const MatchAr
 
 // hmax[query][2 * tile + half] = the largest product among the 16 candidates of that half tile that pass the query's
 // filters (-inf if none); blockIdx.y splits the candidate tiles of the query block's range.
-template <int D, bool ANAT>
-__global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
+template <int D, bool ANAT, int G>
+__global__ __launch_bounds__(MATCH_BLOCK * 2 / G) void match_mfma_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
                                                                  const float *q_mf, const float *c_mf, float *hmax)
 {
     constexpr int STEPS = (D + 2) / 2;              // MFMA instructions per 32 x 32 tile (K = 2 each)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t g0 = (blockIdx.x * MATCH_BLOCK + wave * 64) / MF_TILE;       // the wave's two query groups: g0, g0 + 1
+    // a wavefront multiplies every candidate tile it loads with G groups of 32 queries (g0 .. g0 + G - 1); the block's
+    // MATCH_BLOCK / (32 G) wavefronts cover the MATCH_BLOCK queries that share a candidate range
+    const uint32_t g0 = (blockIdx.x * MATCH_BLOCK + wave * 32 * G) / MF_TILE;
     const uint32_t n_qgroups = (a.nq + MF_TILE - 1) / MF_TILE;
     if (g0 >= n_qgroups) return;
 
-    float b[2][STEPS], qx[2], qy[2], qz[2];
-    uint32_t qfirst[2], qcount[2], qidx[2];
-    bool qvalid[2];
+    float b[G][STEPS], qx[G], qy[G], qz[G];
+    uint32_t qfirst[G], qcount[G], qidx[G];
+    bool qvalid[G];
     #pragma unroll
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < G; g++) {
         const uint32_t grp = min(g0 + g, n_qgroups - 1);
         const float *src = q_mf + (size_t)grp * STEPS * 64 + lane;
         #pragma unroll
@@ -359,17 +361,18 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
             #pragma unroll
             for (int s2 = 0; s2 < STEPS; s2++) nx[s2] = src[s2 * 64];
         }
-        f32x16 acc0, acc1;
+        f32x16 acc[G];
         #pragma unroll
-        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        for (int g = 0; g < G; g++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[g][r] = 0.f;
         #pragma unroll
-        for (int s2 = 0; s2 < STEPS; s2++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b[0][s2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b[1][s2], acc1, 0, 0, 0);
-        }
+        for (int s2 = 0; s2 < STEPS; s2++)
+            #pragma unroll
+            for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], b[g][s2], acc[g], 0, 0, 0);
         const uint32_t base = t * MF_TILE + 4 * h;
         #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < G; g++) {
             float hm = -INFINITY;
             #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void match_mfma_kernel(const MatchArgs
                     const float ex = qx[g] - a.c_xyz[3 * (size_t)cc], ey = qy[g] - a.c_xyz[3 * (size_t)cc + 1], ez = qz[g] - a.c_xyz[3 * (size_t)cc + 2];
                     pass = pass && !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
                 }
-                hm = fmaxf(hm, pass ? (g == 0 ? acc0[r] : acc1[r]) : -INFINITY);
+                hm = fmaxf(hm, pass ? acc[g][r] : -INFINITY);
             }
             if (qvalid[g]) hmax[(size_t)qidx[g] * a.hmax_stride + t * 2 + h] = hm;  // read back 16 entries at a time by the query's team
         }
@@ -853,10 +856,14 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 const dim3 mgrid(q_blocks, a.splits);
                 int *dst = d_out + (size_t)slot * max_n;
                 const bool anat = o->anat != 0.f;
+                // query groups per wavefront: 4 halves the candidate loads per product but needs 234 registers (2 wavefronts per
+                // SIMD instead of 3); measured the same within noise (5 971 vs 5 982 image pairs/s), so 2 stays the default
+                static const int mf_groups = getenv("FROG_MATCH_GROUPS") && atoi(getenv("FROG_MATCH_GROUPS")) == 4 ? 4 : 2;
                 match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, st>>>(a, qr, rg);
 #define MF_LAUNCH(DD, AA)                                                                                               \
                 do {                                                                                                    \
-                    match_mfma_kernel<DD, AA><<<mgrid, MATCH_BLOCK, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm);           \
+                    if (mf_groups == 4) match_mfma_kernel<DD, AA, 4><<<mgrid, MATCH_BLOCK / 2, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm); \
+                    else match_mfma_kernel<DD, AA, 2><<<mgrid, MATCH_BLOCK, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm);       \
                     match_scan_kernel<DD, AA><<<(nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16), SCAN_BLOCK, 0, st>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
                                                                                        o->threshold, o->dist2second, dst); \
                 } while (0)
