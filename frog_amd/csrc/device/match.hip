@@ -261,8 +261,12 @@ __global__ void match_decide_kernel(const Partial *partial, uint32_t nq, uint32_
 // The sign / scale filters of a query select ONE contiguous range of the sorted candidates (see the header),
 // found per query by binary search (match_qrange_kernel): the test is two integer compares.
 constexpr int MF_TILE = 32;             // points per MFMA operand group
-// |(-2 x product) - reference distance| <= MF_EPS * (|q|^2 + |c|^2): D + 2 products and sums in f32 in the chain,
-// D sums in the reference's own chain, the rounded norms: under 2^-24 * 512 (D <= 64) in all
+// |(-2 x product) - reference distance| <= MF_EPS * (|q|^2 + |c|^2), with u = 2^-24 and S = |q|^2 + |c|^2:
+//   reference: sub, mul and D - 1 adds in f32 per term    -> |d_ref - d| <= (D + 3) u d <= 2 (D + 3) u S   (d <= 2 S)
+//   product:   an fmaf chain of D + 2 steps (one rounding each) over terms whose magnitudes add up to at most S
+//                                                         -> |P - P_exact| <= (D + 2) u S
+//   the stored half norms are the f64 sums rounded to f32 -> |-2 P_exact - d| <= u S
+// together (4 D + 11) u S = 267 u S at D = 64, 1.6e-5 S; MF_EPS = 2^-15 = 3.1e-5 leaves a factor 2.
 constexpr float MF_EPS = 1.0f / 32768.0f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
         #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t e = e0 + 16 * k + tl;
-            if (e < n_entries && v[k] >= thr) {
+            if (e < n_entries && v[k] >= thr && v[k] > -INFINITY) {     // -inf: no candidate of that half tile passes the filters
                 const unsigned int p = atomicAdd(&n_hits[team], 1u);
                 if (p < (unsigned int)SCAN_HITS) hits[team][p] = (unsigned short)e;
             }
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
         if (k < n_mine) verify(hits[team][k]);
     if (overflow)
         for (uint32_t e = 0; e < n_entries; e++)
-            if (hrow[e] >= thr) verify(e);
+            if (hrow[e] >= thr && hrow[e] > -INFINITY) verify(e);
     #pragma unroll
     for (int off = 8; off > 0; off >>= 1) {                             // merge the team's partials (as match_decide_kernel)
         const float od1 = __shfl_xor(d1, off, 64), od2 = __shfl_xor(d2, off, 64);
