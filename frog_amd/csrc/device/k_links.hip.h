@@ -453,13 +453,16 @@ __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partia
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
+    if (!last) return;
+    // the last block: all block sums fetched side by side (one thread each: 128 dependent loads by one thread took
+    // longer than a second launch), then added in block order by one thread
+    __threadfence();
+    if (threadIdx.x < 2 * gridDim.x && threadIdx.x < 256)
+        sh[0][threadIdx.x] = __hip_atomic_load(&block_sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
         double s0 = 0, s1 = 0;
-        for (unsigned int k = 0; k < gridDim.x; k++) {
-            s0 += __hip_atomic_load(&block_sums[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += __hip_atomic_load(&block_sums[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (unsigned int k = 0; k < gridDim.x; k++) { s0 += sh[0][2 * k]; s1 += sh[0][2 * k + 1]; }
         energy[0] = s0; energy[1] = s1; energy[2] = 0.0; energy[3] = 0.0;
         *ticket = 0u;                                       // ready for the next launch (same stream: ordered)
     }
