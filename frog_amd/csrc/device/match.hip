@@ -792,7 +792,10 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     RCHECK(hipMalloc((void **)&partial, (size_t)RING * splits_max * max_n * sizeof(Partial)));
     RCHECK(hipMalloc((void **)&qrange, (size_t)RING * max_n * sizeof(QRange)));
     const size_t hmax_slot = (size_t)((max_n + MF_TILE - 1) / MF_TILE) * 2 * max_n;
-    if (!force_valu && m->dp <= 64) RCHECK(hipMalloc((void **)&hmax, (size_t)RING * hmax_slot * sizeof(float)));
+    // the half-tile maxima need n^2 / 16 floats per image pair in flight (100 MB at 20 000 keypoints): images beyond
+    // ~90 000 keypoints (16 GB for the ring) take the vector kernel
+    const bool hmax_fits = (double)RING * (double)hmax_slot * sizeof(float) <= 16.0 * 1024 * 1024 * 1024;
+    if (!force_valu && m->dp <= 64 && hmax_fits) RCHECK(hipMalloc((void **)&hmax, (size_t)RING * hmax_slot * sizeof(float)));
     RCHECK(hipMalloc((void **)&ranges, (size_t)RING * q_blocks_max * sizeof(uint2)));
     RCHECK(hipMalloc((void **)&d_out, (size_t)RING * max_n * sizeof(int)));
     RCHECK(hipHostMalloc((void **)&h_out, (size_t)RING * max_n * sizeof(int)));
@@ -847,7 +850,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
             a.partial = partial + (size_t)slot * splits_max * max_n;
             a.n_dist = m->n_dist;
             uint2 *rg = ranges + (size_t)slot * q_blocks_max;
-            const bool mfma = !force_valu && m->dp <= 64 && Q.finite && C.finite && C.n > 0;
+            const bool mfma = hmax != nullptr && Q.finite && C.finite && C.n > 0;
             if (mfma) {
                 // candidate tiles per block: few = even load over the 256 CUs (the query blocks' ranges differ a lot in
                 // length), many = the block's 256 queries are loaded as operands less often.  Measured, image pairs/s
