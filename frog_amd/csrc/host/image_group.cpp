@@ -77,7 +77,10 @@ void ImageGroup::check(int rc, const char *what)
 void ImageGroup::readPairs(const char *fileName)
 {
     int status = 0;
+    const auto t_read = std::chrono::steady_clock::now();
     frog_pairs *p = frog_pairs_read(fileName, &status);
+    if (std::getenv("FROG_TIMING"))
+        cout << "[timing] readPairs : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read).count() << "s" << endl;
     if (!p) {
         // a block of size 0 is the reference's "Error : number of pairs is 0", exit(1)
         cout << "Error : number of pairs is 0 or unreadable file " << fileName << endl;
@@ -172,7 +175,8 @@ void ImageGroup::run()
         exit(1);
     }
     if (numberOfFixedImages) readAndApplyFixedImagesTransforms();       // :34
-    createContext();                                                    // :36 setupStats
+    { const auto t_ctx = clk::now(); createContext();                   // :36 setupStats
+      if (std::getenv("FROG_TIMING")) cout << "[timing] frog_create : " << std::chrono::duration<double>(clk::now() - t_ctx).count() << "s" << endl; }
     check(frog_linear_init(ctx, linearInitializationAnchor), "frog_linear_init");   // :37
     check(frog_transform_points(ctx, 0), "frog_transform_points");      // :38
 
@@ -282,17 +286,26 @@ void ImageGroup::run()
         cout << "Grids per level : ";
         for (int n : gridsPerLevel) { total += n; cout << n << " "; }
         cout << endl << "Total number of grids : " << total << endl;
-        saveErrorMaps();                                                // :141
+        { auto t = clk::now(); saveErrorMaps();                         // :141
+          if (std::getenv("FROG_TIMING")) cout << "[timing] error maps : " << std::chrono::duration<double>(clk::now() - t).count() << "s" << endl; }
     }
 
     displayStats();                                                     // :144
+    const bool timing = std::getenv("FROG_TIMING") != nullptr;         // new: where the time after the solve goes
+    auto lap = [&, last = clk::now()](const char *what) mutable {
+        if (timing) cout << "[timing] " << what << " : " << std::chrono::duration<double>(clk::now() - last).count() << "s" << endl;
+        last = clk::now();
+    };
     saveDistanceHistograms("histograms.csv");
     saveMeasures(outputFileName);
+    lap("histograms + measures");
     saveTransforms();
+    lap("transforms");
     saveLandmarkDistances();                                            // :149
     saveTransformedLandmarks();                                         // :150
     if (writePairs) writeLinksDistances();                              // :151
     saveStatsJSON();
+    lap("landmarks + pairs + bbox.json");
 }
 
 // saveErrorMaps, imageGroup.cxx:475-567: the residual sums come from the device (one sweep),
@@ -302,17 +315,26 @@ void ImageGroup::saveErrorMaps()
     std::filesystem::create_directory(errorMapsSubdirectory.c_str());
     check(frog_residual_sums(ctx), "frog_residual_sums");
     const uint32_t n = frog_num_images(ctx);
-    std::vector<float> map;
+    std::vector<frog_grid_info> infos(n);
+    std::vector<std::vector<float>> maps(n);
     for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :481
-        frog_grid_info info;
-        check(frog_get_error_map(ctx, image, &info, nullptr, 0), "frog_get_error_map");
-        map.resize((size_t)4 * info.dims[0] * info.dims[1] * info.dims[2]);
-        check(frog_get_error_map(ctx, image, &info, map.data(), map.size()), "frog_get_error_map");
+        check(frog_get_error_map(ctx, image, &infos[image], nullptr, 0), "frog_get_error_map");
+        maps[image].resize((size_t)4 * infos[image].dims[0] * infos[image].dims[1] * infos[image].dims[2]);
+        check(frog_get_error_map(ctx, image, &infos[image], maps[image].data(), maps[image].size()), "frog_get_error_map");
+    }
+    int failed = 0;
+    #pragma omp parallel for schedule(dynamic, 1)                                   // compression and file output on all host threads
+    for (int image = numberOfFixedImages; image < (int)n; image++) {
+        const frog_grid_info &info = infos[image];
         std::ostringstream file;
         file << errorMapsSubdirectory << "/" << image << ".nii.gz";
         const uint32_t dims[3] = { (uint32_t)info.dims[0], (uint32_t)info.dims[1], (uint32_t)info.dims[2] };
-        check(frog_nifti_write(file.str().c_str(), dims, info.spacing, info.origin, 4, map.data()), "frog_nifti_write");
+        if (frog_nifti_write(file.str().c_str(), dims, info.spacing, info.origin, 4, maps[image].data())) {
+            #pragma omp atomic
+            failed++;
+        }
     }
+    if (failed) check(FROG_E_IO, "frog_nifti_write");
 }
 
 // Stats::getInlierProbability + chipdf, stats.h:10-16,84-92 (promotions as upstream)
@@ -620,24 +642,37 @@ void ImageGroup::saveTransforms()
     std::filesystem::create_directory(transformSubdirectory.c_str());
     const uint32_t n = frog_num_images(ctx);
     const int nGrids = frog_num_grids(ctx);
+    // first everything comes back from the device (one thread, the context's stream), then the files are formatted,
+    // compressed and written image by image on all host threads: gzip of 700 sidecars is what this function costs
+    // (1.76 s on one thread for 100 images x 7 lattices)
+    struct Fetched { double m[16]; std::vector<frog_grid_info> info; std::vector<std::vector<float>> coeffs; };
+    std::vector<Fetched> all(n);
     for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :1464
+        Fetched &f = all[image];
+        check(frog_get_linear(ctx, image, f.m), "frog_get_linear");
+        f.info.resize(nGrids); f.coeffs.resize(nGrids);
+        for (int k = 0; k < nGrids; k++) {
+            check(frog_get_grid(ctx, image, k, &f.info[k], nullptr, 0), "frog_get_grid");
+            f.coeffs[k].resize((size_t)3 * f.info[k].dims[0] * f.info[k].dims[1] * f.info[k].dims[2]);
+            check(frog_get_grid(ctx, image, k, &f.info[k], f.coeffs[k].data(), f.coeffs[k].size()), "frog_get_grid");
+        }
+    }
+    int failed = 0;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int image = numberOfFixedImages; image < (int)n; image++) {
+        const Fetched &f = all[image];
         frogjson::Value transforms = frogjson::Value::array();
         {
-            double m[16];
-            check(frog_get_linear(ctx, image, m), "frog_get_linear");
             frogjson::Value t = frogjson::Value::object();
             t["type"] = frogjson::Value("vtkMatrixToLinearTransform");
             frogjson::Value mat = frogjson::Value::array();
-            for (int k = 0; k < 16; k++) mat.push(frogjson::Value(m[k]));
+            for (int k = 0; k < 16; k++) mat.push(frogjson::Value(f.m[k]));
             t["matrix"] = mat;
             transforms.push(t);
         }
         for (int k = 0; k < nGrids; k++) {
-            frog_grid_info info;
-            check(frog_get_grid(ctx, image, k, &info, nullptr, 0), "frog_get_grid");
-            const size_t nv = (size_t)3 * info.dims[0] * info.dims[1] * info.dims[2];
-            std::vector<float> c(nv);
-            check(frog_get_grid(ctx, image, k, &info, c.data(), nv), "frog_get_grid");
+            const frog_grid_info &info = f.info[k];
+            const std::vector<float> &c = f.coeffs[k];
             frogjson::Value t = frogjson::Value::object();
             t["type"] = frogjson::Value("vtkBSplineTransform");
             if (!writeSingleFileTransforms) {
@@ -646,7 +681,10 @@ void ImageGroup::saveTransforms()
                 t["file"] = frogjson::Value(base.str());
                 const std::string path = transformSubdirectory + "/" + base.str();
                 const uint32_t d3[3] = { (uint32_t)info.dims[0], (uint32_t)info.dims[1], (uint32_t)info.dims[2] };
-                check(frog_nifti_write(path.c_str(), d3, info.spacing, info.origin, 3, c.data()), "frog_nifti_write");
+                if (frog_nifti_write(path.c_str(), d3, info.spacing, info.origin, 3, c.data())) {
+                    #pragma omp atomic
+                    failed++;
+                }
                 transforms.push(t);
                 continue;
             }
@@ -658,8 +696,8 @@ void ImageGroup::saveTransforms()
             }
             t["dimensions"] = dims; t["origin"] = ori; t["spacing"] = sp;
             frogjson::Value coeffs = frogjson::Value::array();
-            coeffs.arr.reserve(nv);
-            for (size_t j = 0; j < nv; j++) coeffs.arr.push_back(frogjson::Value((double)c[j]));
+            coeffs.arr.reserve(c.size());
+            for (size_t j = 0; j < c.size(); j++) coeffs.arr.push_back(frogjson::Value((double)c[j]));
             t["coeffs"] = coeffs;
             transforms.push(t);
         }
@@ -672,6 +710,7 @@ void ImageGroup::saveTransforms()
         fs << root.serialize();
         fs.close();
     }
+    if (failed) check(FROG_E_IO, "frog_nifti_write");
 }
 
 // bbox.json: the `stats` object of the reference (imageGroup.cxx:152-155) =
