@@ -3,6 +3,7 @@
 // no CPU path in this library.
 
 #include "ctx.h"
+#include <hip/hip_ext.h>
 #include "prep.h"
 #include "k_links.hip.h"
 #include "k_stats.hip.h"
@@ -35,17 +36,19 @@ static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1
 // RAII bracket: records a HIP event pair around the launches issued in its scope.
 struct Span {
     frog_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
-    Span(frog_ctx *ctx, int s) : c(ctx), slot(s)
+    bool attached;          // the events ride on ONE kernel's own dispatch packet (hipExtLaunchKernelGGL) instead of being
+                            // recorded around it: no marker packets, so no bubbles before and after the kernel
+    Span(frog_ctx *ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach)
     {
         if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE)) return;
         if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        (void)hipEventRecord(a, c->stream);
+        if (!attached) (void)hipEventRecord(a, c->stream);
     }
     ~Span()
     {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        if (!attached) (void)hipEventRecord(b, c->stream);
         c->spans.push_back({ a, b, slot });
     }
 };
@@ -80,16 +83,18 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
 }
 
 template <int MODE>
-static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s)
+static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
 {
     uint32_t widest = 0;
     for (uint32_t g = 0; g < ctx->n_groups; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
+    const SweepArgs args = sweep_args(ctx, sub);
+    const dim3 grid(sweep_blocks(ctx)), block(256);
     if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
-        sweep_kernel<MODE, true, false><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, false>), grid, block, 0, s, ea, eb, 0, args);
     else if (widest <= (uint32_t)EMD_LDS_IMAGES)
-        sweep_kernel<MODE, true, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, true>), grid, block, 0, s, ea, eb, 0, args);
     else
-        sweep_kernel<MODE, false, true><<<sweep_blocks(ctx), 256, 0, s>>>(sweep_args(ctx, sub));
+        hipExtLaunchKernelGGL((sweep_kernel<MODE, false, true>), grid, block, 0, s, ea, eb, 0, args);
 }
 
 extern "C" {
@@ -580,9 +585,9 @@ int frog_linear_step_local(frog_ctx *ctx)
     if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
     hipStream_t s = ctx->stream;
     {
-        Span span(ctx, FROG_K_SWEEP_LINEAR);
+        Span span(ctx, FROG_K_SWEEP_LINEAR, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
-            launch_sweep<SWEEP_LINEAR>(ctx, sub, s);
+            launch_sweep<SWEEP_LINEAR>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr);
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, ctx->mat.p,
@@ -799,9 +804,9 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     const uint32_t nO = ctx->n_owned();
     // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
     {
-        Span span(ctx, FROG_K_SWEEP_DEFORMABLE);
+        Span span(ctx, FROG_K_SWEEP_DEFORMABLE, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
-            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
+            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr);
     }
     FROG_HIP_CHECK(hipGetLastError());
     {
