@@ -242,11 +242,10 @@ class ShardedImageGroup:
         if len({e - b for b, e in rows}) == 1 and rows[0][0] == 0 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])):
             # equal shards: one all-gather (ncclAllGather over xGMI) straight into the replica
             b, e = rows[self.rank]
-            mine = self.engine.xyz2[b:e]
-            # RCCL/NCCL gathers in place when the input is this rank's slice of the output (ncclAllGather with
-            # sendbuff == recvbuff + rank * count); other backends get a private copy
-            if self._dist.get_backend(self.group) != "nccl":
-                mine = mine.clone()
+            # the rank's own rows go through a private copy (a few MB, microseconds): gathering in place, with the input
+            # aliasing this rank's slice of the output, is legal for ncclAllGather but could not be exercised on the
+            # one-GPU boxes this was developed on
+            mine = self.engine.xyz2[b:e].clone()
             self._dist.all_gather_into_tensor(self.engine.xyz2[:rows[-1][1]], mine, group=self.group)
             return
         # ragged shards: still ONE collective -- every rank contributes its rows padded to the longest
