@@ -251,6 +251,7 @@ struct frog_ctx {
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 
     // live timing
+    bool point_sums_stale = false;             // the last deformable step left the per-point sums as N_XCD partial sums
     int profiling = 0;                         // 0 off, 1 every kernel group, 2 the two half-link sweeps only
     struct TimedSpan { hipEvent_t a, b; int slot; };
     std::vector<TimedSpan> spans;             // recorded, not yet read

@@ -811,8 +811,13 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     FROG_HIP_CHECK(hipGetLastError());
     {
         Span span(ctx, FROG_K_COMBINE);
-        combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
-            ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
+        // the per-point sums are only materialised when something other than the scatter reads them (landmark
+        // constraints here, frog_get_point_sums later): the scatter adds the N_XCD partial sums itself
+        static const bool always_combine = getenv("FROG_COMBINE") != nullptr;      // test hook
+        ctx->point_sums_stale = !(ctx->n_hard || always_combine);
+        if (!ctx->point_sums_stale)
+            combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
+                ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
         energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
                                                            ctx->energy_ticket.p, ctx->energy.p);
         if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
@@ -825,7 +830,9 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);
         const size_t tile_bytes = (size_t)(gd.brick + 3) * (gd.brick + 3) * (gd.brick + 3) * sizeof(float4);
-        scatter_kernel<<<ctx->n_scatter_blocks, 64, tile_bytes, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->perm.p,
+        scatter_kernel<<<ctx->n_scatter_blocks, 64, tile_bytes, s>>>(ctx->pos.p, ctx->point_sums.p,
+                                                           ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
+                                                           ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
                                                            reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                                                            ctx->gradf.p, ctx->scatter_stage.p, gd);
         lattice_reduce_kernel<<<div_up((size_t)nO * gd.n_cp, 256), 256, 0, s>>>(ctx->scatter_stage.p, ctx->brick_slot_ptr.p,
@@ -1164,6 +1171,12 @@ int frog_get_error_map(frog_ctx *ctx, uint32_t image, frog_grid_info *info, floa
 int frog_get_point_sums(frog_ctx *ctx, float *out)
 {
     CTX_GUARD(ctx);
+    if (ctx->point_sums_stale && ctx->own_pt_end > ctx->own_pt_begin) {
+        combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, ctx->stream>>>(
+            ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        ctx->point_sums_stale = false;
+    }
     std::vector<float4> h(ctx->P);
     FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->point_sums.p, h.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));

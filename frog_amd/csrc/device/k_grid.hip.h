@@ -423,6 +423,7 @@ struct ScatterPoint {
 static_assert(sizeof(ScatterPoint) == 80, "ScatterPoint layout");
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
+                                                     const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
                                                      const uint32_t *perm, const ScatterBlock *blocks,
                                                      float4 *gradf, float4 *stage, const GeomDev g)
 {
@@ -459,7 +460,20 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
         me.base = -1;
         if (s < blk.end) {
             const uint32_t p = perm[s];
-            const float4 sm = point_sums[p];
+            float4 sm;
+            if (group_sums) {
+                // the point's sums straight from the N_XCD partial sums of the sweep, added in group order exactly as
+                // combine_groups_kernel does (same bits): saves that kernel's pass over 288 MB
+                const uint32_t li = p - own_pt_begin;
+                float4 part[N_XCD];
+                #pragma unroll
+                for (int q = 0; q < N_XCD; q++) part[q] = group_sums[(size_t)q * own_points + li];
+                sm = part[0];
+                #pragma unroll
+                for (int q = 1; q < N_XCD; q++) { sm.x += part[q].x; sm.y += part[q].y; sm.z += part[q].z; sm.w += part[q].w; }
+            } else {
+                sm = point_sums[p];
+            }
             if (sm.w != 0.f) {                       // imageGroup.cxx:299
                 const float4 v = pos[p];
                 const float in[3] = { v.x, v.y, v.z };
