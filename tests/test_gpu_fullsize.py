@@ -153,3 +153,24 @@ def test_matcher_at_pipeline_size():
     n = len(got[0][0])
     assert np.array_equal(sym[0][:n], got[0][0]) and np.array_equal(sym[1][:n], got[0][1])
     assert np.all(np.diff(sym[0][n:].astype(np.int64)) > 0)
+
+
+def test_ransac_at_pipeline_size():
+    # the incremental-registration stage of tools/register.py at the pipeline's keypoint count: one image of
+    # 20 000 keypoints against 19 fixed ones (2.0e5 half-links), 5 000 candidates as upstream's default
+    pairs = Pairs.synthetic(20, 20000, 10526, seed=1, scale_min=1.0, scale_max=1.0)
+    n = pairs.n_images
+    g = ImageGroup(pairs, n_fixed_images=n - 1)
+    ref = OracleGroup(pairs.model, _abi.FrogOptions.default(n_fixed_images=n - 1))
+    ref.setup_stats()
+    g.setupLinearTransforms(); ref.linear_init()
+    g.transformPoints(); ref.transform_points()
+    a = g.RANSAC(n - 1, iterations=5000, batches=8)
+    b = ref.ransac(n - 1, iterations=5000, batches=8)
+    assert a == b > 20000                                              # an integer census: identical
+    m = g.matrix(n - 1)
+    assert np.allclose(m, ref.matrix(n - 1), rtol=1e-9, atol=1e-9)
+    s = np.cbrt(np.linalg.det(m[:3, :3]))
+    assert np.allclose(m[:3, :3] @ m[:3, :3].T, s * s * np.eye(3), atol=1e-9) and 0.9 < s < 1.1
+    g.transformPoints(); ref.transform_points()
+    assert np.array_equal(g.points()[1], ref.xyz2())                   # same matrix to 1e-13, f32 positions identical
