@@ -174,3 +174,34 @@ def test_ransac_at_pipeline_size():
     assert np.allclose(m[:3, :3] @ m[:3, :3].T, s * s * np.eye(3), atol=1e-9) and 0.9 < s < 1.1
     g.transformPoints(); ref.transform_points()
     assert np.array_equal(g.points()[1], ref.xyz2())                   # same matrix to 1e-13, f32 positions identical
+
+
+def test_reslice_at_volume_size():
+    # VolumeTransform's kernel on a 192^3 int16 volume through the INVERSE of a 1 + 3 link chain: identity chain = the
+    # volume itself (every voxel), a slab against the oracle, and the size-independent property that resampling
+    # through T^-1 and looking a voxel centre up through T meet in the same place
+    from frog_amd.chain import Chain, Link, invert
+    from oracle.oracle_api import chain_apply, chain_reslice
+    rng = np.random.default_rng(2)
+    M = np.eye(4); M[:3, 3] = [2.0, -1.0, 1.5]
+    links = [Link.linear(M)]
+    for k in (4, 8, 8):
+        dims = (k + 3, k + 3, k + 3)
+        sp = tuple(300.0 / k for _ in range(3))
+        links.append(Link.bspline(dims, tuple(-s for s in sp), sp, (1.5 * rng.normal(size=(dims[0] ** 3, 3))).astype(np.float32)))
+    n = 192
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    vol = (1000 + 600 * np.sin(x / 7.0) * np.cos(y / 9.0) + 3 * z).astype(np.int16)
+    o, s = (0.0, 0.0, 0.0), (300.0 / n,) * 3
+    assert np.array_equal(Chain([]).reslice(vol, o, s, (n, n, n), o, s, 1, -1.0), vol)
+    inv = invert(links)
+    c = Chain(inv)
+    got = c.reslice(vol, o, s, (n, n, n), o, s, 1, -1.0)
+    slab_o = (0.0, 0.0, 60 * s[2])
+    want = np.clip(np.floor(chain_reslice(inv, vol, o, s, (n, n, 8), slab_o, s, 1, -1.0) + 0.5), -32768, 32767)
+    assert np.abs(got[60:68] - want).max() <= 1 and (got[60:68] != want).mean() < 2e-3
+    # voxel p of the output shows the source at T^-1(p): pushing that point through T must give p back
+    idx = rng.integers(20, n - 20, (2000, 3))
+    p = idx[:, ::-1] * np.array(s)                                      # (x, y, z) of voxel [z, y, x]
+    back = chain_apply(links, c.apply(p))
+    assert np.abs(back - p).max() < 2e-3                                # VTK's inverse tolerance
