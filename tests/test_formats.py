@@ -245,3 +245,33 @@ def test_volume_files_round_trip_and_independent_readers(tmp_path, dtype):
     open(tmp_path / "bad.nii", "wb").write(b"\0" * 400)
     with pytest.raises(OSError):
         read_volume(tmp_path / "bad.nii")
+
+
+@pytest.mark.parametrize("self_block", [False, True])
+def test_link_order_on_a_larger_random_group(self_block):
+    """The link table is built by one thread per image (serially when a block pairs an image with itself): in both
+    cases a point's links must come out in readPairs' push_back order (imageGroup.cxx:1405-1406), repeated image
+    pairs and duplicate links included."""
+    rng = np.random.default_rng(17)
+    sizes = [30, 1, 57, 12, 40, 8]
+    po = np.concatenate([[0], np.cumsum(sizes)])
+    blocks = []
+    pairs_of_images = [(0, 2), (0, 4), (2, 4), (1, 2), (3, 5), (0, 2), (4, 5), (2, 3)]       # (0, 2) twice
+    if self_block:
+        pairs_of_images.insert(3, (2, 2))
+    for i1, i2 in pairs_of_images:
+        n = int(rng.integers(1, 60))
+        blocks.append((i1, i2, rng.integers(0, sizes[i1], n).astype(np.uint32), rng.integers(0, sizes[i2], n).astype(np.uint32)))
+    p = Pairs.from_arrays(po, np.zeros((po[-1], 3), np.float32), blocks)
+    links = {}
+    for i1, i2, a, b in blocks:
+        for x, y in zip(a.tolist(), b.tolist()):
+            links.setdefault((i1, x), []).append((i2, y))
+            links.setdefault((i2, y), []).append((i1, x))
+    rp, li, lp = p.row_ptr, p.link_image, p.link_point
+    for im in range(len(sizes)):
+        for pt in range(sizes[im]):
+            g = po[im] + pt
+            got = list(zip(li[rp[g]:rp[g + 1]].tolist(), lp[rp[g]:rp[g + 1]].tolist()))
+            assert got == links.get((im, pt), []), (im, pt)
+    assert rp[-1] == 2 * sum(len(b[2]) for b in blocks)
