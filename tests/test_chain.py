@@ -172,3 +172,22 @@ def test_reslice_oracle_closed_forms():
     zz, yy, xx = np.meshgrid(np.arange(3), np.arange(4), np.arange(5), indexing="ij")
     P = np.stack([oo[0] + os_[0] * xx, oo[1] + os_[1] * yy, oo[2] + os_[2] * zz, np.ones_like(xx)], -1) @ A.T
     assert not np.isnan(out).any() and np.allclose(out, 2.0 * P[..., 0] - P[..., 1] + 0.5 * P[..., 2])
+
+
+def test_invert_links_is_host_side_and_involutive():
+    """frog_chain_invert_links (vtkGeneralTransform::Inverse, VolumeTransform.cxx:55-57) needs no device: reversed
+    order, inverted matrices, lattices switched between forward and Newton evaluation; twice = the chain itself."""
+    from frog_amd.chain import BSPLINE, BSPLINE_INVERSE, LINEAR, invert
+    links = smooth_chain()
+    inv = invert(links)
+    assert [l.kind for l in inv] == [BSPLINE_INVERSE, LINEAR]
+    assert np.allclose(inv[1].matrix @ links[0].matrix, np.eye(4), atol=1e-13)
+    assert inv[0].dims == links[1].dims and np.array_equal(inv[0].coeffs, links[1].coeffs)
+    back = invert(inv)
+    assert [l.kind for l in back] == [LINEAR, BSPLINE] and np.allclose(back[0].matrix, links[0].matrix, atol=1e-13)
+    pts = np.random.default_rng(3).uniform(0, 80, (500, 3))
+    assert np.abs(chain_apply(inv, chain_apply(links, pts)) - pts).max() < 2e-3
+    singular = [Link.linear(np.diag([1.0, 0.0, 1.0, 1.0]))]
+    with pytest.raises(RuntimeError):
+        invert(singular)
+    assert invert([]) == []
