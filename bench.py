@@ -204,14 +204,25 @@ def main():
                 "frac": achieved / 8000.0, "traffic": None,
                 "avg_launch_ms": ms / launches if launches else None, "launches": int(launches),
                 "algorithmic_bytes_per_launch": alg_bytes, "half_links_per_launch": l_own}
+    # Certified outlier culling (frog_hip.h): the deformable sweep decides EVERY half-link, most false matches by a
+    # distance bound instead of an evaluation.  `achieved` above prices the launch at the reference's bytes for all L
+    # half-links; `frac_listed` prices it at the half-links it actually walked.
+    lists_built, listed, owned = engine.cull_stats()
+    if lists_built and launches:
+        roofline["culling"] = {"lists_built": int(lists_built), "listed_half_links": int(listed),
+                               "listed_fraction": listed / max(owned, 1),
+                               "frac_listed": (20.0 * listed + 12.0 * p_own) / (ms / launches * 1e-3) / 1e9 / 8000.0}
     # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE collected in their own
     # rocprofv3 passes by scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
     # doubled on gfx950).  Counters cannot be read from inside this process, so the committed measurement of
-    # the same workload is reported; null when there is none for this workload / shard size.
+    # the same workload is reported; null when there is none for this workload / shard size, or when the device
+    # sources have changed since it was taken (profiles/hbm_traffic.json "measured_at").
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tr = json.load(fh)
-        if tr.get("kernel") == dom and tr.get("half_links_per_launch") == l_own:
+        # keyed on the workload AND on the device sources the counters were collected with: stale after any kernel change
+        if (tr.get("kernel") == dom and tr.get("half_links_per_launch") == l_own
+                and tr.get("measured_at") == _abi.device_source_hash()):
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
             roofline["traffic_source"] = tr.get("source")
     except (OSError, ValueError, KeyError):

@@ -10,6 +10,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
+
+
+def device_source_hash():
+    """sha256 (first 16 hex digits) over the HIP sources of libfrog_hip.so, in name order: what a PMC
+    measurement under profiles/ is keyed on, so that bench.py can tell when the kernels have changed since."""
+    import hashlib
+    d = os.path.join(_HERE, "csrc", "device")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -89,7 +105,7 @@ class FrogKernelTime(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
 
 
-FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine"]
+FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM, FROG_E_IO = range(7)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 
@@ -190,6 +206,8 @@ HIP_SYMBOLS = {
     "frog_deformable_phase_a": (C.c_int, [C.c_void_p, C.c_float]),
     "frog_deformable_phase_b": (C.c_int, [C.c_void_p]),
     "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
+    "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "frog_test_inlier_probability": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_size_t, c_float_p, c_float_p]),
     "frog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(FrogKernelTime), C.c_int]),
 }

@@ -250,6 +250,19 @@ struct frog_ctx {
     float pending_alpha = 0;
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 
+    // certified outlier culling of the deformable sweep (k_cull.hip.h)
+    bool cull_enabled = true;                 // FROG_CULL=0 turns it off (every sweep walks all records)
+    bool cull_need_build = true;              // host side: (re)build the list before the next deformable sweep
+    float cull_scale = 2.0f, cull_pad = 25.0f; // list cutoff = scale * certified cutoff + pad (the skin)
+    frog::DevBuf<uint32_t> act_recs32;        // listed records (narrow form), or ...
+    frog::DevBuf<frog::LinkRec> act_recs;     // ... wide form; same offsets as recs32 / recs
+    frog::DevBuf<uint32_t> act_cnt;           // [n_tiles][n_groups]
+    frog::DevBuf<frog::P3> pos2_snap;         // xyz2 of every point when the list was built
+    frog::DevBuf<float> cut_now, cut_list;    // [nI] certified cutoff of the current mixtures / list cutoff at build time
+    frog::DevBuf<uint32_t> disp_bits;         // [nI] largest displacement since the build (f32 bits)
+    frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
+    uint64_t cull_builds = 0, cull_listed = 0; // statistics: lists built, records in the last one
+
     // live timing
     bool point_sums_stale = false;             // the last deformable step left the per-point sums as N_XCD partial sums
     int profiling = 0;                         // 0 off, 1 every kernel group, 2 the two half-link sweeps only

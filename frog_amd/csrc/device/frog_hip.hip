@@ -8,6 +8,7 @@
 #include "k_links.hip.h"
 #include "k_stats.hip.h"
 #include "k_grid.hip.h"
+#include "k_cull.hip.h"
 #include "k_ransac.hip.h"
 #include "similarity.h"
 
@@ -79,15 +80,31 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
+    a.act_recs = nullptr; a.act_cnt = nullptr; a.cull_state = nullptr;
     return a;
 }
 
+// culling applies to the deformable sweeps of a context whose threshold leaves room for the certified margin
+static bool cull_active(const frog_ctx *ctx)
+{
+    return ctx->cull_enabled && ctx->deformable && ctx->opt.inlier_threshold >= 1e-3f && ctx->n_tiles > 0;
+}
+
 template <int MODE>
-static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
+static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr,
+                         bool use_list = false)
 {
     uint32_t widest = 0;
     for (uint32_t g = 0; g < ctx->n_groups; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
-    const SweepArgs args = sweep_args(ctx, sub);
+    // a context without tiles (every owned image is empty): nothing to launch -- a grid of 0 blocks is an invalid
+    // configuration; the reductions that follow read no tile partials and write zero sums
+    if (ctx->n_tiles == 0) return;
+    SweepArgs args = sweep_args(ctx, sub);
+    if (use_list) {         // the caller has run cull_check() for the coordinates this launch reads
+        args.act_recs = ctx->rec_format.narrow ? (const void *)ctx->act_recs32.p : (const void *)ctx->act_recs.p;
+        args.act_cnt = ctx->act_cnt.p;
+        args.cull_state = ctx->cull_state.p;
+    }
     const dim3 grid(sweep_blocks(ctx)), block(256);
     if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
         hipExtLaunchKernelGGL((sweep_kernel<MODE, true, false>), grid, block, 0, s, ea, eb, 0, args);
@@ -185,6 +202,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (rc) { delete c; return fail(rc, err); }
     c->L_own = lay.ref_link.size();
     c->rec_format = lay.format;
+    for (uint32_t g = 0; lay.format.narrow && g < c->n_groups; g++)
+        if (lay.group_begin[g + 1] - lay.group_begin[g] > (uint32_t)EMD_LDS_IMAGES) {
+            delete c;
+            return fail(FROG_E_INVALID, "internal: narrow link records chosen for a partner group of more than 256 images");
+        }
     c->L_recs = lay.format.narrow ? lay.recs32.size() : lay.recs.size();
     c->n_tiles = (uint32_t)lay.tiles.size();
     for (uint32_t g = 0; g <= c->n_groups; g++) c->group_begin[g] = lay.group_begin[g];
@@ -303,6 +325,15 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6));
     em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
+    CREATE_CHECK(hipGetLastError());
+    // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
+    if (const char *e = getenv("FROG_CULL")) c->cull_enabled = atoi(e) != 0;
+    if (const char *e = getenv("FROG_CULL_SKIN")) {
+        float a = 0, b = 0;
+        if (sscanf(e, "%f,%f", &a, &b) == 2 && a >= 1.0f && b >= 0.0f) { c->cull_scale = a; c->cull_pad = b; }
+    }
+    CREATE_CHECK(c->cut_now.alloc(c->nI));
+    cull_cutoff_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->nI, c->opt.inlier_threshold, c->cut_now.p);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     // selection of the first refresh, ahead of time
@@ -443,6 +474,9 @@ int frog_stats_publish(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
     em_derive_kernel<<<div_up(ctx->nI, 256), 256, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI);
+    // the certified outlier cutoffs follow the mixtures (k_cull.hip.h); the check before the next sweep compares them
+    // with the list's
+    cull_cutoff_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -793,6 +827,50 @@ int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out)
     return frog_deformable_setup_bounds(ctx, level, mn, mx, out);
 }
 
+// Certified outlier culling (k_cull.hip.h): (re)build the list when the host knows it is due, then check it against
+// the coordinates and mixtures the sweep is about to read; the sweep takes the result from cull_state on the device.
+static int cull_prepare(frog_ctx *ctx)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t nI = ctx->nI;
+    if (!ctx->act_cnt.p) {
+        if (ctx->rec_format.narrow) {
+            FROG_HIP_CHECK(ctx->act_recs32.alloc(ctx->L_recs));
+            FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs32.p, 0, ctx->act_recs32.bytes(), s));    // null records, as the padding of the full array
+        } else {
+            FROG_HIP_CHECK(ctx->act_recs.alloc(ctx->L_recs));
+            FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs.p, 0, ctx->act_recs.bytes(), s));
+        }
+        FROG_HIP_CHECK(ctx->act_cnt.alloc((size_t)ctx->n_tiles * ctx->n_groups));
+        FROG_HIP_CHECK(ctx->pos2_snap.alloc(ctx->P));
+        FROG_HIP_CHECK(ctx->cut_list.alloc(nI));
+        FROG_HIP_CHECK(ctx->disp_bits.alloc(nI));
+        FROG_HIP_CHECK(ctx->cull_state.alloc(2));
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));
+        ctx->cull_need_build = true;
+    }
+    if (ctx->cull_need_build) {
+        cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->cull_scale, ctx->cull_pad, ctx->cut_list.p);
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2_snap.p, ctx->pos2.p, ctx->P * sizeof(P3), hipMemcpyDeviceToDevice, s));
+        const SweepArgs args = sweep_args(ctx, 0);
+        const dim3 grid(sweep_blocks(ctx), ctx->n_sub);
+        if (ctx->rec_format.narrow)
+            cull_build_kernel<false><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs32.p, ctx->act_cnt.p);
+        else
+            cull_build_kernel<true><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs.p, ctx->act_cnt.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->disp_bits.p, 0, ctx->disp_bits.bytes(), s));
+        ctx->cull_need_build = false;
+        ctx->cull_builds++;
+    }
+    uint32_t max_pts = 1;
+    for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
+    cull_disp_kernel<<<dim3(div_up(max_pts, CULL_BLOCK_POINTS), nI), 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_bits.p);
+    cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_bits.p, nI, ctx->cull_state.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
 // ---- updateDeformableTransforms (imageGroup.cxx:234-472) -----------------------------------
 int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
 {
@@ -803,10 +881,16 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
     // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
+    const bool culled = cull_active(ctx);
+    if (culled) {
+        Span span(ctx, FROG_K_CULL);
+        int rc = cull_prepare(ctx);
+        if (rc) return rc;
+    }
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
-            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr);
+            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr, culled);
     }
     FROG_HIP_CHECK(hipGetLastError());
     {
@@ -819,7 +903,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
                 ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
         energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
-                                                           ctx->energy_ticket.p, ctx->energy.p);
+                                                           ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr);
         if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
             hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
                                                                     ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, ctx->hl_partial.p);
@@ -892,6 +976,7 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     ctx->xyz2_fresh = true;
     FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
     const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
+    if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // this step's sweep found the culling list out of date
     ctx->phase = 0;
     if (E) *E = (ctx->opt.guarantee_diffeomorphism && nbig > 0) ? -1.0 : e;      // :434-439
     return FROG_OK;
@@ -1193,6 +1278,49 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
     const size_t n = std::min(cap, 4 * G);
     FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->gradf.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed, uint64_t *owned)
+{
+    CTX_GUARD(ctx);
+    if (lists_built) *lists_built = ctx->cull_builds;
+    if (owned) *owned = ctx->L_own;
+    if (listed) {
+        *listed = 0;
+        if (ctx->cull_builds && ctx->act_cnt.n) {
+            std::vector<uint32_t> h(ctx->act_cnt.n);
+            FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->act_cnt.p, ctx->act_cnt.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (uint32_t v : h) *listed += v;
+        }
+    }
+    return FROG_OK;
+}
+
+__global__ void test_probability_kernel(const float4 em, const float *d, size_t n, float *fast, float *exact)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = inlier_probability(d[i], em_derived_of(em));
+    exact[i] = inlier_probability_exact(d[i], em);
+}
+
+int frog_test_inlier_probability(int device, const float em3[3], const float *d, size_t n, float *fast, float *exact)
+{
+    if (!em3 || (n && (!d || !fast || !exact))) return fail(FROG_E_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
+    FROG_HIP_CHECK(hipSetDevice(device));
+    if (!n) return FROG_OK;
+    DevBuf<float> dd, df, de;
+    FROG_HIP_CHECK(dd.alloc(n)); FROG_HIP_CHECK(df.alloc(n)); FROG_HIP_CHECK(de.alloc(n));
+    FROG_HIP_CHECK(hipMemcpy(dd.p, d, n * sizeof(float), hipMemcpyHostToDevice));
+    test_probability_kernel<<<div_up(n, 256), 256>>>(make_float4(em3[0], em3[1], em3[2], 0.f), dd.p, n, df.p, de.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return FROG_OK;
 }
 

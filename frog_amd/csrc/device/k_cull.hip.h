@@ -1,0 +1,211 @@
+// k_cull.hip.h -- certified outlier culling for the deformable half-link sweep.
+//
+// In updateDeformableTransforms a half-link whose weight is below inlierThreshold contributes NOTHING:
+// not to the point's sums, not to the energy (imageGroup.cxx:268-278: `if ( weight < inlierThreshold ) continue`).
+// A third of the links of a typical group are false matches whose end points lie hundreds of millimetres
+// apart, and they stay outliers for the whole run -- but the sweep pays a record, a scattered 12-byte gather
+// and four exponentials for each of them, every iteration.  This file lets the sweep skip the links that are
+// PROVABLY outliers, the way a molecular-dynamics code keeps a neighbour list with a skin:
+//
+//   cut_now[k]   per image, refreshed with the mixture: a distance D_k such that every d >= D_k has
+//                getInlierProbability_k(d) <= inlierThreshold / 2 (cull_cutoff_kernel; the probability of a
+//                two-component Maxwell mixture with c1 < c2 decreases in d beyond sqrt(2) c1, see there).
+//                weight = min(pA, pB), so d >= min(D_A, D_B) makes the link an outlier, whatever the other end says.
+//   list         built once in a while (cull_build_kernel): the records of every (tile, partner group) whose
+//                distance at build time is below min(cut_list[A], cut_list[B]), compacted IN THEIR ORDER into a
+//                second record array; cut_list[k] = scale * cut_now[k] + pad is generous (the skin).
+//   check        before every sweep (cull_disp_kernel + cull_validate_kernel): disp[k] = largest distance of a
+//                point of image k from where it was at build time.  A link left out at build time had
+//                d_build >= cut_list[k] for k = A or B, so now d >= cut_list[k] - disp[A] - disp[B]; if
+//                    cut_list[k] - disp[k] - max_j disp[j] >= cut_now[k]  (+ rounding margin)   for EVERY image k
+//                every left-out link is still a certain outlier and the sweep may walk the list instead of all
+//                records.  Otherwise the flag tells the sweep (on the device, same launch) to walk all records,
+//                and the host (through the fourth scalar it reads back per iteration anyway) to rebuild the list.
+//
+// The listed records keep their relative order, the skipped ones would have added +0.0 to f64 sums and nothing
+// to f32 sums: every output is bit-identical to the full sweep (tests/test_gpu_round2.py compares whole runs with
+// FROG_CULL=0 and 1, and with a zero skin that invalidates the list at every step).  Nothing is approximated and
+// no decision is cached: a listed link is evaluated from scratch each iteration.
+#pragma once
+
+#include "ctx.h"
+#include "k_links.hip.h"
+
+namespace frog {
+
+// Stats::getInlierProbability (stats.h:84-92) in f64, real-valued form (no f32 roundings): only used to
+// place the cutoff, with a factor-two margin on the probability, so 1e-6-level differences are irrelevant.
+__device__ inline double mixture_probability(double d, double c1, double c2, double ratio)
+{
+    const double eps = 1e-10, c = 0.797884560802865;
+    const double a = d / (c1 + eps), b = d / (c2 + eps);
+    const double x1 = ratio * c * a * a * exp(-0.5 * a * a) / (c1 + eps);
+    const double x2 = (1.0 - ratio) * c * b * b * exp(-0.5 * b * b) / (c2 + eps);
+    return x1 / (x1 + x2 + eps);
+}
+
+// cut_now[k]: smallest distance (to bisection accuracy, rounded up) from which image k's inlier probability is
+// certainly below the threshold.  p = 1 / (1 + x2/x1 + eps/x1); x2/x1 = A exp(d^2 (1/c1^2 - 1/c2^2) / 2) grows with d
+// when c1 < c2, and eps/x1 grows once chi(d/c1) falls, i.e. for d > sqrt(2) c1: p decreases on [sqrt(2) c1, inf).
+// So p(D) <= threshold/2 at some D >= sqrt(2) c1 implies p(d) <= threshold/2 for all d >= D.  The sweep's f32
+// evaluation is within 1e-5 of the real value (k_links.hip.h, bound at inlier_probability), far inside the margin
+// between threshold/2 and threshold - THRESHOLD_BAND for any threshold >= 1e-3.  No cutoff (+inf: the image's links
+// are always listed) when the mixture is degenerate (c1 >= c2, ratio outside (0,1), non-finite) or the threshold tiny.
+__global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float threshold, float *cut_now)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    const float4 e = em[i];
+    const double c1 = e.x, c2 = e.y, r = e.z;
+    float out = __builtin_inff();
+    if (threshold >= 1e-3f && c1 > 0.0 && c2 > c1 && r > 0.0 && r < 1.0 && c2 < 1e30) {
+        const double target = 0.5 * (double)threshold;
+        double lo = fmax(1.4142135623730951 * (c1 + 1e-10) * 1.000001, 0.2);      // also past the `d < 0.1 -> 1` branch
+        if (mixture_probability(lo, c1, c2, r) <= target) {
+            out = (float)lo;
+        } else {
+            double hi = lo;
+            bool found = false;
+            for (int k = 0; k < 200 && !found; k++) {
+                hi *= 2.0;
+                found = mixture_probability(hi, c1, c2, r) <= target;
+            }
+            if (found) {
+                for (int k = 0; k < 64; k++) {
+                    const double mid = 0.5 * (lo + hi);
+                    if (mixture_probability(mid, c1, c2, r) <= target) hi = mid; else lo = mid;
+                }
+                out = (float)hi;
+            }
+        }
+        // round up: (float) may have rounded down
+        if (out < __builtin_inff()) out = out * 1.000001f + 1e-6f;
+    }
+    cut_now[i] = out;
+}
+
+__global__ void cull_list_cutoff_kernel(const float *cut_now, uint32_t n_images, float scale, float pad, float *cut_list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_images) cut_list[i] = scale * cut_now[i] + pad;          // inf stays inf
+}
+
+// Compacts the records of every (tile, partner group) range whose end points are closer than the list cutoff into
+// act_recs, at the same offsets and in the same chunked / transposed storage as the full array (ctx.h REC_CHUNK), in
+// their order; act_cnt[tile][group] = how many.  One wavefront per range, as the sweep; grid.y = sub-pass.  The
+// distance is the sweep's own expression (f32, no contraction).  Runs when the list is (re)built only: no pipeline.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, const float *cut_list, void *act_recs, uint32_t *act_cnt)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t xcd = blockIdx.x % N_XCD;
+    const uint32_t grp = blockIdx.y * N_XCD + xcd;
+    const uint32_t t = (blockIdx.x / N_XCD) * 4 + wave;
+    if (t >= a.n_tiles) return;
+    const Tile &tl = a.tiles[t];
+    const uint32_t pt_begin = tl.pt_begin, image = tl.image;
+    const uint32_t rec_lo = tl.rec_begin + tl.group_off[grp], rec_n = tl.group_cnt[grp];
+    const uint32_t g_first = a.group_begin[grp];
+    const float cutA = cut_list[image];
+    using Rec = std::conditional_t<WIDE, unsigned long long, unsigned int>;
+    const Rec *src = reinterpret_cast<const Rec *>(a.recs);
+    Rec *dst = reinterpret_cast<Rec *>(act_recs);
+    auto phys = [&](uint32_t k) { return (size_t)rec_lo + (k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u; };
+    uint32_t base = 0;
+    for (uint32_t k0 = 0; k0 < rec_n; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        bool keep = false;
+        Rec rq = 0;
+        if (k < rec_n) {
+            rq = src[phys(k)];
+            const uint32_t ia = (uint32_t)rq & 0xFFu;
+            uint32_t imgB, pb_index;
+            if constexpr (WIDE) {
+                imgB = (uint32_t)rq >> 8;
+                pb_index = (uint32_t)(rq >> 32);
+            } else {
+                imgB = g_first + __builtin_amdgcn_ubfe((uint32_t)rq, 8u, a.img_bits);
+                pb_index = a.poff[imgB] + ((uint32_t)rq >> (8u + a.img_bits));
+            }
+            const P3 pa = a.pos2[pt_begin + ia], pb = a.pos2[pb_index];
+            const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float cut = fminf(cutA, cut_list[imgB]);
+            keep = d2 < cut * cut;                  // NaN or inf distance: left out, and an outlier in the full sweep too
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) dst[phys(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = rq;
+        base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) act_cnt[(size_t)t * a.n_groups + grp] = base;
+}
+
+// disp[k] = max over the points of image k of |xyz2 now - xyz2 at build time| (f32 bits: non-negative floats
+// order like unsigned integers; a NaN compares above every number and invalidates the list, as it should).
+// grid = (chunks of CULL_BLOCK_POINTS points, image).
+constexpr int CULL_BLOCK_POINTS = 2048;
+
+__global__ __launch_bounds__(256) void cull_disp_kernel(const P3 *pos2, const P3 *snap, const uint32_t *poff, uint32_t *disp_bits)
+{
+    __shared__ uint32_t sh[4];
+    const uint32_t img = blockIdx.y;
+    const uint32_t p0 = poff[img] + blockIdx.x * CULL_BLOCK_POINTS, pe = poff[img + 1];
+    if (p0 >= pe) return;
+    const uint32_t p1 = min(p0 + (uint32_t)CULL_BLOCK_POINTS, pe);
+    uint32_t m = 0;
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const P3 u = pos2[p], v = snap[p];
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
+        const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        m = max(m, __float_as_uint(d) & 0x7FFFFFFFu);
+    }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+        if (m) atomicMax(&disp_bits[img], m);
+    }
+}
+
+// state[0] = 1 when some left-out link could have come within its images' cutoff (the sweep then walks all records
+// and the host rebuilds the list), else 0; disp_bits is cleared for the next check.  The margin (1e-4 relative, 0.01
+// absolute on the cutoff, 1e-5 relative on the list cutoff) covers the f32 roundings of the distances involved
+// (a few ulps of coordinates that are < 1e5 in any unit a medical image uses).  One block.
+__global__ __launch_bounds__(256) void cull_validate_kernel(const float *cut_now, const float *cut_list, uint32_t *disp_bits,
+                                                            uint32_t n_images, uint32_t *state)
+{
+    __shared__ float shm[256];
+    __shared__ int bad_s;
+    float mx = 0.f;
+    bool nan = false;
+    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
+        const float d = __uint_as_float(disp_bits[i]);
+        if (d != d) nan = true; else mx = fmaxf(mx, d);
+    }
+    shm[threadIdx.x] = nan ? __builtin_nanf("") : mx;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+        bool anynan = false;
+        for (int k = 0; k < 256; k++) { if (shm[k] != shm[k]) anynan = true; else v = fmaxf(v, shm[k]); }
+        shm[0] = anynan ? __builtin_nanf("") : v;
+    }
+    __syncthreads();
+    const float dispmax = shm[0];
+    int bad = 0;
+    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
+        const float d = __uint_as_float(disp_bits[i]);
+        const float need = cut_now[i] * 1.0001f + 0.01f + d + dispmax;          // inf when the image has no cutoff
+        const float have = cut_list[i] * 0.99999f;
+        if (!(need <= have)) bad = 1;                                           // also catches NaN
+        disp_bits[i] = 0u;
+    }
+    if (bad) atomicOr(&bad_s, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) state[0] = bad_s ? 1u : 0u;
+}
+
+} // namespace frog

@@ -289,19 +289,23 @@ __global__ __launch_bounds__(256) void em_kernel(const float *samples, const uin
 
 // (c1,c2,ratio) -> constants of inlier_probability for ALL images (after the
 // EM table has been made whole by the all-reduce in multi-rank runs).
-__global__ void em_derive_kernel(const float4 *em, EmDerived *emd, uint32_t n_images)
+__device__ __forceinline__ EmDerived em_derived_of(const float4 e)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_images) return;
     const float eps = 1e-10f;
     const float c = 0.797884560802865f;
-    float4 e = em[i];
     EmDerived d;
     d.inv1 = 1.0f / (e.x + eps);
     d.inv2 = 1.0f / (e.y + eps);
     d.k1 = e.z * c * d.inv1;
     d.k2 = (1.0f - e.z) * c * d.inv2;
-    emd[i] = d;
+    return d;
+}
+
+__global__ void em_derive_kernel(const float4 *em, EmDerived *emd, uint32_t n_images)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    emd[i] = em_derived_of(em[i]);
 }
 
 } // namespace frog

@@ -11,9 +11,21 @@
 // from a window of a few images at a time: the gathers hit the 4 MiB per-XCD L2
 // instead of scattering over the whole coordinate table.  Points are first renumbered
 // along a Morton curve inside each image (see Layout).  Within a point the
-// order stays partner-ascending, which is the order readPairs produces for
-// files written by match (blocks i-major, j-ascending: imageGroup.cxx:1405-1406,
-// match.cpp:727-742), so per-point f32 sums keep the reference's order.
+// order is partner-image ascending (stable: links into one partner image keep
+// their file order).  What that guarantees about the f32 per-point sums of the
+// deformable step (imageGroup.cxx:270-278):
+//   * inside ONE partner group (1/8 of the partner images, one XCD) the adds of a
+//     point happen in partner-ascending order, which is the reference's order
+//     for files whose blocks are i-major / j-ascending -- what `match` writes
+//     (match.cpp:727-742) and readPairs then stores (imageGroup.cxx:1405-1406);
+//   * the 8 group sums of a point are added afterwards, in group order: the
+//     association differs from the reference's single running sum (last-ulp
+//     differences, inside the 1e-5 the parity tests allow for these sums);
+//   * for files with another block order (other producers) the order inside a
+//     group is still partner-ascending, i.e. NOT the file's: same class of
+//     last-ulp difference (tests/test_gpu_round2.py checks a shuffled-block file).
+// Weights within 1e-4 of the inlier threshold are re-evaluated with the
+// reference's own arithmetic (k_links.hip.h), so these ulps cannot flip a link.
 #pragma once
 
 #include "ctx.h"
@@ -195,7 +207,9 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
         for (uint32_t i = 0; i < nI; i++) largest_image = std::max(largest_image, poff[i + 1] - poff[i]);
         auto bits_for = [](uint32_t n) { uint32_t b = 1; while ((1ull << b) < n) b++; return b; };   // values 0 .. n-1
         const uint32_t img_bits = bits_for(widest_group), pt_bits = bits_for(largest_image);
-        out.format.narrow = (8 + img_bits + pt_bits <= 32 && !force_wide) ? 1u : 0u;
+        // img_bits <= 8: the narrow kernel keeps the group's constants and first-point table in 2^8-entry LDS arrays
+        // (k_links.hip.h EMD_LDS_IMAGES); a group of more images takes the wide form, whose kernel reads them from memory
+        out.format.narrow = (8 + img_bits + pt_bits <= 32 && img_bits <= 8 && !force_wide) ? 1u : 0u;
         out.format.img_bits = img_bits;
     }
     const bool narrow = out.format.narrow != 0;

@@ -188,6 +188,12 @@ class HipEngine:
                                         xyz2.ctypes.data_as(_abi.c_float_p)), "frog_get_points")
         return xyz, xyz2
 
+    def cull_stats(self):
+        """(lists built, half-links in the last list, half-links owned): frog_cull_stats."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.frog_cull_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats")
+        return a.value, b.value, c.value
+
     def profile_enable(self, on=True):
         """True/1: every kernel group; 2: the half-link sweeps only (cheap); False/0: off."""
         check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")

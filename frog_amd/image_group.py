@@ -256,6 +256,13 @@ class ImageGroup:
         check(self._lib.frog_set_hard_links(self._ctx, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), len(a), float(weight2)),
               "frog_set_hard_links")
 
+    def cull_stats(self):
+        """(lists built, half-links in the last list, half-links owned) of the outlier-culling list
+        (frog_hip.h: frog_cull_stats)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.frog_cull_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats")
+        return a.value, b.value, c.value
+
     def residualSums(self):
         check(self._lib.frog_residual_sums(self._ctx), "frog_residual_sums")
 
@@ -264,3 +271,16 @@ class ImageGroup:
         check(self._lib.frog_get_gradient(self._ctx, image, out.ctypes.data_as(_abi.c_float_p), 4 * n_cp),
               "frog_get_gradient")
         return out
+
+
+def device_inlier_probability(em, d, device=0):
+    """The half-link sweep's inlier weight for distances ``d`` under the mixture ``em`` = (c1, c2, ratio), evaluated on
+    the device: (fast f32 form used for every link, form with the reference's promotions used near the threshold)."""
+    lib = _abi.hip_lib()
+    e = np.ascontiguousarray(em, np.float32)
+    dd = np.ascontiguousarray(d, np.float32)
+    fast, exact = np.empty_like(dd), np.empty_like(dd)
+    check(lib.frog_test_inlier_probability(device, e.ctypes.data_as(_abi.c_float_p), dd.ctypes.data_as(_abi.c_float_p),
+                                           dd.size, fast.ctypes.data_as(_abi.c_float_p),
+                                           exact.ctypes.data_as(_abi.c_float_p)), "frog_test_inlier_probability")
+    return fast, exact

@@ -188,6 +188,24 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha);
 int frog_deformable_phase_b(frog_ctx *ctx);
 int frog_deformable_phase_c(frog_ctx *ctx, double *E);
 
+/* ---- certified outlier culling of the deformable sweep ------------------------------
+ * In updateDeformableTransforms a half-link with weight < inlierThreshold adds nothing
+ * (imageGroup.cxx:268-278).  The library keeps a list of the half-links that are not PROVABLY below
+ * the threshold (distance bound per image from its mixture + the points' displacement since the list
+ * was built; frog_amd/csrc/device/k_cull.hip.h) and sweeps only those; results are bit-identical to
+ * sweeping every half-link.  On by default; the environment variable FROG_CULL=0 at frog_create turns
+ * it off.  frog_cull_stats reports what it did: lists built so far, half-links in the last list and
+ * half-links owned (0 listed = no list yet). */
+int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
+
+/* ---- test hook: the sweep's inlier weight -------------------------------------------
+ * Evaluates, on `device`, Stats::getInlierProbability (stats.h:84-92) for n distances with the mixture
+ * (c1, c2, ratio) twice: `fast` = the f32 form the half-link sweeps use for every link, `exact` = the form
+ * with the reference's own promotions (f64 exp) that decides weights within 1e-4 of the inlier threshold.
+ * tests/test_gpu_round2.py compares both with the reference build of stats.cxx. */
+int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d, size_t n,
+                                 float *fast, float *exact);
+
 /* ---- live kernel timing (HIP events on the context's stream) ------------------ */
 enum {
     FROG_K_SWEEP_LINEAR = 0,   /* half-link sweep of updateLinearTransforms     */
@@ -197,6 +215,7 @@ enum {
     FROG_K_TRANSFORM,          /* transformPoints                               */
     FROG_K_STATS,              /* reservoir + distances + EM fit                */
     FROG_K_COMBINE,            /* per-point sums of the partner groups added up, energy reduction */
+    FROG_K_CULL,               /* outlier-culling list: validity check before a deformable sweep, rebuilds */
     FROG_K_COUNT_
 };
 typedef struct frog_kernel_time {

@@ -87,6 +87,7 @@ def ref_lib():
             return None
         L = C.CDLL(path)
         _bind_stats(L, "refstats_")
+        L.refstats_inlier_probability_n.argtypes = [C.c_void_p, fp, C.c_int, fp]
         L.refstats_chipdf.restype = C.c_float
         L.refstats_chipdf.argtypes = [C.c_float]
         _ref = L
@@ -156,6 +157,13 @@ class Stats:
 
     def prob(self, d):
         return self._f("inlier_probability")(self.h, float(d))
+
+    def prob_n(self, d):
+        """getInlierProbability for an array of distances (reference build only)."""
+        d = np.ascontiguousarray(d, np.float32)
+        out = np.empty_like(d)
+        self.L.refstats_inlier_probability_n(self.h, d.ctypes.data_as(fp), d.size, out.ctypes.data_as(fp))
+        return out
 
     def size(self):
         return self._f("size")(self.h)

@@ -35,6 +35,11 @@ void refstats_add_samples(void *p, const float *v, int n)
 }
 void refstats_estimate(void *p) { ((Stats *)p)->estimateDistribution(); }
 float refstats_inlier_probability(void *p, float d) { return ((Stats *)p)->getInlierProbability(d); }
+void refstats_inlier_probability_n(void *p, const float *d, int n, float *out)
+{
+    Stats *s = (Stats *)p;
+    for (int i = 0; i < n; i++) out[i] = s->getInlierProbability(d[i]);
+}
 void refstats_get_params(void *p, float o[3]) { Stats *s = (Stats *)p; o[0] = s->c1; o[1] = s->c2; o[2] = s->ratio; }
 void refstats_set_params(void *p, const float i[3]) { Stats *s = (Stats *)p; s->c1 = i[0]; s->c2 = i[1]; s->ratio = i[2]; }
 int refstats_size(void *p) { return ((Stats *)p)->size; }

@@ -48,7 +48,10 @@ def main():
             if "WRITE_SIZE" in tot: write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1]
     if fetch is not None and write is not None:
         import json
-        json.dump({"kernel": "sweep_deformable", "fetch_size_kb": fetch, "write_size_kb": write,
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from frog_amd._abi import device_source_hash
+        json.dump({"kernel": "sweep_deformable", "measured_at": device_source_hash(), "fetch_size_kb": fetch, "write_size_kb": write,
                    "traffic_bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
                    "half_links_per_launch": int(sys.argv[-1]) if sys.argv[-1].isdigit() else None,
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"},

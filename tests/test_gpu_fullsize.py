@@ -88,11 +88,16 @@ def test_config3_steps_against_oracle(config3):
         for i in range(0, pairs.n_images, 9):
             assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
     assert relerr(g.point_sums(), ref.point_sums()) < 1e-5
+    # the census is integer work: on identical coordinates and mixtures, 10^8 half-links, every count is equal
+    g.transformPoints(); ref.transform_points()
+    g.set_points2(ref.xyz2())
+    for i in range(pairs.n_images):
+        g.set_em(i, ref.em(i))
     cnt = g.countInliers()
     rcnt = ref.count_inliers((_abi.FrogCounts * pairs.n_images)())
     assert sum(c.pairs for c in cnt) == pairs.n_half_links
     for i in range(pairs.n_images):
-        assert cnt[i].pairs == rcnt[i].pairs and abs(cnt[i].inliers - rcnt[i].inliers) <= 8
+        assert (cnt[i].pairs, cnt[i].inliers, cnt[i].outliers) == (rcnt[i].pairs, rcnt[i].inliers, rcnt[i].outliers)
 
 
 def _short_run(pairs):

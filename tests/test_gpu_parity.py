@@ -32,6 +32,13 @@ def relerr(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)
 
 
+def same_inputs(g, ref):
+    """Identical xyz2 and (c1, c2, ratio) on both sides: integer outputs are then compared with ==."""
+    g.set_points2(ref.xyz2())
+    for i in range(ref.n_images):
+        g.set_em(i, ref.em(i))
+
+
 def start(g, ref):
     g.setupLinearTransforms(); ref.linear_init()
     g.transformPoints(); ref.transform_points()
@@ -61,7 +68,7 @@ def test_update_stats_samples_bit_exact(small_pairs, max_size):
             assert np.array_equal(o, ro), f"ordinals differ, image {i}, refresh {refresh}"
             assert np.array_equal(s, rs), f"sample distances differ, image {i}, refresh {refresh}"
             assert np.array_equal(g.histogram(i), ref.histogram(i))
-            np.testing.assert_allclose(g.em(i), ref.em(i), rtol=2e-5)
+            assert np.array_equal(g.em(i), ref.em(i))       # same samples, sums in sample order: same bits
 
 
 def test_update_stats_without_reservoir(tiny_pairs):
@@ -164,12 +171,14 @@ def test_diffeomorphism_guard_rejects_without_state_change(small_pairs):
 def test_count_inliers(small_pairs):
     g, ref = make(small_pairs)
     _to_deformable(g, ref)
+    same_inputs(g, ref)
     c = g.countInliers()
     rc = ref.count_inliers((_abi.FrogCounts * ref.n_images)())
     for i in range(ref.n_images):
         assert c[i].points == rc[i].points and c[i].pairs == rc[i].pairs
-        # weights agree to a few f32 ulps, so only links within ~1e-6 of the threshold may flip
-        assert abs(c[i].inliers - rc[i].inliers) <= 2
+        # an integer census on identical inputs: weights near the threshold are decided by the reference's own
+        # arithmetic on the device (k_links.hip.h THRESHOLD_BAND), so the counts are equal, not close
+        assert c[i].inliers == rc[i].inliers and c[i].outliers == rc[i].outliers
 
 
 def test_full_run_parity(small_pairs):
@@ -262,10 +271,11 @@ def test_ragged_group_with_duplicate_links():
         assert abs(e - er) / er < 1e-5
         for i in range(pairs.n_images):
             assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
+    same_inputs(g, ref)
     c = g.countInliers()
     rc = ref.count_inliers((_abi.FrogCounts * pairs.n_images)())
     for i in range(pairs.n_images):
-        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+        assert c[i].pairs == rc[i].pairs and c[i].inliers == rc[i].inliers
 
 
 def test_abi_call_order_and_option_validation(tiny_pairs):
@@ -405,10 +415,11 @@ def test_sweep_sub_passes_match_the_oracle(small_pairs, n_sub, monkeypatch):
     assert relerr(g.point_sums(), ref.point_sums()) < 1e-5
     for i in range(ref.n_images):
         assert relerr(g.grid(i, 0)[1], ref.grid(i, 0, _abi.FrogGridInfo())[1]) < REL
+    same_inputs(g, ref)
     c = g.countInliers()
     rc = ref.count_inliers((_abi.FrogCounts * small_pairs.n_images)())
     for i in range(small_pairs.n_images):
-        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+        assert c[i].pairs == rc[i].pairs and c[i].inliers == rc[i].inliers
 
 
 def test_hard_links_of_landmark_constraints(small_pairs):
@@ -491,10 +502,11 @@ def test_fixed_images_match_oracle(small_pairs, n_fixed):
     # the lattices no longer sum to zero over the images (no mean removal)
     tot = sum(g.grid(i, 0)[1].astype(np.float64) for i in range(n_fixed, n))
     assert np.max(np.abs(tot)) > 1e-3
+    same_inputs(g, ref)
     c = g.countInliers()
     rc = ref.count_inliers((_abi.FrogCounts * n)())
     for i in range(n_fixed, n):
-        assert c[i].pairs == rc[i].pairs and abs(c[i].inliers - rc[i].inliers) <= 2
+        assert c[i].pairs == rc[i].pairs and c[i].inliers == rc[i].inliers
     # a context cannot be given a sub-range together with fixed images
     ctx = C.c_void_p()
     o = _abi.FrogOptions.default(n_fixed_images=1)
