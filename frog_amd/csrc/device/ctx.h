@@ -45,13 +45,31 @@ template <class T> struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; n = 0; cap = 0;
     }
-    hipError_t alloc(size_t count)
+    // `reserve` (>= count): capacity to allocate when a new block is needed at all
+    hipError_t alloc(size_t count, size_t reserve = 0)
     {
         if (count <= cap && p) { n = count; return hipSuccess; }
         release();
         if (!count) return hipSuccess;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e == hipSuccess) { n = count; cap = count; }
+        const size_t want = reserve > count ? reserve : count;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess && want > count) {              // no room for the head-room: take what is needed
+            (void)hipGetLastError();
+            e = hipMalloc((void **)&p, count * sizeof(T));
+            if (e == hipSuccess) { n = count; cap = count; }
+            return e;
+        }
+        if (e == hipSuccess) { n = count; cap = want; }
+        return e;
+    }
+    // stream-ordered allocation from the device's pool: no device synchronisation (used on the regrid path)
+    hipError_t alloc_async(size_t count, hipStream_t s)
+    {
+        release();
+        if (!count) return hipSuccess;
+        hipError_t e = hipMallocAsync((void **)&p, count * sizeof(T), s);
+        if (e != hipSuccess) { (void)hipGetLastError(); return alloc(count); }
+        n = count; cap = count;
         return e;
     }
     hipError_t upload(const std::vector<T> &v, hipStream_t s)
@@ -213,7 +231,7 @@ struct frog_ctx {
     // energy / counters
     frog::DevBuf<double> energy;              // [4]
     frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
-    frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel, [1] in cp_center_kernel
+    frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel, [1] in lattice_step_kernel / cp_center_kernel
     double *h_energy = nullptr;               // pinned [4]
 
     // deformable
@@ -227,10 +245,14 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> key_ptr;           // [nOwned*n_bricks*B^3 + 1] (image, brick, cell) -> perm range
     frog::DevBuf<uint32_t> key_cursor;
     frog::DevBuf<uint32_t> key_counts, brick_ptr_scratch, scan_sums;   // set-up scratch, kept between lattices
-    frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[n_scatter_blocks] (k_grid.hip.h)
-    uint32_t n_scatter_blocks = 0;
+    frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[...] longest first (k_grid.hip.h); the count is on the device
+    frog::DevBuf<unsigned char> scatter_blocks_tmp; // the same blocks in brick order
+    frog::DevBuf<uint32_t> len_hist;          // [2][SCATTER_CHUNK + 1] block-length histogram, cursors
+    uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
     frog::DevBuf<unsigned long long> n_big;   // oversize-coefficient counter
+    frog::DevBuf<unsigned int> stray;         // points the last scatter found outside every brick (their taps went to gradf)
+    bool centered_in_a = false;               // phase A of the current step also did phase B's work (whole-group context)
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)
     std::vector<frog::GridRecord> grids;
@@ -261,7 +283,9 @@ struct frog_ctx {
     frog::DevBuf<float> cut_now, cut_list;    // [nI] certified cutoff of the current mixtures / list cutoff at build time
     frog::DevBuf<uint32_t> disp_bits;         // [nI] largest displacement since the build (f32 bits)
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
-    uint64_t cull_builds = 0, cull_listed = 0; // statistics: lists built, records in the last one
+    uint64_t cull_builds = 0;                 // statistics: lists built
+    bool disp_current = false;                // disp_bits holds the displacement of the CURRENT xyz2 from the snapshot
+    bool disp_spec = false;                   // ... of pos2_spec (becomes current when it is published)
 
     // live timing
     bool point_sums_stale = false;             // the last deformable step left the per-point sums as N_XCD partial sums

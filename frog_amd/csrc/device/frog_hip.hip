@@ -114,6 +114,8 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
         hipExtLaunchKernelGGL((sweep_kernel<MODE, false, true>), grid, block, 0, s, ea, eb, 0, args);
 }
 
+static int cull_allocate(frog_ctx *ctx);
+
 extern "C" {
 
 int frog_device_count(void)
@@ -165,6 +167,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         if (rc) return rc;
         rc = frog_create(m, &o2, device, 0, nf, &fixed);
         if (rc) { frog_destroy(moving); return rc; }
+        fixed->cull_enabled = false;                                // a statistics-only context never sweeps a lattice step
+        fixed->act_recs32.release(); fixed->act_recs.release(); fixed->act_cnt.release(); fixed->pos2_snap.release();
         rc = frog_set_stream(fixed, moving->stream);
         if (rc) { frog_destroy(fixed); frog_destroy(moving); return rc; }
         moving->helper = fixed;
@@ -227,7 +231,17 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
 
     CREATE_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 4 * sizeof(double)));
+    {
+        // retired lattices are allocated stream-ordered (hipMallocAsync): keep freed blocks in the pool instead of
+        // returning them to the driver at the next synchronisation
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
+    CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 8 * sizeof(double)));     // [0..3] energy scalars, [4..6] bounding box (6 floats)
     hipStream_t s = c->stream;
 
     // points: xyz | image id
@@ -323,7 +337,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
     CREATE_CHECK(c->n_big.alloc(1));
     CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
-    CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6));
+    CREATE_CHECK(c->stray.alloc(1));
+    CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, sizeof(unsigned int), s));
+    CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
     em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
     CREATE_CHECK(hipGetLastError());
     // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
@@ -333,6 +349,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         if (sscanf(e, "%f,%f", &a, &b) == 2 && a >= 1.0f && b >= 0.0f) { c->cull_scale = a; c->cull_pad = b; }
     }
     CREATE_CHECK(c->cut_now.alloc(c->nI));
+    if (c->cull_enabled && c->opt.inlier_threshold >= 1e-3f && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
+        if (int rc_ = cull_allocate(c)) { frog_destroy(c); return rc_; }
+    }
     cull_cutoff_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->nI, c->opt.inlier_threshold, c->cut_now.p);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
@@ -401,11 +420,18 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
+        ctx->disp_current = false;
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->mat.p,
                                                                         ctx->own_pt_begin, ctx->own_pt_end, apply);
     } else {
+        // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
+        // of the outlier-culling list: the check before the next sweep then has nothing left to compute
+        const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
         transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
-                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply);
+                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
+                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_bits.p);
+        if (out == ctx->pos2.p) ctx->disp_current = with_disp;
+        else ctx->disp_spec = with_disp;
     }
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -419,6 +445,7 @@ int frog_transform_points_local(frog_ctx *ctx, int apply)
     if (ctx->xyz2_fresh && !apply) {
         // already computed behind the last deformable step (frog_deformable_phase_c): publish it
         ctx->xyz2_fresh = false; ctx->res_valid = false;
+        ctx->disp_current = ctx->disp_spec;
         if (ctx->n_owned() == ctx->nI && !ctx->xyz2_exported && ctx->pos2_spec.n == ctx->pos2.n) {
             std::swap(ctx->pos2.p, ctx->pos2_spec.p);           // whole table recomputed, nobody holds its address
             std::swap(ctx->pos2.cap, ctx->pos2_spec.cap);
@@ -654,17 +681,15 @@ int frog_linear_step(frog_ctx *ctx, double *E)
 int frog_bounds_local(frog_ctx *ctx, double mins[3], double maxs[3])
 {
     CTX_GUARD(ctx);
-    bounds_kernel<<<BOUNDS_BLOCKS, 256, 0, ctx->stream>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->bounds_scratch.p);
+    hipStream_t s = ctx->stream;
+    bounds_kernel<<<BOUNDS_BLOCKS, 256, 0, s>>>(ctx->pos.p, ctx->own_pt_begin, ctx->own_pt_end, ctx->bounds_scratch.p);
+    bounds_final_kernel<<<1, 256, 0, s>>>(ctx->bounds_scratch.p, BOUNDS_BLOCKS, ctx->bounds_scratch.p + (size_t)BOUNDS_BLOCKS * 6);
     FROG_HIP_CHECK(hipGetLastError());
-    std::vector<float> h((size_t)BOUNDS_BLOCKS * 6);
-    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->bounds_scratch.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 3; k++) { mins[k] = std::numeric_limits<double>::max(); maxs[k] = -std::numeric_limits<double>::max(); }
-    for (int b = 0; b < BOUNDS_BLOCKS; b++)
-        for (int k = 0; k < 3; k++) {
-            mins[k] = std::min(mins[k], (double)h[(size_t)b * 6 + k]);
-            maxs[k] = std::max(maxs[k], (double)h[(size_t)b * 6 + 3 + k]);
-        }
+    float *h = reinterpret_cast<float *>(ctx->h_energy + 4);       // pinned
+    FROG_HIP_CHECK(hipMemcpyAsync(h, ctx->bounds_scratch.p + (size_t)BOUNDS_BLOCKS * 6, 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    // an empty range leaves (+FLT_MAX, -FLT_MAX): neutral in the callers' min / max reduction over ranks
+    for (int k = 0; k < 3; k++) { mins[k] = (double)h[k]; maxs[k] = (double)h[3 + k]; }
     return FROG_OK;
 }
 
@@ -677,7 +702,7 @@ static int retire_current_grid(frog_ctx *ctx)
     // the finished lattice stays on the device (a copy on the stream: no host round trip inside the
     // regrid path; 43 MB per lattice at level 2 of the 100-image group); frog_get_grid reads it back on demand
     gr.kept = std::make_shared<DevBuf<float4>>();
-    FROG_HIP_CHECK(gr.kept->alloc(std::max<size_t>(1, n)));
+    FROG_HIP_CHECK(gr.kept->alloc_async(std::max<size_t>(1, n), ctx->stream));
     if (n) FROG_HIP_CHECK(hipMemcpyAsync(gr.kept->p, ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     gr.retired = true;
     return FROG_OK;
@@ -728,27 +753,32 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     info.n_grid = (int)ctx->grids.size();
 
     hipStream_t s = ctx->stream;
-    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G));
-    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G));
-    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G));
+    // Buffers that grow with the lattice are allocated with head-room for two more levels (8x the control points
+    // each) the first time, up to a cap: hipFree / hipMalloc synchronise the device and cost a millisecond per level.
+    const size_t reserve = ((size_t)nO * G * 64 * sizeof(float4) <= ((size_t)2 << 30)) ? 64 : (((size_t)nO * G * 8 * sizeof(float4) <= ((size_t)2 << 30)) ? 8 : 1);
+    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));
-    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G));
+    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G, 3 * G * reserve));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
 
-    // sort the owned points by (image, brick, cell) and build the scatter's block table
+    // sort the owned points by (image, brick, cell) and build the scatter's block table -- all on the device, nothing
+    // comes back to the host (the first version read the brick sizes back, built and sorted the table on the host and
+    // uploaded it: 1.0-2.5 ms per lattice, most of it two round trips and the host loop)
     const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
     const size_t n_keys64 = (size_t)nO * nb * keys_per_brick;
     if (n_keys64 >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
     const uint32_t n_keys = (uint32_t)n_keys64;
     const uint32_t n_bricks_total = nO * (uint32_t)nb;
-    frog::DevBuf<uint32_t> &counts = ctx->key_counts, &bptr = ctx->brick_ptr_scratch;
-    FROG_HIP_CHECK(counts.alloc(n_keys));
-    FROG_HIP_CHECK(bptr.alloc((size_t)n_bricks_total + 1));
+    frog::DevBuf<uint32_t> &counts = ctx->key_counts, &chunks = ctx->brick_ptr_scratch;
+    FROG_HIP_CHECK(counts.alloc(n_keys, (size_t)n_keys * reserve));
+    FROG_HIP_CHECK(chunks.alloc((size_t)n_bricks_total + 1, ((size_t)n_bricks_total + 1) * reserve));
     FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
-    FROG_HIP_CHECK(ctx->key_ptr.alloc((size_t)n_keys + 1));
-    FROG_HIP_CHECK(ctx->key_cursor.alloc((size_t)n_keys + 1));
+    FROG_HIP_CHECK(ctx->key_ptr.alloc((size_t)n_keys + 1, ((size_t)n_keys + 1) * reserve));
+    FROG_HIP_CHECK(ctx->key_cursor.alloc((size_t)n_keys + 1, ((size_t)n_keys + 1) * reserve));
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     const GeomDev gd = to_dev(g);
     uint32_t max_img_pts = 0;
@@ -758,20 +788,18 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
-    {
-        const uint32_t n_scan_blocks = div_up(n_keys, SCAN_BLOCK_ITEMS);
+    auto exclusive_scan = [&](const uint32_t *in, uint32_t n, uint32_t *ptr, uint32_t *cursor) -> int {
+        const uint32_t n_scan_blocks = div_up(n, SCAN_BLOCK_ITEMS);
         frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;
-        FROG_HIP_CHECK(bsums.alloc((size_t)n_scan_blocks + 1));
-        scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(counts.p, n_keys, bsums.p);
+        FROG_HIP_CHECK(bsums.alloc((size_t)n_scan_blocks + 1, ((size_t)n_scan_blocks + 1) * reserve));
+        scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p);
         scan_of_sums_kernel<<<1, 1024, 0, s>>>(bsums.p, n_scan_blocks, bsums.p + n_scan_blocks);
-        scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(counts.p, n_keys, bsums.p, bsums.p + n_scan_blocks,
-                                                         ctx->key_ptr.p, ctx->key_cursor.p);
+        scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p, bsums.p + n_scan_blocks, ptr, cursor);
         FROG_HIP_CHECK(hipGetLastError());
-    }
-    brick_ptr_kernel<<<div_up((size_t)n_bricks_total + 1, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, bptr.p);
-    FROG_HIP_CHECK(hipGetLastError());
-    std::vector<uint32_t> h_bptr((size_t)n_bricks_total + 1);
-    FROG_HIP_CHECK(hipMemcpyAsync(h_bptr.data(), bptr.p, h_bptr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        return FROG_OK;
+    };
+    rc = exclusive_scan(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
+    if (rc) return rc;
     if (nPts) {
         brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
@@ -783,29 +811,38 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
         std::swap(ctx->perm.n, ctx->perm_tmp.n);
     }
-    FROG_HIP_CHECK(hipStreamSynchronize(s));      // h_bptr is on the host
-    std::vector<ScatterBlock> blocks;
-    std::vector<uint32_t> slot_ptr(n_bricks_total + 1, 0);        // staging slots of every (image, brick), brick-major
-    for (uint32_t k = 0; k < n_bricks_total; k++) {
-        for (uint32_t b0 = h_bptr[k]; b0 < h_bptr[k + 1]; b0 += SCATTER_CHUNK)
-            blocks.push_back(ScatterBlock{ k, b0, std::min(b0 + (uint32_t)SCATTER_CHUNK, h_bptr[k + 1]), (uint32_t)blocks.size() });
-        slot_ptr[k + 1] = (uint32_t)blocks.size();
-    }
-    FROG_HIP_CHECK(ctx->brick_slot_ptr.upload(slot_ptr, s));
+    // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
+    // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
+    // every non-empty brick ends with at most one partial block
+    const uint32_t max_blocks = std::min(n_bricks_total, nPts) + nPts / SCATTER_CHUNK;
+    FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc((size_t)n_bricks_total + 1, ((size_t)n_bricks_total + 1) * reserve));
+    FROG_HIP_CHECK(ctx->scatter_blocks.alloc(std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock),
+                                             std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock) * reserve));
+    FROG_HIP_CHECK(ctx->scatter_blocks_tmp.alloc(std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock),
+                                                 std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock) * reserve));
+    FROG_HIP_CHECK(ctx->len_hist.alloc(2 * (SCATTER_CHUNK + 1)));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->len_hist.p, 0, ctx->len_hist.bytes(), s));
+    brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
+    if (rc) return rc;
+    ScatterBlock *blk_tmp = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks_tmp.p);
+    ScatterBlock *blk = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks.p);
+    uint32_t *len_hist = ctx->len_hist.p, *len_cursor = ctx->len_hist.p + (SCATTER_CHUNK + 1);
+    const uint32_t *n_blocks_dev = ctx->brick_slot_ptr.p + n_bricks_total;
+    block_fill_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->brick_slot_ptr.p, n_bricks_total, keys_per_brick,
+                                                                 blk_tmp, len_hist);
+    block_len_base_kernel<<<1, 512, 0, s>>>(len_hist, len_cursor);
+    if (max_blocks)
+        block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
+    FROG_HIP_CHECK(hipGetLastError());
+    ctx->n_scatter_blocks = max_blocks;
     {
         const size_t E = (size_t)g.brick + 3;
-        FROG_HIP_CHECK(ctx->scatter_stage.alloc(std::max<size_t>(1, blocks.size()) * E * E * E));
-    }
-    // longest blocks first: a block is one wavefront whose time grows with its point count, and
-    // bricks on the rim of the cloud hold few points -- dispatching the full chunks first shortens
-    // the tail (every block writes its own staging slot, so the launch order does not matter)
-    std::stable_sort(blocks.begin(), blocks.end(), [](const ScatterBlock &x, const ScatterBlock &y) {
-        return x.end - x.begin > y.end - y.begin; });
-    ctx->n_scatter_blocks = (uint32_t)blocks.size();
-    FROG_HIP_CHECK(ctx->scatter_blocks.alloc(std::max<size_t>(1, blocks.size()) * sizeof(ScatterBlock)));
-    if (!blocks.empty()) {
-        FROG_HIP_CHECK(hipMemcpyAsync(ctx->scatter_blocks.p, blocks.data(), blocks.size() * sizeof(ScatterBlock), hipMemcpyHostToDevice, s));
-        FROG_HIP_CHECK(hipStreamSynchronize(s));
+        // tile storage of the largest lattice seen so far is kept (reserve: a finer level needs about as many blocks --
+        // bricks hold fewer points -- but brick edge 8 instead of 4 has 2.4x the tile)
+        FROG_HIP_CHECK(ctx->scatter_stage.alloc(std::max<size_t>(1, max_blocks) * E * E * E,
+                                                std::max<size_t>(1, max_blocks) * E * E * E * std::min<size_t>(reserve, 8)));
     }
 
     GridRecord rec;
@@ -827,28 +864,37 @@ int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out)
     return frog_deformable_setup_bounds(ctx, level, mn, mx, out);
 }
 
+// buffers of the culling list (4 bytes per half-link for the listed records); at frog_create, so that the first deformable
+// step does not pay for them
+static int cull_allocate(frog_ctx *ctx)
+{
+    if (ctx->act_cnt.p) return FROG_OK;
+    hipStream_t s = ctx->stream;
+    if (ctx->rec_format.narrow) {
+        FROG_HIP_CHECK(ctx->act_recs32.alloc(ctx->L_recs));
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs32.p, 0, ctx->act_recs32.bytes(), s));    // null records, as the padding of the full array
+    } else {
+        FROG_HIP_CHECK(ctx->act_recs.alloc(ctx->L_recs));
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs.p, 0, ctx->act_recs.bytes(), s));
+    }
+    FROG_HIP_CHECK(ctx->act_cnt.alloc(std::max<size_t>(1, (size_t)ctx->n_tiles * ctx->n_groups)));
+    FROG_HIP_CHECK(ctx->pos2_snap.alloc(ctx->P));
+    FROG_HIP_CHECK(ctx->cut_list.alloc(ctx->nI));
+    FROG_HIP_CHECK(ctx->disp_bits.alloc(ctx->nI));
+    FROG_HIP_CHECK(ctx->cull_state.alloc(2));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));
+    ctx->cull_need_build = true;
+    return FROG_OK;
+}
+
 // Certified outlier culling (k_cull.hip.h): (re)build the list when the host knows it is due, then check it against
 // the coordinates and mixtures the sweep is about to read; the sweep takes the result from cull_state on the device.
 static int cull_prepare(frog_ctx *ctx)
 {
     hipStream_t s = ctx->stream;
     const uint32_t nI = ctx->nI;
-    if (!ctx->act_cnt.p) {
-        if (ctx->rec_format.narrow) {
-            FROG_HIP_CHECK(ctx->act_recs32.alloc(ctx->L_recs));
-            FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs32.p, 0, ctx->act_recs32.bytes(), s));    // null records, as the padding of the full array
-        } else {
-            FROG_HIP_CHECK(ctx->act_recs.alloc(ctx->L_recs));
-            FROG_HIP_CHECK(hipMemsetAsync(ctx->act_recs.p, 0, ctx->act_recs.bytes(), s));
-        }
-        FROG_HIP_CHECK(ctx->act_cnt.alloc((size_t)ctx->n_tiles * ctx->n_groups));
-        FROG_HIP_CHECK(ctx->pos2_snap.alloc(ctx->P));
-        FROG_HIP_CHECK(ctx->cut_list.alloc(nI));
-        FROG_HIP_CHECK(ctx->disp_bits.alloc(nI));
-        FROG_HIP_CHECK(ctx->cull_state.alloc(2));
-        FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));
-        ctx->cull_need_build = true;
-    }
+    int rc = cull_allocate(ctx);
+    if (rc) return rc;
     if (ctx->cull_need_build) {
         cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->cull_scale, ctx->cull_pad, ctx->cut_list.p);
         FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2_snap.p, ctx->pos2.p, ctx->P * sizeof(P3), hipMemcpyDeviceToDevice, s));
@@ -862,10 +908,16 @@ static int cull_prepare(frog_ctx *ctx)
         FROG_HIP_CHECK(hipMemsetAsync(ctx->disp_bits.p, 0, ctx->disp_bits.bytes(), s));
         ctx->cull_need_build = false;
         ctx->cull_builds++;
+        ctx->disp_current = true;           // the points are where the snapshot has them
     }
-    uint32_t max_pts = 1;
-    for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
-    cull_disp_kernel<<<dim3(div_up(max_pts, CULL_BLOCK_POINTS), nI), 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_bits.p);
+    // displacement since the build: already in disp_bits when the transform that produced the current xyz2 measured it
+    // (launch_transform; whole-group contexts whose xyz2 nobody else writes), else one pass over all points
+    if (!(ctx->disp_current && ctx->whole_group() && !ctx->xyz2_exported)) {
+        uint32_t max_pts = 1;
+        for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
+        cull_disp_kernel<<<dim3(div_up(max_pts, CULL_BLOCK_POINTS), nI), 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_bits.p);
+    }
+    ctx->disp_current = false;              // cull_validate_kernel clears disp_bits
     cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_bits.p, nI, ctx->cull_state.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -880,7 +932,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     hipStream_t s = ctx->stream;
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
-    // the gradient lattice is zero here: set-up clears it and cp_propose_kernel re-clears it (Fill(0), :249)
+    // the gradient lattice proper lives in the staged tiles of the scatter; `gradf` only receives stray points (Fill(0), :249)
     const bool culled = cull_active(ctx);
     if (culled) {
         Span span(ctx, FROG_K_CULL);
@@ -918,14 +970,23 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
                                                            ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
                                                            ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
                                                            reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
-                                                           ctx->gradf.p, ctx->scatter_stage.p, gd);
-        lattice_reduce_kernel<<<div_up((size_t)nO * gd.n_cp, 256), 256, 0, s>>>(ctx->scatter_stage.p, ctx->brick_slot_ptr.p,
-                                                                                ctx->gradf.p, nO, gd);
+                                                           ctx->brick_slot_ptr.p + (size_t)nO * gd.n_bricks,
+                                                           ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p, gd);
         FROG_HIP_CHECK(hipGetLastError());
     }
     {
+        // flush of the staged tiles + control-point step + sum over the owned images; for a context that owns the whole
+        // group also the mean removal and the oversize count (phase B is then empty): one launch
         Span span(ctx, FROG_K_LATTICE);
-        cp_propose_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->coeff.p, ctx->gradf.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p, ctx->n_big.p);
+        LatticeStepArgs la{};
+        la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p; la.gradf = ctx->gradf.p; la.stray = ctx->stray.p;
+        la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
+        la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
+        for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
+        la.n_big = ctx->n_big.p; la.ticket = ctx->energy_ticket.p + 1; la.energy = ctx->energy.p;
+        ctx->centered_in_a = ctx->whole_group();
+        if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), 256, 0, s>>>(la, gd);
+        else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), 256, 0, s>>>(la, gd);
     }
     FROG_HIP_CHECK(hipGetLastError());
     ctx->pending_alpha = alpha;
@@ -940,6 +1001,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     const GridGeom &g = ctx->geom;
     const float maxD = ctx->opt.max_displacement_ratio;
+    if (ctx->centered_in_a) { ctx->phase = 2; return FROG_OK; }       // phase A already removed the group's own mean
     Span span(ctx, FROG_K_LATTICE);
     // :398: the group mean is removed only when no image is fixed
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
@@ -1037,7 +1099,7 @@ int frog_set_points2(frog_ctx *ctx, const float *xyz2)
     std::vector<P3> h(ctx->P);
     for (size_t p = 0; p < ctx->P; p++)
         h[ctx->h_new_of_old[p]] = P3{ xyz2[3 * p], xyz2[3 * p + 1], xyz2[3 * p + 2] };
-    ctx->xyz2_fresh = false; ctx->res_valid = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false; ctx->disp_current = false;
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2.p, h.data(), h.size() * sizeof(P3), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
@@ -1355,7 +1417,7 @@ int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t
     size_t b = 0, rb = 0, re = 0;
     void *p = nullptr;
     switch (which) {
-    case FROG_BUF_XYZ2: ctx->xyz2_exported = true; p = ctx->pos2.p; b = ctx->pos2.bytes(); rb = ctx->own_pt_begin; re = ctx->own_pt_end; break;
+    case FROG_BUF_XYZ2: ctx->xyz2_exported = true; ctx->disp_current = false; p = ctx->pos2.p; b = ctx->pos2.bytes(); rb = ctx->own_pt_begin; re = ctx->own_pt_end; break;
     case FROG_BUF_EM: p = ctx->em.p; b = ctx->em.bytes(); rb = ctx->ib; re = ctx->ie; break;
     case FROG_BUF_ENERGY: p = ctx->energy.p; b = ctx->energy.bytes(); rb = 0; re = 4; break;
     case FROG_BUF_GRIDSUM:

@@ -66,10 +66,14 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 // neighbouring cells and hit L1/L2.
 __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
-                                                                uint32_t image_begin, const GeomDev g, int apply)
+                                                                uint32_t image_begin, const GeomDev g, int apply,
+                                                                const P3 *snap, uint32_t *disp_bits)
 {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_points) return;
+    // every lane computes (the tail of the last block on the last point again, without storing): the displacement
+    // reduction at the end is wave-wide
+    const uint32_t s_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = s_raw < n_points;
+    const uint32_t s = valid ? s_raw : n_points - 1;
     const uint32_t p = perm[s];
     const float4 v = pos[p];
     const float4 *cf = coeff + (size_t)(__float_as_int(v.w) - (int)image_begin) * g.n_cp;
@@ -145,8 +149,27 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
     o.y = (float)((double)in[1] + disp[1] * 1.0);
     o.z = (float)((double)in[2] + disp[2] * 1.0);
     o.w = v.w;
-    pos2[p] = P3{ o.x, o.y, o.z };
-    if (apply) pos[p] = o;
+    if (valid) {
+        pos2[p] = P3{ o.x, o.y, o.z };
+        if (apply) pos[p] = o;
+    }
+    if (snap) {
+        // largest distance of a point of each image from where it was when the outlier-culling list was built
+        // (k_cull.hip.h: what cull_disp_kernel computes, here for free).  Lanes are in (image, brick, cell) order, so a
+        // wavefront is almost always inside one image: one atomic per wavefront.
+        const P3 q = snap[p];
+        const float dx = o.x - q.x, dy = o.y - q.y, dz = o.z - q.z;
+        uint32_t m = valid ? (__float_as_uint(__builtin_sqrtf(dx * dx + dy * dy + dz * dz)) & 0x7FFFFFFFu) : 0u;
+        const int img = __float_as_int(v.w);
+        const int img0 = __builtin_amdgcn_readfirstlane(img);
+        if (__all(img == img0)) {
+            #pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+            if ((threadIdx.x & 63) == 0 && m) atomicMax(&disp_bits[img0], m);
+        } else if (m) {
+            atomicMax(&disp_bits[img], m);
+        }
+    }
 }
 
 // ---- K13: bounding box of the owned xyz (getBoundingBox, imageGroup.cxx:1513) ----
@@ -173,6 +196,27 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float4 *pos, uint32_t
         __syncthreads();
     }
     if (threadIdx.x < 6) block_minmax[blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// the per-block boxes folded into one (6 floats: min xyz, max xyz); one block
+__global__ __launch_bounds__(256) void bounds_final_kernel(const float *block_minmax, int n_blocks, float *out6)
+{
+    __shared__ float sh[6][256];
+    float mn[3] = { 3.402823466e38f, 3.402823466e38f, 3.402823466e38f };
+    float mx[3] = { -3.402823466e38f, -3.402823466e38f, -3.402823466e38f };
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+        for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], block_minmax[b * 6 + k]); mx[k] = fmaxf(mx[k], block_minmax[b * 6 + 3 + k]); }
+    for (int k = 0; k < 3; k++) { sh[k][threadIdx.x] = mn[k]; sh[3 + k][threadIdx.x] = mx[k]; }
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h)
+            for (int k = 0; k < 3; k++) {
+                sh[k][threadIdx.x] = fminf(sh[k][threadIdx.x], sh[k][threadIdx.x + h]);
+                sh[3 + k][threadIdx.x] = fmaxf(sh[3 + k][threadIdx.x], sh[3 + k][threadIdx.x + h]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out6[threadIdx.x] = sh[threadIdx.x][0];
 }
 
 // Cell of a point as the scatter computes it (imageGroup.cxx:303-310): the
@@ -375,11 +419,70 @@ __global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr
     }
 }
 
-// ptr at brick granularity (every B^3-th entry) for the host's block table
-__global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t *out)
+// ---- the scatter's block table, built on the device (no host round trip inside a lattice set-up) ----------
+// A scatter block = (image, brick, run of <= SCATTER_CHUNK of the brick's points).  Brick k (image-major) holds the
+// points perm[ptr[k * keys_per_brick] .. ptr[(k + 1) * keys_per_brick]); it gets ceil(count / SCATTER_CHUNK) blocks,
+// whose staging slots are consecutive (lattice_step_kernel adds a brick's slots in that order).  The blocks are
+// then listed longest first: a block is one wavefront whose time grows with its point count, and bricks on the rim of
+// the cloud hold few points -- dispatching the long ones first shortens the tail.  The order among blocks of equal
+// length comes from atomics and changes from run to run; it only decides WHEN a block runs, every block writes its own
+// staging slot.
+#ifndef FROG_SCATTER_CHUNK
+#define FROG_SCATTER_CHUNK 384
+#endif
+constexpr int SCATTER_CHUNK = FROG_SCATTER_CHUNK;
+
+struct ScatterBlock {
+    uint32_t key;           // image_local * n_bricks + brick
+    uint32_t begin, end;    // range in perm
+    uint32_t slot;          // index of the block's tile in the staging buffer (brick-major order)
+};
+
+// chunks[k] = number of scatter blocks of brick k
+__global__ void brick_chunks_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t *chunks)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n_bricks_total) out[i] = ptr[(size_t)i * keys_per_brick];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_bricks_total) return;
+    const uint32_t n = ptr[(size_t)(k + 1) * keys_per_brick] - ptr[(size_t)k * keys_per_brick];
+    chunks[k] = (n + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
+}
+
+// blocks in brick order + histogram of their lengths (len_hist[SCATTER_CHUNK + 1], zeroed by the caller)
+__global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr, uint32_t n_bricks_total, uint32_t keys_per_brick,
+                                  ScatterBlock *blocks, uint32_t *len_hist)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_bricks_total) return;
+    const uint32_t b = ptr[(size_t)k * keys_per_brick], e = ptr[(size_t)(k + 1) * keys_per_brick];
+    uint32_t slot = slot_ptr[k];
+    for (uint32_t b0 = b; b0 < e; b0 += SCATTER_CHUNK, slot++) {
+        const uint32_t e0 = min(b0 + (uint32_t)SCATTER_CHUNK, e);
+        blocks[slot] = ScatterBlock{ k, b0, e0, slot };
+        atomicAdd(&len_hist[e0 - b0], 1u);
+    }
+}
+
+// first position of every length in the longest-first order; one block of SCATTER_CHUNK + 1 <= 1024 threads
+__global__ void block_len_base_kernel(const uint32_t *len_hist, uint32_t *len_cursor)
+{
+    __shared__ uint32_t sh[SCATTER_CHUNK + 1];
+    const int t = threadIdx.x;
+    if (t <= SCATTER_CHUNK) sh[t] = len_hist[t];
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int len = SCATTER_CHUNK; len >= 0; len--) { const uint32_t c = sh[len]; sh[len] = run; run += c; }
+    }
+    __syncthreads();
+    if (t <= SCATTER_CHUNK) len_cursor[t] = sh[t];
+}
+
+__global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_blocks, uint32_t *len_cursor, ScatterBlock *sorted)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_blocks) return;
+    const ScatterBlock b = blocks[i];
+    sorted[atomicAdd(&len_cursor[b.end - b.begin], 1u)] = b;
 }
 
 // ---- K7: scatter of the per-point sums onto the gradient lattice ----------------
@@ -396,22 +499,12 @@ __global__ void brick_ptr_kernel(const uint32_t *ptr, uint32_t n_bricks_total, u
 // sorted by cell, so consecutive points mostly share their 64 tap addresses and the
 // LDS tile is touched (one ds_read_b128 + ds_write_b128, no atomic: the 64 taps are
 // 64 distinct control points and the tile is private) only when the cell changes.
-// Finally the tile goes to a staging slot; lattice_reduce_kernel sums the slots in a fixed order.
+// Finally the tile goes to a staging slot; lattice_step_kernel sums the slots in a fixed order.
 //
 // Why not LDS float atomics: ds_add_f32 runs at 0.33 lane-ops/clk/CU on gfx950
 // (scripts/microbench/lds_atomic.hip); why not fixed point: control points on the
 // shell of the cloud have total weights ~1e-10 and need f32 relative precision.
-#ifndef FROG_SCATTER_CHUNK
-#define FROG_SCATTER_CHUNK 384
-#endif
-constexpr int SCATTER_CHUNK = FROG_SCATTER_CHUNK;
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
-
-struct ScatterBlock {
-    uint32_t key;           // image_local * n_bricks + brick
-    uint32_t begin, end;    // range in perm
-    uint32_t slot;          // index of the block's tile in the staging buffer (brick-major order)
-};
 
 // per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS
 struct ScatterPoint {
@@ -424,9 +517,11 @@ static_assert(sizeof(ScatterPoint) == 80, "ScatterPoint layout");
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
-                                                     const uint32_t *perm, const ScatterBlock *blocks,
-                                                     float4 *gradf, float4 *stage, const GeomDev g)
+                                                     const uint32_t *perm, const ScatterBlock *blocks, const uint32_t *n_blocks,
+                                                     float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g)
 {
+    // the grid is an upper bound (the block table is built on the device and its length never visits the host)
+    if (blockIdx.x >= *n_blocks) return;
     // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
     // take 5.4 KB instead of the 21 KB of the largest brick and 15 instead of 6 blocks fit a CU
     extern __shared__ float4 tile[];
@@ -492,7 +587,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                     me.base = lx + E * (ly + E * lz);
                 } else {
                     // stray point clamped into this brick (outside the scaled box): its taps go
-                    // straight to HBM, one lane doing all 64
+                    // straight to HBM, one lane doing all 64; lattice_step_kernel then folds the gradient lattice in
+                    atomicAdd(stray, 1u);
                     for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
@@ -553,7 +649,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // the tile goes to the block's slot of the staging buffer as it is; lattice_reduce_kernel adds the
+    // the tile goes to the block's slot of the staging buffer as it is; lattice_step_kernel adds the
     // slots that cover a control point in a fixed order (a flush with float atomics is as fast, but its
     // order changes from run to run, and one ulp in a coefficient can move a half-link across the
     // inlier threshold a few iterations later)
@@ -561,87 +657,152 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     for (int k = lane; k < n_tile; k += 64) dst[k] = tile[k];
 }
 
-// Gradient lattice = sum of the staged tiles that cover each control point, in a fixed order: bricks in
-// (z, y, x) order, the blocks of a brick in point order.  Added to what is already there (zero, or the
-// atomics of stray points).  Thread per (owned image, control point).
-__global__ __launch_bounds__(256) void lattice_reduce_kernel(const float4 *stage, const uint32_t *brick_slot_ptr,
-                                                             float4 *gradf, uint32_t n_owned, const GeomDev g)
+// ---- K7 (flush) + K8 + K9 in one launch ---------------------------------------------------------------------
+// lattice_step_kernel<CENTER>: for a tile of LS_CPB control points (consecutive in x) and ALL owned images
+//   1. gradient g, gw = sum of the staged scatter tiles that cover the control point, in a fixed order: bricks in
+//      (z, y, x) order, the blocks of a brick in point order (+ what stray points added with atomics, if any did);
+//   2. proposal  c + alpha g / gw  (gw > 0, else c), f32 left to right (imageGroup.cxx:346-375) -> grad (w = gw);
+//   3. sum over the images in ASCENDING order, f64, as imageGroup.cxx:411-415 -> gridsum;
+//   CENTER (a context that owns the whole group, so the sum is the group's):
+//   4. subtract sum / nImages from every image's proposal ((float)((double) v - mean), :417-423; nothing when images
+//      are fixed, :398), count coefficients beyond maxDisplacementRatio * spacing (:424-428) -> energy[2].
+// One launch instead of lattice_reduce + cp_propose + cp_center (77 us -> see DESIGN.md), and the gradient lattice is
+// never written to memory.  Images are taken LS_IC at a time: thread = (image, control point) computes steps 1-2 and
+// parks the proposal in LDS, then one thread per (control point, axis) adds the LS_IC values in image order to its
+// running f64 sum -- the reference's order exactly.  Step 4 re-reads the proposals this block has just written (L2).
+// Without CENTER the launch stops after step 3: the host all-reduces gridsum over the ranks and cp_center_kernel does 4.
+constexpr int LS_CPB = 16;          // control points per block
+constexpr int LS_IC = 16;           // images per pass: LS_CPB * LS_IC = 256 threads
+static_assert(LS_CPB * LS_IC == 256 && 3 * LS_CPB <= 256, "lattice_step_kernel thread mapping");
+
+struct LatticeStepArgs {
+    const float4 *stage;            // staged scatter tiles
+    const uint32_t *brick_slot_ptr;
+    float4 *gradf;                  // only read (and cleared) when *stray != 0
+    unsigned int *stray;            // number of stray points of the last scatter
+    const float4 *coeff;
+    float4 *grad;
+    double *gridsum;
+    uint32_t n_owned, n_images;     // n_images = 0: fixed images present, no mean removal
+    float alpha;
+    double lim[3];
+    unsigned long long *n_big;
+    unsigned int *ticket;
+    double *energy;
+};
+
+template <bool CENTER>
+__global__ __launch_bounds__(256) void lattice_step_kernel(const LatticeStepArgs a, const GeomDev g)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)n_owned * g.n_cp) return;
-    const uint32_t img = (uint32_t)(idx / g.n_cp);
-    int q = (int)(idx % g.n_cp);
-    const int c[3] = { q % g.dims[0], (q / g.dims[0]) % g.dims[1], q / (g.dims[0] * g.dims[1]) };
+    __shared__ float prop[LS_IC][LS_CPB][3];
+    __shared__ double mean[LS_CPB][3];
+    __shared__ unsigned int cnt_s[256];
+    const int tid = threadIdx.x;
+    const int c = tid % LS_CPB, il = tid / LS_CPB;
+    const int cp = blockIdx.x * LS_CPB + c;
+    const bool has_stray = *a.stray != 0u;
+    if (!CENTER && blockIdx.x == 0 && tid == 0) *a.n_big = 0ull;        // counted by cp_center_kernel, later in the stream
+
+    // bricks that cover this control point (brick b holds control points b*B .. b*B + B + 2)
     const int B = g.brick, E = B + 3, n_tile = E * E * E;
-    int lo[3], hi[3];
-    #pragma unroll
-    for (int k = 0; k < 3; k++) {                       // brick b holds control points b*B .. b*B + B + 2
-        lo[k] = c[k] <= 2 ? 0 : max(0, (c[k] - 2 + B - 1) / B - 1);     // smallest b with b*B + B + 2 >= c
-        hi[k] = min(g.nbricks[k] - 1, c[k] / B);                        // largest b with b*B <= c
+    int cc[3] = { 0, 0, 0 }, lo[3] = { 0, 0, 0 }, hi[3] = { -1, -1, -1 };
+    if (cp < g.n_cp) {
+        cc[0] = cp % g.dims[0]; cc[1] = (cp / g.dims[0]) % g.dims[1]; cc[2] = cp / (g.dims[0] * g.dims[1]);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = cc[k] <= 2 ? 0 : max(0, (cc[k] - 2 + B - 1) / B - 1);
+            hi[k] = min(g.nbricks[k] - 1, cc[k] / B);
+        }
     }
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int bz = lo[2]; bz <= hi[2]; bz++)
-        for (int by = lo[1]; by <= hi[1]; by++)
-            for (int bx = lo[0]; bx <= hi[0]; bx++) {
-                const uint32_t key = img * g.n_bricks + (uint32_t)(bx + g.nbricks[0] * (by + g.nbricks[1] * bz));
-                const int local = (c[0] - bx * B) + E * ((c[1] - by * B) + E * (c[2] - bz * B));
-                for (uint32_t sl = brick_slot_ptr[key]; sl < brick_slot_ptr[key + 1]; sl++) {
-                    const float4 v = stage[(size_t)sl * n_tile + local];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-                }
+    // summation thread: (control point sc, axis sa)
+    const int sc = tid % LS_CPB, sa = tid / LS_CPB;
+    double run = 0.0;
+
+    for (uint32_t i0 = 0; i0 < a.n_owned; i0 += LS_IC) {
+        const uint32_t img = i0 + il;
+        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (img < a.n_owned && cp < g.n_cp) {
+            const size_t o = (size_t)img * g.n_cp + cp;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int bz = lo[2]; bz <= hi[2]; bz++)
+                for (int by = lo[1]; by <= hi[1]; by++)
+                    for (int bx = lo[0]; bx <= hi[0]; bx++) {
+                        const uint32_t key = img * g.n_bricks + (uint32_t)(bx + g.nbricks[0] * (by + g.nbricks[1] * bz));
+                        const int local = (cc[0] - bx * B) + E * ((cc[1] - by * B) + E * (cc[2] - bz * B));
+                        for (uint32_t sl = a.brick_slot_ptr[key]; sl < a.brick_slot_ptr[key + 1]; sl++) {
+                            const float4 v = a.stage[(size_t)sl * n_tile + local];
+                            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                        }
+                    }
+            if (has_stray) {                    // added to what the stray points' atomics left, as the separate flush did
+                float4 t = a.gradf[o];
+                t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+                s = t;
+                a.gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-    float4 o = gradf[idx];
-    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-    gradf[idx] = o;
+            const float4 c4 = a.coeff[o];
+            if (s.w > 0) {
+                n4.x = c4.x + a.alpha * s.x / s.w;
+                n4.y = c4.y + a.alpha * s.y / s.w;
+                n4.z = c4.z + a.alpha * s.z / s.w;
+            } else {
+                n4.x = c4.x; n4.y = c4.y; n4.z = c4.z;
+            }
+            n4.w = s.w;
+            a.grad[o] = n4;
+        }
+        prop[il][c][0] = n4.x; prop[il][c][1] = n4.y; prop[il][c][2] = n4.z;
+        __syncthreads();
+        if (tid < 3 * LS_CPB) {
+            const uint32_t n = min((uint32_t)LS_IC, a.n_owned - i0);
+            for (uint32_t k = 0; k < n; k++) run += (double)prop[k][sc][sa];
+        }
+        __syncthreads();
+    }
+    if (tid < 3 * LS_CPB) {
+        const int scp = blockIdx.x * LS_CPB + sc;
+        if (scp < g.n_cp) a.gridsum[3 * (size_t)scp + sa] = run;
+        mean[sc][sa] = a.n_images ? run / a.n_images : 0.0;
+    }
+    if (!CENTER) return;
+    __syncthreads();
+    unsigned int cnt = 0;
+    if (cp < g.n_cp) {
+        const double mx = mean[c][0], my = mean[c][1], mz = mean[c][2];
+        for (uint32_t img = il; img < a.n_owned; img += LS_IC) {
+            const size_t o = (size_t)img * g.n_cp + cp;
+            float4 v = a.grad[o];
+            v.x = (float)((double)v.x - mx);
+            v.y = (float)((double)v.y - my);
+            v.z = (float)((double)v.z - mz);
+            a.grad[o] = v;
+            cnt += ((double)fabsf(v.x) > a.lim[0]) + ((double)fabsf(v.y) > a.lim[1]) + ((double)fabsf(v.z) > a.lim[2]);
+        }
+    }
+    cnt_s[tid] = cnt;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) cnt_s[tid] += cnt_s[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (cnt_s[0]) atomicAdd(a.n_big, (unsigned long long)cnt_s[0]);
+        __threadfence();
+        if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {         // the last block: every other block is done
+            __threadfence();
+            a.energy[2] = (double)atomicAdd(a.n_big, 0ull);     // an integer sum: the order of the blocks does not matter
+            *a.n_big = 0ull;
+            *a.stray = 0u;
+            *a.ticket = 0u;
+        }
+    }
 }
 
-// ---- K8 + first half of K9: control-point step and sum over owned images --------
-// thread per control point; images in ascending order (imageGroup.cxx:346-375, :411-415).
-// Both kernels walk the images of one control point in order (the f64 sum keeps the
-// reference's order); with one load per step that walk is a chain of ~n_images memory
-// round trips on a handful of wavefronts (46-76 us at every lattice size).  The loads of
-// CP_BATCH images are therefore issued together before any of them is used.
+// ---- second half of K9 for contexts that own a sub-range of the images: subtract the group mean, count oversize
+// coefficients.  Thread per control point walking its images; the loads of CP_BATCH images are issued together
+// before any of them is used (one load per step made this a chain of ~n_images memory round trips).
 constexpr int CP_BATCH = 10;
 
-__global__ __launch_bounds__(256) void cp_propose_kernel(const float4 *__restrict__ coeff, float4 *__restrict__ gradf,
-                                                         float4 *__restrict__ grad, uint32_t n_owned,
-                                                         int n_cp, float alpha, double *__restrict__ gridsum,
-                                                         unsigned long long *n_big)
-{
-    const int cp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cp == 0) *n_big = 0ull;                 // counted by cp_center_kernel, later in the stream
-    if (cp >= n_cp) return;
-    double sx = 0, sy = 0, sz = 0;
-    for (uint32_t i0 = 0; i0 < n_owned; i0 += CP_BATCH) {
-        float4 g4[CP_BATCH], c4[CP_BATCH];
-        #pragma unroll
-        for (int b = 0; b < CP_BATCH; b++) {
-            const size_t o = (size_t)min(i0 + b, n_owned - 1) * n_cp + cp;
-            g4[b] = gradf[o];
-            c4[b] = coeff[o];
-        }
-        #pragma unroll
-        for (int b = 0; b < CP_BATCH; b++) {
-            if (i0 + b >= n_owned) break;
-            const size_t o = (size_t)(i0 + b) * n_cp + cp;
-            gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);      // Fill(0) for the next step (imageGroup.cxx:249)
-            float4 n4;
-            if (g4[b].w > 0) {
-                n4.x = c4[b].x + alpha * g4[b].x / g4[b].w;
-                n4.y = c4[b].y + alpha * g4[b].y / g4[b].w;
-                n4.z = c4[b].z + alpha * g4[b].z / g4[b].w;
-            } else {
-                n4.x = c4[b].x; n4.y = c4[b].y; n4.z = c4[b].z;
-            }
-            n4.w = g4[b].w;
-            grad[o] = n4;
-            sx += n4.x; sy += n4.y; sz += n4.z;
-        }
-    }
-    gridsum[3 * (size_t)cp] = sx; gridsum[3 * (size_t)cp + 1] = sy; gridsum[3 * (size_t)cp + 2] = sz;
-}
-
-// ---- second half of K9: subtract the group mean, count oversize coefficients -----
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,

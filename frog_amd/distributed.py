@@ -289,8 +289,7 @@ class ShardedImageGroup:
         import time
         t0 = time.perf_counter()
         info = self._setup(level)
-        self._torch.cuda.synchronize() if hasattr(self.engine, "_ctx") else None
-        self.setup_seconds.append(time.perf_counter() - t0)
+        self.setup_seconds.append(time.perf_counter() - t0)      # host side only: the device work is queued, not awaited
         return info
 
     def _setup(self, level):
