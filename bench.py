@@ -29,12 +29,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def schedule(k):
-    """Split K timed iterations into (linear, [level0, level1, level2])."""
-    n_lin = max(1, int(round(k * 50.0 / 650.0))) if k > 1 else k
+# BASELINE.json configs[1], [2] and [4] as generator / solver parameters.  configs[3] is [2]
+# sharded over 8 GPUs: `--gpus 8`.
+CONFIGS = {
+    2: dict(images=20, points=20000, pairs_per_block=10526.0, partners=0, levels=0, what="20 images, ~2 M pairs, linear only"),
+    3: dict(images=100, points=20000, pairs_per_block=10101.0, partners=0, levels=3, what="100 images, ~50 M pairs, linear + 3 deformable levels"),
+    5: dict(images=500, points=20000, pairs_per_block=16667.0, partners=60, levels=5,
+            what="500 images (~60 partner images each), ~2.5e8 pairs, linear + 5 deformable levels, -gd 1"),
+}
+
+
+def schedule(k, levels=3):
+    """Split K timed iterations into (linear, [level0, ...]) in the reference's default mix 50 : 200 per level."""
+    if levels == 0:
+        return k, []
+    n_lin = max(1, int(round(k * 50.0 / (50.0 + 200.0 * levels)))) if k > 1 else k
     rest = k - n_lin
-    per = [rest // 3] * 3
-    per[2] += rest - 3 * (rest // 3)
+    per = [rest // levels] * levels
+    per[-1] += rest - levels * (rest // levels)
     return n_lin, per
 
 
@@ -53,7 +65,7 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
     t = time.perf_counter(); ref.linear_step(); ref.transform_points(); t_lin = time.perf_counter() - t
     ref.transform_points(True)
     t_def = []
-    for level in range(3):
+    for level in range(len(per_level)):
         if per_level[level] == 0:
             t_def.append(0.0)
             continue
@@ -74,12 +86,20 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=650,
-                    help="timed iterations; 650 = the reference's default schedule -li 50 -dl 3 -di 200")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed iterations; default = the reference's schedule for the configuration (650 for config 3: "
+                         "-li 50 -dl 3 -di 200), 130 for config 5")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--images", type=int, default=100)
-    ap.add_argument("--points", type=int, default=20000)
-    ap.add_argument("--pairs-per-block", type=float, default=10101.0)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: 3 (default, the one the metric is quoted on), 2 (linear only), 5 (500 images)")
+    ap.add_argument("--levels", type=int, default=None, help="deformable levels (default: the configuration's)")
+    ap.add_argument("--images", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--pairs-per-block", type=float, default=None)
+    ap.add_argument("--shard-of", type=int, nargs=2, metavar=("R", "N"), default=None,
+                    help="single-GPU proxy of rank R of an N-GPU run: this process owns shard R of N, the other ranks' "
+                         "coordinates stay where the set-up left them, no collective is issued; prints per-phase kernel "
+                         "times of that rank's share (not a metric line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
@@ -115,17 +135,35 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    cfg = CONFIGS[args.config]
+    images = args.images or cfg["images"]
+    points = args.points or cfg["points"]
+    ppb = args.pairs_per_block or cfg["pairs_per_block"]
+    levels = cfg["levels"] if args.levels is None else args.levels
+    if args.steps is None:
+        args.steps = {2: 50, 3: 650, 5: 130}[args.config] if args.levels is None else 50 + 200 * levels
+    if args.config != 3 or args.shard_of:
+        args.no_cpu_baseline = True        # the host baseline is timed on the configuration the metric is quoted on
     t0 = time.perf_counter()
-    pairs = Pairs.synthetic(args.images, args.points, args.pairs_per_block, seed=1)
+    pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=cfg["partners"] if images == cfg["images"] else 0)
     t_gen = time.perf_counter() - t0
-    shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
+    if args.shard_of:
+        if world != 1:
+            raise SystemExit("--shard-of is a single-process proxy")
+        shards = plan_shards(pairs.row_ptr, pairs.point_offset, args.shard_of[1])
+        shards = [shards[args.shard_of[0]]]
+    else:
+        shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
     opts = _abi.FrogOptions.default()
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0
     grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world)
+    grp.time_comm = world > 1 and backend == "nccl"       # per-collective device time in the line ("comm_ms")
+    if args.shard_of:
+        args.kernel_times = True
 
-    n_lin, per_level = schedule(args.steps)
+    n_lin, per_level = schedule(args.steps, levels)
 
     def sync():
         if world > 1:
@@ -171,7 +209,7 @@ def main():
     phase_s["linear"] = time.perf_counter() - tp
     take("linear")
     grids = []
-    for level in range(3):
+    for level in range(levels):
         if per_level[level] == 0:
             continue
         tp = time.perf_counter()
@@ -182,6 +220,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_start
     engine.profile_enable(False)
+    if grp.time_comm:
+        grp.comm_summary()
     if grp.measures:
         e = grp.measures[-1]
 
@@ -197,6 +237,8 @@ def main():
     l_own = int(rp[int(po[own_e])]) - int(rp[int(po[own_b])])
     # dominant kernel: the half-link sweep of the deformable step
     dom = "sweep_deformable" if prof["sweep_deformable"][1] else "sweep_linear"
+    if levels == 0:
+        grp.transformPoints(True)
     ms, launches = prof[dom]
     alg_bytes = 20.0 * l_own + 12.0 * p_own      # 8 B link + 12 B gathered xyz2 per half-link, 12 B own xyz2 per point
     achieved = alg_bytes / (ms / launches * 1e-3) / 1e9 if launches else 0.0
@@ -242,8 +284,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.images} images x {args.points} keypoints, {pairs.n_pairs} pairs "
-                                   f"({pairs.n_half_links} half-links), linear + 3 deformable levels, -g 100 -gd 1 -si 10",
+            "config": {"workload": f"BASELINE.json configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: {images} images x {points} keypoints, "
+                                   f"{pairs.n_pairs} pairs ({pairs.n_half_links} half-links), linear + {levels} deformable "
+                                   f"levels, -g 100 -gd 1 -si 10",
                        "schedule": {"linear": n_lin, "deformable_per_level": per_level},
                        "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
                        "final_E": e},
@@ -252,9 +295,16 @@ def main():
             "kernels_ms_by_phase": phase_k,
             "phase_iterations_per_s": {
                 "linear": n_lin / phase_s["linear"],
-                **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(3) if per_level[l]}},
+                **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(levels) if per_level[l]}},
             "setup_seconds": {"generate": t_gen, "create": t_create, "lattice_setups": grp.setup_seconds},
         }
+        if args.shard_of:
+            out["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
+                            f"other ranks' coordinates static; `value` is NOT the metric")
+            out["proxy_ms_per_iteration"] = {ph: {n: v["ms"] / max(1, (n_lin if ph == "linear" else per_level[int(ph[5:])]))
+                                                   for n, v in ks.items()} for ph, ks in phase_k.items()}
+        if grp.comm_ms:
+            out["comm_ms"] = grp.comm_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)
         print(json.dumps(out), flush=True)

@@ -281,10 +281,11 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> act_cnt;           // [n_tiles][n_groups]
     frog::DevBuf<frog::P3> pos2_snap;         // xyz2 of every point when the list was built
     frog::DevBuf<float> cut_now, cut_list;    // [nI] certified cutoff of the current mixtures / list cutoff at build time
-    frog::DevBuf<uint32_t> disp_bits;         // [nI] largest displacement since the build (f32 bits)
+    frog::DevBuf<uint32_t> disp_part;         // per-block maxima of the points' displacement since the build (f32 bits)
+    uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
     uint64_t cull_builds = 0;                 // statistics: lists built
-    bool disp_current = false;                // disp_bits holds the displacement of the CURRENT xyz2 from the snapshot
+    bool disp_current = false;                // disp_part holds the displacement of the CURRENT xyz2 from the snapshot
     bool disp_spec = false;                   // ... of pos2_spec (becomes current when it is published)
 
     // live timing

@@ -418,6 +418,7 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
 static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
 {
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    if (!n) return FROG_OK;                     // a context whose images are all empty: nothing to launch
     Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
         ctx->disp_current = false;
@@ -429,9 +430,11 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
         transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
                                                                          ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
-                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_bits.p);
+                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p);
+        if (with_disp) ctx->disp_n = div_up(n, 256);
+        // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
-        else ctx->disp_spec = with_disp;
+        else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
     }
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -880,7 +883,11 @@ static int cull_allocate(frog_ctx *ctx)
     FROG_HIP_CHECK(ctx->act_cnt.alloc(std::max<size_t>(1, (size_t)ctx->n_tiles * ctx->n_groups)));
     FROG_HIP_CHECK(ctx->pos2_snap.alloc(ctx->P));
     FROG_HIP_CHECK(ctx->cut_list.alloc(ctx->nI));
-    FROG_HIP_CHECK(ctx->disp_bits.alloc(ctx->nI));
+    {
+        uint32_t blocks = 0;
+        for (uint32_t i = 0; i < ctx->nI; i++) blocks += div_up(ctx->poff[i + 1] - ctx->poff[i], CULL_BLOCK_POINTS);
+        FROG_HIP_CHECK(ctx->disp_part.alloc(std::max<size_t>(1, std::max<size_t>(blocks, div_up(ctx->P, 256)))));
+    }
     FROG_HIP_CHECK(ctx->cull_state.alloc(2));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));
     ctx->cull_need_build = true;
@@ -905,20 +912,21 @@ static int cull_prepare(frog_ctx *ctx)
         else
             cull_build_kernel<true><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs.p, ctx->act_cnt.p);
         FROG_HIP_CHECK(hipGetLastError());
-        FROG_HIP_CHECK(hipMemsetAsync(ctx->disp_bits.p, 0, ctx->disp_bits.bytes(), s));
         ctx->cull_need_build = false;
         ctx->cull_builds++;
-        ctx->disp_current = true;           // the points are where the snapshot has them
+        ctx->disp_n = 0;                    // the points are where the snapshot has them: no displacement to look at
+        ctx->disp_current = true;
     }
-    // displacement since the build: already in disp_bits when the transform that produced the current xyz2 measured it
+    // displacement since the build: already in disp_part when the transform that produced the current xyz2 measured it
     // (launch_transform; whole-group contexts whose xyz2 nobody else writes), else one pass over all points
     if (!(ctx->disp_current && ctx->whole_group() && !ctx->xyz2_exported)) {
         uint32_t max_pts = 1;
         for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
-        cull_disp_kernel<<<dim3(div_up(max_pts, CULL_BLOCK_POINTS), nI), 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_bits.p);
+        const dim3 grid(div_up(max_pts, CULL_BLOCK_POINTS), nI);
+        cull_disp_kernel<<<grid, 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_part.p);
+        ctx->disp_n = grid.x * grid.y;
     }
-    ctx->disp_current = false;              // cull_validate_kernel clears disp_bits
-    cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_bits.p, nI, ctx->cull_state.p);
+    cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI, ctx->cull_state.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -985,8 +993,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
         la.n_big = ctx->n_big.p; la.ticket = ctx->energy_ticket.p + 1; la.energy = ctx->energy.p;
         ctx->centered_in_a = ctx->whole_group();
-        if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), 256, 0, s>>>(la, gd);
-        else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), 256, 0, s>>>(la, gd);
+        if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
+        else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
     }
     FROG_HIP_CHECK(hipGetLastError());
     ctx->pending_alpha = alpha;

@@ -14,10 +14,11 @@
 //   list         built once in a while (cull_build_kernel): the records of every (tile, partner group) whose
 //                distance at build time is below min(cut_list[A], cut_list[B]), compacted IN THEIR ORDER into a
 //                second record array; cut_list[k] = scale * cut_now[k] + pad is generous (the skin).
-//   check        before every sweep (cull_disp_kernel + cull_validate_kernel): disp[k] = largest distance of a
-//                point of image k from where it was at build time.  A link left out at build time had
-//                d_build >= cut_list[k] for k = A or B, so now d >= cut_list[k] - disp[A] - disp[B]; if
-//                    cut_list[k] - disp[k] - max_j disp[j] >= cut_now[k]  (+ rounding margin)   for EVERY image k
+//   check        before every sweep (cull_validate_kernel): D = largest distance of any point from where it was at
+//                build time (measured by the B-spline transform that produced the coordinates, or by
+//                cull_disp_kernel).  A link left out at build time had d_build >= cut_list[k] for k = A or B, so
+//                now d >= cut_list[k] - 2 D; if
+//                    cut_list[k] - 2 D >= cut_now[k]  (+ rounding margin)   for EVERY image k
 //                every left-out link is still a certain outlier and the sweep may walk the list instead of all
 //                records.  Otherwise the flag tells the sweep (on the device, same launch) to walk all records,
 //                and the host (through the fourth scalar it reads back per iteration anyway) to rebuild the list.
@@ -140,20 +141,21 @@ __global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, cons
     if (lane == 0) act_cnt[(size_t)t * a.n_groups + grp] = base;
 }
 
-// disp[k] = max over the points of image k of |xyz2 now - xyz2 at build time| (f32 bits: non-negative floats
-// order like unsigned integers; a NaN compares above every number and invalidates the list, as it should).
-// grid = (chunks of CULL_BLOCK_POINTS points, image).
+// Largest distance of a point from where it was at build time, as per-block maxima (f32 bits: non-negative floats order
+// like unsigned integers; a NaN compares above every number and invalidates the list, as it should).  No atomics: 30 000
+// device-scope atomic maxima on a handful of addresses cost the B-spline transform 100 us when it produced these (it
+// does, for contexts that own every moving point: k_grid.hip.h); every block owns one slot.  grid = (chunks of
+// CULL_BLOCK_POINTS points, image); a chunk past the end of its image stores 0.
 constexpr int CULL_BLOCK_POINTS = 2048;
 
-__global__ __launch_bounds__(256) void cull_disp_kernel(const P3 *pos2, const P3 *snap, const uint32_t *poff, uint32_t *disp_bits)
+__global__ __launch_bounds__(256) void cull_disp_kernel(const P3 *pos2, const P3 *snap, const uint32_t *poff, uint32_t *disp_part)
 {
     __shared__ uint32_t sh[4];
     const uint32_t img = blockIdx.y;
     const uint32_t p0 = poff[img] + blockIdx.x * CULL_BLOCK_POINTS, pe = poff[img + 1];
-    if (p0 >= pe) return;
     const uint32_t p1 = min(p0 + (uint32_t)CULL_BLOCK_POINTS, pe);
     uint32_t m = 0;
-    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+    for (uint32_t p = p0 + threadIdx.x; p < p1 && p0 < pe; p += 256) {
         const P3 u = pos2[p], v = snap[p];
         const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
         const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
@@ -163,45 +165,35 @@ __global__ __launch_bounds__(256) void cull_disp_kernel(const P3 *pos2, const P3
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
-        if (m) atomicMax(&disp_bits[img], m);
-    }
+    if (threadIdx.x == 0) disp_part[blockIdx.y * gridDim.x + blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 }
 
 // state[0] = 1 when some left-out link could have come within its images' cutoff (the sweep then walks all records
-// and the host rebuilds the list), else 0; disp_bits is cleared for the next check.  The margin (1e-4 relative, 0.01
-// absolute on the cutoff, 1e-5 relative on the list cutoff) covers the f32 roundings of the distances involved
-// (a few ulps of coordinates that are < 1e5 in any unit a medical image uses).  One block.
-__global__ __launch_bounds__(256) void cull_validate_kernel(const float *cut_now, const float *cut_list, uint32_t *disp_bits,
-                                                            uint32_t n_images, uint32_t *state)
+// and the host rebuilds the list), else 0.  With D = the largest displacement of any point since the build, a left-out
+// link (d_build >= cut_list[k] for k = A or B) is now at d >= cut_list[k] - 2 D, so the list is good while
+//     cut_list[k] - 2 D >= cut_now[k]   for every image k
+// (+ margin: 1e-4 relative and 0.01 absolute on the cutoff, 1e-5 relative on the list cutoff, for the f32 roundings of the
+// distances involved -- a few ulps of coordinates that are < 1e5 in any unit a medical image uses).  One block.
+__global__ __launch_bounds__(256) void cull_validate_kernel(const float *cut_now, const float *cut_list, const uint32_t *disp_part,
+                                                            uint32_t n_part, uint32_t n_images, uint32_t *state)
 {
-    __shared__ float shm[256];
+    __shared__ uint32_t shm[256];
     __shared__ int bad_s;
-    float mx = 0.f;
-    bool nan = false;
-    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
-        const float d = __uint_as_float(disp_bits[i]);
-        if (d != d) nan = true; else mx = fmaxf(mx, d);
-    }
-    shm[threadIdx.x] = nan ? __builtin_nanf("") : mx;
+    uint32_t mx = 0;
+    for (uint32_t i = threadIdx.x; i < n_part; i += 256) mx = max(mx, disp_part[i]);
+    shm[threadIdx.x] = mx;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float v = 0.f;
-        bool anynan = false;
-        for (int k = 0; k < 256; k++) { if (shm[k] != shm[k]) anynan = true; else v = fmaxf(v, shm[k]); }
-        shm[0] = anynan ? __builtin_nanf("") : v;
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) shm[threadIdx.x] = max(shm[threadIdx.x], shm[threadIdx.x + h]);
+        __syncthreads();
     }
-    __syncthreads();
-    const float dispmax = shm[0];
+    const float dispmax = __uint_as_float(shm[0]);          // NaN bits (> 0x7F800000) are the maximum when present
     int bad = 0;
     for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
-        const float d = __uint_as_float(disp_bits[i]);
-        const float need = cut_now[i] * 1.0001f + 0.01f + d + dispmax;          // inf when the image has no cutoff
+        const float need = cut_now[i] * 1.0001f + 0.01f + 2.0f * dispmax;        // inf when the image has no cutoff
         const float have = cut_list[i] * 0.99999f;
         if (!(need <= have)) bad = 1;                                           // also catches NaN
-        disp_bits[i] = 0u;
     }
     if (bad) atomicOr(&bad_s, 1);
     __syncthreads();

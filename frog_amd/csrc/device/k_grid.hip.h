@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
-                                                                const P3 *snap, uint32_t *disp_bits)
+                                                                const P3 *snap, uint32_t *disp_part)
 {
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
     // reduction at the end is wave-wide
@@ -154,21 +154,17 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
         if (apply) pos[p] = o;
     }
     if (snap) {
-        // largest distance of a point of each image from where it was when the outlier-culling list was built
-        // (k_cull.hip.h: what cull_disp_kernel computes, here for free).  Lanes are in (image, brick, cell) order, so a
-        // wavefront is almost always inside one image: one atomic per wavefront.
+        // largest distance of a point of this block from where it was when the outlier-culling list was built
+        // (k_cull.hip.h: what cull_disp_kernel computes, here for the price of one 12-byte read): one slot per block
+        __shared__ uint32_t sh[4];
         const P3 q = snap[p];
         const float dx = o.x - q.x, dy = o.y - q.y, dz = o.z - q.z;
         uint32_t m = valid ? (__float_as_uint(__builtin_sqrtf(dx * dx + dy * dy + dz * dz)) & 0x7FFFFFFFu) : 0u;
-        const int img = __float_as_int(v.w);
-        const int img0 = __builtin_amdgcn_readfirstlane(img);
-        if (__all(img == img0)) {
-            #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-            if ((threadIdx.x & 63) == 0 && m) atomicMax(&disp_bits[img0], m);
-        } else if (m) {
-            atomicMax(&disp_bits[img], m);
-        }
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) disp_part[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
     }
 }
 
@@ -672,8 +668,10 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
 // running f64 sum -- the reference's order exactly.  Step 4 re-reads the proposals this block has just written (L2).
 // Without CENTER the launch stops after step 3: the host all-reduces gridsum over the ranks and cp_center_kernel does 4.
 constexpr int LS_CPB = 16;          // control points per block
-constexpr int LS_IC = 16;           // images per pass: LS_CPB * LS_IC = 256 threads
-static_assert(LS_CPB * LS_IC == 256 && 3 * LS_CPB <= 256, "lattice_step_kernel thread mapping");
+constexpr int LS_IC = 64;           // images per pass (with 16 a group of 100 images took 7 dependent rounds of
+                                    // slot-pointer -> tile loads per block: 130 us where the three kernels took 77)
+constexpr int LS_THREADS = LS_CPB * LS_IC;
+static_assert(LS_THREADS <= 1024 && 3 * LS_CPB <= LS_THREADS, "lattice_step_kernel thread mapping");
 
 struct LatticeStepArgs {
     const float4 *stage;            // staged scatter tiles
@@ -692,11 +690,11 @@ struct LatticeStepArgs {
 };
 
 template <bool CENTER>
-__global__ __launch_bounds__(256) void lattice_step_kernel(const LatticeStepArgs a, const GeomDev g)
+__global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeStepArgs a, const GeomDev g)
 {
     __shared__ float prop[LS_IC][LS_CPB][3];
     __shared__ double mean[LS_CPB][3];
-    __shared__ unsigned int cnt_s[256];
+    __shared__ unsigned int cnt_s[LS_THREADS];
     const int tid = threadIdx.x;
     const int c = tid % LS_CPB, il = tid / LS_CPB;
     const int cp = blockIdx.x * LS_CPB + c;
@@ -781,7 +779,7 @@ __global__ __launch_bounds__(256) void lattice_step_kernel(const LatticeStepArgs
     }
     cnt_s[tid] = cnt;
     __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
+    for (int h = LS_THREADS / 2; h > 0; h >>= 1) {
         if (tid < h) cnt_s[tid] += cnt_s[tid + h];
         __syncthreads();
     }

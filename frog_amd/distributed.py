@@ -231,10 +231,36 @@ class ShardedImageGroup:
         self.measures = []
         self.gridsPerLevel = []
         self.setup_seconds = []
+        # device time of every collective (events on the stream the collectives are ordered against), summed per kind by
+        # comm_summary(); costs two event records per collective, so only on request
+        self.time_comm = False
+        self._comm_events = []
+        self.comm_ms = {}
+        # ncclAllGather's in-place form (send buffer = this rank's slice of the receive buffer) is what the RCCL path uses;
+        # gloo gets a private copy of the rank's rows
+        self.inplace_gather = self.multi and self._dist.get_backend(group) == "nccl"
 
     @property
     def multi(self):
         return self.world_size > 1
+
+    def _collective(self, kind, fn):
+        if not self.time_comm:
+            return fn()
+        a = self._torch.cuda.Event(enable_timing=True); b = self._torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self._comm_events.append((kind, a, b))
+
+    def comm_summary(self):
+        """{collective kind: {"ms": total device ms, "calls": n}} since the last call (synchronises)."""
+        self._torch.cuda.synchronize()
+        for kind, a, b in self._comm_events:
+            e = self.comm_ms.setdefault(kind, {"ms": 0.0, "calls": 0})
+            e["ms"] += a.elapsed_time(b); e["calls"] += 1
+        self._comm_events = []
+        return self.comm_ms
 
     # -- the six methods -----------------------------------------------------------
     def setupLinearTransforms(self):
@@ -248,11 +274,11 @@ class ShardedImageGroup:
         if len({e - b for b, e in rows}) == 1 and rows[0][0] == 0 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])):
             # equal shards: one all-gather (ncclAllGather over xGMI) straight into the replica
             b, e = rows[self.rank]
-            # the rank's own rows go through a private copy (a few MB, microseconds): gathering in place, with the input
-            # aliasing this rank's slice of the output, is legal for ncclAllGather but could not be exercised on the
-            # one-GPU boxes this was developed on
-            mine = self.engine.xyz2[b:e].clone()
-            self._dist.all_gather_into_tensor(self.engine.xyz2[:rows[-1][1]], mine, group=self.group)
+            # in place on RCCL: the rank's rows are already where ncclAllGather wants them (sendbuff == recvbuff +
+            # rank * sendcount, the form FSDP uses for its flat parameters); a private copy for other backends
+            mine = self.engine.xyz2[b:e] if self.inplace_gather else self.engine.xyz2[b:e].clone()
+            self._collective("all_gather_xyz2", lambda: self._dist.all_gather_into_tensor(
+                self.engine.xyz2[:rows[-1][1]], mine, group=self.group))
             return
         # ragged shards: still ONE collective -- every rank contributes its rows padded to the longest
         # shard, the gathered slab is unpacked into the replica (world_size small device copies).  One
@@ -268,7 +294,7 @@ class ShardedImageGroup:
             self._gather_key = key
         b, e = rows[self.rank]
         self._gather_in[:e - b].copy_(xyz2[b:e])
-        self._dist.all_gather_into_tensor(self._gather_out, self._gather_in, group=self.group)
+        self._collective("all_gather_xyz2", lambda: self._dist.all_gather_into_tensor(self._gather_out, self._gather_in, group=self.group))
         for r, (rb, re_) in enumerate(rows):
             if r != self.rank and re_ > rb:
                 xyz2[rb:re_].copy_(self._gather_out[r * longest:r * longest + (re_ - rb)])
@@ -276,13 +302,13 @@ class ShardedImageGroup:
     def updateStats(self):
         self.engine.update_stats_local()
         if self.multi:
-            self._dist.all_reduce(self.engine.em, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._collective("all_reduce_em", lambda: self._dist.all_reduce(self.engine.em, op=self._dist.ReduceOp.SUM, group=self.group))
         self.engine.stats_publish()
 
     def updateLinearTransforms(self):
         self.engine.linear_step_local()
         if self.multi:
-            self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._collective("all_reduce_energy", lambda: self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group))
         return self.engine.energy_read()[0]
 
     def setupDeformableTransforms(self, level):
@@ -304,10 +330,10 @@ class ShardedImageGroup:
     def updateDeformableTransforms(self, alpha):
         self.engine.phase_a(alpha)
         if self.multi:
-            self._dist.all_reduce(self.engine.gridsum, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._collective("all_reduce_gridsum", lambda: self._dist.all_reduce(self.engine.gridsum, op=self._dist.ReduceOp.SUM, group=self.group))
         self.engine.phase_b()
         if self.multi:
-            self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._collective("all_reduce_energy", lambda: self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group))
         return self.engine.phase_c()
 
     def countInliers(self):

@@ -1,0 +1,64 @@
+/*
+ * frog_comm.h -- C ABI of libfrog_comm.so: the collectives of a multi-GPU registration, for hosts that
+ * drive several contexts of libfrog_hip.so from ONE process (one host thread per GPU).
+ *
+ * The reference parallelises every loop of ImageGroup over images with OpenMP
+ * (registration/imageGroup.cxx:239, :572, :912, :1067) inside one address space; here each GPU owns a
+ * contiguous range of images (frog_create image_begin / image_end) and the four places where a loop
+ * reads ANOTHER image's state become collectives over RCCL (xGMI):
+ *
+ *   transformPoints  (imageGroup.cxx:910-916)   xyz2 of every image is read by the link loops of all
+ *                                               others            -> all-gather of the owned xyz2 rows
+ *   updateStats      (:569-598)                 (c1, c2, ratio) of the partner image  -> all-reduce(sum)
+ *                                               of the table, rows of other ranks zero
+ *   update{Linear,Deformable}Transforms         omp reduction(+) of sDistances / sWeights (:239, :1067)
+ *                                               -> all-reduce(sum) of FROG_BUF_ENERGY
+ *   updateDeformableTransforms phase B          mean of the proposals over ALL images (:400-432): the
+ *                                               shared common-space grid -> all-reduce(sum) of
+ *                                               FROG_BUF_GRIDSUM, then of the oversize count (ENERGY[2])
+ *   setupDeformableTransforms (:159-179)        bounding box over all images -> all-reduce(min / max)
+ *
+ * Every rank calls the same function at the same point of the schedule, from its own host thread
+ * (hipSetDevice is per thread); calls are enqueued on the context's stream, nothing blocks the host
+ * except frog_comm_all_reduce_bounds (it returns host values).  Kept out of libfrog_hip.so so that a host
+ * that brings its own collectives (e.g. torch.distributed, frog_amd/distributed.py) never loads RCCL twice.
+ */
+#ifndef FROG_COMM_H
+#define FROG_COMM_H
+
+#include "frog_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct frog_comm frog_comm;
+
+/* One communicator per rank, for the devices devices[0..n_ranks) (ncclCommInitAll: all n created by ONE
+ * call, from one thread, before the per-rank threads start).  out[r] belongs to rank r. */
+int frog_comm_create_rccl(int n_ranks, const int *devices, frog_comm **out);
+/* The same interface without RCCL, for n_ranks contexts that may share one device: the collectives go
+ * through a host staging area and barriers between the ranks' threads.  For tests and for rehearsing the
+ * multi-rank control flow on a single GPU; not a fast path. */
+int frog_comm_create_loopback(int n_ranks, frog_comm **out);
+/* Destroys all n communicators of one create call (pass the array it filled). */
+void frog_comm_destroy_all(int n_ranks, frog_comm **comms);
+
+/* `ctx` must be the context of this communicator's rank; image_begin[r] .. image_begin[r + 1] are the
+ * images of rank r (n_ranks + 1 entries, the same on every rank). */
+int frog_comm_bind(frog_comm *comm, frog_ctx *ctx, const uint32_t *image_begin);
+
+/* all-gather of the owned rows of FROG_BUF_XYZ2, in place in every rank's replica (one grouped RCCL
+ * operation of n broadcasts: shards are ragged) */
+int frog_comm_all_gather_xyz2(frog_comm *comm);
+/* all-reduce(sum) of FROG_BUF_EM (float), FROG_BUF_ENERGY or FROG_BUF_GRIDSUM (double), in place */
+int frog_comm_all_reduce(frog_comm *comm, int which);
+/* group-wide box from the ranks' own boxes (frog_bounds_local): mins / maxs are replaced */
+int frog_comm_all_reduce_bounds(frog_comm *comm, double mins[3], double maxs[3]);
+/* host-side barrier between the ranks' threads (both kinds) */
+int frog_comm_barrier(frog_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FROG_COMM_H */
