@@ -376,6 +376,14 @@ int frog_set_stream(frog_ctx *ctx, void *hip_stream)
     return FROG_OK;
 }
 
+int frog_get_stream(frog_ctx *ctx, void **hip_stream, int *device)
+{
+    if (!ctx) return fail(FROG_E_INVALID, "null context");
+    if (hip_stream) *hip_stream = (void *)ctx->stream;
+    if (device) *device = ctx->device;
+    return FROG_OK;
+}
+
 int frog_synchronize(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);

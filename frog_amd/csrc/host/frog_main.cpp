@@ -7,7 +7,8 @@
 // a time, -j is the only valueless flag and -lanchor takes three values.
 // Outputs go to the current directory.
 //
-// Additions of this build:  -dev <n> HIP device, -q 0/1 quiet iterations,
+// Additions of this build:  -dev <n> HIP device, -q 0/1 quiet iterations, -ng <n> images sharded over n GPUs
+// (one host thread per GPU, RCCL collectives; -ngl <n>: n contexts on one device, host-staged collectives),
 // and a generator mode   frog --synth out.bin nImages pointsPerImage pairsPerBlock [seed]
 // that writes a synthetic pairs.bin (the reference ships no data).
 
@@ -83,6 +84,8 @@ int main(int argc, char *argv[])
         cout << "-j            : outputs a single big JSON file for each transform. Default : " << group.writeSingleFileTransforms << endl;
         cout << "-ts subdir    : subdirectory where transforms will be written. Default : " << group.transformSubdirectory << endl;
         cout << "-dev number   : HIP device. Default : " << group.device << endl;
+        cout << "-ng number    : shard the images over this many GPUs (devices dev .. dev+n-1), RCCL collectives. Default : " << group.nGpus << endl;
+        cout << "-ngl number   : the same with n contexts on ONE device and host-staged collectives (rehearsal)" << endl;
         cout << "-q 0/1        : do not print one line per iteration. Default : " << group.quiet << endl;
         return 1;
     }
@@ -132,6 +135,8 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-mf") == 0) group.outputFileName = value;
         if (strcmp(key, "-wp") == 0) group.writePairs = atoi(value);
         if (strcmp(key, "-dev") == 0) group.device = atoi(value);
+        if (strcmp(key, "-ng") == 0) { group.nGpus = atoi(value); group.loopback = false; }
+        if (strcmp(key, "-ngl") == 0) { group.nGpus = atoi(value); group.loopback = true; }
         if (strcmp(key, "-q") == 0) group.quiet = atoi(value);
         if (strcmp(key, "-j") == 0) {
             group.writeSingleFileTransforms = true;

@@ -19,6 +19,46 @@
 #include <omp.h>
 #include <zlib.h>
 #include <sstream>
+#include <dlfcn.h>
+
+#include "../../../include/frog_comm.h"
+
+// libfrog_comm.so (RCCL) is loaded on demand, for -ng / -ngl only: a process that brings its own communicator (the Python
+// drivers over torch.distributed) uses this library without ever mapping a second RCCL.
+namespace {
+struct CommApi {
+    decltype(&frog_comm_create_rccl) create_rccl = nullptr;
+    decltype(&frog_comm_create_loopback) create_loopback = nullptr;
+    decltype(&frog_comm_destroy_all) destroy_all = nullptr;
+    decltype(&frog_comm_bind) bind = nullptr;
+    decltype(&frog_comm_all_gather_xyz2) all_gather_xyz2 = nullptr;
+    decltype(&frog_comm_all_reduce) all_reduce = nullptr;
+    decltype(&frog_comm_all_reduce_bounds) all_reduce_bounds = nullptr;
+    decltype(&frog_comm_barrier) barrier = nullptr;
+    bool load(std::string &err)
+    {
+        if (create_rccl) return true;
+        Dl_info info;
+        std::string dir;
+        if (dladdr((void *)&frog_pairs_read, &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+        }
+        void *h = dlopen((dir + "libfrog_comm.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libfrog_comm.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) { err = dlerror(); return false; }
+#define LOAD(field, name) field = (decltype(field))dlsym(h, name); if (!field) { err = std::string("missing symbol ") + name; return false; }
+        LOAD(create_rccl, "frog_comm_create_rccl"); LOAD(create_loopback, "frog_comm_create_loopback");
+        LOAD(destroy_all, "frog_comm_destroy_all"); LOAD(bind, "frog_comm_bind");
+        LOAD(all_gather_xyz2, "frog_comm_all_gather_xyz2"); LOAD(all_reduce, "frog_comm_all_reduce");
+        LOAD(all_reduce_bounds, "frog_comm_all_reduce_bounds"); LOAD(barrier, "frog_comm_barrier");
+#undef LOAD
+        return true;
+    }
+};
+CommApi g_comm;
+}
 
 using std::cout;
 using std::endl;
@@ -62,8 +102,218 @@ ImageGroup::ImageGroup()
 
 ImageGroup::~ImageGroup()
 {
-    if (ctx) frog_destroy(ctx);
+    if (!comms.empty() && g_comm.destroy_all) g_comm.destroy_all((int)comms.size(), comms.data());
+    if (!ctxs.empty()) { for (frog_ctx *c : ctxs) if (c) frog_destroy(c); }
+    else if (ctx) frog_destroy(ctx);
     if (pairs && ownPairs) frog_pairs_free(pairs);
+}
+
+frog_ctx *ImageGroup::ctxOf(uint32_t image) const
+{
+    if (ctxs.empty()) return ctx;
+    for (size_t r = 0; r + 1 < shardBegin.size(); r++)
+        if (image >= shardBegin[r] && image < shardBegin[r + 1]) return ctxs[r];
+    return ctx;
+}
+
+// Contiguous image ranges, one per rank, balanced by half-link count (the cost of every loop of the solver is
+// proportional to the half-links of the images it walks); every rank gets at least one image.
+void ImageGroup::planShards()
+{
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    const uint32_t nI = m.n_images;
+    if ((uint32_t)nGpus > nI) { cout << "Error : more GPUs than images" << endl; exit(1); }
+    const uint64_t total = m.row_ptr[m.point_offset[nI]];
+    shardBegin.assign(1, 0);
+    for (int r = 1; r < nGpus; r++) {
+        const double target = (double)total * r / nGpus;
+        uint32_t i = shardBegin.back() + 1;
+        // nearest image boundary to the target, leaving room for the ranks on both sides
+        while (i < nI - (uint32_t)(nGpus - r) && (double)m.row_ptr[m.point_offset[i]] < target
+               && std::fabs((double)m.row_ptr[m.point_offset[i + 1]] - target) <= std::fabs((double)m.row_ptr[m.point_offset[i]] - target))
+            i++;
+        shardBegin.push_back(i);
+    }
+    shardBegin.push_back(nI);
+}
+
+void ImageGroup::createShardedContexts()
+{
+    std::string err;
+    if (!g_comm.load(err)) { cout << "Error : cannot load libfrog_comm.so (" << err << ")" << endl; exit(1); }
+    if (numberOfFixedImages) { cout << "Error : -fi cannot be combined with -ng / -ngl" << endl; exit(1); }
+    planShards();
+    frog_options o;
+    frog_options_default(&o);
+    o.linear_alpha = linearAlpha; o.use_scale = useScale; o.initial_grid_size = initialGridSize;
+    o.bounding_box_margin = boundingBoxMargin; o.inlier_threshold = inlierThreshold;
+    o.guarantee_diffeomorphism = guaranteeDiffeomorphism; o.max_displacement_ratio = maxDisplacementRatio;
+    o.stats_max_size = statsMaxSize; o.stats_max_iterations = statsMaxIterations; o.stats_epsilon = statsEpsilon;
+    frog_model m;
+    frog_pairs_model(pairs, &m);
+    std::vector<int> devices(nGpus);
+    for (int r = 0; r < nGpus; r++) devices[r] = loopback ? device : device + r;
+    comms.assign(nGpus, nullptr);
+    check(loopback ? g_comm.create_loopback(nGpus, comms.data()) : g_comm.create_rccl(nGpus, devices.data(), comms.data()),
+          "frog_comm_create");
+    ctxs.assign(nGpus, nullptr);
+    cout << "Images sharded over " << nGpus << (loopback ? " contexts on device " : " GPUs, first device ") << device << " :";
+    for (int r = 0; r < nGpus; r++) cout << " [" << shardBegin[r] << "," << shardBegin[r + 1] << ")";
+    cout << endl;
+    for (int r = 0; r < nGpus; r++)        // one after the other: the layout build of each context already uses all host threads
+        check(frog_create(&m, &o, devices[r], shardBegin[r], shardBegin[r + 1], &ctxs[r]), "frog_create");
+    ctx = ctxs[0];
+    if (!hardLinks.empty()) {
+        std::vector<uint64_t> a, b;
+        for (const auto &hl : hardLinks) {
+            a.push_back((uint64_t)m.point_offset[hl.first.image] + hl.first.point);
+            b.push_back((uint64_t)m.point_offset[hl.second.image] + hl.second.point);
+        }
+        const float constraintWeight = m.n_images * landmarksConstraintsWeight;
+        for (frog_ctx *c : ctxs)        // every context keeps the links of its own points
+            check(frog_set_hard_links(c, a.data(), b.data(), a.size(), constraintWeight * constraintWeight), "frog_set_hard_links");
+    }
+    counts.assign(m.n_images, frog_counts{});
+}
+
+// run()'s loops for images sharded over several GPUs (imageGroup.cxx:31-128): one host thread per rank, all executing
+// the same control flow on their own context; the places where the reference's loops read another image's state are
+// collectives (include/frog_comm.h).  E and the oversize count are all-reduced, so every rank takes the same branch.
+// Rank 0 prints and records the measures.
+void ImageGroup::runSharded()
+{
+    using clk = std::chrono::steady_clock;
+    const int N = nGpus;
+    #pragma omp parallel num_threads(N)
+    {
+        const int r = omp_get_thread_num();
+        frog_ctx *c = ctxs[r];
+        frog_comm *cm = comms[r];
+        const bool root = r == 0;
+        auto ck = [&](int rc, const char *what) { if (rc) { 
+            #pragma omp critical
+            { cout << "Error : " << what << " failed on rank " << r << " (" << rc << "): " << frog_last_error() << endl; exit(1); } } };
+        auto transformPoints = [&](int apply) {
+            ck(frog_transform_points_local(c, apply), "frog_transform_points_local");
+            ck(g_comm.all_gather_xyz2(cm), "frog_comm_all_gather_xyz2");
+        };
+        auto updateStats = [&]() {
+            ck(frog_update_stats_local(c), "frog_update_stats_local");
+            ck(g_comm.all_reduce(cm, FROG_BUF_EM), "frog_comm_all_reduce");
+            ck(frog_stats_publish(c), "frog_stats_publish");
+        };
+        auto setup = [&](int level) {
+            double mn[3], mx[3];
+            frog_grid_info info;
+            ck(frog_bounds_local(c, mn, mx), "frog_bounds_local");
+            ck(g_comm.all_reduce_bounds(cm, mn, mx), "frog_comm_all_reduce_bounds");
+            ck(frog_deformable_setup_bounds(c, level, mn, mx, &info), "frog_deformable_setup_bounds");
+            if (root) {
+                double length[3];
+                for (int k = 0; k < 3; k++) length[k] = info.bbox[2 * k + 1] - info.bbox[2 * k];
+                cout << "Bounding box : "; print(info.bbox, 6);
+                cout << "Box length : "; print(length, 3);
+                cout << "Grid origin : "; print(info.origin, 3);
+                cout << "Grid spacing : "; print(info.spacing, 3);
+                cout << "Grid dimensions (control points): "; print(info.dims, 3);
+            }
+        };
+        auto census = [&]() {
+            ck(frog_count_inliers(c, counts.data()), "frog_count_inliers");       // every rank fills its own images' entries
+            g_comm.barrier(cm);
+            if (root) {
+                long long nPairs = 0, nInliers = 0, nOutliers = 0;
+                for (const auto &x : counts) { nPairs += x.pairs; nInliers += x.inliers; nOutliers += x.outliers; }
+                cout << "Stats:" << endl << nPairs << " half pairs" << endl << nInliers << " inliers" << endl << nOutliers << " outliers" << endl;
+                cout << "Outlier ratio (%): " << (float)100 * nOutliers / nPairs << endl;
+            }
+            g_comm.barrier(cm);
+        };
+
+        std::vector<uint32_t> sb(shardBegin);
+        ck(g_comm.bind(cm, c, sb.data()), "frog_comm_bind");
+        ck(frog_linear_init(c, linearInitializationAnchor), "frog_linear_init");       // :37
+        transformPoints(0);                                                           // :38
+
+        if (root) cout << endl << "Linear registration" << endl;
+        g_comm.barrier(cm);
+        auto t0 = clk::now();
+        for (int iteration = 0; iteration < linearIterations; iteration++) {
+            if (root && !quiet) cout << "Linear registration, iteration " << iteration + 1 << "/" << linearIterations << endl;
+            if (!(iteration % statIntervalUpdate)) updateStats();
+            ck(frog_linear_step_local(c), "frog_linear_step_local");
+            ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");
+            double E = 0;
+            ck(frog_energy_read(c, &E, nullptr), "frog_energy_read");
+            transformPoints(0);
+            if (root) computeLandmarkDistances((float)E);
+        }
+        g_comm.barrier(cm);
+        if (root) { loopSeconds += std::chrono::duration<double>(clk::now() - t0).count(); loopIterations += linearIterations; }
+        transformPoints(1);                                                           // :70
+        ck(frog_synchronize(c), "frog_synchronize");
+        g_comm.barrier(cm);
+        if (root) saveDistanceHistograms("histograms_linear.csv");                    // :71 (reads every rank's samples)
+        g_comm.barrier(cm);
+
+        if (deformableLevels) {
+            if (root) cout << endl << "Deformable registration" << endl;
+            census();                                                                 // :76
+            for (int level = 0; level < deformableLevels; level++) {
+                if (root) cout << endl << "Level " << level + 1 << "/" << deformableLevels << endl;
+                setup(level);                                                         // :81
+                transformPoints(0);
+                int numberOfGrids = 1;
+                float alpha = deformableAlpha;
+                if (root) cout << "alpha = " << alpha << endl;
+                int numberOfDiffeomorphicIterations = 0;
+                g_comm.barrier(cm);
+                t0 = clk::now();
+                for (int iteration = 0; iteration < deformableIterations; iteration++) {
+                    if (root && !quiet)
+                        cout << "Level " << level + 1 << "/" << deformableLevels << ", Iteration " << iteration + 1 << "/"
+                             << deformableIterations << endl;
+                    if (!(iteration % statIntervalUpdate)) updateStats();
+                    ck(frog_deformable_phase_a(c, alpha), "frog_deformable_phase_a");
+                    ck(g_comm.all_reduce(cm, FROG_BUF_GRIDSUM), "frog_comm_all_reduce");        // the shared common-space grid, :400-432
+                    ck(frog_deformable_phase_b(c), "frog_deformable_phase_b");
+                    ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");         // energy sums + oversize count
+                    double E = 0;
+                    ck(frog_deformable_phase_c(c, &E), "frog_deformable_phase_c");
+                    const float e = (float)E;
+                    if (e < 0) {                                                  // :97-115, the same on every rank
+                        if (root) cout << endl << "Diffeomorphism is not guaranteed : Iteration canceled" << endl;
+                        if (numberOfDiffeomorphicIterations == 0) {
+                            alpha /= 2;
+                            if (root) cout << "Halving alpha. New Value : " << alpha << endl;
+                        }
+                        if (root) cout << " creating new grid" << endl;
+                        numberOfGrids++;
+                        iteration--;
+                        transformPoints(1);
+                        setup(level);
+                        transformPoints(0);
+                        numberOfDiffeomorphicIterations = 0;
+                        continue;
+                    }
+                    numberOfDiffeomorphicIterations++;
+                    transformPoints(0);
+                    if (root) computeLandmarkDistances(e);
+                }
+                g_comm.barrier(cm);
+                if (root) { loopSeconds += std::chrono::duration<double>(clk::now() - t0).count(); loopIterations += deformableIterations; }
+                census();                                                             // :123
+                if (root) {
+                    cout << "Number of grids for this level : " << numberOfGrids << endl;
+                    gridsPerLevel.push_back(numberOfGrids);
+                }
+                transformPoints(1);
+            }
+        }
+        ck(frog_synchronize(c), "frog_synchronize");
+        g_comm.barrier(cm);
+    }
 }
 
 void ImageGroup::check(int rc, const char *what)
@@ -174,6 +424,15 @@ void ImageGroup::run()
         cout << "Error : -fi must leave at least one image to register" << endl;
         exit(1);
     }
+    if (nGpus > 1) {
+        // images sharded over several GPUs: the loops run in runSharded(), everything after them (error maps, files)
+        // below is shared with the single-GPU path and asks the context that owns each image
+        { const auto t_ctx = clk::now(); createShardedContexts();
+          if (std::getenv("FROG_TIMING")) cout << "[timing] frog_create x " << nGpus << " : " << std::chrono::duration<double>(clk::now() - t_ctx).count() << "s" << endl; }
+        runSharded();
+        finishRun();
+        return;
+    }
     if (numberOfFixedImages) readAndApplyFixedImagesTransforms();       // :34
     { const auto t_ctx = clk::now(); createContext();                   // :36 setupStats
       if (std::getenv("FROG_TIMING")) cout << "[timing] frog_create : " << std::chrono::duration<double>(clk::now() - t_ctx).count() << "s" << endl; }
@@ -282,6 +541,15 @@ void ImageGroup::run()
             gridsPerLevel.push_back(numberOfGrids);
             check(frog_transform_points(ctx, 1), "frog_transform_points");
         }
+    }
+    finishRun();
+}
+
+// run(), imageGroup.cxx:130-155: everything after the iteration loops
+void ImageGroup::finishRun()
+{
+    using clk = std::chrono::steady_clock;
+    if (deformableLevels) {
         int total = 0;
         cout << "Grids per level : ";
         for (int n : gridsPerLevel) { total += n; cout << n << " "; }
@@ -313,14 +581,15 @@ void ImageGroup::run()
 void ImageGroup::saveErrorMaps()
 {
     std::filesystem::create_directory(errorMapsSubdirectory.c_str());
-    check(frog_residual_sums(ctx), "frog_residual_sums");
+    if (ctxs.empty()) check(frog_residual_sums(ctx), "frog_residual_sums");
+    else for (frog_ctx *c : ctxs) check(frog_residual_sums(c), "frog_residual_sums");      // every rank: its own images
     const uint32_t n = frog_num_images(ctx);
     std::vector<frog_grid_info> infos(n);
     std::vector<std::vector<float>> maps(n);
     for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :481
-        check(frog_get_error_map(ctx, image, &infos[image], nullptr, 0), "frog_get_error_map");
+        check(frog_get_error_map(ctxOf(image), image, &infos[image], nullptr, 0), "frog_get_error_map");
         maps[image].resize((size_t)4 * infos[image].dims[0] * infos[image].dims[1] * infos[image].dims[2]);
-        check(frog_get_error_map(ctx, image, &infos[image], maps[image].data(), maps[image].size()), "frog_get_error_map");
+        check(frog_get_error_map(ctxOf(image), image, &infos[image], maps[image].data(), maps[image].size()), "frog_get_error_map");
     }
     int failed = 0;
     #pragma omp parallel for schedule(dynamic, 1)                                   // compression and file output on all host threads
@@ -555,7 +824,7 @@ void ImageGroup::displayStats()
         float em[3];
         check(frog_get_em(ctx, i, em), "frog_get_em");
         int s = 0;
-        check(frog_get_samples(ctx, i, smp.data(), nullptr, (int)smp.size(), &s), "frog_get_samples");
+        check(frog_get_samples(ctxOf(i), i, smp.data(), nullptr, (int)smp.size(), &s), "frog_get_samples");
         s = std::min<int>(s, (int)smp.size());
         cout << "Stats " << i << ":";
         cout << "c1=" << em[0] << ",c2=" << em[1] << ",r=" << em[2] << ",nSamples=" << s;
@@ -576,7 +845,7 @@ void ImageGroup::displayLinearTransforms()
     const uint32_t n = frog_num_images(ctx);
     for (uint32_t i = numberOfFixedImages; i < n; i++) {                           // :602
         double m[16];
-        check(frog_get_linear(ctx, i, m), "frog_get_linear");
+        check(frog_get_linear(ctxOf(i), i, m), "frog_get_linear");
         cout << "Image " << i << ", translation=" << m[3] << " " << m[7] << " " << m[11] << endl;
         cout << "scale=" << m[0] << " " << m[5] << " " << m[10] << endl;
     }
@@ -605,9 +874,9 @@ void ImageGroup::saveDistanceHistograms(const char *file)
     fs.open(file, std::fstream::out | std::fstream::trunc);
     for (uint32_t i = 0; i < n; i++) {
         int sz = 0;
-        check(frog_get_histogram(ctx, i, nullptr, 0, &sz), "frog_get_histogram");
+        check(frog_get_histogram(ctxOf(i), i, nullptr, 0, &sz), "frog_get_histogram");
         hist[i].assign((size_t)sz, 0.f);
-        if (sz) check(frog_get_histogram(ctx, i, hist[i].data(), sz, &sz), "frog_get_histogram");
+        if (sz) check(frog_get_histogram(ctxOf(i), i, hist[i].data(), sz, &sz), "frog_get_histogram");
         maxSize = std::max(maxSize, hist[i].size());
         fs << "image " << i;
         if (i < n - 1) fs << ","; else fs << endl;
@@ -649,12 +918,13 @@ void ImageGroup::saveTransforms()
     std::vector<Fetched> all(n);
     for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :1464
         Fetched &f = all[image];
-        check(frog_get_linear(ctx, image, f.m), "frog_get_linear");
+        frog_ctx *owner = ctxOf(image);
+        check(frog_get_linear(owner, image, f.m), "frog_get_linear");
         f.info.resize(nGrids); f.coeffs.resize(nGrids);
         for (int k = 0; k < nGrids; k++) {
-            check(frog_get_grid(ctx, image, k, &f.info[k], nullptr, 0), "frog_get_grid");
+            check(frog_get_grid(owner, image, k, &f.info[k], nullptr, 0), "frog_get_grid");
             f.coeffs[k].resize((size_t)3 * f.info[k].dims[0] * f.info[k].dims[1] * f.info[k].dims[2]);
-            check(frog_get_grid(ctx, image, k, &f.info[k], f.coeffs[k].data(), f.coeffs[k].size()), "frog_get_grid");
+            check(frog_get_grid(owner, image, k, &f.info[k], f.coeffs[k].data(), f.coeffs[k].size()), "frog_get_grid");
         }
     }
     int failed = 0;
@@ -759,6 +1029,17 @@ void ImageGroup::saveStatsJSON()
     const uint64_t P = frog_num_points(ctx);
     std::vector<float> xyz(3 * P);
     check(frog_get_points(ctx, xyz.data(), nullptr), "frog_get_points");
+    if (!ctxs.empty()) {
+        // a context re-bases only its own images' xyz: take every image's rows from its owner
+        frog_model m;
+        frog_pairs_model(pairs, &m);
+        std::vector<float> part(3 * P);
+        for (size_t r = 1; r < ctxs.size(); r++) {
+            check(frog_get_points(ctxs[r], part.data(), nullptr), "frog_get_points");
+            const size_t b = 3 * (size_t)m.point_offset[shardBegin[r]], e = 3 * (size_t)m.point_offset[shardBegin[r + 1]];
+            std::copy(part.begin() + b, part.begin() + e, xyz.begin() + b);
+        }
+    }
     double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
     for (uint64_t p = 0; p < P; p++)
         for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], (double)xyz[3 * p + k]); mx[k] = std::max(mx[k], (double)xyz[3 * p + k]); }

@@ -52,7 +52,10 @@ public:
 
     int RANSACBatches = 0;       // candidate batches (new: -rb; 0 = omp_get_num_procs() as upstream, imageGroup.cxx:635)
     std::vector<std::pair<int, long long>> ransacInliers;   // (image, best census) for bbox.json
-    int device = 0;              // HIP device ordinal (new: -dev)
+    int device = 0;              // HIP device ordinal (new: -dev); with -ng N the devices are device .. device + N - 1
+    int nGpus = 1;               // new: -ng N, images sharded over N GPUs, one host thread per GPU, collectives over RCCL
+    bool loopback = false;       // new: -ngl N, the same control flow with N contexts on ONE device and host-staged
+                                 // collectives (rehearsal / tests on a single-GPU box)
     bool quiet = false;          // suppress per-iteration lines (new: -q)
 
     // results of run()
@@ -70,8 +73,17 @@ public:
 protected:
     frog_pairs *pairs = nullptr;
     bool ownPairs = false;
-    frog_ctx *ctx = nullptr;
+    frog_ctx *ctx = nullptr;     // rank 0's context (the only one with one GPU)
     std::vector<frog_counts> counts;
+    // -ng N: one context and one communicator per rank, rank r owns images [shardBegin[r], shardBegin[r + 1])
+    std::vector<frog_ctx *> ctxs;
+    std::vector<struct frog_comm *> comms;
+    std::vector<uint32_t> shardBegin;
+    frog_ctx *ctxOf(uint32_t image) const;       // the context that owns (updates) `image`
+    void planShards();
+    void createShardedContexts();
+    void runSharded();                           // run()'s loops, executed by one thread per rank in lockstep
+    void finishRun();                            // :130-155, everything after the loops
 
     void createContext();
     void readAndApplyFixedImagesTransforms();    // :1419

@@ -56,6 +56,9 @@ void frog_destroy(frog_ctx *ctx);
  * the stream a host framework issues its collectives against.  Default: a
  * stream created by frog_create. */
 int frog_set_stream(frog_ctx *ctx, void *hip_stream);
+/* The stream the context's work is enqueued on and its device: what a caller needs to order its own collectives
+ * (RCCL: include/frog_comm.h) against the library's kernels.  Either pointer may be NULL. */
+int frog_get_stream(frog_ctx *ctx, void **hip_stream, int *device);
 int frog_synchronize(frog_ctx *ctx);
 
 /* ---- the six methods run() calls ------------------------------------------- */

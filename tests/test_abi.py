@@ -34,6 +34,19 @@ def test_host_library_exports_every_declared_symbol():
     assert sorted(_abi.HOST_SYMBOLS) == names
 
 
+def test_comm_library_exports_every_declared_symbol():
+    # libfrog_comm.so links RCCL: loaded in a child process, so that this one never maps it next to torch's own copy
+    import subprocess
+    import sys
+    names = declared("frog_comm.h")
+    assert len(names) >= 8
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); "
+            "missing = [n for n in sys.argv[2:] if not hasattr(L, n)]; print(missing); sys.exit(1 if missing else 0)")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(_abi.LIB_DIR, "libfrog_comm.so")] + names,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_struct_layouts_match_the_headers():
     assert C.sizeof(_abi.FrogOptions) == 4 * 10 + 4 * 6
     assert C.sizeof(_abi.FrogGridInfo) == 16 + 8 * 12

@@ -372,3 +372,57 @@ def test_cli_incremental_registration_with_fixed_images(tmp_path):
     b = Chain(read_transform(second / "transforms" / f"{n - 1}.json")).apply(own)
     print("median distance", np.median(np.linalg.norm(a - b, axis=1)), np.median(np.linalg.norm(a - own, axis=1)))
     assert np.median(np.linalg.norm(a - b, axis=1)) < 5.0 < np.median(np.linalg.norm(a - own, axis=1))
+
+
+def _run_frog(cwd, *flags):
+    r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-li", "12", "-dl", "2", "-di", "10", "-j", "-q", "1", *flags],
+                       cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _compare_runs(a, b, n_images, tol=1e-6):
+    ea = np.array([float(x[1]) for x in list(csv.reader(open(a / "measures.csv")))[1:]])
+    eb = np.array([float(x[1]) for x in list(csv.reader(open(b / "measures.csv")))[1:]])
+    assert len(ea) == len(eb) and np.max(np.abs(ea - eb) / eb) < 1e-5       # six printed digits
+    for i in range(n_images):
+        ta = json.load(open(a / "transforms" / f"{i}.json"))["transforms"]
+        tb = json.load(open(b / "transforms" / f"{i}.json"))["transforms"]
+        assert len(ta) == len(tb)
+        assert relerr(ta[0]["matrix"], tb[0]["matrix"]) < tol
+        for x, y in zip(ta[1:], tb[1:]):
+            assert x["dimensions"] == y["dimensions"] and relerr(x["coeffs"], y["coeffs"]) < 10 * tol
+    ba, bb = json.load(open(a / "bbox.json")), json.load(open(b / "bbox.json"))
+    assert ba["halfPairs"] == bb["halfPairs"] and abs(ba["inliers"] - bb["inliers"]) <= 2
+    assert relerr(ba["bbox"], bb["bbox"]) < tol
+    ha = list(csv.reader(open(a / "histograms.csv"))); hb = list(csv.reader(open(b / "histograms.csv")))
+    assert ha[0] == hb[0] and len(ha) == len(hb)
+
+
+def test_cli_sharded_over_three_contexts_on_one_gpu(tmp_path, small_pairs):
+    """bin/frog -ngl 3: the C++ multi-GPU host (one thread per rank, image shards, the collectives of
+    include/frog_comm.h) with its ranks sharing this box's one GPU and host-staged collectives.  Everything but the
+    transport is what -ng 3 runs: same shards, same split phases, same files -- which must agree with the one-context run
+    (sums over ranks associate differently: 1e-6, not bits)."""
+    one, three = tmp_path / "one", tmp_path / "three"
+    for d in (one, three):
+        d.mkdir()
+        small_pairs.write(d / "pairs.bin")
+    _run_frog(one)
+    out = _run_frog(three, "-ngl", "3")
+    assert "Images sharded over 3 contexts" in out
+    _compare_runs(one, three, small_pairs.n_images)
+    assert os.path.exists(three / "errorMaps" / "5.nii.gz")
+
+
+def test_cli_sharded_over_two_gpus_rccl(tmp_path, small_pairs):
+    """bin/frog -ng 2: the same over RCCL.  Needs two devices; the round-end driver's GPU box has one."""
+    if _abi.hip_lib().frog_device_count() < 2:
+        pytest.skip("needs >= 2 HIP devices (RCCL refuses two ranks on one device); -ngl covers the control flow")
+    one, two = tmp_path / "one", tmp_path / "two"
+    for d in (one, two):
+        d.mkdir()
+        small_pairs.write(d / "pairs.bin")
+    _run_frog(one)
+    _run_frog(two, "-ng", "2")
+    _compare_runs(one, two, small_pairs.n_images)
