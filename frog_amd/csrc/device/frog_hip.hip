@@ -115,6 +115,8 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
 }
 
 static int cull_allocate(frog_ctx *ctx);
+static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], const double maxs[3], GridGeom &g, frog_grid_info &info);
+static int lattice_alloc(frog_ctx *ctx, const GridGeom &g);
 
 extern "C" {
 
@@ -355,6 +357,22 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     cull_cutoff_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->nI, c->opt.inlier_threshold, c->cut_now.p);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
+    if (!getenv("FROG_LATTICE_LAZY")) {
+        // the lattice buffers of level 0 (with their head-room) for the box of the model as it is: close enough to what
+        // the first frog_deformable_setup will ask for that it finds them allocated
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t i = c->ib; i < c->ie; i++)
+            for (int k = 0; k < 3; k++) {
+                if (c->poff[i + 1] == c->poff[i]) continue;
+                mn[k] = std::min(mn[k], c->h_img_bbox[(size_t)i * 6 + k]); mx[k] = std::max(mx[k], c->h_img_bbox[(size_t)i * 6 + 3 + k]);
+            }
+        GridGeom g0{};
+        frog_grid_info i0{};
+        if (mn[0] <= mx[0] && make_geometry(c, 0, mn, mx, g0, i0) == FROG_OK) {
+            g0.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)g0.n_cp * 3 / 2);      // the registered box differs a little
+            if (int rc_ = lattice_alloc(c, g0)) { (void)rc_; (void)hipGetLastError(); }  // best effort: the set-up allocates again
+        }
+    }
     // selection of the first refresh, ahead of time
     c->sel_ready = 0; c->sel_used = 1;
     select_kernel<<<c->n_owned(), SELECT_THREADS, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
@@ -704,6 +722,84 @@ int frog_bounds_local(frog_ctx *ctx, double mins[3], double maxs[3])
     return FROG_OK;
 }
 
+// upper bound of the scatter's block count: every non-empty brick ends with at most one partial block
+static uint32_t scatter_max_blocks(uint32_t n_bricks_total, uint32_t n_points)
+{
+    return std::min(n_bricks_total, n_points) + n_points / SCATTER_CHUNK;
+}
+
+// box.ScaleAboutCenter(1 + 2*margin) then the lattice (imageGroup.cxx:161-179), and the brick partition of its cells
+static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], const double maxs[3], GridGeom &g, frog_grid_info &info)
+{
+    const double size = (double)ctx->opt.initial_grid_size / std::pow(2, level);
+    const float sc = 1 + 2 * ctx->opt.bounding_box_margin;
+    for (int k = 0; k < 3; k++) {
+        const double cen = 0.5 * (mins[k] + maxs[k]);
+        const double lo = cen + (double)sc * (mins[k] - cen);
+        const double hi = cen + (double)sc * (maxs[k] - cen);
+        const double length = hi - lo;
+        int d = (int)std::round(length / size);
+        if (d < 1) d = 1;
+        g.spacing[k] = length / d;
+        g.origin[k] = lo - g.spacing[k];
+        g.cells[k] = d;
+        g.dims[k] = d + 3;
+        info.bbox[2 * k] = lo; info.bbox[2 * k + 1] = hi;
+        info.dims[k] = g.dims[k]; info.origin[k] = g.origin[k]; info.spacing[k] = g.spacing[k];
+    }
+    const size_t G = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
+    if (G > 0x7FFFFFFFull) return fail(FROG_E_INVALID, "lattice too large");
+    g.n_cp = (int)G;
+    const uint32_t nO = ctx->n_owned();
+    const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
+    auto bricks_for = [&](int B) { size_t n = 1; for (int k = 0; k < 3; k++) n *= (size_t)((g.cells[k] + B - 1) / B); return n; };
+    // brick edge: 4 cells (5.5 KB tile, many resident wavefronts) while bricks keep enough points to
+    // amortise their flush, else 8
+    g.brick = ((double)nPts / ((double)nO * (double)bricks_for(4)) >= 24.0) ? 4 : 8;
+    for (int k = 0; k < 3; k++) g.nbricks[k] = (g.cells[k] + g.brick - 1) / g.brick;
+    const size_t nb = bricks_for(g.brick);
+    if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
+    g.n_bricks = (int)nb;
+    if ((size_t)nO * nb * (size_t)(g.brick * g.brick * g.brick) >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
+    return FROG_OK;
+}
+
+// Every buffer whose size follows the lattice.  Allocated with head-room for two more levels (8x the control points
+// each) whenever a new block is needed, up to a cap: hipFree / hipMalloc synchronise the device and cost a millisecond
+// per level.  frog_create calls this with the lattice the model's own bounding box would give at level 0, so that a
+// run's first set-up finds its buffers (and with them those of levels 1 and 2) already there.
+static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
+{
+    const size_t G = (size_t)g.n_cp;
+    const uint32_t nO = ctx->n_owned();
+    const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
+    const size_t reserve = ((size_t)nO * G * 64 * sizeof(float4) <= ((size_t)2 << 30)) ? 64 : (((size_t)nO * G * 8 * sizeof(float4) <= ((size_t)2 << 30)) ? 8 : 1);
+    const size_t n_keys = (size_t)nO * g.n_bricks * (size_t)(g.brick * g.brick * g.brick);
+    const size_t n_bricks_total = (size_t)nO * g.n_bricks;
+    const size_t max_blocks = std::max<size_t>(1, scatter_max_blocks((uint32_t)n_bricks_total, nPts));
+    const size_t E = (size_t)g.brick + 3;
+    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G, 3 * G * reserve));
+    FROG_HIP_CHECK(ctx->key_counts.alloc(n_keys, n_keys * reserve));
+    FROG_HIP_CHECK(ctx->brick_ptr_scratch.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
+    FROG_HIP_CHECK(ctx->key_ptr.alloc(n_keys + 1, (n_keys + 1) * reserve));
+    FROG_HIP_CHECK(ctx->key_cursor.alloc(n_keys + 1, (n_keys + 1) * reserve));
+    FROG_HIP_CHECK(ctx->scan_sums.alloc(div_up(n_keys, SCAN_BLOCK_ITEMS) + 2, (div_up(n_keys, SCAN_BLOCK_ITEMS) + 2) * reserve));
+    if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
+    if (ctx->perm_tmp.n != nPts) FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
+    if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
+    FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
+    FROG_HIP_CHECK(ctx->scatter_blocks.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
+    FROG_HIP_CHECK(ctx->scatter_blocks_tmp.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
+    FROG_HIP_CHECK(ctx->len_hist.alloc(2 * (SCATTER_CHUNK + 1)));
+    // tile storage: a finer level needs about as many blocks (bricks hold fewer points) but brick edge 8 instead of 4 has
+    // 2.4x the tile
+    FROG_HIP_CHECK(ctx->scatter_stage.alloc(max_blocks * E * E * E, max_blocks * E * E * E * std::min<size_t>(reserve, 8)));
+    return FROG_OK;
+}
+
 static int retire_current_grid(frog_ctx *ctx)
 {
     if (ctx->grids.empty() || ctx->grids.back().retired) return FROG_OK;
@@ -727,51 +823,20 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     int rc = retire_current_grid(ctx);
     if (rc) return rc;
 
-    // box.ScaleAboutCenter(1 + 2*margin) then the lattice (imageGroup.cxx:161-179)
     GridGeom g{};
     frog_grid_info info{};
-    const double size = (double)ctx->opt.initial_grid_size / std::pow(2, level);
-    const float sc = 1 + 2 * ctx->opt.bounding_box_margin;
-    for (int k = 0; k < 3; k++) {
-        const double cen = 0.5 * (mins[k] + maxs[k]);
-        const double lo = cen + (double)sc * (mins[k] - cen);
-        const double hi = cen + (double)sc * (maxs[k] - cen);
-        const double length = hi - lo;
-        int d = (int)std::round(length / size);
-        if (d < 1) d = 1;
-        g.spacing[k] = length / d;
-        g.origin[k] = lo - g.spacing[k];
-        g.cells[k] = d;
-        g.dims[k] = d + 3;
-        info.bbox[2 * k] = lo; info.bbox[2 * k + 1] = hi;
-        info.dims[k] = g.dims[k]; info.origin[k] = g.origin[k]; info.spacing[k] = g.spacing[k];
-    }
-    const size_t G = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
-    if (G > 0x7FFFFFFFull) return fail(FROG_E_INVALID, "lattice too large");
-    g.n_cp = (int)G;
+    rc = make_geometry(ctx, level, mins, maxs, g, info);
+    if (rc) return rc;
     const uint32_t nO = ctx->n_owned();
     const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
-    // brick edge: 8 cells while bricks keep enough points to amortise their flush
-    auto bricks_for = [&](int B) { size_t n = 1; for (int k = 0; k < 3; k++) n *= (size_t)((g.cells[k] + B - 1) / B); return n; };
-    // brick edge: 4 cells (5.5 KB tile, many resident wavefronts) while bricks keep enough points to
-    // amortise their flush, else 8
-    g.brick = ((double)nPts / ((double)nO * (double)bricks_for(4)) >= 24.0) ? 4 : 8;
-    for (int k = 0; k < 3; k++) g.nbricks[k] = (g.cells[k] + g.brick - 1) / g.brick;
-    const size_t nb = bricks_for(g.brick);
-    if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
-    g.n_bricks = (int)nb;
+    const size_t nb = (size_t)g.n_bricks;
     ctx->geom = g;
     info.n_grid = (int)ctx->grids.size();
 
     hipStream_t s = ctx->stream;
-    // Buffers that grow with the lattice are allocated with head-room for two more levels (8x the control points
-    // each) the first time, up to a cap: hipFree / hipMalloc synchronise the device and cost a millisecond per level.
-    const size_t reserve = ((size_t)nO * G * 64 * sizeof(float4) <= ((size_t)2 << 30)) ? 64 : (((size_t)nO * G * 8 * sizeof(float4) <= ((size_t)2 << 30)) ? 8 : 1);
-    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
-    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
-    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    rc = lattice_alloc(ctx, g);                 // within the head-room reserved earlier, as a rule: no hipMalloc here
+    if (rc) return rc;
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));
-    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G, 3 * G * reserve));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
@@ -785,12 +850,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     const uint32_t n_keys = (uint32_t)n_keys64;
     const uint32_t n_bricks_total = nO * (uint32_t)nb;
     frog::DevBuf<uint32_t> &counts = ctx->key_counts, &chunks = ctx->brick_ptr_scratch;
-    FROG_HIP_CHECK(counts.alloc(n_keys, (size_t)n_keys * reserve));
-    FROG_HIP_CHECK(chunks.alloc((size_t)n_bricks_total + 1, ((size_t)n_bricks_total + 1) * reserve));
     FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
-    FROG_HIP_CHECK(ctx->key_ptr.alloc((size_t)n_keys + 1, ((size_t)n_keys + 1) * reserve));
-    FROG_HIP_CHECK(ctx->key_cursor.alloc((size_t)n_keys + 1, ((size_t)n_keys + 1) * reserve));
-    if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     const GeomDev gd = to_dev(g);
     uint32_t max_img_pts = 0;
     for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
@@ -801,8 +861,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     }
     auto exclusive_scan = [&](const uint32_t *in, uint32_t n, uint32_t *ptr, uint32_t *cursor) -> int {
         const uint32_t n_scan_blocks = div_up(n, SCAN_BLOCK_ITEMS);
-        frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;
-        FROG_HIP_CHECK(bsums.alloc((size_t)n_scan_blocks + 1, ((size_t)n_scan_blocks + 1) * reserve));
+        frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;      // sized for the longer of the two scans by lattice_alloc
         scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p);
         scan_of_sums_kernel<<<1, 1024, 0, s>>>(bsums.p, n_scan_blocks, bsums.p + n_scan_blocks);
         scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p, bsums.p + n_scan_blocks, ptr, cursor);
@@ -815,7 +874,6 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
         FROG_HIP_CHECK(hipGetLastError());
         // canonical order inside every cell (the placement's atomics make it arbitrary): reproducible sums
-        FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
         cell_order_kernel<<<div_up(n_keys, 4), 256, 0, s>>>(ctx->key_ptr.p, n_keys, ctx->perm.p, ctx->perm_tmp.p);
         FROG_HIP_CHECK(hipGetLastError());
         std::swap(ctx->perm.p, ctx->perm_tmp.p);
@@ -825,13 +883,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
     // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
     // every non-empty brick ends with at most one partial block
-    const uint32_t max_blocks = std::min(n_bricks_total, nPts) + nPts / SCATTER_CHUNK;
-    FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc((size_t)n_bricks_total + 1, ((size_t)n_bricks_total + 1) * reserve));
-    FROG_HIP_CHECK(ctx->scatter_blocks.alloc(std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock),
-                                             std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock) * reserve));
-    FROG_HIP_CHECK(ctx->scatter_blocks_tmp.alloc(std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock),
-                                                 std::max<size_t>(1, max_blocks) * sizeof(ScatterBlock) * reserve));
-    FROG_HIP_CHECK(ctx->len_hist.alloc(2 * (SCATTER_CHUNK + 1)));
+    const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts);
     FROG_HIP_CHECK(hipMemsetAsync(ctx->len_hist.p, 0, ctx->len_hist.bytes(), s));
     brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
     FROG_HIP_CHECK(hipGetLastError());
@@ -848,13 +900,6 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->n_scatter_blocks = max_blocks;
-    {
-        const size_t E = (size_t)g.brick + 3;
-        // tile storage of the largest lattice seen so far is kept (reserve: a finer level needs about as many blocks --
-        // bricks hold fewer points -- but brick edge 8 instead of 4 has 2.4x the tile)
-        FROG_HIP_CHECK(ctx->scatter_stage.alloc(std::max<size_t>(1, max_blocks) * E * E * E,
-                                                std::max<size_t>(1, max_blocks) * E * E * E * std::min<size_t>(reserve, 8)));
-    }
 
     GridRecord rec;
     rec.info = info;
