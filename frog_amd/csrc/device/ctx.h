@@ -141,10 +141,10 @@ struct RecFormat {
 static_assert(TILE_POINTS <= 256, "own-point index must fit 8 bits of LinkRec::a");
 
 // Per-image constants derived from (c1, c2, ratio) for getInlierProbability
-// (stats.h:84-92): inv1 = 1/(c1+eps), inv2 = 1/(c2+eps),
+// (stats.h:84-92): with inv_k = 1/(c_k+eps): q_k = inv_k^2 (so that (d/c_k)^2 = d2 * q_k, no square root on the way),
 // k1 = ratio*c*inv1, k2 = (1-ratio)*c*inv2 with c = 0.797884560802865f.
 struct EmDerived {
-    float inv1, inv2, k1, k2;
+    float q1, q2, k1, k2;
 };
 
 struct GridGeom {

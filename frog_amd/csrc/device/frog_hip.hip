@@ -1421,17 +1421,17 @@ int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed, uint
     return FROG_OK;
 }
 
-__global__ void test_probability_kernel(const float4 em, const float *d, size_t n, float *fast, float *exact)
+__global__ void test_probability_kernel(const float4 em, const float *d2, size_t n, float *fast, float *exact)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fast[i] = inlier_probability(d[i], em_derived_of(em));
-    exact[i] = inlier_probability_exact(d[i], em);
+    fast[i] = inlier_probability(d2[i], em_derived_of(em));             // exactly what a sweep step does with its d2
+    exact[i] = inlier_probability_exact(sqrt_rn(d2[i]), em);
 }
 
-int frog_test_inlier_probability(int device, const float em3[3], const float *d, size_t n, float *fast, float *exact)
+int frog_test_inlier_probability(int device, const float em3[3], const float *d2, size_t n, float *fast, float *exact)
 {
-    if (!em3 || (n && (!d || !fast || !exact))) return fail(FROG_E_INVALID, "null argument");
+    if (!em3 || (n && (!d2 || !fast || !exact))) return fail(FROG_E_INVALID, "null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FROG_E_NODEVICE, "no HIP device");
     if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
@@ -1439,7 +1439,7 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d,
     if (!n) return FROG_OK;
     DevBuf<float> dd, df, de;
     FROG_HIP_CHECK(dd.alloc(n)); FROG_HIP_CHECK(df.alloc(n)); FROG_HIP_CHECK(de.alloc(n));
-    FROG_HIP_CHECK(hipMemcpy(dd.p, d, n * sizeof(float), hipMemcpyHostToDevice));
+    FROG_HIP_CHECK(hipMemcpy(dd.p, d2, n * sizeof(float), hipMemcpyHostToDevice));
     test_probability_kernel<<<div_up(n, 256), 256>>>(make_float4(em3[0], em3[1], em3[2], 0.f), dd.p, n, df.p, de.p);
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -13,10 +13,10 @@
 // Arithmetic contract (reference lines in the comments):
 //   dist2, dist  -- f32, no FMA contraction, correctly rounded sqrt: bit-exact
 //                   with the reference, so `d < 0.1` and the sample values agree.
-//   inlier weight -- f32 with reciprocals and exp (exp_nonpos, div_rn below): within a few f32 ulps of the
-//                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92);
-//                   the reference rounds d/c to f32 before squaring, which already
-//                   perturbs the exponent by more than this.
+//   inlier weight -- f32 from d2 with reciprocals and exp (exp_nonpos, div_fast below): within 2^-16 of the
+//                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92), bound derived at
+//                   inlier_probability; weights within 1e-4 of the inlier threshold are recomputed with the
+//                   reference's own arithmetic, so no decision depends on the fast form.
 //   linear sums  -- f32 products, f64 accumulation (imageGroup.cxx:1102-1117);
 //                   per-tile partials reduced in a fixed order (deterministic).
 //   deformable   -- f32 products and f32 per-point running sums in partner order,
@@ -86,9 +86,11 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r;
 }
 
-// expf(x) for x <= 0: two-word product x*log2(e), v_exp_f32 on the fraction, ldexp.  Dropped:
-// the overflow select (x <= 0) and the underflow select (ldexp already rounds to 0 there;
-// the clamp keeps -inf out of the two-word product).
+// expf(x) for x <= 0: two-word product x log2(e) = ph + pl, v_exp_f32 on the head (the instruction reduces its own
+// argument: 1 ulp over the whole range) and the tail applied to first order, 2^pl = 1 + pl ln 2 (|pl| < 2^-17: the second
+// order is below 2^-36).  Same accuracy class as the compiler's expansion (the product error |x| 2^-24 would otherwise
+// enter the result relative), seven instructions instead of its sixteen.  The clamp keeps -inf out of the product;
+// results below the normal range flush towards 0, where the weight they enter is 0 to twenty digits anyway.
 __device__ __forceinline__ float exp_nonpos(float x)
 {
     x = __builtin_amdgcn_fmed3f(x, -200.0f, 0.0f);
@@ -96,21 +98,18 @@ __device__ __forceinline__ float exp_nonpos(float x)
     const float ph = x * L_hi;
     float pl = __builtin_fmaf(x, L_hi, -ph);
     pl = __builtin_fmaf(x, L_lo, pl);
-    const float n = __builtin_rintf(ph);
-    const float f = (ph - n) + pl;
-    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+    const float e = __builtin_amdgcn_exp2f(ph);
+    return __builtin_fmaf(e, pl * 0.69314718055994531f, e);
 }
 
-// Correctly rounded n / d for d in the normal range: the Newton sequence of the compiler's
-// division without its operand scaling and special-case fix-up (here d >= 1e-10 and
-// 0 <= n <= d).
-__device__ __forceinline__ float div_rn(float n, float d)
+// n / d for d >= 1e-10 and 0 <= n <= d: v_rcp_f32 (1 ulp), one Newton step on the reciprocal, one product: within 1.5 ulp
+// of the quotient.  (The correctly rounded sequence is twice as long; what the weight needs is the bound below, and the
+// decisions near the threshold are taken by inlier_probability_exact.)
+__device__ __forceinline__ float div_fast(float n, float d)
 {
     float r = __builtin_amdgcn_rcpf(d);
     r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    float q = n * r;
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return n * r;
 }
 
 // getInlierProbability with the reference's own promotions (stats.h:10-16, 84-92: f32 quotients, the exp
@@ -136,39 +135,41 @@ __device__ __noinline__ float inlier_probability_exact(float d, const float4 em)
     return x1 / (x1 + x2 + eps);
 }
 
-// getInlierProbability (stats.h:84-92) from precomputed per-image constants.
+// getInlierProbability (stats.h:84-92) from precomputed per-image constants, as a function of the SQUARED distance (the
+// sweeps of the deformable stage never need the distance itself: the energy there is sum w2 d2, imageGroup.cxx:275).
 //
 // Error bound against the reference's form (f32 quotients, f64 exp: chi_pdf_exact / inlier_probability_exact above).
-// e = 2^-24 is the relative error of one f32 rounding, u_k = (d / c_k)^2.
-//   argument   reference: x = fl(d / c), u = fl(x x): u_true (1 + 3e).  Here: inv = fl(1 / c), x = fl(d inv), u = fl(x x):
-//              u_true (1 + 5e).  The two differ by at most 8e relative.
-//   exp        exp(-u/2) inherits |du| / 2 <= 4e u relative from its argument; exp_nonpos adds <= 3e of its own (two-word
-//              product: 2^-46 relative in the argument; v_exp_f32: 1 ulp = 2e; the reduced fraction: < e), the reference's
+// e = 2^-24 is the relative error of one f32 rounding, u_k = (d / c_k)^2, d2 the f32 squared distance both sides compute
+// with the same bits.
+//   argument   reference: d = fl(sqrt(d2)), x = fl(d / c), u = fl(x x): (d2 / c^2) (1 + 5e).  Here: inv = fl(1 / c),
+//              q = fl(inv inv), u = fl(d2 q): (d2 / c^2) (1 + 4e).  The two differ by at most 9e relative.
+//   exp        exp(-u/2) inherits |du| / 2 <= 4.5e u relative from its argument; exp_nonpos adds <= 4e of its own (two-word
+//              product: 2^-46 relative in the argument; v_exp_f32: 1 ulp = 2e; tail product and fma: 2e), the reference's
 //              f64 exp nothing visible in f32.
 //   x_k        reference: fl(c x2), f64 product rounded to f32, fl(ratio ..), fl(.. / c): 4 roundings.  Here: k = fl(fl(ratio
-//              c) inv) (3 with inv's own), fl(k u), fl(.. exp): 5, plus u's 8e and the exp's 3e + 4e u.
-//              => |x_k / x_k,ref - 1| <= (20 + 4 u_k) e.
-//   p          p = x1 / (x1 + x2 + eps): dp = p (1 - p) (dx1/x1 - dx2/x2) + three more roundings (two sums, div_rn is
-//              correctly rounded) => |p - p_ref| <= p (1 - p) (40 + 4 u1 + 4 u2) e + 3 e p.
+//              c) inv) (3 with inv's own), fl(k u), fl(.. exp): 5, plus u's 9e and the exp's 4e + 4.5e u.
+//              => |x_k / x_k,ref - 1| <= (22 + 4.5 u_k) e.
+//   p          p = x1 / (x1 + x2 + eps): dp = p (1 - p) (dx1/x1 - dx2/x2) + two roundings of the sums + div_fast (3e)
+//              => |p - p_ref| <= p (1 - p) (44 + 4.5 u1 + 4.5 u2) e + 5 e p.
 // p (1 - p) is only non-negligible where x1 ~ x2, i.e. u1/2 ~ 3 ln(c2 / c1) + ln((1 - r) / r): u1 <= 64 covers c2/c1 up to
 // 4 10^4 at any ratio in [1e-6, 1 - 1e-6]; beyond it p <= exp(-u1 / 2) (c2/c1)^3 r / (1 - r) is itself below 1e-9.  With
-// u2 <= u1: |p - p_ref| <= 0.25 (40 + 512) e + 3 e = 141 e = 8.4e-6 in the worst case; INLIER_PROBABILITY_BOUND = 2^-16
+// u2 <= u1: |p - p_ref| <= 0.25 (44 + 576) e + 5 e = 160 e = 9.5e-6 in the worst case; INLIER_PROBABILITY_BOUND = 2^-16
 // rounds that up.  tests/test_gpu_round2.py::test_inlier_probability_against_the_reference_build evaluates this function
 // on the device against the reference build of stats.cxx over d/c1 in [0.02, 60] for a set of mixtures and asserts the
-// bound (observed maximum: 1.07e-6; the exact form reproduced the reference build on all 2.9 M values).  The bound is what THRESHOLD_BAND (1e-4, six times
-// larger) relies on: a weight farther than the band from the threshold is on the same side of it as the reference's, a
-// weight inside the band is recomputed with the reference's own arithmetic.
+// bound (the observed maximum is in DESIGN.md section 2; the exact form reproduces the reference build on every value).
+// The bound is what THRESHOLD_BAND (1e-4, six times larger) relies on: a weight farther than the band from the threshold
+// is on the same side of it as the reference's, a weight inside the band is recomputed with the reference's own arithmetic.
 constexpr float INLIER_PROBABILITY_BOUND = 1.52587890625e-05f;      // 2^-16
-__device__ __forceinline__ float inlier_probability(float d, const EmDerived e)
+// `d < 0.1` (stats.h:87, d = the correctly rounded f32 sqrt of d2) in terms of d2: sqrt is monotone, and 0x3c23d70a
+// (0.01f) is the smallest f32 whose square root rounds to >= 0.1f (checked over the 40 neighbouring floats).
+constexpr float D2_FIX = __builtin_bit_cast(float, 0x3c23d70au);
+__device__ __forceinline__ float inlier_probability(float d2, const EmDerived e)
 {
-    // `d < 0.1` compares (double)d with 0.1; no float lies in [0.1, 0.1f), so
-    // the f32 comparison with 0.1f selects the same values.
-    if (d < 0.1f) return 1.0f;
-    float u1 = d * e.inv1; u1 *= u1;
-    float u2 = d * e.inv2; u2 *= u2;
-    float x1 = e.k1 * u1 * exp_nonpos(-0.5f * u1);
-    float x2 = e.k2 * u2 * exp_nonpos(-0.5f * u2);
-    return div_rn(x1, x1 + x2 + 1e-10f);
+    if (d2 < D2_FIX) return 1.0f;
+    const float u1 = d2 * e.q1, u2 = d2 * e.q2;
+    const float x1 = e.k1 * u1 * exp_nonpos(-0.5f * u1);
+    const float x2 = e.k2 * u2 * exp_nonpos(-0.5f * u2);
+    return div_fast(x1, x1 + x2 + 1e-10f);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -309,18 +310,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
-        const float d = sqrt_rn(d2);
-        float w = fminf(inlier_probability(d, eA), inlier_probability(d, eB));
+        float w = fminf(inlier_probability(d2, eA), inlier_probability(d2, eB));
         if constexpr (MODE != SWEEP_LINEAR) {
             // the threshold decision is taken on the reference's own arithmetic when it is close
             if (fabsf(w - a.threshold) < THRESHOLD_BAND) {
                 const uint32_t imgB = img_of(rq) + (WIDE && !EMD_LDS ? 0u : g_first);
+                const float d = sqrt_rn(d2);
                 w = fminf(inlier_probability_exact(d, a.em[image]), inlier_probability_exact(d, a.em[imgB]));
             }
         }
 
         if constexpr (MODE == SWEEP_LINEAR) {
             // imageGroup.cxx:1102-1117
+            const float d = sqrt_rn(d2);
             s[16] += (double)(w * w * d * d);
             s[17] += (double)(w * w);
             s[0] += (double)(w * dx); s[1] += (double)(w * dy); s[2] += (double)(w * dz);

@@ -294,10 +294,11 @@ __device__ __forceinline__ EmDerived em_derived_of(const float4 e)
     const float eps = 1e-10f;
     const float c = 0.797884560802865f;
     EmDerived d;
-    d.inv1 = 1.0f / (e.x + eps);
-    d.inv2 = 1.0f / (e.y + eps);
-    d.k1 = e.z * c * d.inv1;
-    d.k2 = (1.0f - e.z) * c * d.inv2;
+    const float inv1 = 1.0f / (e.x + eps), inv2 = 1.0f / (e.y + eps);
+    d.q1 = inv1 * inv1;
+    d.q2 = inv2 * inv2;
+    d.k1 = e.z * c * inv1;
+    d.k2 = (1.0f - e.z) * c * inv2;
     return d;
 }
 

@@ -273,12 +273,13 @@ class ImageGroup:
         return out
 
 
-def device_inlier_probability(em, d, device=0):
-    """The half-link sweep's inlier weight for distances ``d`` under the mixture ``em`` = (c1, c2, ratio), evaluated on
-    the device: (fast f32 form used for every link, form with the reference's promotions used near the threshold)."""
+def device_inlier_probability(em, d2, device=0):
+    """The half-link sweep's inlier weight for SQUARED distances ``d2`` (f32, what a sweep step has in hand) under the
+    mixture ``em`` = (c1, c2, ratio), evaluated on the device: (fast f32 form used for every link, form with the
+    reference's promotions at sqrt(d2) used near the threshold)."""
     lib = _abi.hip_lib()
     e = np.ascontiguousarray(em, np.float32)
-    dd = np.ascontiguousarray(d, np.float32)
+    dd = np.ascontiguousarray(d2, np.float32)
     fast, exact = np.empty_like(dd), np.empty_like(dd)
     check(lib.frog_test_inlier_probability(device, e.ctypes.data_as(_abi.c_float_p), dd.ctypes.data_as(_abi.c_float_p),
                                            dd.size, fast.ctypes.data_as(_abi.c_float_p),

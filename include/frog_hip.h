@@ -202,11 +202,12 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E);
 int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
 
 /* ---- test hook: the sweep's inlier weight -------------------------------------------
- * Evaluates, on `device`, Stats::getInlierProbability (stats.h:84-92) for n distances with the mixture
- * (c1, c2, ratio) twice: `fast` = the f32 form the half-link sweeps use for every link, `exact` = the form
- * with the reference's own promotions (f64 exp) that decides weights within 1e-4 of the inlier threshold.
- * tests/test_gpu_round2.py compares both with the reference build of stats.cxx. */
-int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d, size_t n,
+ * Evaluates, on `device`, Stats::getInlierProbability (stats.h:84-92) for n SQUARED distances d2 (what a sweep step
+ * has in hand: the f32 sum of three squared differences) with the mixture (c1, c2, ratio), twice: `fast` = the f32
+ * form the half-link sweeps use for every link, `exact` = the form with the reference's own promotions (f64 exp,
+ * evaluated at the correctly rounded f32 square root of d2, the reference's `dist`) that decides weights within 1e-4
+ * of the inlier threshold.  tests/test_gpu_round2.py compares both with the reference build of stats.cxx. */
+int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d2, size_t n,
                                  float *fast, float *exact);
 
 /* ---- live kernel timing (HIP events on the context's stream) ------------------ */

@@ -9,6 +9,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --no-cpu-baseline --kernel-times > $O/bench_kernel_times.json 2>> $O/bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err     # the round-end driver's command line
 ARGS="bench.py --steps 65 --warmup 10 --no-cpu-baseline --kernel-times"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python3 $ARGS > $O/under_rocprof.json 2> $O/trace.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/fetch.log
@@ -18,9 +19,18 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/sq -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/sq.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -d $O/ta -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/ta.log
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum -d $O/lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/lat.log
+# the same sweep without the outlier-culling list (every half-link walked), for the before / after of the counters
+export FROG_CULL=0
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/nocull_trace -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/nocull_trace.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/nocull_sq -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/nocull_sq.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum -d $O/nocull_ta -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/nocull_ta.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum -d $O/nocull_lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/nocull_lat.log
+unset FROG_CULL
+python3 scripts/summarize_profile.py gpurun_out/${TAG}_nocull_n1.txt $O/nocull_trace $O/nocull_sq $O/nocull_ta $O/nocull_lat > /dev/null
 python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat $(python3 -c "import json; print(json.load(open('$O/bench.json'))['roofline']['half_links_per_launch'])") > /dev/null
 cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
 cp $O/bench_kernel_times.json gpurun_out/${TAG}_bench_n1_kernel_times.json
+cp $O/bench_steps20.json gpurun_out/${TAG}_bench_n1_steps20.json
 cp $O/under_rocprof.json gpurun_out/${TAG}_bench_n1_under_rocprof.json
 head -12 gpurun_out/${TAG}_bench_n1.txt
 python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_n1.json')); print(d['value'], d['roofline'], d['cpu_baseline']['value'])"

@@ -82,8 +82,26 @@ def test_cli_outputs_match_oracle(tmp_path, small_pairs):
             info, c = ref.grid(i, k, _abi.FrogGridInfo())
             assert t[1 + k]["type"] == "vtkBSplineTransform" and t[1 + k]["dimensions"] == list(info.dims)
             assert relerr(np.array(t[1 + k]["coeffs"]).reshape(-1, 3), c) < REL
+    # bbox.json = countInliers' records (imageGroup.cxx:1036-1058, what FROG.py's consumers read) + the bounding box
+    # (:1493-1511), every field.  Both sides are free-running here, so coordinates agree to rounding, not bits: the
+    # integer fields that do not depend on them are equal, the census may differ by the few links that sit on the
+    # threshold (its exactness on identical inputs is test_gpu_round2.py::test_census_is_exact_on_identical_inputs).
     bbox = json.load(open(tmp_path / "bbox.json"))
+    rc = ref.count_inliers((_abi.FrogCounts * small_pairs.n_images)())
+    assert sorted(bbox) == ["bbox", "halfPairs", "images", "inliers", "outlierRatio", "outliers"]
     assert bbox["halfPairs"] == small_pairs.n_half_links and len(bbox["images"]) == small_pairs.n_images
+    tot_in = tot_out = 0
+    for i, rec in enumerate(bbox["images"]):
+        assert sorted(rec) == ["EMStats", "inliers", "outliers", "pairs", "points"]
+        assert rec["points"] == rc[i].points and rec["pairs"] == rc[i].pairs
+        assert rec["inliers"] + rec["outliers"] == rec["pairs"] and abs(rec["inliers"] - rc[i].inliers) <= 2
+        for k, want in (("c1", rc[i].c1), ("c2", rc[i].c2), ("ratio", rc[i].ratio)):
+            assert abs(rec["EMStats"][k] - want) <= 1e-4 * abs(want), (i, k)
+        tot_in += rec["inliers"]; tot_out += rec["outliers"]
+    assert bbox["inliers"] == tot_in and bbox["outliers"] == tot_out
+    assert abs(bbox["outlierRatio"] - tot_out / bbox["halfPairs"]) < 1e-12
+    x = ref.xyz().astype(np.float64)
+    assert relerr(bbox["bbox"], [x.min(axis=0), x.max(axis=0)]) < 1e-6
     assert os.path.exists(tmp_path / "histograms.csv")
 
 

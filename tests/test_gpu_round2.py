@@ -62,12 +62,16 @@ def test_inlier_probability_against_the_reference_build():
         centre = d[k]
         dense = centre + (np.arange(-10000, 10000) * np.spacing(centre)).astype(np.float32)
         d = np.concatenate([d, dense.astype(np.float32)])
-        want = ref.prob_n(d)
-        fast, exact = device_inlier_probability((c1, c2, r), d)
+        # a sweep step holds d2 (f32) and the reference's `dist` is its correctly rounded f32 square root: feed the
+        # device the squares and the reference build the roots of exactly those squares
+        d2 = (d * d).astype(np.float32)
+        d2 = np.concatenate([d2, np.nextafter(np.float32(0.01), np.float32([0.0, 1.0])), np.float32([0.01])])   # the `d < 0.1` edge in d2
+        want = ref.prob_n(np.sqrt(d2))
+        fast, exact = device_inlier_probability((c1, c2, r), d2)
         assert np.all(np.isfinite(fast)) and np.all(np.isfinite(exact))
         worst_fast = max(worst_fast, float(np.max(np.abs(fast.astype(np.float64) - want))))
         worst_exact += int(np.count_nonzero(exact != want))
-        n_total += d.size
+        n_total += d2.size
     note("inlier_probability_fast_max_abs_dev", worst_fast)
     note("inlier_probability_exact_mismatches", f"{worst_exact} of {n_total}")
     assert worst_fast <= bound, worst_fast
