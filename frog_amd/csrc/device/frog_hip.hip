@@ -506,8 +506,13 @@ int frog_update_stats_local(frog_ctx *ctx)
             ctx->sample_ord[cur].p, ctx->sample_count[cur].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
             ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->pos2.p, ctx->samples.p);
         FROG_HIP_CHECK(hipGetLastError());
-        em_kernel<<<nO, 256, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
-                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+        static const bool em_serial = getenv("FROG_EM_SERIAL") != nullptr;     // test hook: the term-by-term form
+        if (em_serial)
+            em_kernel<<<nO, 256, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
+                                         ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+        else
+            em_scan_kernel<<<nO, EM_THREADS, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
+                                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
         FROG_HIP_CHECK(hipGetLastError());
     }
     FROG_HIP_CHECK(hipEventRecord(ctx->ord_read[cur], s));

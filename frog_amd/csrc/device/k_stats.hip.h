@@ -287,6 +287,158 @@ __global__ __launch_bounds__(256) void em_kernel(const float *samples, const uin
     if (threadIdx.x == 0) em[image_begin + img] = make_float4(c1, c2, ratio, 0.f);
 }
 
+// ---- K2, second form: the same sums, bit for bit, without walking them one term at a time -------------------
+// Every accumulator of estimateDistribution is  s <- fl32(s + v)  with v >= 0 (sum1, sum2: f32 adds; sum3, sum4: an f64
+// add rounded back to f32, stats.cxx:33-37).  While s stays inside one binade [2^e, 2^(e+1)) it is a multiple S u of
+// u = 2^(e-23), and fl32(S u + v) = (S + r) u with r = v / u rounded to the nearest integer: the 64 terms of a batch
+// become 64 integers, and the 64 dependent additions an integer prefix sum across the wavefront (6 DPP steps).  What
+// that argument does not cover is handled by taking the one offending term through the real arithmetic and going on
+// behind it:
+//   * the term at which S + r reaches 2^24 (the sum leaves its binade: coarser grid from there on);
+//   * a term whose fraction v/u - floor(v/u) is within 2^-20 of 1/2: a tie (round to even depends on S), or close
+//     enough to one that the intermediate f64 rounding of sum3 / sum4 (at most 2^-28 u) could decide -- everywhere
+//     else the two roundings of fl32(fl64(s + v)) and the single one of the integer form agree;
+//   * s = 0 or denormal (the first non-zero term of every sum), non-finite values.
+// About one batch in five stops once; the chain of a batch costs ~60 instructions instead of 64 dependent additions
+// of 30+ cycles each.  The memberships t, which do not depend on each other, are computed by all sixteen wavefronts
+// of the block for a chunk of samples at a time (LDS), then three wavefronts run the four chains over the chunk.
+// Checked against em_kernel (the term-by-term form, kept: FROG_EM_SERIAL=1) and against the oracle, bit for bit.
+constexpr int EM_THREADS = 1024;
+constexpr int EM_CHUNK = 8192;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane)
+{
+    // row_shr:1,2,4,8 inside rows of 16 lanes, then row_bcast:15 / row_bcast:31 across rows (GCN / CDNA DPP)
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); if ((lane & 15) >= 1) v += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); if ((lane & 15) >= 2) v += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); if ((lane & 15) >= 4) v += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); if ((lane & 15) >= 8) v += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, false); if ((lane & 31) >= 16) v += t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, false); if (lane >= 32) v += t;
+    return v;
+}
+
+// s <- fl32(fl64(s + v_0)), then v_1, ... v_{cnt-1} (v of lane k = term k), all lanes return the result
+__device__ __forceinline__ float em_chain(float s, const double v, const int cnt, const int lane)
+{
+    int j = 0;
+    while (j < cnt) {                                   // wave-uniform
+        const uint32_t sb = __float_as_uint(s);
+        const uint32_t ex = sb >> 23;                   // s >= 0: no sign bit
+        const bool active = lane >= j && lane < cnt;
+        int stop;
+        if (ex == 0u || ex >= 255u) {
+            // zero / denormal / non-finite sum: skip the terms that leave a zero sum alone, take the next one directly
+            if (sb == 0u) {
+                const unsigned long long nz = __ballot(active && v != 0.0);
+                stop = nz ? (int)__ffsll((long long)nz) - 1 : cnt;
+            } else {
+                stop = j;
+            }
+        } else {
+            const int e = (int)ex - 127;
+            uint32_t r = 0;
+            bool odd = false;
+            if (active) {
+                const double x = __builtin_ldexp(v, 23 - e);        // v / ulp(s), exact
+                if (!(x < 16777216.0)) {
+                    odd = true;                                     // far beyond the binade (or NaN)
+                } else {
+                    const uint32_t f = (uint32_t)x;                 // x >= 0: truncation is floor
+                    const double frac = x - (double)f;
+                    odd = __builtin_fabs(frac - 0.5) < 9.5367431640625e-07;      // 2^-20
+                    r = f + (frac > 0.5 ? 1u : 0u);
+                }
+            }
+            const uint32_t P = wave_inclusive_scan_u32(r, lane);    // < 64 * 2^24
+            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+            const unsigned long long halt = __ballot(active && (odd || S + P >= 0x1000000u));
+            stop = halt ? (int)__ffsll((long long)halt) - 1 : cnt;
+            if (stop > j) {
+                const uint32_t Pp = (uint32_t)__builtin_amdgcn_readlane((int)P, stop - 1);
+                s = __builtin_ldexpf((float)(S + Pp), e - 23);      // S + Pp < 2^24: exact
+            }
+        }
+        if (stop < cnt) {
+            const long long bits = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), stop);
+            const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), stop);
+            const double vs = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            s = (float)((double)s + vs);                            // the reference's own step
+        }
+        j = stop + 1;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(EM_THREADS) void em_scan_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
+                                                             uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
+{
+    __shared__ float t_s[EM_CHUNK];
+    __shared__ float sums_s[4];
+    const uint32_t img = blockIdx.x;
+    const uint32_t n = sample_count[img];
+    const float *smp = samples + (size_t)img * cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 e0 = em[image_begin + img];
+    float c1 = e0.x, c2 = e0.y, ratio = e0.z;
+    const float esp = 1.59576912160573f;
+    int iteration = 0;
+    while (iteration++ < max_iterations) {
+        float sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += EM_CHUNK) {
+            const uint32_t m = min((uint32_t)EM_CHUNK, n - c0);
+            // membership of the chunk's samples under the current parameters (stats.cxx:30-32), all wavefronts
+            for (uint32_t i = threadIdx.x; i < m; i += EM_THREADS) {
+                const float x = smp[c0 + i];
+                const float f1 = ratio * chi_pdf_ref(x / c1) / c1;
+                const float f2 = (float)((1.0 - (double)ratio) * (double)chi_pdf_ref(x / c2) / (double)c2);
+                t_s[i] = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
+            }
+            __syncthreads();
+            if (wave < 3) {
+                for (uint32_t b = 0; b < m; b += 64) {
+                    const uint32_t i = b + lane;
+                    const int cnt = (int)min(64u, m - b);
+                    const float t = i < m ? t_s[i] : 0.f;
+                    const float p = (i < m ? smp[c0 + i] : 0.f) * 1.0f;     // weights are all 1 (addSample's default)
+                    if (wave == 0) {                                         // sum1 += t*p; sum2 += t*w   (:33-35)
+                        sum1 = em_chain(sum1, (double)(t * p), cnt, lane);
+                        sum2 = em_chain(sum2, (double)t, cnt, lane);
+                    } else if (wave == 1) {                                  // sum3 += (1.0 - t) * p         (:36)
+                        sum3 = em_chain(sum3, (1.0 - (double)t) * (double)p, cnt, lane);
+                    } else {                                                 // sum4 += (1.0 - t) * w         (:37)
+                        sum4 = em_chain(sum4, (1.0 - (double)t) * 1.0, cnt, lane);
+                    }
+                }
+            }
+            __syncthreads();                            // t_s is rewritten by the next chunk / iteration
+        }
+        if (lane == 0) {
+            if (wave == 0) { sums_s[0] = sum1; sums_s[1] = sum2; }
+            if (wave == 1) sums_s[2] = sum3;
+            if (wave == 2) sums_s[3] = sum4;
+        }
+        __syncthreads();
+        sum1 = sums_s[0]; sum2 = sums_s[1]; sum3 = sums_s[2]; sum4 = sums_s[3];
+        __syncthreads();                                // sums_s is rewritten by the next iteration
+        float sum5 = (float)n;                          // n additions of 1.0f, exact below 2^24
+        sum2 = fmaxf(sum2, epsilon);
+        sum3 = fmaxf(sum3, epsilon);
+        sum5 = fmaxf(sum5, epsilon);
+        const float nc1 = fmaxf(epsilon, sum1 / sum2 / esp);
+        const float nc2 = fmaxf(epsilon, sum3 / sum4 / esp);
+        const float nr = fmaxf(epsilon, sum2 / sum5);
+        const bool done = (double)fabsf((c1 - nc1) / nc1) < 0.001
+                       && (double)fabsf((c2 - nc2) / nc2) < 0.001
+                       && (double)fabsf((nr - ratio) / nr) < 0.001;
+        c1 = nc1; c2 = nc2; ratio = nr;
+        if (done) break;
+    }
+    if (threadIdx.x == 0) em[image_begin + img] = make_float4(c1, c2, ratio, 0.f);
+}
+
 // (c1,c2,ratio) -> constants of inlier_probability for ALL images (after the
 // EM table has been made whole by the all-reduce in multi-rank runs).
 __device__ __forceinline__ EmDerived em_derived_of(const float4 e)

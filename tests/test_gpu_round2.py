@@ -169,67 +169,7 @@ SWEEP = [(dict(n=6, pts=3000, ppb=1500, seed=s), {}) for s in (1, 2, 3)] + [
     (dict(n=10, pts=1500, ppb=600, seed=9), dict(stats_max_size=3000)),
     (dict(n=3, pts=6000, ppb=4000, seed=10), dict(linear_alpha=0.3)),
 ]
-# A control point's step is alpha * g / gw = alpha * (weighted mean of the per-point ratios sDisp_p / sWeight_p over the
-# points p in its support, weights w_p * sWeight_p, w_p = product of three cubic basis values).  Two implementations whose
-# point coordinates differ by k f32 ulps (6e-8 * 300 mm = 2e-5 mm, i.e. dt = k * 2e-5 / spacing = k * 2..8e-7 in lattice
-# units) disagree on a TAIL weight (1 - t)^3 / 6 by 3 dt / (1 - t) relative, and the weighted mean moves by that times
-# the spread of the ratios (several mm) -- against max|c| of a lattice of ~0.1 mm per step.  For the mean to stay within
-# 1e-4 max|c| at k ~ 4 the supporting points need (1 - t) >~ 0.2 on every axis, i.e. basis weights >~ 1e-3: a control
-# point whose TOTAL support is below 1e-2 cannot promise that in the reference's own f32 arithmetic (measured: 1.4e-4 on
-# one such control point with identical per-point sums and xyz differing in the last bit).  So:
-#   * control points with support >= SUPPORT_TAU, or none at all (value = -group mean): 1e-4 of max|c|;
-#   * the others (the rim of the box, 13-23 % of a lattice): 1e-2 of max|c| -- they still have to be the same numbers;
-#   * and the quantity that matters, the displacement field at EVERY point of the image: 1e-4 of its maximum.
-SUPPORT_TAU = 1e-2
-RIM_REL = 1e-2
-
-
-def bspline_weights(f):
-    """imageGroup.cxx:221-232, vectorised; f: fractions in [0, 1)."""
-    f2 = f * f
-    F3 = f2 * f / 6.0
-    F0 = (f2 - f) * 0.5 - F3 + 1.0 / 6.0
-    F2 = f + F0 - 2.0 * F3
-    F1 = 1.0 - F0 - F2 - F3
-    return np.stack([F0, F1, F2, F3], axis=-1)
-
-
-def lattice_taps(xyz, info):
-    """Control-point indices [n, 64] and basis weights [n, 64] of the points xyz [n, 3] on the lattice `info`."""
-    dims = np.array(list(info.dims)); origin = np.array(list(info.origin)); spacing = np.array(list(info.spacing))
-    q = (xyz.astype(np.float64) - origin) / spacing
-    fl = np.floor(q)
-    w = [bspline_weights(q[:, k] - fl[:, k]) for k in range(3)]
-    i0 = fl.astype(np.int64) - 1
-    idx = np.empty((len(xyz), 64), np.int64); wt = np.empty((len(xyz), 64))
-    t = 0
-    for k in range(4):
-        for j in range(4):
-            for i in range(4):
-                idx[:, t] = (i0[:, 0] + i) + dims[0] * ((i0[:, 1] + j) + dims[1] * (i0[:, 2] + k))
-                wt[:, t] = w[0][:, i] * w[1][:, j] * w[2][:, k]
-                t += 1
-    return idx, wt
-
-
-def compare_lattice(g, ref, k, i, pts):
-    """Lattice k of image i on both sides; pts = the reference's re-based coordinates of the image's points the
-    lattice acts on.  Returns (largest deviation of the compared coefficients / max|c_ref|, largest deviation of the
-    displacement field over all points / max displacement, number of exempt control points, control points)."""
-    info, c = g.grid(i, k)
-    rinfo, rc = ref.grid(i, k, _abi.FrogGridInfo())
-    assert list(info.dims) == list(rinfo.dims)
-    idx, wt = lattice_taps(pts, rinfo)
-    support = np.zeros(len(rc)); np.add.at(support, idx.ravel(), wt.ravel())
-    ok = (support >= SUPPORT_TAU) | (support == 0.0)
-    scale = max(float(np.max(np.abs(rc))), 1e-30)
-    dev_c = float(np.max(np.abs(c[ok].astype(np.float64) - rc[ok]))) / scale if ok.any() else 0.0
-    dev_rim = float(np.max(np.abs(c[~ok].astype(np.float64) - rc[~ok]))) / scale if (~ok).any() else 0.0
-    assert dev_rim <= RIM_REL, f"lattice {k} image {i}: weakly supported coefficients off by {dev_rim:.2e}"
-    disp = np.einsum("nt,ntk->nk", wt, c.astype(np.float64)[idx])
-    rdisp = np.einsum("nt,ntk->nk", wt, rc.astype(np.float64)[idx])
-    dev_d = float(np.max(np.abs(disp - rdisp))) / max(float(np.max(np.abs(rdisp))), 1e-30)
-    return dev_c, dev_d, int(np.count_nonzero(~ok)), len(rc)
+from lattice_util import RIM_REL, SUPPORT_TAU, compare_lattice, lattice_taps      # noqa: E402,F401  (criterion: see there)
 
 
 @pytest.mark.parametrize("case", range(len(SWEEP)))
