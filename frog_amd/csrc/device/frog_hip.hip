@@ -506,7 +506,7 @@ int frog_update_stats_local(frog_ctx *ctx)
             ctx->sample_ord[cur].p, ctx->sample_count[cur].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
             ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->pos2.p, ctx->samples.p);
         FROG_HIP_CHECK(hipGetLastError());
-        static const bool em_serial = getenv("FROG_EM_SERIAL") != nullptr;     // test hook: the term-by-term form
+        const bool em_serial = getenv("FROG_EM_SERIAL") != nullptr;            // test hook: the term-by-term form
         if (em_serial)
             em_kernel<<<nO, 256, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
                                          ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
@@ -1450,6 +1450,22 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d2
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
     FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return FROG_OK;
+}
+
+int frog_test_em_refit(frog_ctx *ctx, int term_by_term)
+{
+    CTX_GUARD(ctx);
+    const uint32_t nO = ctx->n_owned(), cap = (uint32_t)ctx->sample_cap;
+    const int cur = ctx->sel_used;
+    hipStream_t s = ctx->stream;
+    if (term_by_term)
+        em_kernel<<<nO, 256, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
+                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+    else
+        em_scan_kernel<<<nO, EM_THREADS, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
+                                                 ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+    FROG_HIP_CHECK(hipGetLastError());
+    return frog_stats_publish(ctx);
 }
 
 int frog_profile_enable(frog_ctx *ctx, int on)

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256) void em_kernel(const float *samples, const uin
 // About one batch in five stops once; the chain of a batch costs ~60 instructions instead of 64 dependent additions
 // of 30+ cycles each.  The memberships t, which do not depend on each other, are computed by all sixteen wavefronts
 // of the block for a chunk of samples at a time (LDS), then three wavefronts run the four chains over the chunk.
-// Checked against em_kernel (the term-by-term form, kept: FROG_EM_SERIAL=1) and against the oracle, bit for bit.
+// Checked against em_kernel (the term-by-term form, kept: FROG_EM_SERIAL=1, frog_test_em_refit) bit for bit
+// (tests/test_gpu_fullsize.py).
 constexpr int EM_THREADS = 1024;
 constexpr int EM_CHUNK = 8192;
 
@@ -372,6 +373,52 @@ __device__ __forceinline__ float em_chain(float s, const double v, const int cnt
     return s;
 }
 
+// the same for f32 terms (sum1, sum2): v / ulp(s), its floor and its fraction are exact in f32 too
+__device__ __forceinline__ float em_chain_f32(float s, const float v, const int cnt, const int lane)
+{
+    int j = 0;
+    while (j < cnt) {
+        const uint32_t sb = __float_as_uint(s);
+        const uint32_t ex = sb >> 23;
+        const bool active = lane >= j && lane < cnt;
+        int stop;
+        if (ex == 0u || ex >= 255u) {
+            if (sb == 0u) {
+                const unsigned long long nz = __ballot(active && v != 0.0f);
+                stop = nz ? (int)__ffsll((long long)nz) - 1 : cnt;
+            } else {
+                stop = j;
+            }
+        } else {
+            const int e = (int)ex - 127;
+            uint32_t r = 0;
+            bool odd = false;
+            if (active) {
+                const float x = __builtin_ldexpf(v, 23 - e);        // exact unless it overflows (-> inf: caught below)
+                if (!(x < 16777216.0f)) {
+                    odd = true;
+                } else {
+                    const uint32_t f = (uint32_t)x;
+                    const float frac = x - (float)f;                // exact: the low bits of x
+                    odd = frac == 0.5f;                             // f32 terms: a single rounding, only the exact tie is special
+                    r = f + (frac > 0.5f ? 1u : 0u);
+                }
+            }
+            const uint32_t P = wave_inclusive_scan_u32(r, lane);
+            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+            const unsigned long long halt = __ballot(active && (odd || S + P >= 0x1000000u));
+            stop = halt ? (int)__ffsll((long long)halt) - 1 : cnt;
+            if (stop > j) {
+                const uint32_t Pp = (uint32_t)__builtin_amdgcn_readlane((int)P, stop - 1);
+                s = __builtin_ldexpf((float)(S + Pp), e - 23);
+            }
+        }
+        if (stop < cnt) s += lane_f32(v, stop);                     // the reference's own step
+        j = stop + 1;
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(EM_THREADS) void em_scan_kernel(const float *samples, const uint32_t *sample_count, uint32_t cap,
                                                              uint32_t image_begin, float4 *em, int max_iterations, float epsilon)
 {
@@ -397,28 +444,25 @@ __global__ __launch_bounds__(EM_THREADS) void em_scan_kernel(const float *sample
                 t_s[i] = (float)((double)f1 / ((double)(f1 + f2) + 1e-16));
             }
             __syncthreads();
-            if (wave < 3) {
+            if (wave < 4) {                                  // one wavefront per accumulator
                 for (uint32_t b = 0; b < m; b += 64) {
                     const uint32_t i = b + lane;
                     const int cnt = (int)min(64u, m - b);
                     const float t = i < m ? t_s[i] : 0.f;
                     const float p = (i < m ? smp[c0 + i] : 0.f) * 1.0f;     // weights are all 1 (addSample's default)
-                    if (wave == 0) {                                         // sum1 += t*p; sum2 += t*w   (:33-35)
-                        sum1 = em_chain(sum1, (double)(t * p), cnt, lane);
-                        sum2 = em_chain(sum2, (double)t, cnt, lane);
-                    } else if (wave == 1) {                                  // sum3 += (1.0 - t) * p         (:36)
-                        sum3 = em_chain(sum3, (1.0 - (double)t) * (double)p, cnt, lane);
-                    } else {                                                 // sum4 += (1.0 - t) * w         (:37)
-                        sum4 = em_chain(sum4, (1.0 - (double)t) * 1.0, cnt, lane);
-                    }
+                    if (wave == 0) sum1 = em_chain_f32(sum1, t * p, cnt, lane);                                  // sum1 += t*p         (:33)
+                    else if (wave == 1) sum2 = em_chain_f32(sum2, t, cnt, lane);                                 // sum2 += t*w         (:35)
+                    else if (wave == 2) sum3 = em_chain(sum3, (1.0 - (double)t) * (double)p, cnt, lane);         // sum3 += (1.0-t)*p   (:36)
+                    else sum4 = em_chain(sum4, (1.0 - (double)t) * 1.0, cnt, lane);                              // sum4 += (1.0-t)*w   (:37)
                 }
             }
             __syncthreads();                            // t_s is rewritten by the next chunk / iteration
         }
         if (lane == 0) {
-            if (wave == 0) { sums_s[0] = sum1; sums_s[1] = sum2; }
-            if (wave == 1) sums_s[2] = sum3;
-            if (wave == 2) sums_s[3] = sum4;
+            if (wave == 0) sums_s[0] = sum1;
+            if (wave == 1) sums_s[1] = sum2;
+            if (wave == 2) sums_s[2] = sum3;
+            if (wave == 3) sums_s[3] = sum4;
         }
         __syncthreads();
         sum1 = sums_s[0]; sum2 = sums_s[1]; sum3 = sums_s[2]; sum4 = sums_s[3];

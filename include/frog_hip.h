@@ -210,6 +210,11 @@ int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_
 int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d2, size_t n,
                                  float *fast, float *exact);
 
+/* Test hook: Stats::estimateDistribution (stats.cxx:14-70) again, on the samples the last refresh retained and from
+ * the CURRENT (c1, c2, ratio) of every owned image (set them with frog_set_em first), with the term-by-term form of
+ * the accumulators (term_by_term != 0) or the prefix-sum form frog_update_stats uses.  Both must give the same bits. */
+int frog_test_em_refit(frog_ctx *ctx, int term_by_term);
+
 /* ---- live kernel timing (HIP events on the context's stream) ------------------ */
 enum {
     FROG_K_SWEEP_LINEAR = 0,   /* half-link sweep of updateLinearTransforms     */

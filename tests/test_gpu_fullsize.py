@@ -100,6 +100,39 @@ def test_config3_steps_against_oracle(config3):
         assert (cnt[i].pairs, cnt[i].inliers, cnt[i].outliers) == (rcnt[i].pairs, rcnt[i].inliers, rcnt[i].outliers)
 
 
+@pytest.mark.parametrize("max_size", [10000, 20000, 700])
+def test_em_prefix_sum_form_equals_term_by_term(max_size):
+    """Stats::estimateDistribution on the device: the prefix-sum form of its f32 accumulators (em_scan_kernel, what
+    updateStats runs) against the term-by-term form (em_kernel) on the SAME retained samples from the SAME starting
+    parameters (frog_test_em_refit), over refreshes at different coordinates: cold start from (10, 300, 0.5), warm
+    starts, one / two / three LDS chunks of samples (-ss 700 / 10000 / 20000).  Same bits, and the oracle agrees."""
+    pairs = Pairs.synthetic(20, 20000, 10526, seed=4)
+    g = ImageGroup(pairs, stats_max_size=max_size)
+    ref = OracleGroup(pairs.model, _abi.FrogOptions.default(stats_max_size=max_size))
+    ref.setup_stats()
+    g.setupLinearTransforms(); ref.linear_init()
+    g.transformPoints(); ref.transform_points()
+    lib = _abi.hip_lib()
+    for it in range(16):
+        if it % 5 == 0:
+            before = [g.em(i).copy() for i in range(pairs.n_images)]
+            ref.set_xyz2(g.points()[1])
+            for i in range(pairs.n_images):
+                ref.set_em(i, before[i])
+            g.updateStats(); ref.update_stats()
+            after = [g.em(i).copy() for i in range(pairs.n_images)]
+            fits = []
+            for term_by_term in (1, 0):
+                for i in range(pairs.n_images):
+                    g.set_em(i, before[i])
+                assert lib.frog_test_em_refit(g._ctx, term_by_term) == _abi.FROG_OK
+                fits.append([g.em(i).copy() for i in range(pairs.n_images)])
+            for i in range(pairs.n_images):
+                assert np.array_equal(fits[0][i], fits[1][i]), f"image {i}, iteration {it}: {fits[0][i]} vs {fits[1][i]}"
+                assert np.array_equal(after[i], fits[1][i]) and np.array_equal(after[i], ref.em(i))
+        g.updateLinearTransforms(); g.transformPoints()
+
+
 def _short_run(pairs):
     g = ImageGroup(pairs)
     g.linearIterations, g.deformableLevels, g.deformableIterations = 12, 2, 6
