@@ -441,7 +441,7 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
 }
 
 // ---- transformPoints (imageGroup.cxx:910-916, image.cxx:3-13) -----------------------
-static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
+static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step = false)
 {
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     if (!n) return FROG_OK;                     // a context whose images are all empty: nothing to launch
@@ -456,7 +456,9 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply)
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
         transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
                                                                          ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
-                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p);
+                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
+                                                                         after_step ? ctx->grad.p : nullptr, ctx->energy.p,
+                                                                         ctx->opt.guarantee_diffeomorphism);
         if (with_disp) ctx->disp_n = div_up(n, 256);
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
@@ -1082,29 +1084,26 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
 {
     CTX_GUARD(ctx);
     if (ctx->phase != 2) return fail(FROG_E_STATE, "phase_c without phase_b");
-    // Commit on the device if the (all-reduced) oversize count allows it, then already
-    // compute, into a shadow buffer, the transformPoints() that run() calls next in either
-    // case (accepted: :118 with the new coefficients; rejected: the coefficients are
-    // unchanged) -- the GPU keeps working while the host waits for the three scalars.
-    // The host only needs the scalars: they are copied out first, and the wait below is for
-    // that copy alone, so commit and transform run while the host is already preparing the
-    // next call.
+    // The accept / reject decision (imageGroup.cxx:434-439) is on the device: the (all-reduced) oversize count.
+    // Queued here, before the host knows it: the transformPoints() that run() calls next in either case (accepted: :118
+    // with the proposal lattice; rejected: with the standing coefficients), into a shadow buffer -- the GPU keeps working
+    // while the host waits for the four scalars, which are copied out first; the wait below is for that copy alone.
+    // The commit itself (:441-468) costs nothing: once the host has the decision it exchanges the two buffers.
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipEventRecord(ctx->energy_copied, ctx->stream));
-    const size_t n = (size_t)ctx->n_owned() * ctx->geom.n_cp;
-    {
-        Span span(ctx, FROG_K_LATTICE);
-        cp_commit_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->coeff.p, ctx->grad.p, n, ctx->energy.p,
-                                                                 ctx->opt.guarantee_diffeomorphism);
-    }
-    FROG_HIP_CHECK(hipGetLastError());
-    if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
-    int rc = launch_transform(ctx, ctx->pos2_spec.p, 0);        // xyz2 itself changes only when the caller asks
+    // the transformPoints() that run() calls next, from the lattice the guard's decision selects (on the device)
+    int rc = launch_transform(ctx, ctx->pos2_spec.p, 0, true);  // xyz2 itself changes only when the caller asks
     if (rc) return rc;
     ctx->xyz2_fresh = true;
     FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
     const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
     if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // this step's sweep found the culling list out of date
+    if (!(ctx->opt.guarantee_diffeomorphism && nbig > 0)) {
+        // accepted (:441-468): the proposal lattice becomes the coefficients -- the two buffers change roles
+        std::swap(ctx->coeff.p, ctx->grad.p);
+        std::swap(ctx->coeff.cap, ctx->grad.cap);
+        std::swap(ctx->coeff.n, ctx->grad.n);
+    }
     ctx->phase = 0;
     if (E) *E = (ctx->opt.guarantee_diffeomorphism && nbig > 0) ? -1.0 : e;      // :434-439
     return FROG_OK;

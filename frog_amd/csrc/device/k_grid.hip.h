@@ -64,11 +64,17 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 // ---- K11: cubic B-spline forward transform (vtkBSplineTransform, BorderModeZero) --
 // Thread per point in brick order (perm), so a wavefront's taps fall into a few
 // neighbouring cells and hit L1/L2.
+// `proposal` / `energy` (both null in ordinary calls): the launch that follows a deformable step is queued before
+// the host knows whether the diffeomorphism guard accepted it (imageGroup.cxx:434-439); it reads the proposal lattice
+// when the device-side oversize count says "accepted" and the standing coefficients otherwise.  The host then swaps
+// the two buffers instead of copying one onto the other (the commit of :441-468 is a pointer exchange).
 __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
-                                                                const P3 *snap, uint32_t *disp_part)
+                                                                const P3 *snap, uint32_t *disp_part,
+                                                                const float4 *proposal, const double *energy, int guarantee)
 {
+    if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
     // reduction at the end is wave-wide
     const uint32_t s_raw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -846,20 +852,6 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
             *ticket = 0u;
         }
     }
-}
-
-// ---- K10: commit (imageGroup.cxx:441-468) -------------------------------------------
-// The accept / reject decision (imageGroup.cxx:434-439) is taken on the device from the
-// (all-reduced) oversize count, so the host does not have to read it back first.
-__global__ __launch_bounds__(256) void cp_commit_kernel(float4 *coeff, const float4 *grad, size_t n,
-                                                        const double *energy, int guarantee)
-{
-    if (guarantee && energy[2] > 0.0) return;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 v = grad[i];
-    v.w = 0.f;
-    coeff[i] = v;
 }
 
 } // namespace frog

@@ -12,7 +12,7 @@ import pytest
 from frog_amd import _abi
 from frog_amd.image_group import ImageGroup
 from oracle.oracle_api import OracleGroup
-from lattice_util import compare_lattice
+from lattice_util import compare_lattice, node_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -44,8 +44,9 @@ def lattices_agree(g, ref, pairs, k=0):
     """Lattice k of every image: coefficients and displacement field by the criterion of tests/lattice_util.py (a raw
     max-norm over ALL control points also measures the conditioning of the rim of the box: 1e-4 per ulp of coordinate)."""
     x, po = ref.xyz(), np.asarray(pairs.point_offset)
+    w = node_weights(ref, k, po, x)
     for i in range(ref.n_images):
-        dev_c, dev_d, _, _ = compare_lattice(g, ref, k, i, x[po[i]:po[i + 1]])
+        dev_c, dev_d, _, _ = compare_lattice(g, ref, k, i, x[po[i]:po[i + 1]], w)
         assert dev_c <= REL and dev_d <= REL, f"lattice {k} image {i}: coefficients {dev_c:.2e}, field {dev_d:.2e}"
 
 

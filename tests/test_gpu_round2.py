@@ -169,7 +169,7 @@ SWEEP = [(dict(n=6, pts=3000, ppb=1500, seed=s), {}) for s in (1, 2, 3)] + [
     (dict(n=10, pts=1500, ppb=600, seed=9), dict(stats_max_size=3000)),
     (dict(n=3, pts=6000, ppb=4000, seed=10), dict(linear_alpha=0.3)),
 ]
-from lattice_util import compare_lattice      # noqa: E402  (the criterion is explained there)
+from lattice_util import compare_lattice, node_weights      # noqa: E402  (the criterion is explained there)
 
 
 @pytest.mark.parametrize("case", range(len(SWEEP)))
@@ -177,8 +177,8 @@ def test_parity_sweep(case):
     """Full schedule (50 linear + 3 levels x 40, regrids included), both sides free-running from the same pairs.
     Asserted for EVERY case, with no case-dependent exemption:
       * lattices per level, energy series (1e-4), matrices (1e-4);
-      * coefficients of every control point, weighted by min(1, support) (support = sum of the basis weights of its
-        image's points on that lattice; tests/lattice_util.py): |c - c_ref| min(1, support) <= 1e-4 max|c_ref|;
+      * coefficients of every control point, weighted by how well the group's points determine its node
+        (tests/lattice_util.py): |c - c_ref| w <= 1e-4 max|c_ref|, w = min(1, smallest non-zero support over the images);
       * the displacement field of every lattice evaluated at EVERY point of its image: <= 1e-4 of the largest displacement;
       * the final coordinates.
     and every coefficient, unweighted, within 1e-2."""
@@ -235,15 +235,16 @@ def test_parity_sweep(case):
         assert relerr(np.diag(m)[:3], np.diag(mr)[:3]) < REL and relerr(m[:3, 3], mr[:3, 3]) < REL
     worst_c, worst_d, n_unsupported, n_cp_total = 0.0, 0.0, 0, 0
     for k in range(ref.num_grids()):
+        w = node_weights(ref, k, po, snapshots[k])
         for i in range(pairs.n_images):
-            dev_c, dev_d, n_ex, n_cp = compare_lattice(g, ref, k, i, snapshots[k][po[i]:po[i + 1]])
+            dev_c, dev_d, n_ex, n_cp = compare_lattice(g, ref, k, i, snapshots[k][po[i]:po[i + 1]], w)
             n_unsupported += n_ex; n_cp_total += n_cp
             worst_c, worst_d = max(worst_c, dev_c), max(worst_d, dev_d)
             assert dev_c <= REL, f"lattice {k} image {i}: supported coefficients off by {dev_c:.2e}"
             assert dev_d <= REL, f"lattice {k} image {i}: displacement field off by {dev_d:.2e}"
     assert relerr(g.points()[0], ref.xyz()) < 1e-6
     note(f"parity_sweep_case_{case}", f"E {worst_e:.2e} coeff {worst_c:.2e} field {worst_d:.2e} "
-                                     f"cps_with_support_below_1 {n_unsupported}/{n_cp_total}")
+                                     f"nodes_weighted_below_1 {n_unsupported}/{n_cp_total}")
 
 
 # ---- certified outlier culling ---------------------------------------------------------------------------------
@@ -388,10 +389,11 @@ def test_blocks_in_shuffled_file_order():
     e, er = g.updateDeformableTransforms(0.02), ref.deformable_step(0.02)
     assert er > 0 and abs(e - er) / er < 1e-6
     assert relerr(g.point_sums(), ref.point_sums()) < 1e-5
+    w = node_weights(ref, 0, po, snapshot)
     for i in range(pairs.n_images):
         # same criterion as the parity sweep: the summation order differs from the file's here, and a control point on
         # the rim of the box turns one ulp of a per-point sum into 1e-4 of its value
-        dev_c, dev_d, _, _ = compare_lattice(g, ref, 0, i, snapshot[po[i]:po[i + 1]])
+        dev_c, dev_d, _, _ = compare_lattice(g, ref, 0, i, snapshot[po[i]:po[i + 1]], w)
         assert dev_c <= REL and dev_d <= REL, (i, dev_c, dev_d)
     same_inputs(g, ref)
     census_equal(g, ref)
