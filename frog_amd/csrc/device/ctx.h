@@ -262,6 +262,7 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> hl_point, hl_ptr, hl_partner;
     frog::DevBuf<double> hl_partial;          // [n_hard][2]
     frog::DevBuf<uint32_t> perm_tmp;          // second buffer of the cell-order pass
+    frog::DevBuf<uint32_t> perm_key;          // (image, brick, cell) key of every sorted slot
     frog::DevBuf<float4> scatter_stage;       // [scatter blocks][(B+3)^3] tiles of the last scatter
     frog::DevBuf<uint32_t> brick_slot_ptr;    // [owned images * bricks + 1] staging slots per (image, brick)
     frog::DevBuf<uint32_t> subset_idx;        // frog_get_points2_subset scratch

@@ -339,8 +339,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
     CREATE_CHECK(c->n_big.alloc(1));
     CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
-    CREATE_CHECK(c->stray.alloc(1));
-    CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, sizeof(unsigned int), s));
+    CREATE_CHECK(c->stray.alloc(2));
+    CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
     em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
     CREATE_CHECK(hipGetLastError());
@@ -763,6 +763,7 @@ static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], c
     // brick edge: 4 cells (5.5 KB tile, many resident wavefronts) while bricks keep enough points to
     // amortise their flush, else 8
     g.brick = ((double)nPts / ((double)nO * (double)bricks_for(4)) >= 24.0) ? 4 : 8;
+    if (const char *e = getenv("FROG_BRICK")) { const int b = atoi(e); if (b == 4 || b == 8) g.brick = b; }      // test hook
     for (int k = 0; k < 3; k++) g.nbricks[k] = (g.cells[k] + g.brick - 1) / g.brick;
     const size_t nb = bricks_for(g.brick);
     if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
@@ -796,6 +797,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->scan_sums.alloc(div_up(n_keys, SCAN_BLOCK_ITEMS) + 2, (div_up(n_keys, SCAN_BLOCK_ITEMS) + 2) * reserve));
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     if (ctx->perm_tmp.n != nPts) FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
+    if (ctx->perm_key.n != nPts) FROG_HIP_CHECK(ctx->perm_key.alloc(nPts));
     if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
     FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
     FROG_HIP_CHECK(ctx->scatter_blocks.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
@@ -878,10 +880,10 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     rc = exclusive_scan(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
     if (rc) return rc;
     if (nPts) {
-        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p);
+        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p, ctx->perm_key.p);
         FROG_HIP_CHECK(hipGetLastError());
         // canonical order inside every cell (the placement's atomics make it arbitrary): reproducible sums
-        cell_order_kernel<<<div_up(n_keys, 4), 256, 0, s>>>(ctx->key_ptr.p, n_keys, ctx->perm.p, ctx->perm_tmp.p);
+        cell_order_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->perm_key.p, nPts, ctx->perm.p, ctx->perm_tmp.p);
         FROG_HIP_CHECK(hipGetLastError());
         std::swap(ctx->perm.p, ctx->perm_tmp.p);
         std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
@@ -1448,6 +1450,17 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d2
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
     FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FROG_OK;
+}
+
+int frog_test_stray_points(frog_ctx *ctx, uint64_t *n)
+{
+    CTX_GUARD(ctx);
+    if (!n) return fail(FROG_E_INVALID, "null output");
+    unsigned int v = 0;
+    FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->stray.p + 1, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n = v;
     return FROG_OK;
 }
 

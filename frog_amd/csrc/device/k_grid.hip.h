@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void brick_count_kernel(const float4 *pos, con
 
 __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, const uint32_t *poff,
                                                           uint32_t image_begin, const GeomDev g,
-                                                          uint32_t *cursor, uint32_t *perm)
+                                                          uint32_t *cursor, uint32_t *perm, uint32_t *perm_key)
 {
     __shared__ uint32_t h[BRICK_LDS_KEYS];
     const uint32_t img = blockIdx.y;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
         if (p < p1) {
             key[m] = point_key(pos[p], g);
             if (lds) rank[m] = atomicAdd(&h[key[m]], 1u);           // rank inside this block
-            else perm[atomicAdd(&gcur[key[m]], 1u)] = p;
+            else { const uint32_t slot = atomicAdd(&gcur[key[m]], 1u); perm[slot] = p; perm_key[slot] = img * (uint32_t)nk + key[m]; }
         }
     }
     if (!lds) return;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void brick_place_kernel(const float4 *pos, con
     #pragma unroll
     for (int m = 0; m < PER; m++) {
         const uint32_t p = p0 + threadIdx.x + 256 * m;
-        if (p < p1) perm[h[key[m]] + rank[m]] = p;
+        if (p < p1) { const uint32_t slot = h[key[m]] + rank[m]; perm[slot] = p; perm_key[slot] = img * (uint32_t)nk + key[m]; }
     }
 }
 
@@ -404,21 +404,23 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *counts
 
 // The placement above hands out slots with atomics, so the order of the points INSIDE a cell changes
 // from run to run -- and with it the order of the f32 additions of the scatter.  This pass puts every
-// cell's points in ascending index order (one wavefront per cell; rank = number of smaller entries,
-// O(n^2 / 64) reads that hit L1: cells hold 5 to a few hundred points, and it runs once per lattice).
-__global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr, uint32_t n_keys,
+// cell's points in ascending index order: thread = sorted slot, rank = number of smaller entries in its
+// cell (cells hold 5 to a few hundred points; the reads hit L1; it runs once per lattice).  Per slot, not
+// per cell: a fine lattice of a large group has 10^8..10^9 cells, nearly all of them empty (the first
+// version launched one wavefront per cell, and past 2^32 threads the launch silently covered only part
+// of them: unsorted, partly unwritten permutation, 60 % of the points of a 500-image group taken for
+// strays by the scatter and sent through global atomics -- 75 ms per step instead of 0.5).
+__global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr, const uint32_t *perm_key, uint32_t n_points,
                                                          const uint32_t *perm_in, uint32_t *perm_out)
 {
-    const uint32_t key = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (key >= n_keys) return;
-    const uint32_t b = key_ptr[key], n = key_ptr[key + 1] - b;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t v = perm_in[b + i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; j++) rank += perm_in[b + j] < v ? 1u : 0u;
-        perm_out[b + rank] = v;
-    }
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_points) return;
+    const uint32_t key = perm_key[s];
+    const uint32_t b = key_ptr[key], e = key_ptr[key + 1];
+    const uint32_t v = perm_in[s];
+    uint32_t rank = 0;
+    for (uint32_t j = b; j < e; j++) rank += perm_in[j] < v ? 1u : 0u;
+    perm_out[b + rank] = v;
 }
 
 // ---- the scatter's block table, built on the device (no host round trip inside a lattice set-up) ----------
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                     // stray point clamped into this brick (outside the scaled box): its taps go
                     // straight to HBM, one lane doing all 64; lattice_step_kernel then folds the gradient lattice in
                     atomicAdd(stray, 1u);
+                    atomicAdd(stray + 1, 1u);       // running total, never cleared (frog_test_stray_points)
                     for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;

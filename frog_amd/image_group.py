@@ -263,6 +263,12 @@ class ImageGroup:
         check(self._lib.frog_cull_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats")
         return a.value, b.value, c.value
 
+    def stray_points(self):
+        """Points the scatter found outside their brick since creation (frog_test_stray_points): 0 unless the sort is broken."""
+        n = C.c_uint64()
+        check(self._lib.frog_test_stray_points(self._ctx, C.byref(n)), "frog_test_stray_points")
+        return n.value
+
     def residualSums(self):
         check(self._lib.frog_residual_sums(self._ctx), "frog_residual_sums")
 

@@ -210,6 +210,11 @@ int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_
 int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d2, size_t n,
                                  float *fast, float *exact);
 
+/* Test hook: how many points the B-spline scatter has found outside the brick they were sorted into since the context
+ * was created (they are handled, through global atomics: slowly and in no fixed order).  Inside the lattice's box --
+ * always, for the group's own points -- this must stay 0; a non-zero count means the (image, brick, cell) sort is broken. */
+int frog_test_stray_points(frog_ctx *ctx, uint64_t *n);
+
 /* Test hook: Stats::estimateDistribution (stats.cxx:14-70) again, on the samples the last refresh retained and from
  * the CURRENT (c1, c2, ratio) of every owned image (set them with frog_set_em first), with the term-by-term form of
  * the accumulators (term_by_term != 0) or the prefix-sum form frog_update_stats uses.  Both must give the same bits. */

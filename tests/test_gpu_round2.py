@@ -399,6 +399,27 @@ def test_blocks_in_shuffled_file_order():
     census_equal(g, ref)
 
 
+def test_brick_edge_8_equals_brick_edge_4(small_pairs, monkeypatch):
+    """Sparse lattices (fewer than 24 points per 4^3-cell brick) use bricks of 8^3 cells in the scatter: 11^3-node tiles,
+    another sort key.  Forced on a small group (FROG_BRICK): same lattices as with edge 4 up to the order of the f32
+    additions, no point outside the brick it was sorted into."""
+    def run(brick):
+        monkeypatch.setenv("FROG_BRICK", str(brick))
+        g = ImageGroup(small_pairs)
+        g.linearIterations, g.deformableLevels, g.deformableIterations = 12, 3, 10
+        E = g.run()
+        assert g.stray_points() == 0
+        return E, [[g.grid(i, k)[1] for k in range(g.num_grids())] for i in range(small_pairs.n_images)], g.gridsPerLevel
+    E4, L4, G4 = run(4)
+    E8, L8, G8 = run(8)
+    assert G4 == G8 and len(E4) == len(E8)
+    assert np.max(np.abs(np.array(E4) - np.array(E8)) / np.array(E4)) < 1e-6
+    for a, b in zip(L4, L8):
+        for x, y in zip(a, b):
+            assert np.max(np.abs(x - y)) <= 1e-2 * max(float(np.max(np.abs(x))), 1e-30)      # rim nodes: tests/lattice_util.py
+    assert relerr(np.concatenate([l[-1] for l in L8]), np.concatenate([l[-1] for l in L4])) < 1e-2
+
+
 def test_context_that_owns_only_empty_images():
     """A shard may hold only images without points (plan_shards balances half-links): its sweeps have nothing to
     launch, and the split-phase entry points must still succeed with zero sums (no zero-block launch)."""
