@@ -680,6 +680,7 @@ constexpr int LS_CPB = 16;          // control points per block
 constexpr int LS_IC = 64;           // images per pass (with 16 a group of 100 images took 7 dependent rounds of
                                     // slot-pointer -> tile loads per block: 130 us where the three kernels took 77)
 constexpr int LS_THREADS = LS_CPB * LS_IC;
+constexpr int LS_KEEP = 8;          // passes whose proposals stay in registers until the mean is known
 static_assert(LS_THREADS <= 1024 && 3 * LS_CPB <= LS_THREADS, "lattice_step_kernel thread mapping");
 
 struct LatticeStepArgs {
@@ -724,8 +725,13 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
     // summation thread: (control point sc, axis sa)
     const int sc = tid % LS_CPB, sa = tid / LS_CPB;
     double run = 0.0;
+    // CENTER: the proposals of up to LS_KEEP passes (groups of up to 512 images) wait in registers for the mean, so that
+    // every coefficient is written once; larger groups write the raw proposals and re-read them (the blocks' own L2 lines)
+    float4 keep[LS_KEEP];
+    const bool kept = CENTER && a.n_owned <= (uint32_t)(LS_KEEP * LS_IC);
 
-    for (uint32_t i0 = 0; i0 < a.n_owned; i0 += LS_IC) {
+    // steps 1-2 for this thread's (image i0 + il, control point): the proposal (0 for threads without one)
+    auto propose = [&](uint32_t i0, bool store) {
         const uint32_t img = i0 + il;
         float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (img < a.n_owned && cp < g.n_cp) {
@@ -756,8 +762,12 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
                 n4.x = c4.x; n4.y = c4.y; n4.z = c4.z;
             }
             n4.w = s.w;
-            a.grad[o] = n4;
+            if (store) a.grad[o] = n4;
         }
+        return n4;
+    };
+    // step 3 for one pass: the LS_IC proposals of every control point added in image order
+    auto accumulate = [&](uint32_t i0, const float4 n4) {
         prop[il][c][0] = n4.x; prop[il][c][1] = n4.y; prop[il][c][2] = n4.z;
         __syncthreads();
         if (tid < 3 * LS_CPB) {
@@ -765,6 +775,17 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
             for (uint32_t k = 0; k < n; k++) run += (double)prop[k][sc][sa];
         }
         __syncthreads();
+    };
+    if (kept) {
+        #pragma unroll
+        for (int pass = 0; pass < LS_KEEP; pass++) {
+            const uint32_t i0 = (uint32_t)pass * LS_IC;
+            if (i0 >= a.n_owned) break;                 // block-uniform
+            keep[pass] = propose(i0, false);
+            accumulate(i0, keep[pass]);
+        }
+    } else {
+        for (uint32_t i0 = 0; i0 < a.n_owned; i0 += LS_IC) accumulate(i0, propose(i0, true));
     }
     if (tid < 3 * LS_CPB) {
         const int scp = blockIdx.x * LS_CPB + sc;
@@ -776,14 +797,21 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
     unsigned int cnt = 0;
     if (cp < g.n_cp) {
         const double mx = mean[c][0], my = mean[c][1], mz = mean[c][2];
-        for (uint32_t img = il; img < a.n_owned; img += LS_IC) {
-            const size_t o = (size_t)img * g.n_cp + cp;
-            float4 v = a.grad[o];
+        auto centre = [&](uint32_t img, float4 v) {
             v.x = (float)((double)v.x - mx);
             v.y = (float)((double)v.y - my);
             v.z = (float)((double)v.z - mz);
-            a.grad[o] = v;
+            a.grad[(size_t)img * g.n_cp + cp] = v;
             cnt += ((double)fabsf(v.x) > a.lim[0]) + ((double)fabsf(v.y) > a.lim[1]) + ((double)fabsf(v.z) > a.lim[2]);
+        };
+        if (kept) {
+            #pragma unroll
+            for (int pass = 0; pass < LS_KEEP; pass++) {
+                const uint32_t img = (uint32_t)pass * LS_IC + il;
+                if (img < a.n_owned) centre(img, keep[pass]);
+            }
+        } else {
+            for (uint32_t img = il; img < a.n_owned; img += LS_IC) centre(img, a.grad[(size_t)img * g.n_cp + cp]);
         }
     }
     cnt_s[tid] = cnt;
