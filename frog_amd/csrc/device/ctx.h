@@ -248,6 +248,7 @@ struct frog_ctx {
     frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[...] longest first (k_grid.hip.h); the count is on the device
     frog::DevBuf<unsigned char> scatter_blocks_tmp; // the same blocks in brick order
     frog::DevBuf<uint32_t> len_hist;          // [2][SCATTER_CHUNK + 1] block-length histogram, cursors
+    frog::DevBuf<int> brick_box;              // [nOwned][6] box of every image's non-empty bricks
     uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
     frog::DevBuf<unsigned long long> n_big;   // oversize-coefficient counter

@@ -803,6 +803,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->scatter_blocks.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
     FROG_HIP_CHECK(ctx->scatter_blocks_tmp.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
     FROG_HIP_CHECK(ctx->len_hist.alloc(2 * (SCATTER_CHUNK + 1)));
+    FROG_HIP_CHECK(ctx->brick_box.alloc((size_t)6 * nO));
     // tile storage: a finer level needs about as many blocks (bricks hold fewer points) but brick edge 8 instead of 4 has
     // 2.4x the tile
     FROG_HIP_CHECK(ctx->scatter_stage.alloc(max_blocks * E * E * E, max_blocks * E * E * E * std::min<size_t>(reserve, 8)));
@@ -896,6 +897,8 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     FROG_HIP_CHECK(hipMemsetAsync(ctx->len_hist.p, 0, ctx->len_hist.bytes(), s));
     brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
     FROG_HIP_CHECK(hipGetLastError());
+    brick_box_init_kernel<<<div_up(nO, 256), 256, 0, s>>>(ctx->brick_box.p, nO);
+    brick_box_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(chunks.p, n_bricks_total, gd, ctx->brick_box.p);
     rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
     if (rc) return rc;
     ScatterBlock *blk_tmp = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks_tmp.p);
@@ -1049,7 +1052,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         // group also the mean removal and the oversize count (phase B is then empty): one launch
         Span span(ctx, FROG_K_LATTICE);
         LatticeStepArgs la{};
-        la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p; la.gradf = ctx->gradf.p; la.stray = ctx->stray.p;
+        la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p; la.brick_box = ctx->brick_box.p;
+        la.gradf = ctx->gradf.p; la.stray = ctx->stray.p;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
