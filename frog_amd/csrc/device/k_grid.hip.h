@@ -761,27 +761,43 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
         float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (img < a.n_owned && cp < g.n_cp) {
             const size_t o = (size_t)img * g.n_cp + cp;
+            const float4 c4 = a.coeff[o];                       // needed last, asked for first
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             const int *bb = a.brick_box + 6 * (size_t)img;      // the same 24 bytes for the 16 lanes of an image
             const int x0 = max(lo[0], bb[0]), y0 = max(lo[1], bb[1]), z0 = max(lo[2], bb[2]);
             const int x1 = min(hi[0], bb[3]), y1 = min(hi[1], bb[4]), z1 = min(hi[2], bb[5]);
-            for (int bz = z0; bz <= z1; bz++)
-                for (int by = y0; by <= y1; by++)
-                    for (int bx = x0; bx <= x1; bx++) {
-                        const uint32_t key = img * g.n_bricks + (uint32_t)(bx + g.nbricks[0] * (by + g.nbricks[1] * bz));
-                        const int local = (cc[0] - bx * B) + E * ((cc[1] - by * B) + E * (cc[2] - bz * B));
-                        for (uint32_t sl = a.brick_slot_ptr[key]; sl < a.brick_slot_ptr[key + 1]; sl++) {
-                            const float4 v = a.stage[(size_t)sl * n_tile + local];
-                            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-                        }
-                    }
+            // At most two bricks per axis cover a node (E = B + 3 <= 2 B).  The eight candidates in (z, y, x) order; their
+            // slot ranges, then the first tile of each, are fetched side by side (this used to be a chain of dependent
+            // loads per candidate: the kernel spent its time waiting), the sums are then formed in the fixed order.
+            uint32_t kb[8], ke[8];
+            int loc[8];
+            #pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const int bx = x0 + (n & 1), by = y0 + ((n >> 1) & 1), bz = z0 + (n >> 2);
+                const bool in = bx <= x1 && by <= y1 && bz <= z1;
+                const uint32_t key = img * g.n_bricks + (uint32_t)(bx + g.nbricks[0] * (by + g.nbricks[1] * bz));
+                kb[n] = in ? a.brick_slot_ptr[key] : 0u;
+                ke[n] = in ? a.brick_slot_ptr[key + 1] : 0u;
+                loc[n] = (cc[0] - bx * B) + E * ((cc[1] - by * B) + E * (cc[2] - bz * B));
+            }
+            float4 first[8];
+            #pragma unroll
+            for (int n = 0; n < 8; n++)
+                first[n] = kb[n] < ke[n] ? a.stage[(size_t)kb[n] * n_tile + loc[n]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            #pragma unroll
+            for (int n = 0; n < 8; n++) {
+                if (kb[n] < ke[n]) { s.x += first[n].x; s.y += first[n].y; s.z += first[n].z; s.w += first[n].w; }
+                for (uint32_t sl = kb[n] + 1; sl < ke[n]; sl++) {            // bricks of more than SCATTER_CHUNK points
+                    const float4 v = a.stage[(size_t)sl * n_tile + loc[n]];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
             if (has_stray) {                    // added to what the stray points' atomics left, as the separate flush did
                 float4 t = a.gradf[o];
                 t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
                 s = t;
                 a.gradf[o] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            const float4 c4 = a.coeff[o];
             if (s.w > 0) {
                 n4.x = c4.x + a.alpha * s.x / s.w;
                 n4.y = c4.y + a.alpha * s.y / s.w;
