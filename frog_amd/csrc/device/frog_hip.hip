@@ -454,12 +454,26 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
-        transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
-                                                                         ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
-                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
-                                                                         after_step ? ctx->grad.p : nullptr, ctx->energy.p,
-                                                                         ctx->opt.guarantee_diffeomorphism);
-        if (with_disp) ctx->disp_n = div_up(n, 256);
+        // bricks of 8^3 cells (sparse lattices) would need 32 KB of LDS per wavefront: those stay with the thread-per-point form
+        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE");
+        if (tiled) {
+            // one wavefront per scatter block, the brick's coefficients in LDS as f64 (k_grid.hip.h)
+            const GeomDev gd = to_dev(ctx->geom);
+            const size_t E = (size_t)gd.brick + 3, lds = 3 * E * E * E * sizeof(double);
+            transform_bspline_tile_kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
+                ctx->pos.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
+                ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
+                with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
+                after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism);
+            if (with_disp) ctx->disp_n = ctx->n_scatter_blocks;
+        } else {
+            transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
+                                                                             ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
+                                                                             with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
+                                                                             after_step ? ctx->grad.p : nullptr, ctx->energy.p,
+                                                                             ctx->opt.guarantee_diffeomorphism);
+            if (with_disp) ctx->disp_n = div_up(n, 256);
+        }
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
         else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
@@ -951,7 +965,9 @@ static int cull_allocate(frog_ctx *ctx)
     {
         uint32_t blocks = 0;
         for (uint32_t i = 0; i < ctx->nI; i++) blocks += div_up(ctx->poff[i + 1] - ctx->poff[i], CULL_BLOCK_POINTS);
-        FROG_HIP_CHECK(ctx->disp_part.alloc(std::max<size_t>(1, std::max<size_t>(blocks, div_up(ctx->P, 256)))));
+        // one slot per producer block: cull_disp_kernel's, or the B-spline transform's (at most one block per point + one per
+        // SCATTER_CHUNK points in its tiled form)
+        FROG_HIP_CHECK(ctx->disp_part.alloc(std::max<size_t>(blocks, (size_t)ctx->P + ctx->P / SCATTER_CHUNK + 16)));
     }
     FROG_HIP_CHECK(ctx->cull_state.alloc(2));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));

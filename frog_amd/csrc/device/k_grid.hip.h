@@ -174,6 +174,22 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
     }
 }
 
+// ---- K11, tiled form: one wavefront per scatter block (image, brick, <= SCATTER_CHUNK points) -----------------
+// The thread-per-point form above issues 64 float4 tap loads per point (texture path busy 67 % of the kernel, 222
+// registers, 2 wavefronts per SIMD) and converts each of the 192 tap components to f64.  Here the brick's (B+3)^3
+// coefficients are loaded ONCE per block, converted ONCE, and kept in LDS as three f64 arrays; a point's taps are LDS
+// reads.  Same operations in the same order on the same f64 values as the form above: identical bits
+// (tests/test_gpu_round2.py::test_tiled_transform_equals_pointwise).  A point whose f64 cell (vtkBSplineTransform floors
+// the f64 lattice coordinate) is not the f32-rounded cell it was sorted by (imageGroup.cxx:303-310 rounds the coordinate
+// to f32 first: they differ for points within one f32 ulp of a cell face) may need taps outside the tile and reads them
+// from memory.  ScatterBlock is declared further down, with the table's construction.
+struct ScatterBlock;
+__global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+                                                                    const uint32_t *perm, const ScatterBlock *blocks,
+                                                                    const uint32_t *n_blocks, const GeomDev g, int apply,
+                                                                    const P3 *snap, uint32_t *disp_part,
+                                                                    const float4 *proposal, const double *energy, int guarantee);
+
 // ---- K13: bounding box of the owned xyz (getBoundingBox, imageGroup.cxx:1513) ----
 // doubles of floats are exact, min/max are order independent -> deterministic.
 __global__ __launch_bounds__(256) void bounds_kernel(const float4 *pos, uint32_t pt_begin, uint32_t pt_end,
@@ -511,6 +527,121 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
     if (i >= *n_blocks) return;
     const ScatterBlock b = blocks[i];
     sorted[atomicAdd(&len_cursor[b.end - b.begin], 1u)] = b;
+}
+
+__global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+                                                                    const uint32_t *perm, const ScatterBlock *blocks,
+                                                                    const uint32_t *n_blocks, const GeomDev g, int apply,
+                                                                    const P3 *snap, uint32_t *disp_part,
+                                                                    const float4 *proposal, const double *energy, int guarantee)
+{
+    extern __shared__ double tile64[];          // [3][(B+3)^3]: x, y, z components of the brick's coefficients
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= *n_blocks) {              // the grid is an upper bound of the block count
+        if (snap && lane == 0) disp_part[blockIdx.x] = 0u;
+        return;
+    }
+    if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
+    const ScatterBlock blk = blocks[blockIdx.x];
+    const int E = g.brick + 3, n_tile = E * E * E;
+    double *tx = tile64, *ty = tile64 + n_tile, *tz = tile64 + 2 * n_tile;
+    const uint32_t img = blk.key / g.n_bricks;
+    uint32_t bidx = blk.key - img * g.n_bricks;
+    const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
+    const int by = bidx % g.nbricks[1];
+    const int bz = bidx / g.nbricks[1];
+    const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
+    const int dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
+    const float4 *cf = coeff + (size_t)img * g.n_cp;
+    for (int k = lane; k < n_tile; k += 64) {
+        const int x = cp0[0] + k % E, y = cp0[1] + (k / E) % E, z = cp0[2] + k / (E * E);
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
+        if (x < dx && y < dy && z < dz) c = cf[(size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z)];
+        tx[k] = (double)c.x; ty[k] = (double)c.y; tz[k] = (double)c.z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t dmax = 0;
+    for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
+        const uint32_t s = batch + lane;
+        if (s >= blk.end) continue;
+        const uint32_t p = perm[s];
+        const float4 v = pos[p];
+        const float in[3] = { v.x, v.y, v.z };
+        double F[3][4];
+        int i0[3];
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double q = ((double)in[k] - g.origin[k]) / g.spacing[k];
+            double fl = floor(q);
+            i0[k] = (int)fl - 1;
+            bspline_weights(F[k], q - fl);
+        }
+        const int l0 = i0[0] - cp0[0], l1 = i0[1] - cp0[1], l2 = i0[2] - cp0[2];
+        double disp[3] = { 0, 0, 0 };
+        if (l0 >= 0 && l1 >= 0 && l2 >= 0 && l0 + 3 < E && l1 + 3 < E && l2 + 3 < E) {
+            const int base = l0 + E * (l1 + E * l2);
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double vz[3] = { 0, 0, 0 };
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    double vy[3] = { 0, 0, 0 };
+                    const int row = base + E * (j + E * k);
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const double f = F[0][i];
+                        vy[0] = fma(tx[row + i], f, vy[0]); vy[1] = fma(ty[row + i], f, vy[1]); vy[2] = fma(tz[row + i], f, vy[2]);
+                    }
+                    const double f = F[1][j];
+                    vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
+                }
+                const double f = F[2][k];
+                disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
+            }
+        } else {
+            for (int k = 0; k < 4; k++) {               // stencil not inside the tile: from memory, border = zero
+                const int z = i0[2] + k;
+                if (z < 0 || z >= dz) continue;
+                double vz[3] = { 0, 0, 0 };
+                for (int j = 0; j < 4; j++) {
+                    const int y = i0[1] + j;
+                    if (y < 0 || y >= dy) continue;
+                    double vy[3] = { 0, 0, 0 };
+                    const float4 *row = cf + (size_t)dx * ((size_t)y + (size_t)dy * z);
+                    for (int i = 0; i < 4; i++) {
+                        const int x = i0[0] + i;
+                        if (x < 0 || x >= dx) continue;
+                        const float4 c = row[x];
+                        const double f = F[0][i];
+                        vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
+                    }
+                    const double f = F[1][j];
+                    vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
+                }
+                const double f = F[2][k];
+                disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
+            }
+        }
+        float4 o;
+        o.x = (float)((double)in[0] + disp[0] * 1.0);
+        o.y = (float)((double)in[1] + disp[1] * 1.0);
+        o.z = (float)((double)in[2] + disp[2] * 1.0);
+        o.w = v.w;
+        pos2[p] = P3{ o.x, o.y, o.z };
+        if (apply) pos[p] = o;
+        if (snap) {
+            const P3 q = snap[p];
+            const float ex = o.x - q.x, ey = o.y - q.y, ez = o.z - q.z;
+            dmax = max(dmax, __float_as_uint(__builtin_sqrtf(ex * ex + ey * ey + ez * ez)) & 0x7FFFFFFFu);
+        }
+    }
+    if (snap) {                                 // all 64 lanes are back together here
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+        if (lane == 0) disp_part[blockIdx.x] = dmax;
+    }
 }
 
 // ---- K7: scatter of the per-point sums onto the gradient lattice ----------------

@@ -420,6 +420,26 @@ def test_brick_edge_8_equals_brick_edge_4(small_pairs, monkeypatch):
     assert relerr(np.concatenate([l[-1] for l in L8]), np.concatenate([l[-1] for l in L4])) < 1e-2
 
 
+def test_tiled_transform_equals_pointwise(small_pairs, monkeypatch):
+    """transformPoints through a lattice (vtkBSplineTransform): the form that keeps a brick's coefficients in LDS as f64
+    (one wavefront per scatter block) against the thread-per-point form (FROG_K11_POINTWISE=1) -- the same operations in
+    the same order on the same values: every coordinate of a whole run has the same bits."""
+    def run(pointwise):
+        if pointwise:
+            monkeypatch.setenv("FROG_K11_POINTWISE", "1")
+        else:
+            monkeypatch.delenv("FROG_K11_POINTWISE", raising=False)
+        g = ImageGroup(small_pairs)
+        g.linearIterations, g.deformableLevels, g.deformableIterations = 10, 3, 12
+        E = g.run()
+        return E, g.points(), [g.grid(i, g.num_grids() - 1)[1] for i in range(small_pairs.n_images)]
+    E0, (x0, y0), L0 = run(True)
+    E1, (x1, y1), L1 = run(False)
+    assert E0 == E1 and np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    for a, b in zip(L0, L1):
+        assert np.array_equal(a, b)
+
+
 def test_context_that_owns_only_empty_images():
     """A shard may hold only images without points (plan_shards balances half-links): its sweeps have nothing to
     launch, and the split-phase entry points must still succeed with zero sums (no zero-block launch)."""
