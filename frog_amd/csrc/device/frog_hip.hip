@@ -454,8 +454,12 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
-        // bricks of 8^3 cells (sparse lattices) would need 32 KB of LDS per wavefront: those stay with the thread-per-point form
-        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE");
+        // The tiled form pays the staging of 343 coefficients per block: measured on cfg 3, 0.081 against 0.100 ms at 1 700 and
+        // 210 points per brick (levels 0, 1), 0.119 against 0.110 ms at 80 (level 2).  Bricks of 8^3 cells (sparse lattices)
+        // would need 32 KB of LDS per wavefront.  FROG_K11_POINTWISE / FROG_K11_TILED force one form (tests).
+        const double per_brick = (double)n / ((double)ctx->n_owned() * (double)std::max(1, ctx->geom.n_bricks));
+        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE")
+                           && (per_brick >= 150.0 || getenv("FROG_K11_TILED"));
         if (tiled) {
             // one wavefront per scatter block, the brick's coefficients in LDS as f64 (k_grid.hip.h)
             const GeomDev gd = to_dev(ctx->geom);

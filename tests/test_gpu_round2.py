@@ -426,9 +426,9 @@ def test_tiled_transform_equals_pointwise(small_pairs, monkeypatch):
     the same order on the same values: every coordinate of a whole run has the same bits."""
     def run(pointwise):
         if pointwise:
-            monkeypatch.setenv("FROG_K11_POINTWISE", "1")
+            monkeypatch.setenv("FROG_K11_POINTWISE", "1"); monkeypatch.delenv("FROG_K11_TILED", raising=False)
         else:
-            monkeypatch.delenv("FROG_K11_POINTWISE", raising=False)
+            monkeypatch.delenv("FROG_K11_POINTWISE", raising=False); monkeypatch.setenv("FROG_K11_TILED", "1")
         g = ImageGroup(small_pairs)
         g.linearIterations, g.deformableLevels, g.deformableIterations = 10, 3, 12
         E = g.run()
