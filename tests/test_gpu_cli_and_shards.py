@@ -433,6 +433,20 @@ def test_cli_sharded_over_three_contexts_on_one_gpu(tmp_path, small_pairs):
     assert os.path.exists(three / "errorMaps" / "5.nii.gz")
 
 
+def test_cli_sharded_eight_ways_on_one_gpu(tmp_path):
+    """BASELINE.json configs[3] is configs[2] sharded 8 ways: the 8-rank control flow (ragged shards of 2-3 images,
+    eight contexts, every collective of include/frog_comm.h) on a group that fits the test, ranks sharing the one GPU."""
+    pairs = Pairs.synthetic(20, 2000, 700, seed=21)
+    one, eight = tmp_path / "one", tmp_path / "eight"
+    for d in (one, eight):
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+    _run_frog(one)
+    out = _run_frog(eight, "-ngl", "8")
+    assert "Images sharded over 8 contexts" in out
+    _compare_runs(one, eight, pairs.n_images)
+
+
 def test_cli_sharded_over_two_gpus_rccl(tmp_path, small_pairs):
     """bin/frog -ng 2: the same over RCCL.  Needs two devices; the round-end driver's GPU box has one."""
     if _abi.hip_lib().frog_device_count() < 2:
