@@ -118,7 +118,7 @@ def main():
     import torch.distributed as dist
     from frog_amd import _abi
     from frog_amd.pairs import Pairs
-    from frog_amd.distributed import HipEngine, ShardedImageGroup, plan_shards
+    from frog_amd.distributed import HipEngine, NativeComm, ShardedImageGroup, plan_shards
 
     if _abi.hip_lib().frog_device_count() < 1:
         raise SystemExit("no HIP device: bench.py measures the HIP path only")
@@ -158,7 +158,13 @@ def main():
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0
-    grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world)
+    # N > 1 over RCCL: the collectives are issued from C (libfrog_comm.so, include/frog_comm.h) on the context's stream --
+    # ncclCommInitRank with an id carried by torch.distributed; FROG_NATIVE_COMM=0, or any rank failing to set it up,
+    # keeps them in torch.distributed
+    native = None
+    if world > 1 and backend == "nccl" and os.environ.get("FROG_NATIVE_COMM", "1") != "0":
+        native = NativeComm.create(engine, shards, pairs.point_offset, rank, world, dist, local_rank)
+    grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world, native=native)
     grp.time_comm = world > 1 and backend == "nccl"       # per-collective device time in the line ("comm_ms")
     if args.shard_of:
         args.kernel_times = True
@@ -284,6 +290,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "collectives": ("none" if world == 1 else "libfrog_comm (RCCL from C)" if native else f"torch.distributed/{backend}"),
             "config": {"workload": f"BASELINE.json configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: {images} images x {points} keypoints, "
                                    f"{pairs.n_pairs} pairs ({pairs.n_half_links} half-links), linear + {levels} deformable "
                                    f"levels, -g 100 -gd 1 -si 10",

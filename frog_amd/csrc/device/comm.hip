@@ -41,6 +41,7 @@ struct Barrier {
 struct Shared {
     int n = 0;
     bool rccl = false;
+    bool one_rank_per_process = false;                  // frog_comm_create_rank: no other rank's thread to meet at a barrier
     Barrier barrier;
     std::vector<size_t> row_begin, row_end;             // xyz2 rows of every rank
     // loopback staging
@@ -119,6 +120,46 @@ int frog_comm_create_loopback(int n, frog_comm **out)
     return FROG_OK;
 }
 
+int frog_comm_unique_id(unsigned char id_out[128])
+{
+    if (!id_out) return comm_fail(FROG_E_INVALID, "null id");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    COMM_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return FROG_OK;
+}
+
+int frog_comm_create_rank(int n, int rank, const unsigned char id_in[128], int device, frog_comm **out)
+{
+    if (n < 1 || rank < 0 || rank >= n || !id_in || !out) return comm_fail(FROG_E_INVALID, "bad communicator arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return comm_fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return comm_fail(FROG_E_INVALID, "device index out of range");
+    COMM_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof id);
+    ncclComm_t nc = nullptr;
+    COMM_NCCL(ncclCommInitRank(&nc, n, id, rank));
+    auto sh = std::make_shared<Shared>();
+    sh->n = n; sh->rccl = true; sh->one_rank_per_process = true; sh->barrier.n = 1;
+    sh->row_begin.assign(n, 0); sh->row_end.assign(n, 0);
+    frog_comm *c = new frog_comm;
+    c->sh = sh; c->rank = rank; c->device = device; c->nccl = nc;
+    *out = c;
+    return FROG_OK;
+}
+
+int frog_comm_set_rows(frog_comm *c, const uint64_t *row_begin)
+{
+    if (!c || !row_begin) return comm_fail(FROG_E_INVALID, "null argument");
+    for (int r = 0; r < c->sh->n; r++) {
+        if (row_begin[r + 1] < row_begin[r]) return comm_fail(FROG_E_INVALID, "rows must be ascending");
+        c->sh->row_begin[r] = (size_t)row_begin[r]; c->sh->row_end[r] = (size_t)row_begin[r + 1];
+    }
+    return FROG_OK;
+}
+
 void frog_comm_destroy_all(int n, frog_comm **comms)
 {
     if (!comms) return;
@@ -149,6 +190,7 @@ int frog_comm_bind(frog_comm *c, frog_ctx *ctx, const uint32_t *image_begin)
     c->sh->row_begin[c->rank] = rb; c->sh->row_end[c->rank] = re;
     if (!c->d_box) COMM_HIP(hipMalloc((void **)&c->d_box, 6 * sizeof(double)));
     if (!c->h_box) COMM_HIP(hipHostMalloc((void **)&c->h_box, 6 * sizeof(double)));
+    if (c->sh->one_rank_per_process) return FROG_OK;    // the other ranks' rows come through frog_comm_set_rows
     c->sh->barrier.wait();          // every rank's rows are known to all
     for (int r = 0; r + 1 < c->sh->n; r++)
         if (c->sh->row_end[r] != c->sh->row_begin[r + 1]) return comm_fail(FROG_E_INVALID, "shards must be contiguous and in rank order");
@@ -159,6 +201,14 @@ int frog_comm_bind(frog_comm *c, frog_ctx *ctx, const uint32_t *image_begin)
 int frog_comm_barrier(frog_comm *c)
 {
     if (!c) return comm_fail(FROG_E_INVALID, "null communicator");
+    if (c->sh->one_rank_per_process) {
+        // across processes: a one-element all-reduce, awaited
+        if (!c->d_box || !c->stream) return comm_fail(FROG_E_STATE, "communicator not bound");
+        COMM_HIP(hipSetDevice(c->device));
+        COMM_NCCL(ncclAllReduce(c->d_box, c->d_box, 1, ncclDouble, ncclMax, c->nccl, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        return FROG_OK;
+    }
     c->sh->barrier.wait();
     return FROG_OK;
 }

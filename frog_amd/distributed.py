@@ -204,6 +204,80 @@ class HipEngine:
         return {n: (arr[i].ms_total, arr[i].launches) for i, n in enumerate(_abi.FROG_K_NAMES)}
 
 
+class NativeComm:
+    """The collectives of include/frog_comm.h (libfrog_comm.so: RCCL called from C, on the context's stream) for one
+    rank of a one-process-per-GPU run.  The unique id travels over ``torch.distributed``; afterwards an iteration costs a
+    handful of ctypes calls instead of three ``torch.distributed`` collectives (tens of microseconds of host time each --
+    more than a rank's kernels take at 8 GPUs).  ``create`` returns None when any rank could not set it up: the caller
+    then keeps the ``torch.distributed`` collectives."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    @classmethod
+    def create(cls, engine, shards, point_offset, rank, world_size, dist, device):
+        import os
+        import torch
+        ok, lib, h = 1, None, C.c_void_p()
+        try:
+            lib = C.CDLL(os.path.join(_abi.LIB_DIR, "libfrog_comm.so"))
+            for name in ("frog_comm_unique_id", "frog_comm_create_rank", "frog_comm_bind", "frog_comm_set_rows",
+                         "frog_comm_all_gather_xyz2", "frog_comm_all_reduce", "frog_comm_all_reduce_bounds", "frog_comm_barrier"):
+                getattr(lib, name).restype = C.c_int
+            lib.frog_comm_destroy_all.restype = None
+        except OSError:
+            ok = 0
+        ident = [None]
+        if rank == 0 and ok:
+            buf = (C.c_ubyte * 128)()
+            ok = int(lib.frog_comm_unique_id(buf) == 0)
+            ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=0)
+        if ok and ident[0] is not None:
+            idb = (C.c_ubyte * 128).from_buffer_copy(ident[0])
+            ok = int(lib.frog_comm_create_rank(world_size, rank, idb, device, C.byref(h)) == 0)
+            if ok:
+                ib = (C.c_uint32 * (world_size + 1))(*([s[0] for s in shards] + [shards[-1][1]]))
+                ok = int(lib.frog_comm_bind(h, engine._ctx, ib) == 0)
+            if ok:
+                po = np.asarray(point_offset, dtype=np.int64)
+                rows = (C.c_uint64 * (world_size + 1))(*([int(po[s[0]]) for s in shards] + [int(po[shards[-1][1]])]))
+                ok = int(lib.frog_comm_set_rows(h, rows) == 0)
+            if ok:
+                ok = int(lib.frog_comm_barrier(h) == 0)          # a first collective on the new communicator, awaited
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if h:
+                arr = (C.c_void_p * 1)(h)
+                lib.frog_comm_destroy_all(1, arr)
+            return None
+        return cls(lib, h)
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed ({rc}): {_abi.hip_lib().frog_last_error().decode()}")
+
+    def all_gather_xyz2(self):
+        self._check(self._lib.frog_comm_all_gather_xyz2(self._h), "frog_comm_all_gather_xyz2")
+
+    def all_reduce(self, which):
+        self._check(self._lib.frog_comm_all_reduce(self._h, which), "frog_comm_all_reduce")
+
+    def all_reduce_bounds(self, mn, mx):
+        a, b = (C.c_double * 3)(*mn), (C.c_double * 3)(*mx)
+        self._check(self._lib.frog_comm_all_reduce_bounds(self._h, a, b), "frog_comm_all_reduce_bounds")
+        return list(a), list(b)
+
+    def close(self):
+        if self._h:
+            arr = (C.c_void_p * 1)(self._h)
+            self._lib.frog_comm_destroy_all(1, arr)
+            self._h = None
+
+
 class ShardedImageGroup:
     """ImageGroup's methods (imageGroup.cxx) over image shards, one rank per GPU.
 
@@ -214,11 +288,12 @@ class ShardedImageGroup:
     point offsets.  With world_size 1 no collective is issued.
     """
 
-    def __init__(self, engine, shards, point_offset, rank, world_size, group=None):
+    def __init__(self, engine, shards, point_offset, rank, world_size, group=None, native=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.engine = engine
+        self.native = native            # NativeComm: the collectives through libfrog_comm.so instead of torch.distributed
         self.shards = list(shards)
         self.po = np.asarray(point_offset, dtype=np.int64)
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -270,6 +345,9 @@ class ShardedImageGroup:
         self.engine.transform_points_local(apply)
         if not self.multi:
             return
+        if self.native:
+            self._collective("all_gather_xyz2", self.native.all_gather_xyz2)
+            return
         rows = [(int(self.po[ib]), int(self.po[ie])) for ib, ie in self.shards]
         if len({e - b for b, e in rows}) == 1 and rows[0][0] == 0 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])):
             # equal shards: one all-gather (ncclAllGather over xGMI) straight into the replica
@@ -301,15 +379,23 @@ class ShardedImageGroup:
 
     def updateStats(self):
         self.engine.update_stats_local()
-        if self.multi:
+        if self.multi and self.native:
+            self._collective("all_reduce_em", lambda: self.native.all_reduce(_abi.FROG_BUF_EM))
+        elif self.multi:
             self._collective("all_reduce_em", lambda: self._dist.all_reduce(self.engine.em, op=self._dist.ReduceOp.SUM, group=self.group))
         self.engine.stats_publish()
 
     def updateLinearTransforms(self):
         self.engine.linear_step_local()
         if self.multi:
-            self._collective("all_reduce_energy", lambda: self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group))
+            self._reduce_energy()
         return self.engine.energy_read()[0]
+
+    def _reduce_energy(self):
+        if self.native:
+            self._collective("all_reduce_energy", lambda: self.native.all_reduce(_abi.FROG_BUF_ENERGY))
+        else:
+            self._collective("all_reduce_energy", lambda: self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group))
 
     def setupDeformableTransforms(self, level):
         import time
@@ -320,7 +406,9 @@ class ShardedImageGroup:
 
     def _setup(self, level):
         mn, mx = self.engine.bounds_local()
-        if self.multi:
+        if self.multi and self.native:
+            mn, mx = self.native.all_reduce_bounds(mn, mx)
+        elif self.multi:
             t = self.engine.make_tensor(list(mx) + [-v for v in mn], self._torch.float64)
             self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
             v = t.cpu().tolist()
@@ -329,11 +417,13 @@ class ShardedImageGroup:
 
     def updateDeformableTransforms(self, alpha):
         self.engine.phase_a(alpha)
-        if self.multi:
+        if self.multi and self.native:
+            self._collective("all_reduce_gridsum", lambda: self.native.all_reduce(_abi.FROG_BUF_GRIDSUM))
+        elif self.multi:
             self._collective("all_reduce_gridsum", lambda: self._dist.all_reduce(self.engine.gridsum, op=self._dist.ReduceOp.SUM, group=self.group))
         self.engine.phase_b()
         if self.multi:
-            self._collective("all_reduce_energy", lambda: self._dist.all_reduce(self.engine.energy, op=self._dist.ReduceOp.SUM, group=self.group))
+            self._reduce_energy()
         return self.engine.phase_c()
 
     def countInliers(self):

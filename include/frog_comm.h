@@ -41,7 +41,15 @@ int frog_comm_create_rccl(int n_ranks, const int *devices, frog_comm **out);
  * through a host staging area and barriers between the ranks' threads.  For tests and for rehearsing the
  * multi-rank control flow on a single GPU; not a fast path. */
 int frog_comm_create_loopback(int n_ranks, frog_comm **out);
-/* Destroys all n communicators of one create call (pass the array it filled). */
+/* One process per GPU (torch.distributed.run, MPI): rank 0 obtains an id (frog_comm_unique_id: ncclGetUniqueId, 128
+ * bytes), the launcher's own channel carries it to the other ranks, then every process creates ITS communicator
+ * (ncclCommInitRank on `device`).  The collectives below then work exactly as in the one-process form; the xyz2 row
+ * range of every rank, which one process reads from its contexts, has to be told: frog_comm_set_rows. */
+int frog_comm_unique_id(unsigned char id_out[128]);
+int frog_comm_create_rank(int n_ranks, int rank, const unsigned char id[128], int device, frog_comm **out);
+/* row_begin[r] .. row_begin[r + 1] = the xyz2 rows (points) of rank r; n_ranks + 1 entries.  Call after frog_comm_bind. */
+int frog_comm_set_rows(frog_comm *comm, const uint64_t *row_begin);
+/* Destroys all n communicators of one create call (pass the array it filled; n = 1 for frog_comm_create_rank). */
 void frog_comm_destroy_all(int n_ranks, frog_comm **comms);
 
 /* `ctx` must be the context of this communicator's rank; image_begin[r] .. image_begin[r + 1] are the
