@@ -13,13 +13,14 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 
 def device_source_hash():
-    """sha256 (first 16 hex digits) over the HIP sources of libfrog_hip.so, in name order: what a PMC
-    measurement under profiles/ is keyed on, so that bench.py can tell when the kernels have changed since."""
+    """sha256 (first 16 hex digits) over the HIP sources of the registration kernels (everything under csrc/device
+    except the matcher, the transform chains and the collectives library), in name order: what a PMC measurement under
+    profiles/ is keyed on, so that bench.py can tell when the kernels have changed since."""
     import hashlib
     d = os.path.join(_HERE, "csrc", "device")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h")) and name not in ("comm.hip", "match.hip", "chain.hip"):
             h.update(name.encode())
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(fh.read())
