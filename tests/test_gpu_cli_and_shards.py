@@ -458,3 +458,33 @@ def test_cli_sharded_over_two_gpus_rccl(tmp_path, small_pairs):
     _run_frog(one)
     _run_frog(two, "-ng", "2")
     _compare_runs(one, two, small_pairs.n_images)
+
+
+def test_native_communicator_single_rank_over_rccl():
+    """libfrog_comm.so's one-process-per-GPU form (frog_comm_unique_id / frog_comm_create_rank: ncclGetUniqueId,
+    ncclCommInitRank) with ONE rank -- all the box allows -- through a real RCCL: the id, the communicator, bind, rows, a
+    first awaited all-reduce (frog_comm_barrier), and the collectives' single-rank paths.  In a child process, as a host
+    would load it."""
+    import sys
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+from frog_amd import _abi
+from frog_amd.pairs import Pairs
+from frog_amd.distributed import HipEngine
+pairs = Pairs.synthetic(4, 600, 300, seed=3)
+eng = HipEngine(pairs, _abi.FrogOptions.default(), 0, (0, 4))
+lib = C.CDLL(os.path.join(_abi.LIB_DIR, "libfrog_comm.so"))
+buf = (C.c_ubyte * 128)()
+assert lib.frog_comm_unique_id(buf) == 0
+h = C.c_void_p()
+assert lib.frog_comm_create_rank(1, 0, buf, 0, C.byref(h)) == 0, _abi.hip_lib().frog_last_error()
+assert lib.frog_comm_bind(h, eng._ctx, (C.c_uint32 * 2)(0, 4)) == 0
+assert lib.frog_comm_set_rows(h, (C.c_uint64 * 2)(0, 2400)) == 0
+assert lib.frog_comm_barrier(h) == 0, _abi.hip_lib().frog_last_error()
+assert lib.frog_comm_all_gather_xyz2(h) == 0 and lib.frog_comm_all_reduce(h, _abi.FROG_BUF_ENERGY) == 0
+arr = (C.c_void_p * 1)(h); lib.frog_comm_destroy_all.restype = None; lib.frog_comm_destroy_all(1, arr)
+print("native comm ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "native comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
