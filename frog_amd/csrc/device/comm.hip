@@ -203,7 +203,7 @@ int frog_comm_barrier(frog_comm *c)
     if (!c) return comm_fail(FROG_E_INVALID, "null communicator");
     if (c->sh->one_rank_per_process) {
         // across processes: a one-element all-reduce, awaited
-        if (!c->d_box || !c->stream) return comm_fail(FROG_E_STATE, "communicator not bound");
+        if (!c->d_box || !c->ctx) return comm_fail(FROG_E_STATE, "communicator not bound");      // (the stream may be the null stream)
         COMM_HIP(hipSetDevice(c->device));
         COMM_NCCL(ncclAllReduce(c->d_box, c->d_box, 1, ncclDouble, ncclMax, c->nccl, c->stream));
         COMM_HIP(hipStreamSynchronize(c->stream));
