@@ -93,6 +93,19 @@ constexpr int MAX_GROUPS = N_XCD * MAX_SUBPASS;
 //   (k / 128) * 128 + (k % 64) * 2 + (k % 128) / 64.
 // Every range is padded with null records to a whole number of chunks.
 constexpr int REC_CHUNK = 128;
+// Layout of the per-XCD partial sums of the deformable sweep (group_sums): false = [group][point] (a wavefront of the
+// sweep stores 64 consecutive float4: 8 full lines; the scatter reads 8 lines per point, about half of each used);
+// true = [point][group] (one 128-byte line per point for the scatter; the sweep's stores become 16-byte pieces of 64
+// lines that eight XCDs complete).  Measured (cfg 3): the second form takes the sweep from 0.32 to 0.475 ms -- partial
+// lines written from eight L2s -- and the scatter from 0.121 only to 0.113-0.120 ms.  Kept at false.
+#ifndef FROG_SUMS_POINT_MAJOR
+#define FROG_SUMS_POINT_MAJOR 0
+#endif
+constexpr bool SUMS_POINT_MAJOR = FROG_SUMS_POINT_MAJOR != 0;
+__host__ __device__ inline size_t group_sum_index(uint32_t group, uint32_t point, uint32_t own_points)
+{
+    return SUMS_POINT_MAJOR ? (size_t)point * N_XCD + group : (size_t)group * own_points + point;
+}
 // Partner-image groups: n_groups = 8 * n_sub.  The sweep is launched n_sub times; launch `sub`
 // lets XCD x read group sub*8 + x and continues XCD x's partial sums, so that a group's xyz2 slice
 // can be made small enough to stay in one 4 MiB L2.  n_sub is 1 unless FROG_SUBPASSES sets it:

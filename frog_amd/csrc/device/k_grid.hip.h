@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                 const uint32_t li = p - own_pt_begin;
                 float4 part[N_XCD];
                 #pragma unroll
-                for (int q = 0; q < N_XCD; q++) part[q] = group_sums[(size_t)q * own_points + li];
+                for (int q = 0; q < N_XCD; q++) part[q] = group_sums[group_sum_index(q, li, own_points)];
                 sm = part[0];
                 #pragma unroll
                 for (int q = 1; q < N_XCD; q++) { sm.x += part[q].x; sm.y += part[q].y; sm.z += part[q].z; sm.w += part[q].w; }

@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
 
     if (MODE == SWEEP_DEFORMABLE) {
-        const float4 *prev = a.group_sums + (size_t)xcd * a.own_points + (pt_begin - a.own_pt_begin);
         for (int k = lane; k < TILE_POINTS; k += 64) {
-            my[k] = (a.sub > 0 && (uint32_t)k < pt_count) ? prev[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            my[k] = (a.sub > 0 && (uint32_t)k < pt_count) ? a.group_sums[group_sum_index(xcd, pt_begin - a.own_pt_begin + k, a.own_points)]
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
             own[k] = 0xFFFFFFFFu;
         }
     }
@@ -390,11 +390,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             a.tile_partial[((size_t)t * a.n_groups + grp) * 2 + 1] = v1;
         }
         __syncthreads();
-        float4 *dst = a.group_sums + (size_t)xcd * a.own_points + (pt_begin - a.own_pt_begin);
         typedef float v4f __attribute__((ext_vector_type(4)));
         for (uint32_t k = lane; k < pt_count; k += 64) {                 // written once, read once: non-temporal
             const float4 v = my[k];
-            __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f *>(dst + k));
+            float4 *dst = a.group_sums + group_sum_index(xcd, pt_begin - a.own_pt_begin + k, a.own_points);
+            if (SUMS_POINT_MAJOR) *dst = v;                              // pieces of a line other XCDs complete: let the caches merge them
+            else __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f *>(dst));
         }
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);
@@ -411,10 +412,10 @@ __global__ __launch_bounds__(256) void combine_groups_kernel(const float4 *group
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= own_points) return;
-    float4 s = group_sums[i];
+    float4 s = group_sums[group_sum_index(0, i, own_points)];
     #pragma unroll
     for (int g = 1; g < N_XCD; g++) {
-        const float4 v = group_sums[(size_t)g * own_points + i];
+        const float4 v = group_sums[group_sum_index(g, i, own_points)];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     point_sums[own_pt_begin + i] = s;
