@@ -231,10 +231,22 @@ def main():
     if grp.measures:
         e = grp.measures[-1]
 
+    replicas_identical = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # after the timed region: every rank holds a replica of all transformed coordinates (the all-gather's product) and
+        # of the mixture table; they must be the same bits on every rank, whatever carried the collectives
+        grp.transformPoints(True)
+        torch.cuda.synchronize()
+        chk = torch.stack([engine.xyz2.double().sum(), engine.xyz2.double().abs().sum(), engine.em.double().sum()])
+        if backend != "nccl":
+            chk = chk.cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
 
     k = n_lin + sum(per_level)
     own_b, own_e = shards[rank]
@@ -312,6 +324,8 @@ def main():
                                                    for n, v in ks.items()} for ph, ks in phase_k.items()}
         if grp.comm_ms:
             out["comm_ms"] = grp.comm_ms
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)
         print(json.dumps(out), flush=True)

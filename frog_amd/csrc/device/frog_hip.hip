@@ -68,6 +68,17 @@ template <class T> static int download_points(frog_ctx *ctx, const T *src, float
 
 static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 4) * N_XCD; }     // per sub-pass
 
+// Entries of the sweep's LDS tables (EM constants and first point of the partner group's images; dynamic LDS, 20 bytes
+// each): narrow records index them with an img_bits-wide field -- also the prefetched records past a range, which may
+// hold any value -- so 2^img_bits; wide records with the largest group's size; 0 when a group is too large for LDS.
+static uint32_t sweep_lds_images(const frog_ctx *ctx)
+{
+    if (ctx->rec_format.narrow) return 1u << ctx->rec_format.img_bits;
+    uint32_t widest = 0;
+    for (uint32_t g = 0; g < ctx->n_groups; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
+    return widest <= (uint32_t)EMD_LDS_IMAGES ? widest : 0u;
+}
+
 static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
 {
     SweepArgs a;
@@ -76,7 +87,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     for (uint32_t g = 0; g <= ctx->n_groups; g++) a.group_begin[g] = ctx->group_begin[g];
     a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p; a.em = ctx->em.p;
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
-    a.img_bits = ctx->rec_format.img_bits; a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
+    a.img_bits = ctx->rec_format.img_bits; a.lds_images = sweep_lds_images(ctx); a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
@@ -106,10 +117,11 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
         args.cull_state = ctx->cull_state.p;
     }
     const dim3 grid(sweep_blocks(ctx)), block(256);
+    const size_t lds = (size_t)args.lds_images * (sizeof(EmDerived) + sizeof(uint32_t));
     if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
-        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, false>), grid, block, 0, s, ea, eb, 0, args);
+        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, false>), grid, block, lds, s, ea, eb, 0, args);
     else if (widest <= (uint32_t)EMD_LDS_IMAGES)
-        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, true>), grid, block, 0, s, ea, eb, 0, args);
+        hipExtLaunchKernelGGL((sweep_kernel<MODE, true, true>), grid, block, lds, s, ea, eb, 0, args);
     else
         hipExtLaunchKernelGGL((sweep_kernel<MODE, false, true>), grid, block, 0, s, ea, eb, 0, args);
 }

@@ -40,6 +40,8 @@ constexpr int BODY_STEPS = 6;
 static_assert(BODY_STEPS == 2 * CHUNK_RING && BODY_STEPS % PT_RING == 0 && PT_AHEAD < PT_RING && CHUNK_AHEAD < CHUNK_RING
               && 2 * CHUNK_AHEAD >= PT_AHEAD + 2, "ring periods must divide the unrolled body; a gather needs its record");
 constexpr int EMD_LDS_IMAGES = 256;     // partner groups up to this many images keep their constants in LDS
+constexpr int OWNER_WORDS = TILE_POINTS / 2;      // election words per wavefront (deformable sweep)
+static_assert((OWNER_WORDS & (OWNER_WORDS - 1)) == 0, "the election word of a point is its index masked");
 static_assert(EMD_LDS_IMAGES == 1 << 8, "prep.h admits narrow records for img_bits <= 8 only");
 constexpr int LINEAR_SUMS = 18;     // sDisp3 sPosA3 sPosB3 sPosA2_3 sPosB2_3 sWeight sDistances sWeights
 
@@ -48,6 +50,7 @@ struct SweepArgs {
     const void *recs;           // LinkRec (wide) or uint32_t (narrow) records, ctx.h
     const uint32_t *poff;       // [n_images + 1] first point of every image
     uint32_t img_bits;          // narrow records: bits of the partner image field
+    uint32_t lds_images;        // entries of the block's LDS tables of partner-image constants (sweep_lds_images)
     uint32_t point_last;        // index of the last point of the model
     const P3 *pos2;
     const EmDerived *emd;
@@ -197,15 +200,22 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
     // reference's (imageGroup.cxx:256-257), plus one ownership word per point
     __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
-    __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
+    // one election word per pair of points (k, k + TILE_POINTS / 2): the lanes of a step hold a stretch of about
+    // half a tile's points (records are partner-major, then point order), so the two rarely meet -- and when they do,
+    // the higher lane waits one more round, nothing else
+    __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? 4 * OWNER_WORDS : 1];
     // Scattered vector loads cost ~48 CU-cycles per wave-instruction through the texture
     // path even when they hit L1 (measured: the sweep takes 0.26 ms without its three
     // gathers per step, 0.68 ms with them), so everything that can be staged is: the xyz2
     // of the tile's own points (per wave) and the EM constants of the partner group's
     // images (per block) live in LDS; only the partner point is gathered from memory.
     __shared__ float own_x[4 * TILE_POINTS], own_y[4 * TILE_POINTS], own_z[4 * TILE_POINTS];
-    __shared__ EmDerived emd_s[EMD_LDS_IMAGES];
-    __shared__ uint32_t img_base_s[WIDE ? 1 : EMD_LDS_IMAGES];      // narrow records: first point of the group's images
+    // a.lds_images entries each, sized at launch (sweep_lds_images: a power of two >= the largest group): with the
+    // 30 KB above, a block stays under 32 KB and FIVE blocks share a CU's 160 KB -- the sweep's time follows its
+    // resident wavefronts almost in proportion (measured: 12 instead of 16 per CU, +21 %)
+    extern __shared__ __align__(16) unsigned char sweep_dyn_lds[];
+    EmDerived *emd_s = reinterpret_cast<EmDerived *>(sweep_dyn_lds);
+    uint32_t *img_base_s = reinterpret_cast<uint32_t *>(sweep_dyn_lds + (size_t)a.lds_images * sizeof(EmDerived));   // narrow records: first point of the group's images
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -235,13 +245,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     pt_count = __builtin_amdgcn_readfirstlane(pt_count);
     image = __builtin_amdgcn_readfirstlane(image);
     float4 *my = acc + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
-    unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * TILE_POINTS : 0);
+    unsigned int *own = owner + (MODE == SWEEP_DEFORMABLE ? wave * OWNER_WORDS : 0);
 
     if (MODE == SWEEP_DEFORMABLE) {
         for (int k = lane; k < TILE_POINTS; k += 64) {
             my[k] = (a.sub > 0 && (uint32_t)k < pt_count) ? a.group_sums[group_sum_index(xcd, pt_begin - a.own_pt_begin + k, a.own_points)]
                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            own[k] = 0xFFFFFFFFu;
+            if (k < OWNER_WORDS) own[k] = 0xFFFFFFFFu;
         }
     }
     float *px = own_x + wave * TILE_POINTS, *py = own_y + wave * TILE_POINTS, *pz = own_z + wave * TILE_POINTS;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     if (EMD_LDS)
         for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
     if (!WIDE)
-        for (uint32_t k = threadIdx.x; k < (uint32_t)EMD_LDS_IMAGES; k += 256) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
+        for (uint32_t k = threadIdx.x; k < a.lds_images; k += 256) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
     __syncthreads();
 
     const EmDerived eA = a.emd[image];
@@ -343,15 +353,16 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             s[1] += (double)(inlier ? w2 : 0.0f);         // adding +0.0 leaves the f64 sums unchanged
             s[0] += (double)(inlier ? w2 * d2 : 0.0f);
             bool pending = inlier;
+            const uint32_t io = ia & (OWNER_WORDS - 1);
             while (__ballot(pending)) {
-                if (pending) atomicMin(&own[ia], (unsigned int)lane);
+                if (pending) atomicMin(&own[io], (unsigned int)lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (pending && __hip_atomic_load(&own[ia], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == (unsigned int)lane) {
+                if (pending && __hip_atomic_load(&own[io], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == (unsigned int)lane) {
                     float4 t = my[ia];
                     t.x += w2 * dx; t.y += w2 * dy; t.z += w2 * dz; t.w += w2;
                     my[ia] = t;
-                    own[ia] = 0xFFFFFFFFu;
+                    own[io] = 0xFFFFFFFFu;
                     pending = false;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
