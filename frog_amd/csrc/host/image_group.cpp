@@ -424,7 +424,10 @@ void ImageGroup::run()
         cout << "Error : -fi must leave at least one image to register" << endl;
         exit(1);
     }
-    if (nGpus > 1) {
+    // FROG_SHARDED_ALWAYS: `-ng 1` also takes the sharded host (one rank, a real RCCL communicator of one device): the only
+    // way to execute that code path -- ncclCommInitAll, grouped broadcasts, all-reduces on the context's stream -- on a
+    // machine with a single GPU (tests)
+    if (nGpus > 1 || (nGpus == 1 && std::getenv("FROG_SHARDED_ALWAYS"))) {
         // images sharded over several GPUs: the loops run in runSharded(), everything after them (error maps, files)
         // below is shared with the single-GPU path and asks the context that owns each image
         { const auto t_ctx = clk::now(); createShardedContexts();

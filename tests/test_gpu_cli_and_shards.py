@@ -392,9 +392,9 @@ def test_cli_incremental_registration_with_fixed_images(tmp_path):
     assert np.median(np.linalg.norm(a - b, axis=1)) < 5.0 < np.median(np.linalg.norm(a - own, axis=1))
 
 
-def _run_frog(cwd, *flags):
+def _run_frog(cwd, *flags, env=None):
     r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", "-li", "12", "-dl", "2", "-di", "10", "-j", "-q", "1", *flags],
-                       cwd=cwd, capture_output=True, text=True, timeout=600)
+                       cwd=cwd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 
@@ -458,6 +458,20 @@ def test_cli_sharded_over_two_gpus_rccl(tmp_path, small_pairs):
     _run_frog(one)
     _run_frog(two, "-ng", "2")
     _compare_runs(one, two, small_pairs.n_images)
+
+
+def test_cli_sharded_host_over_a_one_device_rccl_communicator(tmp_path, small_pairs):
+    """The C++ multi-GPU host (runSharded) with ONE rank on a real RCCL communicator (ncclCommInitAll of one device):
+    every collective of include/frog_comm.h is issued on the context's stream exactly as with N ranks -- what a box with
+    a single GPU can execute of `bin/frog -ng N`.  Same files as the plain single-context run."""
+    one, sharded = tmp_path / "one", tmp_path / "sharded"
+    for d in (one, sharded):
+        d.mkdir()
+        small_pairs.write(d / "pairs.bin")
+    _run_frog(one)
+    out = _run_frog(sharded, "-ng", "1", env=dict(os.environ, FROG_SHARDED_ALWAYS="1"))
+    assert "Images sharded over 1 GPUs" in out
+    _compare_runs(one, sharded, small_pairs.n_images)
 
 
 def test_native_communicator_single_rank_over_rccl():

@@ -399,6 +399,37 @@ def test_blocks_in_shuffled_file_order():
     census_equal(g, ref)
 
 
+def test_duplicate_links_are_added_in_the_reference_order():
+    """Every linked pair closer than 0.1 mm has weight exactly 1 on both sides (stats.h:87), so the f32 per-point sums
+    (imageGroup.cxx:270-278) depend on the ORDER of the adds and on nothing else: three links of every point of image 0
+    into image 1, in steps where all 64 lanes carry duplicates and the points k and k + 128 of a tile share an election
+    word (k_links.hip.h).  Bit-equal sums = the reference's order."""
+    rng = np.random.default_rng(21)
+    n = 700
+    a = rng.uniform(0, 200, (n, 3)).astype(np.float32)
+    b = (np.repeat(a, 3, axis=0) + rng.uniform(-0.025, 0.025, (3 * n, 3))).astype(np.float32)
+    pairs = Pairs.from_arrays([0, n, 4 * n], np.concatenate([a, b]),
+                              [(0, 1, np.repeat(np.arange(n), 3).astype(np.uint32), np.arange(3 * n, dtype=np.uint32))])
+    g = ImageGroup(pairs)
+    ref = OracleGroup(pairs.model, _abi.FrogOptions.default())
+    ref.setup_stats()
+    g.setupLinearTransforms(); ref.linear_init()
+    g.transformPoints(); ref.transform_points()
+    g.transformPoints(True); ref.transform_points(True)
+    g.setupDeformableTransforms(0); ref.deformable_setup(0, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    g.updateStats(); ref.update_stats()
+    same_inputs(g, ref)
+    x2 = ref.xyz2()
+    d = np.linalg.norm(np.repeat(x2[:n], 3, axis=0) - x2[n:], axis=1)
+    assert d.max() < 0.095                                  # every weight is the constant 1
+    e, er = g.updateDeformableTransforms(0.02), ref.deformable_step(0.02)
+    ps, rps = np.asarray(g.point_sums()), np.asarray(ref.point_sums())
+    assert np.all(rps[:n, 3] == 3.0) and np.all(rps[n:, 3] == 1.0)
+    assert np.array_equal(ps, rps)
+    assert abs(e - er) <= 1e-6 * abs(er)
+
+
 def test_brick_edge_8_equals_brick_edge_4(small_pairs, monkeypatch):
     """Sparse lattices (fewer than 24 points per 4^3-cell brick) use bricks of 8^3 cells in the scatter: 11^3-node tiles,
     another sort key.  Forced on a small group (FROG_BRICK): same lattices as with edge 4 up to the order of the f32
