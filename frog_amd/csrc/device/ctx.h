@@ -153,11 +153,11 @@ struct RecFormat {
 };
 static_assert(TILE_POINTS <= 256, "own-point index must fit 8 bits of LinkRec::a");
 
-// Per-image constants derived from (c1, c2, ratio) for getInlierProbability
-// (stats.h:84-92): with inv_k = 1/(c_k+eps): q_k = inv_k^2 (so that (d/c_k)^2 = d2 * q_k, no square root on the way),
-// k1 = ratio*c*inv1, k2 = (1-ratio)*c*inv2 with c = 0.797884560802865f.
+// Per-image constants derived from (c1, c2, ratio) for getInlierProbability (stats.h:84-92), k_links.hip.h: with
+// inv_k = 1 / (c_k + eps), c0 = 0.797884560802865f:  kq1 = ratio c0 inv1^3, kq2 = (1 - ratio) c0 inv2^3 and
+// s_k = -log2(e) inv_k^2 / 2, so that x_k = kq_k d2 2^(s_k d2) -- no square root and no division on the way.
 struct EmDerived {
-    float q1, q2, k1, k2;
+    float kq1, kq2, s1, s2;
 };
 
 struct GridGeom {

@@ -8,12 +8,12 @@
 // touches the coordinates of ONE partner group, which stay in its XCD's L2.  Nothing here is
 // GEMM shaped: it is a gather + weighted reduction, no MFMA.  What bounds it (rocprofv3, DESIGN.md
 // section 4): the ~64 cache-line requests a CU's L1 keeps in flight and, about equally, vector-ALU
-// issue (136 instructions per step, most of them the two inlier probabilities).
+// issue (most of a step's instructions are the two inlier probabilities).
 //
 // Arithmetic contract (reference lines in the comments):
 //   dist2, dist  -- f32, no FMA contraction, correctly rounded sqrt: bit-exact
 //                   with the reference, so `d < 0.1` and the sample values agree.
-//   inlier weight -- f32 from d2 with reciprocals and exp (exp_nonpos, div_fast below): within 2^-16 of the
+//   inlier weight -- f32 from d2 with precomputed constants, v_exp_f32 and div_fast below: within 2^-16 of the
 //                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92), bound derived at
 //                   inlier_probability; weights within 1e-4 of the inlier threshold are recomputed with the
 //                   reference's own arithmetic, so no decision depends on the fast form.
@@ -71,11 +71,9 @@ struct SweepArgs {
     const uint32_t *cull_state; // [0] != 0: the list is not valid for the current coordinates -> walk every record
 };
 
-// The sweep is bound by vector-instruction issue (rocprofv3: ~175 VALU instructions per
-// 64-link step, VALU busy 80 % of the kernel), and more than half of those are the
-// compiler's generic expansions of sqrtf, expf and the f32 division: each carries range
-// handling this kernel cannot need.  The three helpers below are those same expansions
-// (same operations in the same order, so the same bits) without it.
+// The sweep is bound by vector-instruction issue (rocprofv3), and the compiler's generic
+// expansions of sqrtf, expf and the f32 division carry range handling this kernel cannot need: the helpers below do
+// without it.
 
 // Correctly rounded sqrt: v_sqrt_f32 (1 ulp) and the two one-ulp corrections.  Dropped: the
 // rescaling of denormal arguments (a denormal d2 means d < 0.1, where the weight is 1).
@@ -87,22 +85,6 @@ __device__ __forceinline__ float sqrt_rn(float x)
     float r = (0.0f >= e_lo) ? lo : s;
     r = (0.0f < e_hi) ? hi : r;
     return r;
-}
-
-// expf(x) for x <= 0: two-word product x log2(e) = ph + pl, v_exp_f32 on the head (the instruction reduces its own
-// argument: 1 ulp over the whole range) and the tail applied to first order, 2^pl = 1 + pl ln 2 (|pl| < 2^-17: the second
-// order is below 2^-36).  Same accuracy class as the compiler's expansion (the product error |x| 2^-24 would otherwise
-// enter the result relative), seven instructions instead of its sixteen.  The clamp keeps -inf out of the product;
-// results below the normal range flush towards 0, where the weight they enter is 0 to twenty digits anyway.
-__device__ __forceinline__ float exp_nonpos(float x)
-{
-    x = __builtin_amdgcn_fmed3f(x, -200.0f, 0.0f);
-    constexpr float L_hi = __builtin_bit_cast(float, 0x3fb8aa3bu), L_lo = __builtin_bit_cast(float, 0x32a5705fu);
-    const float ph = x * L_hi;
-    float pl = __builtin_fmaf(x, L_hi, -ph);
-    pl = __builtin_fmaf(x, L_lo, pl);
-    const float e = __builtin_amdgcn_exp2f(ph);
-    return __builtin_fmaf(e, pl * 0.69314718055994531f, e);
 }
 
 // n / d for d >= 1e-10 and 0 <= n <= d: v_rcp_f32 (1 ulp), one Newton step on the reciprocal, one product: within 1.5 ulp
@@ -138,41 +120,46 @@ __device__ __noinline__ float inlier_probability_exact(float d, const float4 em)
     return x1 / (x1 + x2 + eps);
 }
 
-// getInlierProbability (stats.h:84-92) from precomputed per-image constants, as a function of the SQUARED distance (the
-// sweeps of the deformable stage never need the distance itself: the energy there is sum w2 d2, imageGroup.cxx:275).
+// getInlierProbability (stats.h:84-92) from precomputed per-image constants (EmDerived, ctx.h), as a function of the
+// SQUARED distance (the sweeps of the deformable stage never need the distance itself: the energy there is sum w2 d2,
+// imageGroup.cxx:275):   x_k = kq_k d2 2^(s_k d2),   kq_k = ratio_k c0 / c_k^3,   s_k = -log2(e) / (2 c_k^2)
+// -- eleven vector instructions for one probability (the product x log2(e) used to be formed in two words and the
+// argument passed through (d / c)^2 first: twenty-two; the error analysis below shows what the second word bought: nothing
+// that the argument's own roundings had not already spent).
 //
 // Error bound against the reference's form (f32 quotients, f64 exp: chi_pdf_exact / inlier_probability_exact above).
-// e = 2^-24 is the relative error of one f32 rounding, u_k = (d / c_k)^2, d2 the f32 squared distance both sides compute
-// with the same bits.
-//   argument   reference: d = fl(sqrt(d2)), x = fl(d / c), u = fl(x x): (d2 / c^2) (1 + 5e).  Here: inv = fl(1 / c),
-//              q = fl(inv inv), u = fl(d2 q): (d2 / c^2) (1 + 4e).  The two differ by at most 9e relative.
-//   exp        exp(-u/2) inherits |du| / 2 <= 4.5e u relative from its argument; exp_nonpos adds <= 4e of its own (two-word
-//              product: 2^-46 relative in the argument; v_exp_f32: 1 ulp = 2e; tail product and fma: 2e), the reference's
-//              f64 exp nothing visible in f32.
-//   x_k        reference: fl(c x2), f64 product rounded to f32, fl(ratio ..), fl(.. / c): 4 roundings.  Here: k = fl(fl(ratio
-//              c) inv) (3 with inv's own), fl(k u), fl(.. exp): 5, plus u's 9e and the exp's 4e + 4.5e u.
-//              => |x_k / x_k,ref - 1| <= (22 + 4.5 u_k) e.
+// e = 2^-24 bounds the relative error of one f32 rounding, u_k = (d / c_k)^2 in real numbers, d2 the f32 squared
+// distance both sides compute with the same bits, c' = fl(c + eps) on both sides.
+//   reference  d = fl(sqrt d2), x = fl(d / c'), u = fl(x x): u (1 + 5e).  chi = fl(c0 u), the f64 product with exp(-u/2)
+//              rounded to f32, fl(ratio chi), fl(.. / c'): four more roundings, and the exponent's 5e enters as 2.5e u
+//              => X_ref = X (1 + (9 + 2.5 u) e).
+//   here       inv = fl(1 / c'), q = fl(inv inv): 3e.  s = fl(q K) with K = fl(-log2(e)/2): 5e.  ph = fl(d2 s): 6e relative
+//              in the exponent, i.e. ln 2 |ph| 6e = 3e u relative in 2^ph; v_exp_f32: 1 ulp = 2e (it reduces its own argument;
+//              results below the normal range flush towards 0, where the weight they enter is 0 to thirty digits).
+//              kq = fl(fl(fl(ratio c0) inv) q): 7e (8e for 1 - ratio).  x = fl(kq fl(d2 2^ph)): 2e.
+//              => x = X (1 + (12 + 3 u) e).
+//   x_k        |x_k / x_k,ref - 1| <= (21 + 5.5 u_k) e.
 //   p          p = x1 / (x1 + x2 + eps): dp = p (1 - p) (dx1/x1 - dx2/x2) + two roundings of the sums + div_fast (3e)
-//              => |p - p_ref| <= p (1 - p) (44 + 4.5 u1 + 4.5 u2) e + 5 e p.
+//              => |p - p_ref| <= p (1 - p) (42 + 5.5 u1 + 5.5 u2) e + 5 e p.
 // p (1 - p) is only non-negligible where x1 ~ x2, i.e. u1/2 ~ 3 ln(c2 / c1) + ln((1 - r) / r): u1 <= 64 covers c2/c1 up to
 // 4 10^4 at any ratio in [1e-6, 1 - 1e-6]; beyond it p <= exp(-u1 / 2) (c2/c1)^3 r / (1 - r) is itself below 1e-9.  With
-// u2 <= u1: |p - p_ref| <= 0.25 (44 + 576) e + 5 e = 160 e = 9.5e-6 in the worst case; INLIER_PROBABILITY_BOUND = 2^-16
+// u2 <= u1: |p - p_ref| <= 0.25 (42 + 704) e + 5 e = 192 e = 1.14e-5 in the worst case; INLIER_PROBABILITY_BOUND = 2^-16
 // rounds that up.  tests/test_gpu_round2.py::test_inlier_probability_against_the_reference_build evaluates this function
 // on the device against the reference build of stats.cxx over d/c1 in [0.02, 60] for a set of mixtures and asserts the
 // bound (the observed maximum is in DESIGN.md section 2; the exact form reproduces the reference build on every value).
 // The bound is what THRESHOLD_BAND (1e-4, six times larger) relies on: a weight farther than the band from the threshold
 // is on the same side of it as the reference's, a weight inside the band is recomputed with the reference's own arithmetic.
+// Finite for every finite d2: c' >= 1e-10 keeps kq <= 8e29 and s finite; 2^(-inf) = 0 and d2 * 0 = 0.
 constexpr float INLIER_PROBABILITY_BOUND = 1.52587890625e-05f;      // 2^-16
 // `d < 0.1` (stats.h:87, d = the correctly rounded f32 sqrt of d2) in terms of d2: sqrt is monotone, and 0x3c23d70a
 // (0.01f) is the smallest f32 whose square root rounds to >= 0.1f (checked over the 40 neighbouring floats).
 constexpr float D2_FIX = __builtin_bit_cast(float, 0x3c23d70au);
 __device__ __forceinline__ float inlier_probability(float d2, const EmDerived e)
 {
-    if (d2 < D2_FIX) return 1.0f;
-    const float u1 = d2 * e.q1, u2 = d2 * e.q2;
-    const float x1 = e.k1 * u1 * exp_nonpos(-0.5f * u1);
-    const float x2 = e.k2 * u2 * exp_nonpos(-0.5f * u2);
-    return div_fast(x1, x1 + x2 + 1e-10f);
+    const float e1 = __builtin_amdgcn_exp2f(d2 * e.s1), e2 = __builtin_amdgcn_exp2f(d2 * e.s2);
+    const float x1 = e.kq1 * (d2 * e1), x2 = e.kq2 * (d2 * e2);
+    const float p = div_fast(x1, x1 + x2 + 1e-10f);
+    return d2 < D2_FIX ? 1.0f : p;
 }
 
 __device__ __forceinline__ double wave_sum(double v)

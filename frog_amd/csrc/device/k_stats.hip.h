@@ -489,12 +489,14 @@ __device__ __forceinline__ EmDerived em_derived_of(const float4 e)
 {
     const float eps = 1e-10f;
     const float c = 0.797884560802865f;
+    const float K = -0.72134752044448170368f;           // -log2(e) / 2
     EmDerived d;
     const float inv1 = 1.0f / (e.x + eps), inv2 = 1.0f / (e.y + eps);
-    d.q1 = inv1 * inv1;
-    d.q2 = inv2 * inv2;
-    d.k1 = e.z * c * inv1;
-    d.k2 = (1.0f - e.z) * c * inv2;
+    const float q1 = inv1 * inv1, q2 = inv2 * inv2;
+    d.kq1 = e.z * c * inv1 * q1;
+    d.kq2 = (1.0f - e.z) * c * inv2 * q2;
+    d.s1 = q1 * K;
+    d.s2 = q2 * K;
     return d;
 }
 
