@@ -210,6 +210,7 @@ HIP_SYMBOLS = {
     "frog_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_stray_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "frog_test_cull_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_em_refit": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_test_inlier_probability": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_size_t, c_float_p, c_float_p]),
     "frog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1457,7 +1457,7 @@ int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed, uint
             std::vector<uint32_t> h(ctx->act_cnt.n);
             FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->act_cnt.p, ctx->act_cnt.bytes(), hipMemcpyDeviceToHost, ctx->stream));
             FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            for (uint32_t v : h) *listed += v;
+            for (uint32_t v : h) *listed += v & ~CULL_DUP_BIT;
         }
     }
     return FROG_OK;
@@ -1486,6 +1486,23 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d2
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
     FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FROG_OK;
+}
+
+int frog_test_cull_ranges(frog_ctx *ctx, uint64_t *ranges, uint64_t *with_election)
+{
+    CTX_GUARD(ctx);
+    if (!ranges || !with_election) return fail(FROG_E_INVALID, "null output");
+    *ranges = 0; *with_election = 0;
+    if (ctx->cull_builds && ctx->act_cnt.n) {
+        std::vector<uint32_t> h(ctx->act_cnt.n);
+        FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->act_cnt.p, ctx->act_cnt.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t v : h) {
+            if (v & ~CULL_DUP_BIT) (*ranges)++;
+            if (v & CULL_DUP_BIT) (*with_election)++;
+        }
+    }
     return FROG_OK;
 }
 

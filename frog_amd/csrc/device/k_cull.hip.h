@@ -112,6 +112,17 @@ __global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, cons
     const Rec *src = reinterpret_cast<const Rec *>(a.recs);
     Rec *dst = reinterpret_cast<Rec *>(act_recs);
     auto phys = [&](uint32_t k) { return (size_t)rec_lo + (k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u; };
+    // Does any step of the LISTED range (64 consecutive listed records = the lanes of one sweep step) hold two records of
+    // the same own point?  last_step[point] = the step its latest listed record went to; ds_wrxchg is serialised per
+    // address, so two lanes of one trip that carry the same point see each other.  Ranges without such a step (records are
+    // partner-major then point order: all of them, unless a point has several links into one partner image or a tile
+    // has fewer than 64 links into a partner image) are swept without the lane election (CULL_DUP_BIT clear).
+    __shared__ uint32_t last_step_s[4][TILE_POINTS];
+    uint32_t *last_step = last_step_s[wave];
+    for (int k = lane; k < TILE_POINTS; k += 64) last_step[k] = 0xFFFFFFFFu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool dup = false;
     uint32_t base = 0;
     // UNROLL steps of 64 records per trip, all their loads issued before the first is used (a dependent chain of
     // record -> two coordinates per step left the wavefront idle most of the time: 0.77 ms for 1e8 records)
@@ -149,11 +160,16 @@ __global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, cons
             const float cut = have[u] ? fminf(cutA, cut_list[imgB[u]]) : 0.f;
             const bool keep = have[u] && d2 < cut * cut;      // NaN or inf distance: left out, and an outlier in the full sweep too
             const unsigned long long m = __ballot(keep);
-            if (keep) dst[phys(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = rq[u];
+            if (keep) {
+                const uint32_t to = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                dst[phys(to)] = rq[u];
+                dup |= atomicExch(&last_step[(uint32_t)rq[u] & 0xFFu], to >> 6) == (to >> 6);
+            }
             base += (uint32_t)__popcll(m);
         }
     }
-    if (lane == 0) act_cnt[(size_t)t * a.n_groups + grp] = base;
+    const bool any_dup = __ballot(dup) != 0ull;
+    if (lane == 0) act_cnt[(size_t)t * a.n_groups + grp] = base | (any_dup ? CULL_DUP_BIT : 0u);
 }
 
 // Largest distance of a point from where it was at build time, as per-block maxima (f32 bits: non-negative floats order

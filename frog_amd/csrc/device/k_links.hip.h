@@ -40,6 +40,9 @@ constexpr int BODY_STEPS = 6;
 static_assert(BODY_STEPS == 2 * CHUNK_RING && BODY_STEPS % PT_RING == 0 && PT_AHEAD < PT_RING && CHUNK_AHEAD < CHUNK_RING
               && 2 * CHUNK_AHEAD >= PT_AHEAD + 2, "ring periods must divide the unrolled body; a gather needs its record");
 constexpr int EMD_LDS_IMAGES = 256;     // partner groups up to this many images keep their constants in LDS
+// act_cnt: set when some step of the listed range holds two records of one own point (k_cull.hip.h); a range without
+// one is swept without the lane election
+constexpr uint32_t CULL_DUP_BIT = 0x80000000u;
 constexpr int OWNER_WORDS = TILE_POINTS / 2;      // election words per wavefront (deformable sweep)
 static_assert((OWNER_WORDS & (OWNER_WORDS - 1)) == 0, "the election word of a point is its index masked");
 static_assert(EMD_LDS_IMAGES == 1 << 8, "prep.h admits narrow records for img_bits <= 8 only");
@@ -67,7 +70,7 @@ struct SweepArgs {
     uint32_t group_begin[MAX_GROUPS + 1];   // first image of every partner group
     // certified outlier culling (k_cull.hip.h), deformable sweep only; all three null = walk every record
     const void *act_recs;       // the listed records, same offsets and storage as `recs`
-    const uint32_t *act_cnt;    // [n_tiles][n_groups] listed records per range
+    const uint32_t *act_cnt;    // [n_tiles][n_groups] listed records per range | CULL_DUP_BIT
     const uint32_t *cull_state; // [0] != 0: the list is not valid for the current coordinates -> walk every record
 };
 
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // gathers per step, 0.68 ms with them), so everything that can be staged is: the xyz2
     // of the tile's own points (per wave) and the EM constants of the partner group's
     // images (per block) live in LDS; only the partner point is gathered from memory.
-    __shared__ float own_x[4 * TILE_POINTS], own_y[4 * TILE_POINTS], own_z[4 * TILE_POINTS];
+    // one array, x / y / z planes a constant 4 KB apart: one address computation per step, the planes are DS offsets
+    __shared__ float own_xyz[3 * 4 * TILE_POINTS];
     // a.lds_images entries each, sized at launch (sweep_lds_images: a power of two >= the largest group): with the
     // 30 KB above, a block stays under 32 KB and FIVE blocks share a CU's 160 KB -- the sweep's time follows its
     // resident wavefronts almost in proportion (measured: 12 instead of 16 per CU, +21 %)
@@ -225,7 +229,13 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     // the listed records only, when there is a list and the check before this launch found it valid (k_cull.hip.h)
     bool listed = false;
     if constexpr (MODE == SWEEP_DEFORMABLE) listed = a.act_cnt != nullptr && a.cull_state[0] == 0u;
-    if (listed && live) rec_n = a.act_cnt[(size_t)t * a.n_groups + grp];
+    bool elect = true;          // wave-uniform: lanes of one step may meet on a point (always assumed for unlisted ranges)
+    if (listed && live) {
+        const uint32_t c = a.act_cnt[(size_t)t * a.n_groups + grp];
+        rec_n = c & ~CULL_DUP_BIT;
+        elect = (c & CULL_DUP_BIT) != 0u;
+    }
+    elect = __builtin_amdgcn_readfirstlane((uint32_t)elect) != 0u;
     rec_lo = __builtin_amdgcn_readfirstlane(rec_lo);      // the same in every lane: keep them in SGPRs
     rec_n = __builtin_amdgcn_readfirstlane(rec_n);
     pt_begin = __builtin_amdgcn_readfirstlane(pt_begin);
@@ -241,10 +251,11 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             if (k < OWNER_WORDS) own[k] = 0xFFFFFFFFu;
         }
     }
-    float *px = own_x + wave * TILE_POINTS, *py = own_y + wave * TILE_POINTS, *pz = own_z + wave * TILE_POINTS;
+    float *px = own_xyz + wave * TILE_POINTS;
+    constexpr int PLANE = 4 * TILE_POINTS;
     for (uint32_t k = lane; k < pt_count; k += 64) {
         const P3 p = a.pos2[pt_begin + k];
-        px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+        px[k] = p.x; px[k + PLANE] = p.y; px[k + 2 * PLANE] = p.z;
     }
     const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
     if (EMD_LDS)
@@ -300,9 +311,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     #pragma unroll
     for (int k = 0; k < PT_RING; k++) pbq[k] = (k < PT_AHEAD) ? gather((k & 1) ? cq[k / 2].y : cq[k / 2].x) : P3{ 0.f, 0.f, 0.f };
 
-    auto step = [&](const Rec rq, const P3 pb) __attribute__((always_inline)) {
+    auto step = [&](const Rec rq, const P3 pb, auto elect_c) __attribute__((always_inline)) {
+        constexpr bool ELECT = decltype(elect_c)::value;
         const uint32_t ia = own_of(rq);                 // own point inside the tile
-        const P3 pa = { px[ia], py[ia], pz[ia] };
+        const P3 pa = { px[ia], px[ia + PLANE], px[ia + 2 * PLANE] };
         const EmDerived eB = EMD_LDS ? emd_s[img_of(rq)] : a.emd[img_of(rq)];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
@@ -339,6 +351,17 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             const float w2 = w * w;
             s[1] += (double)(inlier ? w2 : 0.0f);         // adding +0.0 leaves the f64 sums unchanged
             s[0] += (double)(inlier ? w2 * d2 : 0.0f);
+            if constexpr (!ELECT) {
+                // no two lanes of this step hold the same point (certified when the list was built)
+                if (inlier) {
+                    float4 t = my[ia];
+                    t.x += w2 * dx; t.y += w2 * dy; t.z += w2 * dz; t.w += w2;
+                    my[ia] = t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next step may touch this point from another lane
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
             bool pending = inlier;
             const uint32_t io = ia & (OWNER_WORDS - 1);
             while (__ballot(pending)) {
@@ -362,18 +385,22 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     };
 
     const uint32_t n_steps = (rec_n + 63) / 64;          // wave-uniform
-    for (uint32_t base = 0; base < n_steps; base += BODY_STEPS) {
-        #pragma unroll
-        for (int j = 0; j < BODY_STEPS; j++) {
-            const uint32_t r = lane + 64 * (base + j);   // step base+j, lane -> record r of the range
-            if (j % 2 == 0) cq[(j / 2 + CHUNK_AHEAD) % CHUNK_RING] = chunk_at(base / 2 + j / 2 + CHUNK_AHEAD);
-            {
-                const Chunk ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
-                pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
+    auto walk = [&](auto elect_c) __attribute__((always_inline)) {
+        for (uint32_t base = 0; base < n_steps; base += BODY_STEPS) {
+            #pragma unroll
+            for (int j = 0; j < BODY_STEPS; j++) {
+                const uint32_t r = lane + 64 * (base + j);   // step base+j, lane -> record r of the range
+                if (j % 2 == 0) cq[(j / 2 + CHUNK_AHEAD) % CHUNK_RING] = chunk_at(base / 2 + j / 2 + CHUNK_AHEAD);
+                {
+                    const Chunk ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
+                    pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
+                }
+                if (r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING], elect_c);
             }
-            if (r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING]);
         }
-    }
+    };
+    if (MODE != SWEEP_DEFORMABLE || elect) walk(std::true_type{});
+    else walk(std::false_type{});
 
     if constexpr (MODE == SWEEP_LINEAR) {
         #pragma unroll

@@ -263,6 +263,12 @@ class ImageGroup:
         check(self._lib.frog_cull_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats")
         return a.value, b.value, c.value
 
+    def cull_ranges(self):
+        """(non-empty ranges of the culling list, ranges swept with the lane election) -- frog_test_cull_ranges."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.frog_test_cull_ranges(self._ctx, C.byref(a), C.byref(b)), "frog_test_cull_ranges")
+        return a.value, b.value
+
     def stray_points(self):
         """Points the scatter found outside their brick since creation (frog_test_stray_points): 0 unless the sort is broken."""
         n = C.c_uint64()

@@ -214,6 +214,9 @@ int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const f
  * was created (they are handled, through global atomics: slowly and in no fixed order).  Inside the lattice's box --
  * always, for the group's own points -- this must stay 0; a non-zero count means the (image, brick, cell) sort is broken. */
 int frog_test_stray_points(frog_ctx *ctx, uint64_t *n);
+/* test hook: non-empty (tile, partner group) ranges of the current culling list, and how many of them hold a step in
+ * which two lanes carry the same point (those are swept with the lane election, the others without; k_cull.hip.h) */
+int frog_test_cull_ranges(frog_ctx *ctx, uint64_t *ranges, uint64_t *with_election);
 
 /* Test hook: Stats::estimateDistribution (stats.cxx:14-70) again, on the samples the last refresh retained and from
  * the CURRENT (c1, c2, ratio) of every owned image (set them with frog_set_em first), with the term-by-term form of

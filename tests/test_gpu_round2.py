@@ -285,7 +285,27 @@ def test_culled_sweep_is_bit_identical_to_the_full_sweep(small_pairs, monkeypatc
     assert built0 == 0 and listed0 == 0
     assert 1 <= built1 <= 10 and 0 < listed1 < owned1 == small_pairs.n_half_links     # the false matches are left out
     assert built2 > 20                                                               # zero skin: rebuilt all the time
-    note("cull_small_pairs", f"builds {built1} listed {listed1} of {owned1}; zero skin builds {built2}")
+    ranges, elected = g1.cull_ranges()
+    assert 0 <= elected < ranges          # 128 links per tile and partner image: most steps cannot hold a point twice
+    note("cull_small_pairs", f"builds {built1} listed {listed1} of {owned1}; zero skin builds {built2}; "
+                             f"ranges {ranges}, with election {elected}")
+
+
+def test_culled_sweep_with_and_without_lane_election(monkeypatch):
+    """The list builder certifies, per (tile, partner group) range, that no step of 64 listed records holds a point
+    twice; such ranges are swept without the lane election (k_cull.hip.h CULL_DUP_BIT).  A group of many small images
+    has ranges of both kinds (a step spans several partner images): same bits as the full sweep, which always elects."""
+    pairs = Pairs.synthetic(24, 400, 150, seed=5)
+    g0, E0, L0, S0, C0, X0 = _run_schedule(pairs, monkeypatch, False)
+    g1, E1, L1, S1, C1, X1 = _run_schedule(pairs, monkeypatch, True)
+    assert g0.gridsPerLevel == g1.gridsPerLevel and E0 == E1
+    for a, b in zip(L0, L1):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert np.array_equal(S0, S1) and C0 == C1 and np.array_equal(X0, X1)
+    ranges, elected = g1.cull_ranges()
+    assert 0 < elected < ranges
+    note("cull_many_small_images", f"ranges {ranges}, with election {elected}")
 
 
 def test_culling_follows_coordinates_and_mixtures_set_from_outside(small_pairs):
