@@ -147,6 +147,13 @@ void frog_destroy(frog_ctx *ctx)
     if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+#ifdef FROG_SCATTER_TRACE
+    if (const char *path = getenv("FROG_SCATTER_TRACE_FILE")) {
+        std::vector<unsigned long long> h(4 * 65536);
+        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_scatter_trace), h.size() * 8);
+        if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+    }
+#endif
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->sel_done) (void)hipEventDestroy(ctx->sel_done);
     if (ctx->energy_copied) (void)hipEventDestroy(ctx->energy_copied);

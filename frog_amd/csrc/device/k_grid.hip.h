@@ -649,46 +649,78 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
 // the brick, from the table built at set-up).  LDS: the brick's (B+3)^3 control
 // points as float4 (sum w*sDisp xyz, sum w*sWeight), private to the wavefront.
 //
-// Batches of 64 points.  Phase 1, lane = point: cell, the 12 cubic weights in f64
-// as the reference computes them (imageGroup.cxx:303-310), rounded once to f32, and
-// the tile offset of the point's first tap, written to a small LDS scratch.  Phase 2,
-// lane = tap (i + 4j + 16k): the point's values are read back with lane-constant offsets
-// (one point ahead), w = wx[i]*wy[j]*wz[k]
-// (imageGroup.cxx:322) and the four products are added into REGISTERS; points are
-// sorted by cell, so consecutive points mostly share their 64 tap addresses and the
-// LDS tile is touched (one ds_read_b128 + ds_write_b128, no atomic: the 64 taps are
-// 64 distinct control points and the tile is private) only when the cell changes.
-// Finally the tile goes to a staging slot; lattice_step_kernel sums the slots in a fixed order.
+// Batches of 64 points.  Phase 1, lane = point: the point's sums (loaded a batch ahead), cell, weights, the products
+// wx wy and the tile offset of its first tap, handed over through an LDS scratch.  Phase 2, lane = tap (i + 4j + 16k),
+// one point per trip: w = (wx[i] wy[j]) wz[k] (imageGroup.cxx:322) and the four products added into registers, the
+// LDS tile touched only when the cell changes.  Finally the tile goes to a staging slot; lattice_step_kernel sums the
+// slots in a fixed order.
 //
 // Why not LDS float atomics: ds_add_f32 runs at 0.33 lane-ops/clk/CU on gfx950
 // (scripts/microbench/lds_atomic.hip); why not fixed point: control points on the
 // shell of the cloud have total weights ~1e-10 and need f32 relative precision.
+#ifdef FROG_SCATTER_TRACE
+__device__ unsigned long long g_scatter_trace[4 * 65536];
+#endif
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 
-// per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS
-struct ScatterPoint {
-    float w[12];            // wx[4], wy[4], wz[4], rounded to f32
-    float sx, sy, sz, sw;   // sDisp xyz, sWeight
-    int base;               // tile offset of tap (0,0,0); < 0: does not contribute
-    int pad_[3];
+// Per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS, one array per value
+// (lane-consecutive writes and reads: no bank conflicts).  The products wx[i] * wy[j] are formed in phase 1, where one
+// instruction serves 64 points; in phase 2 an instruction serves ONE point, and that loop is where a block spends its time
+// (per-block trace, -DFROG_SCATTER_TRACE + scripts/microbench/scatter_trace_an.py: 63 % of a block's 52 us before this
+// layout, with the three weights read separately and multiplied per point).
+constexpr int SC_AHEAD = 3, SC_RING = 4;        // phase 2 fetches a point's values SC_AHEAD points before it uses them
+constexpr int SC_PTS = 64 + SC_AHEAD;           // ... unconditionally, so up to SC_AHEAD entries past the batch are read (unused)
+struct ScatterScratch {
+    float wxy[16][SC_PTS];      // wx[i] * wy[j] at [4 j + i]: f32 products of the f32-rounded weights (imageGroup.cxx:322, left to right)
+    float wz[4][SC_PTS];
+    float4 sm[SC_PTS];          // sDisp xyz, sWeight
+    int base[SC_PTS];           // tile offset of tap (0,0,0)
 };
-static_assert(sizeof(ScatterPoint) == 80, "ScatterPoint layout");
+static_assert(offsetof(ScatterScratch, sm) % 16 == 0, "ScatterScratch::sm is read with ds_read_b128");
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
                                                      const uint32_t *perm, const ScatterBlock *blocks, const uint32_t *n_blocks,
                                                      float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g)
 {
+#ifdef FROG_SCATTER_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    unsigned tr_load = 0, tr_p1 = 0, tr_p2 = 0;
+#endif
     // the grid is an upper bound (the block table is built on the device and its length never visits the host)
     if (blockIdx.x >= *n_blocks) return;
     // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
-    // take 5.4 KB instead of the 21 KB of the largest brick and 15 instead of 6 blocks fit a CU
+    // take 5.4 KB instead of the 21 KB of the largest brick
     extern __shared__ float4 tile[];
-    __shared__ ScatterPoint pts[64];
+    __shared__ ScatterScratch sc;
     const ScatterBlock blk = blocks[blockIdx.x];
     const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
     const int n_tile = E * E * E;
+
+    // The loads run ahead of the arithmetic: a block is ONE wavefront, and perm -> (sums, position) is a chain of two
+    // memory round trips per batch that nothing else on the wavefront hides (11 of a block's 38 us were spent waiting for
+    // it).  The index of batch b + 2 and the values of batch b + 1 are requested before batch b is worked on; every load is
+    // unconditional, from an index clamped into the block (see k_links.hip.h on loads under lane-dependent branches).
+    const uint32_t s_last = blk.end - 1u;
+    const auto load_index = [&](uint32_t s) -> uint32_t { return perm[min(s, s_last)]; };
+    const auto load_point = [&](uint32_t p, float4 (&part)[N_XCD], float4 &v) __attribute__((always_inline)) {
+        if (group_sums) {                        // kernel-uniform
+            const uint32_t li = p - own_pt_begin;
+            #pragma unroll
+            for (int q = 0; q < N_XCD; q++) part[q] = group_sums[group_sum_index(q, li, own_points)];
+        } else {
+            part[0] = point_sums[p];
+        }
+        v = pos[p];
+    };
+    uint32_t p_cur = load_index(blk.begin + lane);
+    uint32_t p_nxt = load_index(blk.begin + 64 + lane);
+    float4 part_cur[N_XCD], v_cur;
+    #pragma unroll
+    for (int q = 1; q < N_XCD; q++) part_cur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_point(p_cur, part_cur, v_cur);
+
     for (int k = lane; k < n_tile; k += 64) tile[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const uint32_t img = blk.key / g.n_bricks;
@@ -708,42 +740,49 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     float4 run = make_float4(0.f, 0.f, 0.f, 0.f);      // contributions of the current cell, this lane's tap
     int run_base = -1;
     for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
-        // ---- phase 1: lane = point
-        const uint32_t s = batch + lane;
-        ScatterPoint me;
-        me.base = -1;
-        if (s < blk.end) {
-            const uint32_t p = perm[s];
-            float4 sm;
+        const uint32_t p_far = load_index(batch + 128 + lane);
+        float4 part_nxt[N_XCD], v_nxt;
+        #pragma unroll
+        for (int q = 1; q < N_XCD; q++) part_nxt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        load_point(p_nxt, part_nxt, v_nxt);
+#ifdef FROG_SCATTER_TRACE
+        const unsigned long long tb0 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the current batch's loads are the oldest
+        const unsigned long long tb1 = wall_clock64();
+#endif
+        // ---- phase 1: lane = point.  Cell, the 12 cubic weights in f64 as the reference computes them
+        // (imageGroup.cxx:303-310), rounded once to f32, the 16 products wx wy, the tile offset of the first tap.
+        float wxy[16], wz[4];
+        float4 sm = part_cur[0];
+        int base = -1;
+        if (batch + lane < blk.end) {
             if (group_sums) {
-                // the point's sums straight from the N_XCD partial sums of the sweep, added in group order exactly as
+                // the point's sums from the N_XCD partial sums of the sweep, added in group order exactly as
                 // combine_groups_kernel does (same bits): saves that kernel's pass over 288 MB
-                const uint32_t li = p - own_pt_begin;
-                float4 part[N_XCD];
                 #pragma unroll
-                for (int q = 0; q < N_XCD; q++) part[q] = group_sums[group_sum_index(q, li, own_points)];
-                sm = part[0];
-                #pragma unroll
-                for (int q = 1; q < N_XCD; q++) { sm.x += part[q].x; sm.y += part[q].y; sm.z += part[q].z; sm.w += part[q].w; }
-            } else {
-                sm = point_sums[p];
+                for (int q = 1; q < N_XCD; q++) { sm.x += part_cur[q].x; sm.y += part_cur[q].y; sm.z += part_cur[q].z; sm.w += part_cur[q].w; }
             }
             if (sm.w != 0.f) {                       // imageGroup.cxx:299
-                const float4 v = pos[p];
-                const float in[3] = { v.x, v.y, v.z };
+                const float in[3] = { v_cur.x, v_cur.y, v_cur.z };
                 int ic[3]; float fr[3];
                 scatter_cell(in, g, ic, fr);
                 double F[4];
+                float w12[12];
                 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
                     bspline_weights(F, (double)fr[ax]);
                     #pragma unroll
-                    for (int m = 0; m < 4; m++) me.w[ax * 4 + m] = (float)F[m];
+                    for (int m = 0; m < 4; m++) w12[ax * 4 + m] = (float)F[m];
                 }
-                me.sx = sm.x; me.sy = sm.y; me.sz = sm.z; me.sw = sm.w;
+                #pragma unroll
+                for (int j = 0; j < 4; j++)
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) wxy[4 * j + i] = w12[i] * w12[4 + j];
+                #pragma unroll
+                for (int k = 0; k < 4; k++) wz[k] = w12[8 + k];
                 const int lx = ic[0] - 1 - cp0[0], ly = ic[1] - 1 - cp0[1], lz = ic[2] - 1 - cp0[2];
                 if (lx >= 0 && ly >= 0 && lz >= 0 && lx + 3 < E && ly + 3 < E && lz + 3 < E) {
-                    me.base = lx + E * (ly + E * lz);
+                    base = lx + E * (ly + E * lz);
                 } else {
                     // stray point clamped into this brick (outside the scaled box): its taps go
                     // straight to HBM, one lane doing all 64; lattice_step_kernel then folds the gradient lattice in
@@ -752,7 +791,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                     for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
-                        const float w = me.w[i] * me.w[4 + j] * me.w[8 + k];
+                        const float w = wxy[4 * j + i] * wz[k];
                         float *dst = reinterpret_cast<float *>(gimg + ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)));
                         atomicAdd(dst + 0, w * sm.x); atomicAdd(dst + 1, w * sm.y);
                         atomicAdd(dst + 2, w * sm.z); atomicAdd(dst + 3, w * sm.w);
@@ -760,46 +799,83 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                 }
             }
         }
-        // compact the contributing points to the front of the scratch (order kept)
-        const unsigned long long live = __ballot(me.base >= 0);
+        // the contributing points go to the front of the scratch (order kept)
+        const unsigned long long live = __ballot(base >= 0);
         const int n_live = __popcll(live);
-        if (me.base >= 0) pts[__popcll(live & ((1ull << lane) - 1ull))] = me;
+        if (base >= 0) {
+            const int slot = __popcll(live & ((1ull << lane) - 1ull));
+            #pragma unroll
+            for (int k = 0; k < 16; k++) sc.wxy[k][slot] = wxy[k];
+            #pragma unroll
+            for (int k = 0; k < 4; k++) sc.wz[k][slot] = wz[k];
+            sc.sm[slot] = sm;
+            sc.base[slot] = base;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef FROG_SCATTER_TRACE
+        const unsigned long long tb2 = wall_clock64();
+#endif
 
-        // ---- phase 2: lane = tap.  The point's weights are read with lane-constant offsets
-        // (wx[ti], wy[tj], wz[tk]); the next point's values are fetched while this one is used.
-        float wx = 0, wy = 0, wz = 0;
-        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-        int qb = -1;
-        if (n_live > 0) {
-            const ScatterPoint &c = pts[0];
-            wx = c.w[ti]; wy = c.w[4 + tj]; wz = c.w[8 + tk];
-            sm = make_float4(c.sx, c.sy, c.sz, c.sw); qb = c.base;
+        // ---- phase 2: lane = tap (i + 4 j + 16 k); per point two lane-constant reads (wxy[i + 4 j], wz[k]) and one
+        // broadcast (the sums), w = (wx wy) wz (imageGroup.cxx:322) and the four products added into REGISTERS: points
+        // are sorted by cell, so consecutive points mostly share their 64 tap addresses and the LDS tile is touched (one
+        // ds_read_b128 + ds_write_b128, no atomic: the 64 taps are 64 distinct control points and the tile is private)
+        // only when the cell changes -- bit q of `chg`, known before the loop.
+        unsigned long long chg;
+        {
+            const int mine = lane < n_live ? sc.base[lane] : -1;
+            const int before = lane == 0 ? run_base : (lane < n_live ? sc.base[lane - 1] : -1);
+            chg = __ballot(lane < n_live && mine != before);
         }
-        for (int q = 0; q < n_live; q++) {
-            const float cwx = wx, cwy = wy, cwz = wz;
-            const float4 csm = sm;
-            const int cb = qb;
-            if (q + 1 < n_live) {
-                const ScatterPoint &c = pts[q + 1];
-                wx = c.w[ti]; wy = c.w[4 + tj]; wz = c.w[8 + tk];
-                sm = make_float4(c.sx, c.sy, c.sz, c.sw); qb = c.base;
-            }
-            const float w = cwx * cwy * cwz;                // imageGroup.cxx:322
-            if (cb != run_base) {                          // wave-uniform: cell changed -> spill the run
+        float rwxy[SC_RING], rwz[SC_RING];
+        float4 rsm[SC_RING];
+        const float *lane_wxy = sc.wxy[lane & 15], *lane_wz = sc.wz[lane >> 4];
+        auto fetch = [&](int q, int slot) __attribute__((always_inline)) {
+            rwxy[slot] = lane_wxy[q];
+            rwz[slot] = lane_wz[q];
+            rsm[slot] = sc.sm[q];
+        };
+        auto add_point = [&](int q, int slot) __attribute__((always_inline)) {
+            if ((chg >> q) & 1ull) {                               // wave-uniform: cell changed -> spill the run
                 if (run_base >= 0) {
                     float4 t = tile[run_base + tap_off];
                     t.x += run.x; t.y += run.y; t.z += run.z; t.w += run.w;
                     tile[run_base + tap_off] = t;
                 }
                 run = make_float4(0.f, 0.f, 0.f, 0.f);
-                run_base = cb;
+                run_base = __builtin_amdgcn_readfirstlane(sc.base[q]);
             }
+            const float w = rwxy[slot] * rwz[slot];
+            const float4 csm = rsm[slot];
             run.x += w * csm.x; run.y += w * csm.y; run.z += w * csm.z; run.w += w * csm.w;
+        };
+        #pragma unroll
+        for (int j = 0; j < SC_AHEAD; j++) fetch(j, j);
+        const int n_full = n_live & ~(SC_RING - 1);
+        for (int q0 = 0; q0 < n_full; q0 += SC_RING) {
+            #pragma unroll
+            for (int j = 0; j < SC_RING; j++) {
+                fetch(q0 + j + SC_AHEAD, (j + SC_AHEAD) % SC_RING);
+                add_point(q0 + j, j);
+            }
         }
+        #pragma unroll
+        for (int j = 0; j < SC_RING - 1; j++)                       // the last n_live % 4 points: fetched by the last full trip
+            if (n_full + j < n_live) add_point(n_full + j, j);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef FROG_SCATTER_TRACE
+        {
+            const unsigned long long tb3 = wall_clock64();
+            tr_load += __builtin_amdgcn_readfirstlane((unsigned)(tb1 - tb0));
+            tr_p1 += __builtin_amdgcn_readfirstlane((unsigned)(tb2 - tb1));
+            tr_p2 += __builtin_amdgcn_readfirstlane((unsigned)(tb3 - tb2));
+        }
+#endif
+        p_cur = p_nxt; p_nxt = p_far; v_cur = v_nxt;
+        #pragma unroll
+        for (int q = 0; q < N_XCD; q++) part_cur[q] = part_nxt[q];
     }
     if (run_base >= 0) {
         float4 t = tile[run_base + tap_off];
@@ -815,6 +891,18 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     // inlier threshold a few iterations later)
     float4 *dst = stage + (size_t)blk.slot * n_tile;
     for (int k = lane; k < n_tile; k += 64) dst[k] = tile[k];
+#ifdef FROG_SCATTER_TRACE
+    if (lane == 0 && blockIdx.x < 65536) {
+        unsigned int hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_scatter_trace[4 * blockIdx.x + 0] = trace_t0;
+        g_scatter_trace[4 * blockIdx.x + 1] = wall_clock64();
+        g_scatter_trace[4 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_scatter_trace[4 * blockIdx.x + 3] = (unsigned long long)(blk.end - blk.begin) | ((unsigned long long)(tr_load & 0xFFFF) << 16)
+                                              | ((unsigned long long)(tr_p1 & 0xFFFF) << 32) | ((unsigned long long)(tr_p2 & 0xFFFF) << 48);
+    }
+#endif
 }
 
 // ---- K7 (flush) + K8 + K9 in one launch ---------------------------------------------------------------------
@@ -952,11 +1040,17 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
         __syncthreads();
     };
     if (kept) {
+        // all passes' proposals first (independent chains of loads: side by side), then the sums in image order
         #pragma unroll
         for (int pass = 0; pass < LS_KEEP; pass++) {
             const uint32_t i0 = (uint32_t)pass * LS_IC;
             if (i0 >= a.n_owned) break;                 // block-uniform
             keep[pass] = propose(i0, false);
+        }
+        #pragma unroll
+        for (int pass = 0; pass < LS_KEEP; pass++) {
+            const uint32_t i0 = (uint32_t)pass * LS_IC;
+            if (i0 >= a.n_owned) break;
             accumulate(i0, keep[pass]);
         }
     } else {
