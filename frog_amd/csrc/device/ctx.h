@@ -244,7 +244,7 @@ struct frog_ctx {
     // energy / counters
     frog::DevBuf<double> energy;              // [4]
     frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
-    frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel, [1] in lattice_step_kernel / cp_center_kernel
+    frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel
     double *h_energy = nullptr;               // pinned [4]
 
     // deformable
@@ -264,7 +264,6 @@ struct frog_ctx {
     frog::DevBuf<int> brick_box;              // [nOwned][6] box of every image's non-empty bricks
     uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
-    frog::DevBuf<unsigned long long> n_big;   // oversize-coefficient counter
     frog::DevBuf<unsigned int> stray;         // points the last scatter found outside every brick (their taps went to gradf)
     bool centered_in_a = false;               // phase A of the current step also did phase B's work (whole-group context)
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers

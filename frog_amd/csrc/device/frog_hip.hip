@@ -356,8 +356,6 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->energy_ticket.alloc(2));
     CREATE_CHECK(hipMemsetAsync(c->energy_ticket.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
-    CREATE_CHECK(c->n_big.alloc(1));
-    CREATE_CHECK(hipMemsetAsync(c->n_big.p, 0, sizeof(unsigned long long), s));
     CREATE_CHECK(c->stray.alloc(2));
     CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
@@ -1067,7 +1065,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
                 ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
         energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
-                                                           ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr);
+                                                           ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr,
+                                                           ctx->stray.p);
         if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
             hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
                                                                     ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, ctx->hl_partial.p);
@@ -1096,7 +1095,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
-        la.n_big = ctx->n_big.p; la.ticket = ctx->energy_ticket.p + 1; la.energy = ctx->energy.p;
+        la.energy = ctx->energy.p;
         ctx->centered_in_a = ctx->whole_group();
         if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
         else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
@@ -1119,7 +1118,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     // :398: the group mean is removed only when no image is fixed
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
-                                                        (double)maxD * g.spacing[2], ctx->n_big.p, ctx->energy_ticket.p + 1, ctx->energy.p);
+                                                        (double)maxD * g.spacing[2], ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->phase = 2;
     return FROG_OK;

@@ -938,8 +938,6 @@ struct LatticeStepArgs {
     uint32_t n_owned, n_images;     // n_images = 0: fixed images present, no mean removal
     float alpha;
     double lim[3];
-    unsigned long long *n_big;
-    unsigned int *ticket;
     double *energy;
 };
 
@@ -948,12 +946,10 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
 {
     __shared__ float prop[LS_IC][LS_CPB][3];
     __shared__ double mean[LS_CPB][3];
-    __shared__ unsigned int cnt_s[LS_THREADS];
     const int tid = threadIdx.x;
     const int c = tid % LS_CPB, il = tid / LS_CPB;
     const int cp = blockIdx.x * LS_CPB + c;
     const bool has_stray = *a.stray != 0u;
-    if (!CENTER && blockIdx.x == 0 && tid == 0) *a.n_big = 0ull;        // counted by cp_center_kernel, later in the stream
 
     // bricks that cover this control point (brick b holds control points b*B .. b*B + B + 2)
     const int B = g.brick, E = B + 3, n_tile = E * E * E;
@@ -1006,9 +1002,16 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
             #pragma unroll
             for (int n = 0; n < 8; n++) {
                 if (kb[n] < ke[n]) { s.x += first[n].x; s.y += first[n].y; s.z += first[n].z; s.w += first[n].w; }
-                for (uint32_t sl = kb[n] + 1; sl < ke[n]; sl++) {            // bricks of more than SCATTER_CHUNK points
-                    const float4 v = a.stage[(size_t)sl * n_tile + loc[n]];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                // bricks of more than SCATTER_CHUNK points: their further slots four at a time, the loads together (from a
+                // slot index clamped into the brick's range) and then the adds in slot order -- one load per trip made this
+                // a chain of up to 32 memory round trips per pass on the coarsest lattice (24 of a block's 29 us)
+                for (uint32_t sl = kb[n] + 1; sl < ke[n]; sl += 4) {
+                    float4 v[4];
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = a.stage[(size_t)min(sl + j, ke[n] - 1u) * n_tile + loc[n]];
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (sl + j < ke[n]) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
                 }
             }
             if (has_stray) {                    // added to what the stray points' atomics left, as the separate flush did
@@ -1083,23 +1086,11 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
             for (uint32_t img = il; img < a.n_owned; img += LS_IC) centre(img, a.grad[(size_t)img * g.n_cp + cp]);
         }
     }
-    cnt_s[tid] = cnt;
-    __syncthreads();
-    for (int h = LS_THREADS / 2; h > 0; h >>= 1) {
-        if (tid < h) cnt_s[tid] += cnt_s[tid + h];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (cnt_s[0]) atomicAdd(a.n_big, (unsigned long long)cnt_s[0]);
-        __threadfence();
-        if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {         // the last block: every other block is done
-            __threadfence();
-            a.energy[2] = (double)atomicAdd(a.n_big, 0ull);     // an integer sum: the order of the blocks does not matter
-            *a.n_big = 0ull;
-            *a.stray = 0u;
-            *a.ticket = 0u;
-        }
-    }
+    // oversize count -> energy[2] (zeroed by energy_reduce_kernel earlier in the step): integers added as f64 are exact and
+    // their order does not matter.  Hardly any wavefront has something to add; no ticket, no last block.
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += (unsigned int)__shfl_down((int)cnt, off, 64);
+    if ((tid & 63) == 0 && cnt) unsafeAtomicAdd(&a.energy[2], (double)cnt);
 }
 
 // ---- second half of K9 for contexts that own a sub-range of the images: subtract the group mean, count oversize
@@ -1110,9 +1101,8 @@ constexpr int CP_BATCH = 10;
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
-                                                        unsigned long long *n_big, unsigned int *ticket, double *energy)
+                                                        double *energy)
 {
-    __shared__ unsigned int sh[256];
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int cnt = 0;
     if (cp < n_cp) {
@@ -1135,23 +1125,11 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
             }
         }
     }
-    sh[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (sh[0]) atomicAdd(n_big, (unsigned long long)sh[0]);
-        // the block that finishes last publishes the count as a double in the energy buffer (so that one f64
-        // all-reduce carries it); an integer sum: the order of the blocks does not matter
-        __threadfence();
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            __threadfence();
-            energy[2] = (double)atomicAdd(n_big, 0ull);
-            *ticket = 0u;
-        }
-    }
+    // the count goes to energy[2] as a double (so that one f64 all-reduce carries it); energy_reduce_kernel zeroed it
+    // earlier in the step; integers added as f64 are exact, the order of the wavefronts does not matter
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += (unsigned int)__shfl_down((int)cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) unsafeAtomicAdd(&energy[2], (double)cnt);
 }
 
 } // namespace frog

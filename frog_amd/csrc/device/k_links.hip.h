@@ -488,7 +488,8 @@ constexpr int ENERGY_BLOCKS = 64;
 // order, so the result does not depend on which block that is.
 __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partial, uint32_t n, int stride, int off,
                                                             double *block_sums /*[ENERGY_BLOCKS][2]*/, unsigned int *ticket,
-                                                            double *energy, const uint32_t *list_invalid = nullptr)
+                                                            double *energy, const uint32_t *list_invalid = nullptr,
+                                                            unsigned int *stray = nullptr)
 {
     __shared__ double sh[2][256];
     __shared__ bool last;
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partia
         // fourth scalar of the per-iteration read-back: the culling list needs a rebuild (k_cull.hip.h); a sum over
         // ranks when the buffer is all-reduced, any non-zero value means the same
         energy[3] = list_invalid ? (double)list_invalid[0] : 0.0;
+        if (stray) stray[0] = 0u;           // the scatter that follows counts its stray points from 0 (k_grid.hip.h)
         *ticket = 0u;                                       // ready for the next launch (same stream: ordered)
     }
 }
