@@ -471,16 +471,15 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
-        // The tiled form pays the staging of 343 coefficients per block: measured on cfg 3, 0.081 against 0.100 ms at 1 700 and
-        // 210 points per brick (levels 0, 1), 0.119 against 0.110 ms at 80 (level 2).  Bricks of 8^3 cells (sparse lattices)
-        // would need 32 KB of LDS per wavefront.  FROG_K11_POINTWISE / FROG_K11_TILED force one form (tests).
-        const double per_brick = (double)n / ((double)ctx->n_owned() * (double)std::max(1, ctx->geom.n_bricks));
-        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE")
-                           && (per_brick >= 150.0 || getenv("FROG_K11_TILED"));
+        // The tiled form pays the staging of 343 coefficients per block; measured on cfg 3 (points per brick 1 700 / 210 / 80 at
+        // levels 0 / 1 / 2): 0.062 / 0.062 / 0.088 ms against 0.100 / 0.100 / 0.109 ms point by point.  Bricks of 8^3 cells are
+        // only chosen below 24 points per brick of 4^3 (make_geometry), where staging 1 331 coefficients per block cannot pay.
+        // FROG_K11_POINTWISE forces the other form (tests).
+        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE");
         if (tiled) {
-            // one wavefront per scatter block, the brick's coefficients in LDS as f64 (k_grid.hip.h)
+            // one wavefront per scatter block, the brick's coefficients in LDS (k_grid.hip.h)
             const GeomDev gd = to_dev(ctx->geom);
-            const size_t E = (size_t)gd.brick + 3, lds = 3 * E * E * E * sizeof(double);
+            const size_t E = (size_t)gd.brick + 3, lds = E * E * E * sizeof(float4);
             transform_bspline_tile_kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
                 ctx->pos.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,

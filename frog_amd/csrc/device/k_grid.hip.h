@@ -176,9 +176,8 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
 
 // ---- K11, tiled form: one wavefront per scatter block (image, brick, <= SCATTER_CHUNK points) -----------------
 // The thread-per-point form above issues 64 float4 tap loads per point (texture path busy 67 % of the kernel, 222
-// registers, 2 wavefronts per SIMD) and converts each of the 192 tap components to f64.  Here the brick's (B+3)^3
-// coefficients are loaded ONCE per block, converted ONCE, and kept in LDS as three f64 arrays; a point's taps are LDS
-// reads.  Same operations in the same order on the same f64 values as the form above: identical bits
+// registers, 2 wavefronts per SIMD).  Here the brick's (B+3)^3 coefficients are loaded ONCE per block and kept in LDS;
+// a point's taps are LDS reads.  Same operations in the same order on the same f64 values as the form above: identical bits
 // (tests/test_gpu_round2.py::test_tiled_transform_equals_pointwise).  A point whose f64 cell (vtkBSplineTransform floors
 // the f64 lattice coordinate) is not the f32-rounded cell it was sorted by (imageGroup.cxx:303-310 rounds the coordinate
 // to f32 first: they differ for points within one f32 ulp of a cell face) may need taps outside the tile and reads them
@@ -529,13 +528,18 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
     sorted[atomicAdd(&len_cursor[b.end - b.begin], 1u)] = b;
 }
 
-__global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
-                                                                    const uint32_t *perm, const ScatterBlock *blocks,
-                                                                    const uint32_t *n_blocks, const GeomDev g, int apply,
-                                                                    const P3 *snap, uint32_t *disp_part,
-                                                                    const float4 *proposal, const double *energy, int guarantee)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+                                   const uint32_t *perm, const ScatterBlock *blocks,
+                                   const uint32_t *n_blocks, const GeomDev g, int apply,
+                                   const P3 *snap, uint32_t *disp_part,
+                                   const float4 *proposal, const double *energy, int guarantee)
 {
-    extern __shared__ double tile64[];          // [3][(B+3)^3]: x, y, z components of the brick's coefficients
+    // the brick's (B+3)^3 coefficients as they are in memory (f32 x, y, z, pad): one ds_read_b128 per tap.  The first
+    // version kept them as three f64 arrays ("converted once"): 192 ds_read_b64 per point, and the kernel ran at the LDS's
+    // bandwidth (1.5 KB per point; 81 us).  Converting each tap again costs three v_cvt per tap on a vector unit that had
+    // time to spare.
+    extern __shared__ float4 tile4[];
     const int lane = threadIdx.x;
     if (blockIdx.x >= *n_blocks) {              // the grid is an upper bound of the block count
         if (snap && lane == 0) disp_part[blockIdx.x] = 0u;
@@ -543,8 +547,13 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
     }
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     const ScatterBlock blk = blocks[blockIdx.x];
+    // the points' indices and positions run one batch ahead of the arithmetic (one wavefront per block: nothing else hides
+    // the two memory round trips perm -> position); loads unconditional, from an index clamped into the block
+    const uint32_t s_last = blk.end - 1u;
+    uint32_t p_cur = perm[min(blk.begin + lane, s_last)];
+    uint32_t p_nxt = perm[min(blk.begin + 64 + lane, s_last)];
+    float4 v_cur = pos[p_cur];
     const int E = g.brick + 3, n_tile = E * E * E;
-    double *tx = tile64, *ty = tile64 + n_tile, *tz = tile64 + 2 * n_tile;
     const uint32_t img = blk.key / g.n_bricks;
     uint32_t bidx = blk.key - img * g.n_bricks;
     const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
@@ -557,17 +566,19 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
         const int x = cp0[0] + k % E, y = cp0[1] + (k / E) % E, z = cp0[2] + k / (E * E);
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
         if (x < dx && y < dy && z < dz) c = cf[(size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z)];
-        tx[k] = (double)c.x; ty[k] = (double)c.y; tz[k] = (double)c.z;
+        tile4[k] = c;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     uint32_t dmax = 0;
     for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
-        const uint32_t s = batch + lane;
-        if (s >= blk.end) continue;
-        const uint32_t p = perm[s];
-        const float4 v = pos[p];
+        const uint32_t p_far = perm[min(batch + 128 + lane, s_last)];
+        const float4 v_nxt = pos[p_nxt];
+        const uint32_t p = p_cur;
+        const float4 v = v_cur;
+        p_cur = p_nxt; p_nxt = p_far; v_cur = v_nxt;
+        if (batch + lane >= blk.end) continue;
         const float in[3] = { v.x, v.y, v.z };
         double F[3][4];
         int i0[3];
@@ -582,7 +593,9 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
         double disp[3] = { 0, 0, 0 };
         if (l0 >= 0 && l1 >= 0 && l2 >= 0 && l0 + 3 < E && l1 + 3 < E && l2 + 3 < E) {
             const int base = l0 + E * (l1 + E * l2);
-            #pragma unroll
+            // one z-plane of 16 taps at a time: unrolled over all 64 the compiler keeps every tap in registers (232 of them:
+            // two wavefronts per SIMD, and the LDS latency shows)
+            #pragma unroll 1
             for (int k = 0; k < 4; k++) {
                 double vz[3] = { 0, 0, 0 };
                 #pragma unroll
@@ -592,7 +605,8 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                     #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const double f = F[0][i];
-                        vy[0] = fma(tx[row + i], f, vy[0]); vy[1] = fma(ty[row + i], f, vy[1]); vy[2] = fma(tz[row + i], f, vy[2]);
+                        const float4 c = tile4[row + i];
+                        vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
                     }
                     const double f = F[1][j];
                     vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
