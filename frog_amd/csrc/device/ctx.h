@@ -261,7 +261,6 @@ struct frog_ctx {
     frog::DevBuf<unsigned char> scatter_blocks; // ScatterBlock[...] longest first (k_grid.hip.h); the count is on the device
     frog::DevBuf<unsigned char> scatter_blocks_tmp; // the same blocks in brick order
     frog::DevBuf<uint32_t> len_hist;          // [2][SCATTER_CHUNK + 1] block-length histogram, cursors
-    frog::DevBuf<int> brick_box;              // [nOwned][6] box of every image's non-empty bricks
     uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
     frog::DevBuf<unsigned int> stray;         // points the last scatter found outside every brick (their taps went to gradf)
@@ -298,6 +297,8 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> disp_part;         // per-block maxima of the points' displacement since the build (f32 bits)
     uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
+    frog::DevBuf<float> disp_allow;           // [0] displacement up to which the list stays good (cull_allow_kernel)
+    bool cull_check_due = true;               // host side: cutoffs or list changed since the stand-alone check last ran
     uint64_t cull_builds = 0;                 // statistics: lists built
     bool disp_current = false;                // disp_part holds the displacement of the CURRENT xyz2 from the snapshot
     bool disp_spec = false;                   // ... of pos2_spec (becomes current when it is published)

@@ -484,14 +484,16 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 ctx->pos.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
-                after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism);
+                after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
+                ctx->disp_allow.p, ctx->cull_state.p);
             if (with_disp) ctx->disp_n = ctx->n_scatter_blocks;
         } else {
             transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
-                                                                             ctx->opt.guarantee_diffeomorphism);
+                                                                             ctx->opt.guarantee_diffeomorphism,
+                                                                             ctx->disp_allow.p, ctx->cull_state.p);
             if (with_disp) ctx->disp_n = div_up(n, 256);
         }
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
@@ -574,6 +576,7 @@ int frog_stats_publish(frog_ctx *ctx)
     // the certified outlier cutoffs follow the mixtures (k_cull.hip.h); the check before the next sweep compares them
     // with the list's
     cull_cutoff_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p);
+    ctx->cull_check_due = true;         // the next cull_prepare recomputes the allowed displacement and runs the stand-alone check
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -837,7 +840,6 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->scatter_blocks.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
     FROG_HIP_CHECK(ctx->scatter_blocks_tmp.alloc(max_blocks * sizeof(ScatterBlock), max_blocks * sizeof(ScatterBlock) * reserve));
     FROG_HIP_CHECK(ctx->len_hist.alloc(2 * (SCATTER_CHUNK + 1)));
-    FROG_HIP_CHECK(ctx->brick_box.alloc((size_t)6 * nO));
     // tile storage: a finer level needs about as many blocks (bricks hold fewer points) but brick edge 8 instead of 4 has
     // 2.4x the tile
     FROG_HIP_CHECK(ctx->scatter_stage.alloc(max_blocks * E * E * E, max_blocks * E * E * E * std::min<size_t>(reserve, 8)));
@@ -931,8 +933,6 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     FROG_HIP_CHECK(hipMemsetAsync(ctx->len_hist.p, 0, ctx->len_hist.bytes(), s));
     brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
     FROG_HIP_CHECK(hipGetLastError());
-    brick_box_init_kernel<<<div_up(nO, 256), 256, 0, s>>>(ctx->brick_box.p, nO);
-    brick_box_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(chunks.p, n_bricks_total, gd, ctx->brick_box.p);
     rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
     if (rc) return rc;
     ScatterBlock *blk_tmp = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks_tmp.p);
@@ -991,6 +991,8 @@ static int cull_allocate(frog_ctx *ctx)
     }
     FROG_HIP_CHECK(ctx->cull_state.alloc(2));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));
+    FROG_HIP_CHECK(ctx->disp_allow.alloc(1));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->disp_allow.p, 0xFF, sizeof(float), s));        // NaN until the first list exists
     ctx->cull_need_build = true;
     return FROG_OK;
 }
@@ -1017,17 +1019,27 @@ static int cull_prepare(frog_ctx *ctx)
         ctx->cull_builds++;
         ctx->disp_n = 0;                    // the points are where the snapshot has them: no displacement to look at
         ctx->disp_current = true;
+        ctx->cull_check_due = true;
     }
     // displacement since the build: already in disp_part when the transform that produced the current xyz2 measured it
     // (launch_transform; whole-group contexts whose xyz2 nobody else writes), else one pass over all points
-    if (!(ctx->disp_current && ctx->whole_group() && !ctx->xyz2_exported)) {
+    const bool measured = ctx->disp_current && ctx->whole_group() && !ctx->xyz2_exported;
+    if (!measured) {
         uint32_t max_pts = 1;
         for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
         const dim3 grid(div_up(max_pts, CULL_BLOCK_POINTS), nI);
         cull_disp_kernel<<<grid, 256, 0, s>>>(ctx->pos2.p, ctx->pos2_snap.p, ctx->d_poff.p, ctx->disp_part.p);
         ctx->disp_n = grid.x * grid.y;
     }
-    cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI, ctx->cull_state.p);
+    // The transform that measured the displacement has already compared it with disp_allow and raised cull_state if it
+    // had to (k_grid.hip.h); the stand-alone check (which also LOWERS the flag again) runs when the cutoffs or the list
+    // have changed since, or when the displacement was measured here.  While the flag is up the host rebuilds anyway.
+    if (ctx->cull_check_due || !measured) {
+        if (ctx->cull_check_due)
+            cull_allow_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, nI, ctx->disp_allow.p);
+        cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI, ctx->cull_state.p);
+        ctx->cull_check_due = false;
+    }
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1089,7 +1101,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         // group also the mean removal and the oversize count (phase B is then empty): one launch
         Span span(ctx, FROG_K_LATTICE);
         LatticeStepArgs la{};
-        la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p; la.brick_box = ctx->brick_box.p;
+        la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p;
         la.gradf = ctx->gradf.p; la.stray = ctx->stray.p;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images

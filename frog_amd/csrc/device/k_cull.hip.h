@@ -199,6 +199,31 @@ __global__ __launch_bounds__(256) void cull_disp_kernel(const P3 *pos2, const P3
     if (threadIdx.x == 0) disp_part[blockIdx.y * gridDim.x + blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 }
 
+// allow[0] = the largest displacement D (of any point, since the list was built) for which the list is still good:
+// the condition of cull_validate_kernel below solved for D,  min over images of (cut_list 0.99999 - cut_now 1.0001 - 0.01) / 2
+// (images without a cutoff, cut_now = cut_list = inf, allow anything).  Recomputed whenever the mixtures or the list change;
+// the B-spline transform, which measures the displacement of its own block of points anyway, compares with it and raises
+// state[0] itself -- the stand-alone check then only runs when the cutoffs have changed.  One block.
+__global__ __launch_bounds__(256) void cull_allow_kernel(const float *cut_now, const float *cut_list, uint32_t n_images, float *allow)
+{
+    __shared__ float sh[256];
+    float a = __builtin_inff();
+    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
+        const float now = cut_now[i], list = cut_list[i];
+        if (now == __builtin_inff() && list == __builtin_inff()) continue;
+        const float v = 0.5f * (list * 0.99999f - (now * 1.0001f + 0.01f));
+        a = (v < a) ? v : (v == v ? a : -1.0f);                 // NaN: nothing is allowed
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] = fminf(sh[threadIdx.x], sh[threadIdx.x + h]);
+        __syncthreads();
+    }
+    // a shade below the exact bound: the validate kernel adds 2 D in f32, this one divides by 2 -- one ulp of slack
+    if (threadIdx.x == 0) allow[0] = sh[0] - fabsf(sh[0]) * 1e-6f;
+}
+
 // state[0] = 1 when some left-out link could have come within its images' cutoff (the sweep then walks all records
 // and the host rebuilds the list), else 0.  With D = the largest displacement of any point since the build, a left-out
 // link (d_build >= cut_list[k] for k = A or B) is now at d >= cut_list[k] - 2 D, so the list is good while

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
                                                                 const P3 *snap, uint32_t *disp_part,
-                                                                const float4 *proposal, const double *energy, int guarantee)
+                                                                const float4 *proposal, const double *energy, int guarantee,
+                                                                const float *disp_allow, uint32_t *cull_state)
 {
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
@@ -170,7 +171,13 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
         for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) disp_part[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+        if (threadIdx.x == 0) {
+            const uint32_t mb = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+            disp_part[blockIdx.x] = mb;
+            // beyond what the culling list allows (k_cull.hip.h cull_allow_kernel; NaN compares false): the next sweep
+            // walks every record and the host rebuilds the list.  Hardly ever taken: no contention.
+            if (!(__uint_as_float(mb) <= *disp_allow)) atomicOr(cull_state, 1u);
+        }
     }
 }
 
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                                                                     const uint32_t *perm, const ScatterBlock *blocks,
                                                                     const uint32_t *n_blocks, const GeomDev g, int apply,
                                                                     const P3 *snap, uint32_t *disp_part,
-                                                                    const float4 *proposal, const double *energy, int guarantee);
+                                                                    const float4 *proposal, const double *energy, int guarantee,
+                                                                    const float *disp_allow, uint32_t *cull_state);
 
 // ---- K13: bounding box of the owned xyz (getBoundingBox, imageGroup.cxx:1513) ----
 // doubles of floats are exact, min/max are order independent -> deterministic.
@@ -466,30 +474,6 @@ __global__ void brick_chunks_kernel(const uint32_t *ptr, uint32_t n_bricks_total
     chunks[k] = (n + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
 }
 
-// box[img] = smallest box of brick coordinates (min xyz, max xyz) that holds every non-empty brick of the image: outside
-// it the image has no point within two cells, so lattice_step_kernel need not look any tile up there (a group whose
-// images cover a fifth of the common box each -- cfg 5 before registration -- skips three quarters of its look-ups).
-__global__ void brick_box_init_kernel(int *box, uint32_t n_owned)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_owned) return;
-    box[6 * i] = box[6 * i + 1] = box[6 * i + 2] = 0x7FFFFFFF;
-    box[6 * i + 3] = box[6 * i + 4] = box[6 * i + 5] = -1;
-}
-
-__global__ void brick_box_kernel(const uint32_t *chunks, uint32_t n_bricks_total, const GeomDev g, int *box)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_bricks_total || chunks[k] == 0u) return;
-    const uint32_t img = k / g.n_bricks;
-    uint32_t b = k - img * g.n_bricks;
-    const int bx = b % g.nbricks[0]; b /= g.nbricks[0];
-    const int by = b % g.nbricks[1];
-    const int bz = b / g.nbricks[1];
-    atomicMin(&box[6 * img], bx); atomicMin(&box[6 * img + 1], by); atomicMin(&box[6 * img + 2], bz);
-    atomicMax(&box[6 * img + 3], bx); atomicMax(&box[6 * img + 4], by); atomicMax(&box[6 * img + 5], bz);
-}
-
 // blocks in brick order + histogram of their lengths (len_hist[SCATTER_CHUNK + 1], zeroed by the caller)
 __global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr, uint32_t n_bricks_total, uint32_t keys_per_brick,
                                   ScatterBlock *blocks, uint32_t *len_hist)
@@ -533,7 +517,8 @@ void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                    const uint32_t *perm, const ScatterBlock *blocks,
                                    const uint32_t *n_blocks, const GeomDev g, int apply,
                                    const P3 *snap, uint32_t *disp_part,
-                                   const float4 *proposal, const double *energy, int guarantee)
+                                   const float4 *proposal, const double *energy, int guarantee,
+                                   const float *disp_allow, uint32_t *cull_state)
 {
     // the brick's (B+3)^3 coefficients as they are in memory (f32 x, y, z, pad): one ds_read_b128 per tap.  The first
     // version kept them as three f64 arrays ("converted once"): 192 ds_read_b64 per point, and the kernel ran at the LDS's
@@ -654,7 +639,10 @@ void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
     if (snap) {                                 // all 64 lanes are back together here
         #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
-        if (lane == 0) disp_part[blockIdx.x] = dmax;
+        if (lane == 0) {
+            disp_part[blockIdx.x] = dmax;
+            if (!(__uint_as_float(dmax) <= *disp_allow)) atomicOr(cull_state, 1u);      // see transform_bspline_kernel
+        }
     }
 }
 
@@ -943,7 +931,6 @@ static_assert(LS_THREADS <= 1024 && 3 * LS_CPB <= LS_THREADS, "lattice_step_kern
 struct LatticeStepArgs {
     const float4 *stage;            // staged scatter tiles
     const uint32_t *brick_slot_ptr;
-    const int *brick_box;           // [n_owned][6] box of the image's non-empty bricks (brick coordinates)
     float4 *gradf;                  // only read (and cleared) when *stray != 0
     unsigned int *stray;            // number of stray points of the last scatter
     const float4 *coeff;
@@ -992,9 +979,9 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
             const size_t o = (size_t)img * g.n_cp + cp;
             const float4 c4 = a.coeff[o];                       // needed last, asked for first
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int *bb = a.brick_box + 6 * (size_t)img;      // the same 24 bytes for the 16 lanes of an image
-            const int x0 = max(lo[0], bb[0]), y0 = max(lo[1], bb[1]), z0 = max(lo[2], bb[2]);
-            const int x1 = min(hi[0], bb[3]), y1 = min(hi[1], bb[4]), z1 = min(hi[2], bb[5]);
+            // (a per-image box of the non-empty bricks used to trim the candidates: one more memory round trip in front of
+            // the slot ranges, for look-ups that an empty range answers just as well -- slower on every lattice measured)
+            const int x0 = lo[0], y0 = lo[1], z0 = lo[2], x1 = hi[0], y1 = hi[1], z1 = hi[2];
             // At most two bricks per axis cover a node (E = B + 3 <= 2 B).  The eight candidates in (z, y, x) order; their
             // slot ranges, then the first tile of each, are fetched side by side (this used to be a chain of dependent
             // loads per candidate: the kernel spent its time waiting), the sums are then formed in the fixed order.
