@@ -298,6 +298,7 @@ struct frog_ctx {
     uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
     frog::DevBuf<float> disp_allow;           // [0] displacement up to which the list stays good (cull_allow_kernel)
+    bool build_in_sweep = false;              // host side: the sweep of this step also writes the list (k_links.hip.h BUILD)
     bool cull_check_due = true;               // host side: cutoffs or list changed since the stand-alone check last ran
     uint64_t cull_builds = 0;                 // statistics: lists built
     bool disp_current = false;                // disp_part holds the displacement of the CURRENT xyz2 from the snapshot

@@ -92,6 +92,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
     a.act_recs = nullptr; a.act_cnt = nullptr; a.cull_state = nullptr;
+    a.cut_list = nullptr; a.build_recs = nullptr; a.build_cnt = nullptr;
     return a;
 }
 
@@ -101,9 +102,12 @@ static bool cull_active(const frog_ctx *ctx)
     return ctx->cull_enabled && ctx->deformable && ctx->opt.inlier_threshold >= 1e-3f && ctx->n_tiles > 0;
 }
 
+// the narrow deformable sweep can write the culling list while it walks every record (k_links.hip.h BUILD)
+static bool sweep_builds_list(const frog_ctx *ctx) { return ctx->rec_format.narrow != 0; }
+
 template <int MODE>
 static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr,
-                         bool use_list = false)
+                         bool use_list = false, bool build_list = false)
 {
     uint32_t widest = 0;
     for (uint32_t g = 0; g < ctx->n_groups; g++) widest = std::max(widest, ctx->group_begin[g + 1] - ctx->group_begin[g]);
@@ -117,7 +121,15 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
         args.cull_state = ctx->cull_state.p;
     }
     const dim3 grid(sweep_blocks(ctx)), block(256);
-    const size_t lds = (size_t)args.lds_images * (sizeof(EmDerived) + sizeof(uint32_t));
+    const size_t lds = (size_t)args.lds_images * (sizeof(EmDerived) + sizeof(uint32_t) + sizeof(float));
+    if constexpr (MODE == SWEEP_DEFORMABLE) {
+        if (build_list && sweep_builds_list(ctx)) {
+            args.act_recs = nullptr; args.act_cnt = nullptr;         // walks every record
+            args.cut_list = ctx->cut_list.p; args.build_recs = ctx->act_recs32.p; args.build_cnt = ctx->act_cnt.p;
+            hipExtLaunchKernelGGL((sweep_kernel<SWEEP_DEFORMABLE, true, false, true>), grid, block, lds, s, ea, eb, 0, args);
+            return;
+        }
+    }
     if (ctx->rec_format.narrow)                 // implies a group of at most 2^img_bits <= EMD_LDS_IMAGES images
         hipExtLaunchKernelGGL((sweep_kernel<MODE, true, false>), grid, block, lds, s, ea, eb, 0, args);
     else if (widest <= (uint32_t)EMD_LDS_IMAGES)
@@ -1008,13 +1020,18 @@ static int cull_prepare(frog_ctx *ctx)
     if (ctx->cull_need_build) {
         cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->cull_scale, ctx->cull_pad, ctx->cut_list.p);
         FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2_snap.p, ctx->pos2.p, ctx->P * sizeof(P3), hipMemcpyDeviceToDevice, s));
-        const SweepArgs args = sweep_args(ctx, 0);
-        const dim3 grid(sweep_blocks(ctx), ctx->n_sub);
-        if (ctx->rec_format.narrow)
-            cull_build_kernel<false><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs32.p, ctx->act_cnt.p);
-        else
-            cull_build_kernel<true><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs.p, ctx->act_cnt.p);
-        FROG_HIP_CHECK(hipGetLastError());
+        // the list itself: written by the sweep this call prepares (it walks every record anyway: k_links.hip.h BUILD), or,
+        // for the record formats that sweep does not cover, by a pass of its own
+        ctx->build_in_sweep = sweep_builds_list(ctx) && !getenv("FROG_CULL_BUILD_PASS");
+        if (!ctx->build_in_sweep) {
+            const SweepArgs args = sweep_args(ctx, 0);
+            const dim3 grid(sweep_blocks(ctx), ctx->n_sub);
+            if (ctx->rec_format.narrow)
+                cull_build_kernel<false><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs32.p, ctx->act_cnt.p);
+            else
+                cull_build_kernel<true><<<grid, 256, 0, s>>>(args, ctx->cut_list.p, ctx->act_recs.p, ctx->act_cnt.p);
+            FROG_HIP_CHECK(hipGetLastError());
+        }
         ctx->cull_need_build = false;
         ctx->cull_builds++;
         ctx->disp_n = 0;                    // the points are where the snapshot has them: no displacement to look at
@@ -1055,6 +1072,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     const uint32_t nO = ctx->n_owned();
     // the gradient lattice proper lives in the staged tiles of the scatter; `gradf` only receives stray points (Fill(0), :249)
     const bool culled = cull_active(ctx);
+    ctx->build_in_sweep = false;
     if (culled) {
         Span span(ctx, FROG_K_CULL);
         int rc = cull_prepare(ctx);
@@ -1063,7 +1081,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     {
         Span span(ctx, FROG_K_SWEEP_DEFORMABLE, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
-            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr, culled);
+            launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr, culled,
+                                           ctx->build_in_sweep);
     }
     FROG_HIP_CHECK(hipGetLastError());
     {

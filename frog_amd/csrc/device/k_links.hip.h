@@ -72,6 +72,11 @@ struct SweepArgs {
     const void *act_recs;       // the listed records, same offsets and storage as `recs`
     const uint32_t *act_cnt;    // [n_tiles][n_groups] listed records per range | CULL_DUP_BIT
     const uint32_t *cull_state; // [0] != 0: the list is not valid for the current coordinates -> walk every record
+    // BUILD launches (the sweep that walks every record also writes the next list, k_cull.hip.h): per-image list cutoffs
+    // and the list's storage
+    const float *cut_list;
+    void *build_recs;
+    uint32_t *build_cnt;
 };
 
 // The sweep is bound by vector-instruction issue (rocprofv3), and the compiler's generic
@@ -184,9 +189,13 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // be LDS or global compiles to a flat load, whose completion can only be awaited with
 // vmcnt(0) -- which would also wait for the gathers just issued for later steps.
 // WIDE: 8-byte records (ctx.h LinkRec); otherwise the 4-byte form.
-template <int MODE, bool EMD_LDS, bool WIDE>
+// BUILD (deformable sweep, narrow records): while walking EVERY record of its range the wavefront also writes the culling
+// list for the coordinates it reads -- what cull_build_kernel does in a pass of its own (0.6 ms for 1e8 records: a record,
+// two coordinates and a distance per half-link, all of which this kernel has in hand anyway).
+template <int MODE, bool EMD_LDS, bool WIDE, bool BUILD = false>
 __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 {
+    static_assert(!BUILD || (MODE == SWEEP_DEFORMABLE && EMD_LDS && !WIDE), "the list is built by the narrow deformable sweep");
     // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
     // reference's (imageGroup.cxx:256-257), plus one ownership word per point
     __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
@@ -207,6 +216,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     extern __shared__ __align__(16) unsigned char sweep_dyn_lds[];
     EmDerived *emd_s = reinterpret_cast<EmDerived *>(sweep_dyn_lds);
     uint32_t *img_base_s = reinterpret_cast<uint32_t *>(sweep_dyn_lds + (size_t)a.lds_images * sizeof(EmDerived));   // narrow records: first point of the group's images
+    float *cut_s = reinterpret_cast<float *>(img_base_s + a.lds_images);      // BUILD: list cutoff of the group's images
+    __shared__ uint32_t last_step_s[BUILD ? 4 * TILE_POINTS : 1];             // BUILD: see cull_build_kernel
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -262,7 +273,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
     if (!WIDE)
         for (uint32_t k = threadIdx.x; k < a.lds_images; k += 256) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
+    uint32_t *last_step = last_step_s + (BUILD ? wave * TILE_POINTS : 0);
+    if constexpr (BUILD) {
+        for (uint32_t k = threadIdx.x; k < a.lds_images; k += 256) cut_s[k] = k < g_count ? a.cut_list[g_first + k] : 0.f;
+        for (int k = lane; k < TILE_POINTS; k += 64) last_step[k] = 0xFFFFFFFFu;
+    }
     __syncthreads();
+    const float cutA = BUILD ? a.cut_list[image] : 0.f;
+    uint32_t built = 0;                 // BUILD: records listed so far
+    bool dup = false;                   //        some step of the list holds one point twice
 
     const EmDerived eA = a.emd[image];
 
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
     #pragma unroll
     for (int k = 0; k < PT_RING; k++) pbq[k] = (k < PT_AHEAD) ? gather((k & 1) ? cq[k / 2].y : cq[k / 2].x) : P3{ 0.f, 0.f, 0.f };
 
-    auto step = [&](const Rec rq, const P3 pb, auto elect_c) __attribute__((always_inline)) {
+    auto step = [&](const Rec rq, const P3 pb, auto elect_c, const bool valid) __attribute__((always_inline)) {
         constexpr bool ELECT = decltype(elect_c)::value;
         const uint32_t ia = own_of(rq);                 // own point inside the tile
         const P3 pa = { px[ia], px[ia + PLANE], px[ia + 2 * PLANE] };
@@ -319,6 +338,20 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
+        if constexpr (BUILD) {
+            // cull_build_kernel's criterion and compaction, on the distance this step has just formed (all 64 lanes are here:
+            // `valid` = the lane holds a record of the range)
+            const float cut = fminf(cutA, cut_s[img_of(rq)]);
+            const bool keep = valid && d2 < cut * cut;      // NaN or inf distance: left out, and an outlier below too
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const uint32_t to = built + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                reinterpret_cast<Rec *>(a.build_recs)[(size_t)rec_lo + (to / REC_CHUNK) * REC_CHUNK + (to % 64u) * 2u + (to % REC_CHUNK) / 64u] = rq;
+                dup |= atomicExch(&last_step[ia], to >> 6) == (to >> 6);
+            }
+            built += (uint32_t)__popcll(m);
+            if (!valid) return;
+        }
         float w = fminf(inlier_probability(d2, eA), inlier_probability(d2, eB));
         if constexpr (MODE != SWEEP_LINEAR) {
             // the threshold decision is taken on the reference's own arithmetic when it is close
@@ -395,7 +428,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
                     const Chunk ahead = cq[((j + PT_AHEAD) / 2) % CHUNK_RING];
                     pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
                 }
-                if (r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING], elect_c);
+                if (BUILD || r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING], elect_c, r < rec_n);
             }
         }
     };
@@ -413,6 +446,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         if (lane == 0 && live) {
             a.tile_partial[((size_t)t * a.n_groups + grp) * 2] = v0;
             a.tile_partial[((size_t)t * a.n_groups + grp) * 2 + 1] = v1;
+        }
+        if constexpr (BUILD) {
+            const bool any_dup = __ballot(dup) != 0ull;
+            if (lane == 0 && live) a.build_cnt[(size_t)t * a.n_groups + grp] = built | (any_dup ? CULL_DUP_BIT : 0u);
         }
         __syncthreads();
         typedef float v4f __attribute__((ext_vector_type(4)));
