@@ -486,8 +486,11 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         // The tiled form pays the staging of 343 coefficients per block; measured on cfg 3 (points per brick 1 700 / 210 / 80 at
         // levels 0 / 1 / 2): 0.062 / 0.062 / 0.088 ms against 0.100 / 0.100 / 0.109 ms point by point.  Bricks of 8^3 cells are
         // only chosen below 24 points per brick of 4^3 (make_geometry), where staging 1 331 coefficients per block cannot pay.
-        // FROG_K11_POINTWISE forces the other form (tests).
-        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE");
+        // A block is one wavefront walking up to SCATTER_CHUNK points: below about a million points (one rank of eight of cfg 3:
+        // 240 000) there are too few of them to fill the chip and the thread-per-point form wins (16 against 29 us).
+        // FROG_K11_POINTWISE / FROG_K11_TILED force one form (tests).
+        const bool tiled = ctx->n_scatter_blocks > 0 && ctx->geom.brick == 4 && !getenv("FROG_K11_POINTWISE")
+                           && (n >= 1000000u || getenv("FROG_K11_TILED"));
         if (tiled) {
             // one wavefront per scatter block, the brick's coefficients in LDS (k_grid.hip.h)
             const GeomDev gd = to_dev(ctx->geom);
