@@ -42,7 +42,9 @@ def main():
         for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
             tot = collections.defaultdict(lambda: [0.0, 0])
             for r in csv.DictReader(open(f)):
-                if short(r["Kernel_Name"]).startswith("sweep_kernel<1") and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                # the launch that also writes the culling list (last template argument true: once per list) is not the steady state
+                if (short(r["Kernel_Name"]).startswith("sweep_kernel<1") and not short(r["Kernel_Name"]).rstrip().endswith(", true>")
+                        and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")):
                     tot[r["Counter_Name"]][0] += float(r["Counter_Value"]); tot[r["Counter_Name"]][1] += 1
             if "FETCH_SIZE" in tot: fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1]
             if "WRITE_SIZE" in tot: write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1]
