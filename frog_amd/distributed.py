@@ -310,6 +310,7 @@ class ShardedImageGroup:
         # comm_summary(); costs two event records per collective, so only on request
         self.time_comm = False
         self._comm_events = []
+        self._comm_calls = {}
         self.comm_ms = {}
         # ncclAllGather's in-place form (send buffer = this rank's slice of the receive buffer) is what the RCCL path uses;
         # gloo gets a private copy of the rank's rows
@@ -319,8 +320,15 @@ class ShardedImageGroup:
     def multi(self):
         return self.world_size > 1
 
+    COMM_SAMPLE = 8         # every eighth collective of a kind is timed (two event records each: at 8 GPUs an iteration
+                            # is 0.3 ms and has three collectives -- timing all of them would be a tenth of what it measures)
+
     def _collective(self, kind, fn):
         if not self.time_comm:
+            return fn()
+        n = self._comm_calls.get(kind, 0)
+        self._comm_calls[kind] = n + 1
+        if n % self.COMM_SAMPLE:
             return fn()
         a = self._torch.cuda.Event(enable_timing=True); b = self._torch.cuda.Event(enable_timing=True)
         a.record()
@@ -329,12 +337,17 @@ class ShardedImageGroup:
         self._comm_events.append((kind, a, b))
 
     def comm_summary(self):
-        """{collective kind: {"ms": total device ms, "calls": n}} since the last call (synchronises)."""
+        """{collective kind: {"sampled_ms": device ms of the timed calls, "sampled": how many were timed, "calls": all of
+        them, "avg_ms", "est_total_ms" = avg_ms * calls}} (synchronises)."""
         self._torch.cuda.synchronize()
         for kind, a, b in self._comm_events:
-            e = self.comm_ms.setdefault(kind, {"ms": 0.0, "calls": 0})
-            e["ms"] += a.elapsed_time(b); e["calls"] += 1
+            e = self.comm_ms.setdefault(kind, {"sampled_ms": 0.0, "sampled": 0})
+            e["sampled_ms"] += a.elapsed_time(b); e["sampled"] += 1
         self._comm_events = []
+        for kind, e in self.comm_ms.items():
+            e["calls"] = self._comm_calls.get(kind, 0)
+            e["avg_ms"] = e["sampled_ms"] / max(1, e["sampled"])
+            e["est_total_ms"] = e["avg_ms"] * e["calls"]
         return self.comm_ms
 
     # -- the six methods -----------------------------------------------------------
