@@ -227,6 +227,7 @@ struct frog_ctx {
     // other buffer of this pair.
     frog::DevBuf<uint32_t> sample_ord[2];     // [nOwned][cap]
     frog::DevBuf<uint32_t> sample_count[2];   // [nOwned]
+    frog::DevBuf<uint2> sample_ends[2];       // [nOwned][cap] (own point, partner point) of every kept half-link, internal numbering
     int sel_ready = 0;                        // buffer the pending/ready selection is written to
     int sel_used = 0;                         // buffer the last refresh consumed
     hipStream_t side = nullptr;

@@ -337,6 +337,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->samples.alloc((size_t)c->n_owned() * cap));
     for (int b = 0; b < 2; b++) {
         CREATE_CHECK(c->sample_ord[b].alloc((size_t)c->n_owned() * cap));
+        CREATE_CHECK(c->sample_ends[b].alloc((size_t)c->n_owned() * cap));
         CREATE_CHECK(c->sample_count[b].alloc(c->n_owned()));
         CREATE_CHECK(hipMemsetAsync(c->sample_count[b].p, 0, c->sample_count[b].bytes(), s));
         CREATE_CHECK(hipEventCreateWithFlags(&c->ord_read[b], hipEventDisableTiming));
@@ -405,6 +406,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     // selection of the first refresh, ahead of time
     c->sel_ready = 0; c->sel_used = 1;
     select_kernel<<<c->n_owned(), SELECT_THREADS, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
+    sample_resolve_kernel<<<dim3(div_up(cap, 256), c->n_owned()), 256, 0, c->side>>>(
+        c->sample_ord[0].p, c->sample_count[0].p, cap, c->d_poff.p, c->ib, c->own_pt_begin,
+        c->ref_rowptr.p, c->ref_link.p, c->new_of_old.p, c->sample_ends[0].p);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipEventRecord(c->sel_done, c->side));
 #undef CREATE_CHECK
@@ -556,8 +560,7 @@ int frog_update_stats_local(frog_ctx *ctx)
     {
         Span span(ctx, FROG_K_STATS);
         sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
-            ctx->sample_ord[cur].p, ctx->sample_count[cur].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
-            ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->pos2.p, ctx->samples.p);
+            ctx->sample_ends[cur].p, ctx->sample_count[cur].p, cap, ctx->pos2.p, ctx->samples.p);
         FROG_HIP_CHECK(hipGetLastError());
         const bool em_serial = getenv("FROG_EM_SERIAL") != nullptr;            // test hook: the term-by-term form
         if (em_serial)
@@ -574,6 +577,9 @@ int frog_update_stats_local(frog_ctx *ctx)
     const int nxt = cur ^ 1;
     FROG_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ord_read[nxt], 0));
     select_kernel<<<nO, SELECT_THREADS, 0, ctx->side>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p);
+    sample_resolve_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, ctx->side>>>(
+        ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
+        ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->sample_ends[nxt].p);
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipEventRecord(ctx->sel_done, ctx->side));
     ctx->sel_ready = nxt;

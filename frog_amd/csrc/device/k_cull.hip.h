@@ -72,7 +72,7 @@ __global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float th
                 found = mixture_probability(hi, c1, c2, r) <= target;
             }
             if (found) {
-                for (int k = 0; k < 64; k++) {
+                for (int k = 0; k < 32; k++) {           // from a factor-two bracket: 2^-32 relative, the result is stored as f32 (`hi`: certified side)
                     const double mid = 0.5 * (lo + hi);
                     if (mixture_probability(mid, c1, c2, r) <= target) hi = mid; else lo = mid;
                 }

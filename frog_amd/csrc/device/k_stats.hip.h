@@ -137,13 +137,15 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
     if (tid == 0) { st[MT_N] = idx; sample_count[img] = count; }
 }
 
-// K1: distance of every kept half-link (imageGroup.cxx:579-590), thread per slot.
-// ordinal -> owning point by binary search in the reference-order row pointers.
-__global__ __launch_bounds__(256) void sample_distance_kernel(
+// K1: distance of every kept half-link (imageGroup.cxx:579-590), thread per slot, in two parts.  Which half-links a
+// refresh keeps does not depend on the data, so neither do their end points: sample_resolve_kernel turns every kept
+// ordinal into (own point, partner point) -- a binary search of 15 dependent loads in the reference-order row pointers --
+// on the side stream, right behind the selection; what is left on the critical path is two gathers and a distance
+// (62 -> 15 us per refresh).
+__global__ __launch_bounds__(256) void sample_resolve_kernel(
     const uint32_t *sample_ord, const uint32_t *sample_count, uint32_t cap,
     const uint32_t *poff, uint32_t image_begin, uint32_t own_pt_begin,
-    const uint64_t *ref_rowptr, const uint32_t *ref_link, const uint32_t *new_of_old,
-    const P3 *pos2, float *samples)
+    const uint64_t *ref_rowptr, const uint32_t *ref_link, const uint32_t *new_of_old, uint2 *sample_ends)
 {
     const uint32_t img = blockIdx.y;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,8 +159,19 @@ __global__ __launch_bounds__(256) void sample_distance_kernel(
         uint32_t mid = (lo + hi) >> 1;
         if (ref_rowptr[mid] <= l) lo = mid; else hi = mid;
     }
-    const P3 a = pos2[new_of_old[lo]];              // rows are in reference order, coordinates in internal order
-    const P3 b = pos2[ref_link[l]];
+    // rows are in reference order, coordinates in internal order
+    sample_ends[(size_t)img * cap + slot] = make_uint2(new_of_old[lo], ref_link[l]);
+}
+
+__global__ __launch_bounds__(256) void sample_distance_kernel(const uint2 *sample_ends, const uint32_t *sample_count, uint32_t cap,
+                                                              const P3 *pos2, float *samples)
+{
+    const uint32_t img = blockIdx.y;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= sample_count[img]) return;
+    const uint2 ends = sample_ends[(size_t)img * cap + slot];
+    const P3 a = pos2[ends.x];
+    const P3 b = pos2[ends.y];
     // vtkMath::Distance2BetweenPoints(pA, pB), f32
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     samples[(size_t)img * cap + slot] = sqrtf(dx * dx + dy * dy + dz * dz);

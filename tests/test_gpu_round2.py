@@ -308,6 +308,22 @@ def test_culled_sweep_with_and_without_lane_election(monkeypatch):
     note("cull_many_small_images", f"ranges {ranges}, with election {elected}")
 
 
+def test_list_written_by_the_sweep_equals_the_list_of_the_build_pass(small_pairs, monkeypatch):
+    """The sweep that walks every record writes the next culling list as it goes (k_links.hip.h BUILD); the stand-alone
+    pass (cull_build_kernel, FROG_CULL_BUILD_PASS=1: what wide records still use) must list the same half-links and flag
+    the same ranges, and the runs must agree bit for bit."""
+    monkeypatch.delenv("FROG_CULL_BUILD_PASS", raising=False)
+    g1, E1, L1, S1, C1, X1 = _run_schedule(small_pairs, monkeypatch, True, skin="1.2,3.0")
+    monkeypatch.setenv("FROG_CULL_BUILD_PASS", "1")
+    g2, E2, L2, S2, C2, X2 = _run_schedule(small_pairs, monkeypatch, True, skin="1.2,3.0")
+    assert E1 == E2 and C1 == C2 and np.array_equal(S1, S2) and np.array_equal(X1, X2)
+    for a, b in zip(L1, L2):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert g1.cull_stats() == g2.cull_stats() and g1.cull_stats()[0] >= 2        # a thin skin: several lists per run
+    assert g1.cull_ranges() == g2.cull_ranges()
+
+
 def test_culling_follows_coordinates_and_mixtures_set_from_outside(small_pairs):
     """The check before every sweep looks at the coordinates and mixtures as they ARE: overwriting xyz2 or the EM
     parameters between two steps (test hooks) must not leave a stale list in use."""
