@@ -222,6 +222,7 @@ struct frog_ctx {
     frog::DevBuf<float4> em;                  // [nI] c1,c2,ratio,0
     frog::DevBuf<frog::EmDerived> emd;        // [nI]
     frog::DevBuf<float> samples;              // [nOwned][cap]
+    frog::DevBuf<unsigned char> em_guess;     // [nOwned][4][EM_GUESS_BATCHES] exponents of the EM sums' trajectories, last fit (k_stats.hip.h)
     // Which ordinals a refresh keeps does not depend on the data (k_stats.hip.h), so the
     // selection for the NEXT refresh is computed ahead of time on a side stream into the
     // other buffer of this pair.

@@ -335,6 +335,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     c->sample_cap = (int)cap;
     CREATE_CHECK(c->d_virtual.upload(c->h_virtual, s));
     CREATE_CHECK(c->samples.alloc((size_t)c->n_owned() * cap));
+    CREATE_CHECK(c->em_guess.alloc((size_t)c->n_owned() * 4 * EM_GUESS_BATCHES));
+    CREATE_CHECK(hipMemsetAsync(c->em_guess.p, 0, c->em_guess.bytes(), s));
     for (int b = 0; b < 2; b++) {
         CREATE_CHECK(c->sample_ord[b].alloc((size_t)c->n_owned() * cap));
         CREATE_CHECK(c->sample_ends[b].alloc((size_t)c->n_owned() * cap));
@@ -568,7 +570,7 @@ int frog_update_stats_local(frog_ctx *ctx)
                                          ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
         else
             em_scan_kernel<<<nO, EM_THREADS, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
-                                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+                                                     ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon, ctx->em_guess.p);
         FROG_HIP_CHECK(hipGetLastError());
     }
     FROG_HIP_CHECK(hipEventRecord(ctx->ord_read[cur], s));
@@ -1573,7 +1575,7 @@ int frog_test_em_refit(frog_ctx *ctx, int term_by_term)
                                      ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
     else
         em_scan_kernel<<<nO, EM_THREADS, 0, s>>>(ctx->samples.p, ctx->sample_count[cur].p, cap, ctx->ib, ctx->em.p,
-                                                 ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon);
+                                                 ctx->opt.stats_max_iterations, ctx->opt.stats_epsilon, nullptr);     // test hook: from cold guesses
     FROG_HIP_CHECK(hipGetLastError());
     return frog_stats_publish(ctx);
 }
