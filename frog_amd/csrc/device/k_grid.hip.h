@@ -441,8 +441,15 @@ __global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr
     const uint32_t key = perm_key[s];
     const uint32_t b = key_ptr[key], e = key_ptr[key + 1];
     const uint32_t v = perm_in[s];
-    uint32_t rank = 0;
-    for (uint32_t j = b; j < e; j++) rank += perm_in[j] < v ? 1u : 0u;
+    // (the lanes of a wavefront mostly share the cell: the loads are broadcasts, and what a coarse lattice's cells of
+    // ~130 points cost is their number -- four entries per load)
+    uint32_t rank = 0, j = b;
+    for (; j < e && (j & 3u); j++) rank += perm_in[j] < v ? 1u : 0u;
+    for (; j + 4u <= e; j += 4u) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(perm_in + j);
+        rank += (q.x < v ? 1u : 0u) + (q.y < v ? 1u : 0u) + (q.z < v ? 1u : 0u) + (q.w < v ? 1u : 0u);
+    }
+    for (; j < e; j++) rank += perm_in[j] < v ? 1u : 0u;
     perm_out[b + rank] = v;
 }
 
