@@ -265,7 +265,9 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> len_hist;          // [2][SCATTER_CHUNK + 1] block-length histogram, cursors
     uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
-    frog::DevBuf<unsigned int> stray;         // points the last scatter found outside every brick (their taps went to gradf)
+    frog::DevBuf<unsigned int> stray;         // [0], [1]: points the scatter of an even / odd step found outside every brick (their taps went to
+                                              // gradf), [2]: running total
+    uint32_t stray_parity = 0;                // which of the two the current step uses
     bool centered_in_a = false;               // phase A of the current step also did phase B's work (whole-group context)
     frog::DevBuf<long long> img_counts;       // [nOwned][2] inliers, outliers
     std::vector<double> h_img_bbox;           // [nI][6] bbox of the model xyz per image (min xyz, max xyz)

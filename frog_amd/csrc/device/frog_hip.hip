@@ -371,8 +371,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->energy_ticket.alloc(2));
     CREATE_CHECK(hipMemsetAsync(c->energy_ticket.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
-    CREATE_CHECK(c->stray.alloc(2));
-    CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 2 * sizeof(unsigned int), s));
+    CREATE_CHECK(c->stray.alloc(3));
+    CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 3 * sizeof(unsigned int), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
     em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
     CREATE_CHECK(hipGetLastError());
@@ -1083,6 +1083,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     const uint32_t nO = ctx->n_owned();
     // the gradient lattice proper lives in the staged tiles of the scatter; `gradf` only receives stray points (Fill(0), :249)
     const bool culled = cull_active(ctx);
+    bool fused_energy = false;
     ctx->build_in_sweep = false;
     if (culled) {
         Span span(ctx, FROG_K_CULL);
@@ -1105,9 +1106,14 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         if (!ctx->point_sums_stale)
             combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
                 ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
-        energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
-                                                           ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr,
-                                                           ctx->stray.p);
+        // the energy sums: by the first blocks of the scatter's launch (k_grid.hip.h), unless something between here and the
+        // scatter needs them (landmark constraints add to them) or there is no scatter to ride on
+        ctx->stray_parity ^= 1u;
+        fused_energy = ctx->n_scatter_blocks && !ctx->n_hard && !getenv("FROG_ENERGY_PASS");
+        if (!fused_energy)
+            energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, 2, 0, ctx->energy_blocks.p,
+                                                               ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr,
+                                                               ctx->stray.p);
         if (ctx->n_hard) {                                      // landmark constraints, imageGroup.cxx:280-295
             hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
                                                                     ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, ctx->hl_partial.p);
@@ -1118,12 +1124,19 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     if (ctx->n_scatter_blocks) {
         Span span(ctx, FROG_K_SCATTER);
         const size_t tile_bytes = (size_t)(gd.brick + 3) * (gd.brick + 3) * (gd.brick + 3) * sizeof(float4);
-        scatter_kernel<<<ctx->n_scatter_blocks, 64, tile_bytes, s>>>(ctx->pos.p, ctx->point_sums.p,
-                                                           ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
-                                                           ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
-                                                           reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
-                                                           ctx->brick_slot_ptr.p + (size_t)nO * gd.n_bricks,
-                                                           ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p, gd);
+        ScatterEnergy en{};
+        en.stray_total = ctx->stray.p + 2;
+        if (fused_energy) {
+            en.partial = ctx->tile_partial.p; en.n = ctx->n_tiles * ctx->n_groups;
+            en.block_sums = ctx->energy_blocks.p; en.ticket = ctx->energy_ticket.p; en.energy = ctx->energy.p;
+            en.list_invalid = culled ? ctx->cull_state.p : nullptr;
+            en.stray_next = ctx->stray.p + (ctx->stray_parity ^ 1u);
+        }
+        scatter_kernel<<<ctx->n_scatter_blocks + (fused_energy ? ENERGY_BLOCKS : 0), 64, tile_bytes, s>>>(
+            ctx->pos.p, ctx->point_sums.p, ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
+            ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
+            reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p), ctx->brick_slot_ptr.p + (size_t)nO * gd.n_bricks,
+            ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p + ctx->stray_parity, gd, en);
         FROG_HIP_CHECK(hipGetLastError());
     }
     {
@@ -1132,7 +1145,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         Span span(ctx, FROG_K_LATTICE);
         LatticeStepArgs la{};
         la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p;
-        la.gradf = ctx->gradf.p; la.stray = ctx->stray.p;
+        la.gradf = ctx->gradf.p; la.stray = ctx->stray.p + ctx->stray_parity;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
@@ -1558,7 +1571,7 @@ int frog_test_stray_points(frog_ctx *ctx, uint64_t *n)
     CTX_GUARD(ctx);
     if (!n) return fail(FROG_E_INVALID, "null output");
     unsigned int v = 0;
-    FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->stray.p + 1, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->stray.p + 2, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *n = v;
     return FROG_OK;

@@ -691,6 +691,53 @@ __device__ unsigned long long g_scatter_trace[4 * 65536];
 #endif
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
 
+// The energy reduction that rides on the scatter's launch (see scatter_kernel).
+struct ScatterEnergy {
+    const double *partial;          // [n][2] (sDistances, sWeights) per (tile, partner group); null: no reduction in this launch
+    uint32_t n;
+    double *block_sums;             // [ENERGY_BLOCKS][2]
+    unsigned int *ticket;
+    double *energy;                 // [0..1] the sums, [2] = 0 (the lattice step counts into it), [3] = the culling list is out of date
+    const uint32_t *list_invalid;
+    unsigned int *stray_next;       // the OTHER step's stray counter, zeroed here for the scatter after this one
+    unsigned int *stray_total;      // running total of stray points
+};
+
+__device__ __forceinline__ void scatter_energy_block(const ScatterEnergy &en, const uint32_t r, const int lane)
+{
+    const uint32_t per = (en.n + ENERGY_BLOCKS - 1) / ENERGY_BLOCKS;
+    const uint32_t b = min(en.n, r * per), e = min(en.n, b + per);
+    double a0 = 0, a1 = 0;
+    for (uint32_t t = b + lane; t < e; t += 64) { a0 += en.partial[2 * (size_t)t]; a1 += en.partial[2 * (size_t)t + 1]; }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); }
+    bool last = false;
+    if (lane == 0) {
+        __hip_atomic_store(&en.block_sums[2 * r], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&en.block_sums[2 * r + 1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(en.ticket, 1u) == (unsigned int)ENERGY_BLOCKS - 1u;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+    __threadfence();
+    // the last block: the slice sums fetched side by side (two per lane), added in slice order by one lane
+    const double v0 = __hip_atomic_load(&en.block_sums[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v1 = __hip_atomic_load(&en.block_sums[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double s0 = 0, s1 = 0;
+    #pragma unroll 1
+    for (int k = 0; k < ENERGY_BLOCKS; k++) {           // entries 2k and 2k+1 of the 128 values held two per lane
+        const int i0 = 2 * k, i1 = 2 * k + 1;
+        const double x = __shfl(i0 < 64 ? v0 : v1, i0 & 63, 64), y = __shfl(i1 < 64 ? v0 : v1, i1 & 63, 64);
+        s0 += x; s1 += y;
+    }
+    if (lane == 0) {
+        en.energy[0] = s0; en.energy[1] = s1; en.energy[2] = 0.0;
+        en.energy[3] = en.list_invalid ? (double)en.list_invalid[0] : 0.0;
+        *en.stray_next = 0u;
+        *en.ticket = 0u;                                // ready for the next launch (same stream: ordered)
+    }
+}
+
 // Per-point values handed from phase 1 (lane = point) to phase 2 (lane = tap) through LDS, one array per value
 // (lane-consecutive writes and reads: no bank conflicts).  The products wx[i] * wy[j] are formed in phase 1, where one
 // instruction serves 64 points; in phase 2 an instruction serves ONE point, and that loop is where a block spends its time
@@ -709,19 +756,28 @@ static_assert(offsetof(ScatterScratch, sm) % 16 == 0, "ScatterScratch::sm is rea
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
                                                      const uint32_t *perm, const ScatterBlock *blocks, const uint32_t *n_blocks,
-                                                     float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g)
+                                                     float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g,
+                                                     const ScatterEnergy en)
 {
+    // The first ENERGY_BLOCKS blocks of the grid add up the sweep's (sDistances, sWeights) tile partials instead -- a launch
+    // of its own cost 7 us + two gaps of every iteration, and nothing in this kernel waits for the result.  Fixed slices,
+    // fixed tree, the 64 slice sums added in order by whichever block finishes last: deterministic.
+    if (en.partial && blockIdx.x < (uint32_t)ENERGY_BLOCKS) {
+        scatter_energy_block(en, blockIdx.x, threadIdx.x);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - (en.partial ? (uint32_t)ENERGY_BLOCKS : 0u);
 #ifdef FROG_SCATTER_TRACE
     const unsigned long long trace_t0 = wall_clock64();
     unsigned tr_load = 0, tr_p1 = 0, tr_p2 = 0;
 #endif
     // the grid is an upper bound (the block table is built on the device and its length never visits the host)
-    if (blockIdx.x >= *n_blocks) return;
+    if (bid >= *n_blocks) return;
     // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
     // take 5.4 KB instead of the 21 KB of the largest brick
     extern __shared__ float4 tile[];
     __shared__ ScatterScratch sc;
-    const ScatterBlock blk = blocks[blockIdx.x];
+    const ScatterBlock blk = blocks[bid];
     const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
     const int n_tile = E * E * E;
@@ -815,7 +871,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
                     // stray point clamped into this brick (outside the scaled box): its taps go
                     // straight to HBM, one lane doing all 64; lattice_step_kernel then folds the gradient lattice in
                     atomicAdd(stray, 1u);
-                    atomicAdd(stray + 1, 1u);       // running total, never cleared (frog_test_stray_points)
+                    atomicAdd(en.stray_total, 1u);  // running total, never cleared (frog_test_stray_points)
                     for (int k = 0; k < 4; k++) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
@@ -920,14 +976,14 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     float4 *dst = stage + (size_t)blk.slot * n_tile;
     for (int k = lane; k < n_tile; k += 64) dst[k] = tile[k];
 #ifdef FROG_SCATTER_TRACE
-    if (lane == 0 && blockIdx.x < 65536) {
+    if (lane == 0 && bid < 65536) {
         unsigned int hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_scatter_trace[4 * blockIdx.x + 0] = trace_t0;
-        g_scatter_trace[4 * blockIdx.x + 1] = wall_clock64();
-        g_scatter_trace[4 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
-        g_scatter_trace[4 * blockIdx.x + 3] = (unsigned long long)(blk.end - blk.begin) | ((unsigned long long)(tr_load & 0xFFFF) << 16)
+        g_scatter_trace[4 * bid + 0] = trace_t0;
+        g_scatter_trace[4 * bid + 1] = wall_clock64();
+        g_scatter_trace[4 * bid + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_scatter_trace[4 * bid + 3] = (unsigned long long)(blk.end - blk.begin) | ((unsigned long long)(tr_load & 0xFFFF) << 16)
                                               | ((unsigned long long)(tr_p1 & 0xFFFF) << 32) | ((unsigned long long)(tr_p2 & 0xFFFF) << 48);
     }
 #endif

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partia
         // fourth scalar of the per-iteration read-back: the culling list needs a rebuild (k_cull.hip.h); a sum over
         // ranks when the buffer is all-reduced, any non-zero value means the same
         energy[3] = list_invalid ? (double)list_invalid[0] : 0.0;
-        if (stray) stray[0] = 0u;           // the scatter that follows counts its stray points from 0 (k_grid.hip.h)
+        if (stray) stray[0] = stray[1] = 0u;    // the scatters that follow count their stray points from 0 (k_grid.hip.h: [0], [1] = even / odd steps)
         *ticket = 0u;                                       // ready for the next launch (same stream: ordered)
     }
 }
