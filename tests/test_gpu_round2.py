@@ -466,6 +466,56 @@ def test_duplicate_links_are_added_in_the_reference_order():
     assert abs(e - er) <= 1e-6 * abs(er)
 
 
+@pytest.mark.parametrize("energy_pass", [False, True])
+def test_points_outside_the_lattice_take_the_stray_path(small_pairs, monkeypatch, energy_pass):
+    """A lattice whose box does not hold every point (a host that hands frog_deformable_setup_bounds a box of its own:
+    the reference would write outside its gradient array, imageGroup.cxx:303-331).  Here such points are clamped into a
+    rim brick, their taps inside the lattice go to the gradient lattice with atomics and the lattice step folds them in
+    (k_grid.hip.h "stray").  The per-step counter is double-buffered by step parity since the energy reduction moved
+    onto the scatter's launch: several steps in a row must each see their own count."""
+    from frog_amd.distributed import HipEngine
+    if energy_pass:
+        monkeypatch.setenv("FROG_ENERGY_PASS", "1")         # the energy reduction as a launch of its own: the other way the counters are reset
+    else:
+        monkeypatch.delenv("FROG_ENERGY_PASS", raising=False)
+    n = small_pairs.n_images
+    eng = HipEngine(small_pairs, _abi.FrogOptions.default(), 0, (0, n))
+    eng.linear_init((0.5, 0.5, 0.5)); eng.transform_points_local(False)
+    eng.update_stats_local(); eng.stats_publish()
+    for _ in range(4):
+        eng.linear_step_local(); eng.energy_read(); eng.transform_points_local(False)
+    eng.transform_points_local(True)
+    mn, mx = eng.bounds_local()
+    c, h = 0.5 * (mn[0] + mx[0]), 0.30 * (mx[0] - mn[0])            # 60 % of the cloud's extent in x (+ the 20 % margin)
+    eng.deformable_setup_bounds(1, [c - h, mn[1], mn[2]], [c + h, mx[1], mx[2]])
+    eng.transform_points_local(False)
+    eng.update_stats_local(); eng.stats_publish()
+    lib = _abi.hip_lib()
+    counts, E = [], []
+    for it in range(5):
+        eng.phase_a(0.02); eng.phase_b()
+        E.append(eng.phase_c())
+        eng.transform_points_local(False)
+        k = C.c_uint64()
+        assert lib.frog_test_stray_points(eng._ctx, C.byref(k)) == 0
+        counts.append(k.value)
+    per_step = np.diff([0] + counts)
+    assert per_step[0] > 0 and np.all(per_step == per_step[0])        # the same points every step (they do not move in xyz)
+    assert all(np.isfinite(E)) and all(e > 0 for e in E)
+    for i in range(n):
+        cf = eng.grid(i, eng.num_grids() - 1)[1]
+        assert np.all(np.isfinite(cf)) and np.abs(cf).max() > 0
+    x, x2 = eng.points()
+    assert np.all(np.isfinite(x2))
+    eng.close()
+    # both ways of reducing the energy see the same steps (float atomics of the stray taps: not the same bits)
+    seen = test_points_outside_the_lattice_take_the_stray_path.__dict__.setdefault("seen", {})
+    seen[energy_pass] = (per_step[0], E)
+    if len(seen) == 2:
+        assert seen[False][0] == seen[True][0]
+        assert np.allclose(seen[False][1], seen[True][1], rtol=1e-5)
+
+
 def test_brick_edge_8_equals_brick_edge_4(small_pairs, monkeypatch):
     """Sparse lattices (fewer than 24 points per 4^3-cell brick) use bricks of 8^3 cells in the scatter: 11^3-node tiles,
     another sort key.  Forced on a small group (FROG_BRICK): same lattices as with edge 4 up to the order of the f32
