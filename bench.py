@@ -272,6 +272,11 @@ def main():
         roofline["culling"] = {"lists_built": int(lists_built), "listed_half_links": int(listed),
                                "listed_fraction": listed / max(owned, 1),
                                "frac_listed": (20.0 * listed + 12.0 * p_own) / (ms / launches * 1e-3) / 1e9 / 8000.0}
+        # the launches that walked every half-link AND wrote a list (one per list; a different kernel instantiation, its own
+        # row in the rocprofv3 summary) are not in `avg_launch_ms` above: they are reported here
+        bms, bl = prof.get("sweep_build", [0.0, 0])
+        if bl:
+            roofline["culling"]["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl}
     # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE collected in their own
     # rocprofv3 passes by scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
     # doubled on gfx950).  Counters cannot be read from inside this process, so the committed measurement of

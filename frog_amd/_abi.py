@@ -106,7 +106,7 @@ class FrogKernelTime(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
 
 
-FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull"]
+FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull", "sweep_build"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM, FROG_E_IO = range(7)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 

@@ -41,7 +41,7 @@ struct Span {
                             // recorded around it: no marker packets, so no bubbles before and after the kernel
     Span(frog_ctx *ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach)
     {
-        if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE)) return;
+        if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE && s != FROG_K_SWEEP_BUILD)) return;
         if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         if (!attached) (void)hipEventRecord(a, c->stream);
@@ -1091,7 +1091,8 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         if (rc) return rc;
     }
     {
-        Span span(ctx, FROG_K_SWEEP_DEFORMABLE, ctx->n_sub == 1);
+        // a launch that also writes the culling list is timed as a group of its own: it is not the steady-state kernel
+        Span span(ctx, ctx->build_in_sweep ? FROG_K_SWEEP_BUILD : FROG_K_SWEEP_DEFORMABLE, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
             launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr, culled,
                                            ctx->build_in_sweep);

@@ -233,6 +233,7 @@ enum {
     FROG_K_STATS,              /* reservoir + distances + EM fit                */
     FROG_K_COMBINE,            /* per-point sums of the partner groups added up, energy reduction */
     FROG_K_CULL,               /* outlier-culling list: validity check before a deformable sweep, rebuilds */
+    FROG_K_SWEEP_BUILD,        /* the deformable sweep that walks EVERY half-link and writes the next culling list (once per list) */
     FROG_K_COUNT_
 };
 typedef struct frog_kernel_time {
@@ -242,7 +243,7 @@ typedef struct frog_kernel_time {
 /* on = 1: every launch of the kernels above is bracketed by a pair of hipEvents recorded on the
  * context's stream.  The markers keep consecutive kernels from overlapping their tails and
  * ramp-ups: measured 6 % of the iteration rate with all seven groups bracketed.  on = 2 brackets
- * the two half-link sweeps only (the kernels a roofline is quoted for): < 1 %.  on = 0: off. */
+ * the half-link sweeps only (the kernels a roofline is quoted for): < 1 %.  on = 0: off. */
 int frog_profile_enable(frog_ctx *ctx, int on);
 /* Waits for the stream, adds up the recorded pairs into out[FROG_K_COUNT_];
  * reset != 0 clears the accumulators afterwards. */
