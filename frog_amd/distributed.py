@@ -231,8 +231,14 @@ class NativeComm:
         if rank == 0 and ok:
             buf = (C.c_ubyte * 128)()
             ok = int(lib.frog_comm_unique_id(buf) == 0)
-            ident = [bytes(buf)]
+            ident = [bytes(buf)] if ok else [None]
         dist.broadcast_object_list(ident, src=0)
+        # ncclCommInitRank is itself a collective: every rank must know that every other rank will call it (a rank that
+        # could not load the library would otherwise leave the others waiting inside it)
+        ready = torch.tensor([1 if (ok and ident[0] is not None) else 0], dtype=torch.int32, device=f"cuda:{device}")
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if int(ready.item()) != 1:
+            return None
         if ok and ident[0] is not None:
             idb = (C.c_ubyte * 128).from_buffer_copy(ident[0])
             ok = int(lib.frog_comm_create_rank(world_size, rank, idb, device, C.byref(h)) == 0)
