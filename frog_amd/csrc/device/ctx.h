@@ -302,6 +302,7 @@ struct frog_ctx {
     uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
     frog::DevBuf<float> disp_allow;           // [0] displacement up to which the list stays good (cull_allow_kernel)
+    bool coeff_zero = false;                  // host side: the current lattice has not taken a step yet (all coefficients 0)
     bool build_in_sweep = false;              // host side: the sweep of this step also writes the list (k_links.hip.h BUILD)
     bool cull_check_due = true;               // host side: cutoffs or list changed since the stand-alone check last ran
     uint64_t cull_builds = 0;                 // statistics: lists built

@@ -485,6 +485,12 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         ctx->disp_current = false;
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->mat.p,
                                                                         ctx->own_pt_begin, ctx->own_pt_end, apply);
+    } else if (ctx->coeff_zero && !after_step) {
+        // a fresh lattice: identity (k_grid.hip.h); the displacement against the culling list's snapshot is measured by
+        // the check before the next sweep instead
+        ctx->disp_current = false;
+        if (out != ctx->pos2.p) ctx->disp_spec = false;
+        transform_zero_lattice_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->own_pt_begin, ctx->own_pt_end, apply);
     } else {
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
@@ -907,6 +913,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     if (rc) return rc;
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
+    ctx->coeff_zero = true;
     FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
 
@@ -1202,6 +1209,7 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
         std::swap(ctx->coeff.p, ctx->grad.p);
         std::swap(ctx->coeff.cap, ctx->grad.cap);
         std::swap(ctx->coeff.n, ctx->grad.n);
+        ctx->coeff_zero = false;
     }
     ctx->phase = 0;
     if (E) *E = (ctx->opt.guarantee_diffeomorphism && nbig > 0) ? -1.0 : e;      // :434-439

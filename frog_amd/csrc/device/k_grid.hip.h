@@ -181,6 +181,20 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
     }
 }
 
+// ---- K11 for a lattice that is still all zeros (every level and every regrid starts with one: setupDeformableTransforms
+// is followed by transformPoints, imageGroup.cxx:79-80, :107-108): the displacement is +0.0 in every component and the
+// result (float)((double) x + 0.0) = x + 0.0f -- not x: -0.0 becomes +0.0, as through the lattice.  A copy instead of 64
+// taps per point (62-88 us, three to seven times per run).
+__global__ __launch_bounds__(256) void transform_zero_lattice_kernel(float4 *pos, P3 *pos2, uint32_t pt_begin, uint32_t pt_end, int apply)
+{
+    const uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pt_end) return;
+    float4 v = pos[p];
+    v.x += 0.0f; v.y += 0.0f; v.z += 0.0f;
+    pos2[p] = P3{ v.x, v.y, v.z };
+    if (apply) pos[p] = v;
+}
+
 // ---- K11, tiled form: one wavefront per scatter block (image, brick, <= SCATTER_CHUNK points) -----------------
 // The thread-per-point form above issues 64 float4 tap loads per point (texture path busy 67 % of the kernel, 222
 // registers, 2 wavefronts per SIMD).  Here the brick's (B+3)^3 coefficients are loaded ONCE per block and kept in LDS;
