@@ -36,15 +36,17 @@ template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     size_t cap = 0;
+    bool borrowed = false;      // p points into another DevBuf's block (borrow()): nothing to free
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0; cap = 0;
+        if (p && !borrowed) (void)hipFree(p);
+        p = nullptr; n = 0; cap = 0; borrowed = false;
     }
+    void borrow(T *from, size_t count) { release(); p = from; n = count; cap = count; borrowed = true; }
     // `reserve` (>= count): capacity to allocate when a new block is needed at all
     hipError_t alloc(size_t count, size_t reserve = 0)
     {
@@ -302,6 +304,8 @@ struct frog_ctx {
     uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
     frog::DevBuf<float> disp_allow;           // [0] displacement up to which the list stays good (cull_allow_kernel)
+    frog::DevBuf<float4> retired_arena;       // finished lattices are copied here, one after the other (retire_current_grid)
+    size_t retired_used = 0;
     bool coeff_zero = false;                  // host side: the current lattice has not taken a step yet (all coefficients 0)
     bool build_in_sweep = false;              // host side: the sweep of this step also writes the list (k_links.hip.h BUILD)
     bool cull_check_due = true;               // host side: cutoffs or list changed since the stand-alone check last ran

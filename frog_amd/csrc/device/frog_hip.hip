@@ -403,6 +403,14 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         if (mn[0] <= mx[0] && make_geometry(c, 0, mn, mx, g0, i0) == FROG_OK) {
             g0.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)g0.n_cp * 3 / 2);      // the registered box differs a little
             if (int rc_ = lattice_alloc(c, g0)) { (void)rc_; (void)hipGetLastError(); }  // best effort: the set-up allocates again
+            // Finished lattices stay on the device (retire_current_grid).  A stream-ordered allocation per lattice cost 0.25 ms
+            // of host time with the GPU idle at the set-up of level 2 (the pool grows by a driver call whenever it is asked
+            // for a size it has not served yet, however much it holds): one block for them, about what three levels with their
+            // regrids take (1 + 2 x 8 + 3 x 64 lattices of level 0), best effort.
+            const size_t lattice0 = (size_t)c->n_owned() * (size_t)g0.n_cp;
+            const size_t arena = std::min<size_t>(((size_t)2 << 30) / sizeof(float4), 224 * lattice0);
+            if (c->retired_arena.alloc(arena) != hipSuccess) (void)hipGetLastError();
+            c->retired_used = 0;
         }
     }
     // selection of the first refresh, ahead of time
@@ -884,7 +892,13 @@ static int retire_current_grid(frog_ctx *ctx)
     // the finished lattice stays on the device (a copy on the stream: no host round trip inside the
     // regrid path; 43 MB per lattice at level 2 of the 100-image group); frog_get_grid reads it back on demand
     gr.kept = std::make_shared<DevBuf<float4>>();
-    FROG_HIP_CHECK(gr.kept->alloc_async(std::max<size_t>(1, n), ctx->stream));
+    const size_t room = (n + 63) / 64 * 64;
+    if (n && ctx->retired_arena.p && ctx->retired_used + room <= ctx->retired_arena.cap) {
+        gr.kept->borrow(ctx->retired_arena.p + ctx->retired_used, n);
+        ctx->retired_used += room;
+    } else {
+        FROG_HIP_CHECK(gr.kept->alloc_async(std::max<size_t>(1, n), ctx->stream));
+    }
     if (n) FROG_HIP_CHECK(hipMemcpyAsync(gr.kept->p, ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     gr.retired = true;
     return FROG_OK;
