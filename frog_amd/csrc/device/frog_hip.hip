@@ -925,11 +925,24 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     hipStream_t s = ctx->stream;
     rc = lattice_alloc(ctx, g);                 // within the head-room reserved earlier, as a rule: no hipMalloc here
     if (rc) return rc;
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, ctx->gradf.bytes(), s));
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->coeff.p, 0, ctx->coeff.bytes(), s));
-    ctx->coeff_zero = true;
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->grad.p, 0, ctx->grad.bytes(), s));
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->gridsum.p, 0, ctx->gridsum.bytes(), s));
+    {
+        // gradient lattice, coefficients, proposals, their sums, the sort's counters, the block-length histogram: one launch
+        ZeroList z{};
+        auto add = [&](void *p, size_t bytes) {
+            if (!p || !bytes) return;
+            z.p[z.n] = (uint32_t *)p; z.bytes[z.n] = bytes;
+            z.first_block[z.n + 1] = z.first_block[z.n] + (unsigned)((bytes + ZERO_BLOCK_BYTES - 1) / ZERO_BLOCK_BYTES);
+            z.n++;
+        };
+        add(ctx->gradf.p, ctx->gradf.bytes()); add(ctx->coeff.p, ctx->coeff.bytes()); add(ctx->grad.p, ctx->grad.bytes());
+        add(ctx->gridsum.p, ctx->gridsum.bytes()); add(ctx->key_counts.p, ctx->key_counts.bytes());
+        add(ctx->len_hist.p, ctx->len_hist.bytes());
+        if (z.n) {
+            zero_buffers_kernel<<<z.first_block[z.n], 256, 0, s>>>(z);
+            FROG_HIP_CHECK(hipGetLastError());
+        }
+        ctx->coeff_zero = true;
+    }
 
     // sort the owned points by (image, brick, cell) and build the scatter's block table -- all on the device, nothing
     // comes back to the host (the first version read the brick sizes back, built and sorted the table on the host and
@@ -940,7 +953,6 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     const uint32_t n_keys = (uint32_t)n_keys64;
     const uint32_t n_bricks_total = nO * (uint32_t)nb;
     frog::DevBuf<uint32_t> &counts = ctx->key_counts, &chunks = ctx->brick_ptr_scratch;
-    FROG_HIP_CHECK(hipMemsetAsync(counts.p, 0, counts.bytes(), s));
     const GeomDev gd = to_dev(g);
     uint32_t max_img_pts = 0;
     for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
@@ -974,7 +986,6 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
     // every non-empty brick ends with at most one partial block
     const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts);
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->len_hist.p, 0, ctx->len_hist.bytes(), s));
     brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
     FROG_HIP_CHECK(hipGetLastError());
     rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);

@@ -211,6 +211,32 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                                                                     const float4 *proposal, const double *energy, int guarantee,
                                                                     const float *disp_allow, uint32_t *cull_state);
 
+// Zeroes up to ZERO_MAX device buffers in ONE launch (a lattice set-up clears six: every hipMemsetAsync is a launch
+// of its own with a few microseconds of idle stream in front of it).  A block clears ZERO_BLOCK_BYTES of one buffer with
+// 16-byte stores (the buffers are hipMalloc'ed: aligned); sizes are multiples of 4 bytes, the last words of a buffer go
+// one by one.
+constexpr int ZERO_MAX = 8;
+constexpr unsigned ZERO_BLOCK_BYTES = 256 * 16 * 8;
+struct ZeroList {
+    uint32_t *p[ZERO_MAX];
+    unsigned long long bytes[ZERO_MAX];
+    unsigned first_block[ZERO_MAX + 1];     // blocks [first_block[k], first_block[k + 1]) clear buffer k
+    int n;
+};
+__global__ __launch_bounds__(256) void zero_buffers_kernel(const ZeroList z)
+{
+    int k = 0;
+    while (k + 1 < z.n && blockIdx.x >= z.first_block[k + 1]) k++;
+    const unsigned long long begin = (unsigned long long)(blockIdx.x - z.first_block[k]) * ZERO_BLOCK_BYTES;
+    const unsigned long long end = min(z.bytes[k], begin + ZERO_BLOCK_BYTES);
+    unsigned char *base = reinterpret_cast<unsigned char *>(z.p[k]);
+    const unsigned long long vec_end = begin + (end - begin) / 16 * 16;
+    for (unsigned long long o = begin + 16ull * threadIdx.x; o < vec_end; o += 16ull * 256)
+        *reinterpret_cast<uint4 *>(base + o) = make_uint4(0u, 0u, 0u, 0u);
+    for (unsigned long long o = vec_end + 4ull * threadIdx.x; o < end; o += 4ull * 256)
+        *reinterpret_cast<uint32_t *>(base + o) = 0u;
+}
+
 // ---- K13: bounding box of the owned xyz (getBoundingBox, imageGroup.cxx:1513) ----
 // doubles of floats are exact, min/max are order independent -> deterministic.
 __global__ __launch_bounds__(256) void bounds_kernel(const float4 *pos, uint32_t pt_begin, uint32_t pt_end,
