@@ -165,7 +165,8 @@ def main():
     if world > 1 and backend == "nccl" and os.environ.get("FROG_NATIVE_COMM", "1") != "0":
         native = NativeComm.create(engine, shards, pairs.point_offset, rank, world, dist, local_rank)
     grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world, native=native)
-    grp.time_comm = world > 1 and backend == "nccl"       # per-collective device time in the line ("comm_ms")
+    # per-collective device time in the line ("comm_ms", every eighth call of a kind); FROG_BENCH_TIME_COMM=1 also in rehearsals
+    grp.time_comm = world > 1 and (backend == "nccl" or os.environ.get("FROG_BENCH_TIME_COMM") == "1")
     if args.shard_of:
         args.kernel_times = True
 
