@@ -83,6 +83,37 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
             "seconds": {"stats_refresh": t_stats, "linear_iteration": t_lin, "deformable_iteration": t_def}}
 
 
+def free_port():
+    """A TCP port free on 127.0.0.1 right now (the rendezvous port handed to torch.distributed.run)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port=None):
+    """`python bench.py --gpus N ...` without a launcher around it: the command that starts the N ranks, one process
+    per GPU, as children of this one (the form the driver uses itself for N > 1, README / DESIGN section 6)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n, argv):
+    """Start the ranks as FRESH child processes and pass rank 0's line through.  Called before anything in this process
+    has touched the GPU (before `import torch` and before libfrog_hip is loaded): the parent only waits.  Never
+    os.exec*: the children are ordinary subprocesses and this process exits with their return code."""
+    import subprocess
+    cmd = launch_command(n, argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    # torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset; frog_create builds its layout on the host threads
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    if os.environ.get("FROG_BENCH_LAUNCH_DRY_RUN") == "1":
+        print(json.dumps({"launch": cmd, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}), flush=True)
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +139,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (nothing has touched the GPU yet)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -158,11 +189,12 @@ def main():
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0
-    # N > 1 over RCCL: the collectives are issued from C (libfrog_comm.so, include/frog_comm.h) on the context's stream --
-    # ncclCommInitRank with an id carried by torch.distributed; FROG_NATIVE_COMM=0, or any rank failing to set it up,
-    # keeps them in torch.distributed
+    # N > 1 over RCCL: torch.distributed carries the collectives (torch's own RCCL).  FROG_NATIVE_COMM=1 issues them from C
+    # instead (libfrog_comm.so, include/frog_comm.h, on the context's stream: ncclCommInitRank with an id carried by
+    # torch.distributed) -- opt-in until a run with >= 2 GPUs has validated it; it is adopted only if every rank sets it up
+    # AND it passes a known-answer all-reduce and all-gather (NativeComm.create)
     native = None
-    if world > 1 and backend == "nccl" and os.environ.get("FROG_NATIVE_COMM", "1") != "0":
+    if world > 1 and backend == "nccl" and os.environ.get("FROG_NATIVE_COMM", "0") == "1":
         native = NativeComm.create(engine, shards, pairs.point_offset, rank, world, dist, local_rank)
     grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world, native=native)
     # per-collective device time in the line ("comm_ms", every eighth call of a kind); FROG_BENCH_TIME_COMM=1 also in rehearsals
@@ -267,38 +299,65 @@ def main():
     if levels == 0:
         grp.transformPoints(True)
     ms, launches = prof[dom]
-    alg_bytes = 20.0 * l_own + 12.0 * p_own      # 8 B link + 12 B gathered xyz2 per half-link, 12 B own xyz2 per point
-    achieved = alg_bytes / (ms / launches * 1e-3) / 1e9 if launches else 0.0
+    # Units one launch processes: with a culling list the steady-state sweep WALKS the listed
+    # half-links only (the others are decided by a certified distance bound and never touched); the one launch per list
+    # that writes the list ("sweep_build" / "sweep_linear_build") walks every half-link.  `achieved` / `frac` price every
+    # launch at the half-links it walked (20 B each: 8 B link + 12 B gathered xyz2) + 12 B per owned point, over the time
+    # of ALL those launches, list-writing ones included.  The same launches priced at the reference's bytes for all L
+    # half-links (what upstream's loop touches per iteration) are `frac_algorithmic_equiv`: a saving of work,
+    # not a bandwidth.
+    listed = engine.cull_stats_kind(dom)                   # (lists built, half-links in the last list, half-links owned)
+    build_name = {"sweep_deformable": "sweep_build", "sweep_linear": "sweep_linear_build"}[dom]
+    bms, bl = prof.get(build_name, [0.0, 0])
+    walked = float(listed[1]) if listed[0] else float(l_own)
+    all_ms, all_launches = ms + bms, launches + bl
+    walked_bytes = launches * (20.0 * walked + 12.0 * p_own) + bl * (20.0 * l_own + 12.0 * p_own)
+    alg_bytes = 20.0 * l_own + 12.0 * p_own
+    achieved = walked_bytes / (all_ms * 1e-3) / 1e9 if all_launches else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": None,
-                "avg_launch_ms": ms / launches if launches else None, "launches": int(launches),
-                "algorithmic_bytes_per_launch": alg_bytes, "half_links_per_launch": l_own}
-    # Certified outlier culling (frog_hip.h): the deformable sweep decides EVERY half-link, most false matches by a
-    # distance bound instead of an evaluation.  `achieved` above prices the launch at the reference's bytes for all L
-    # half-links; `frac_listed` prices it at the half-links it actually walked.
-    lists_built, listed, owned = engine.cull_stats()
-    if lists_built and launches:
-        roofline["culling"] = {"lists_built": int(lists_built), "listed_half_links": int(listed),
-                               "listed_fraction": listed / max(owned, 1),
-                               "frac_listed": (20.0 * listed + 12.0 * p_own) / (ms / launches * 1e-3) / 1e9 / 8000.0}
-        # the launches that walked every half-link AND wrote a list (one per list; a different kernel instantiation, its own
-        # row in the rocprofv3 summary) are not in `avg_launch_ms` above: they are reported here
-        bms, bl = prof.get("sweep_build", [0.0, 0])
-        if bl:
-            roofline["culling"]["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl}
+                "avg_launch_ms": all_ms / all_launches if all_launches else None, "launches": int(all_launches),
+                "walked_half_links_per_steady_launch": walked, "half_links_owned": l_own, "points_owned": p_own,
+                "bytes_per_steady_launch": 20.0 * walked + 12.0 * p_own,
+                "steady_launches": {"launches": int(launches), "avg_launch_ms": ms / launches if launches else None},
+                "frac_algorithmic_equiv": (alg_bytes * all_launches / (all_ms * 1e-3) / 1e9 / 8000.0) if all_launches else None,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    if bl:
+        roofline["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl, "walks": "every half-link"}
+    if listed[0]:
+        roofline["culling"] = {"lists_built": int(listed[0]), "listed_half_links": int(listed[1]),
+                               "listed_fraction": listed[1] / max(listed[2], 1)}
+    # Whole-iteration fraction = what the metric pays for: the algorithmic bytes of every timed iteration (SURVEY 8d:
+    # B_lin = 20 L + 36 P, B_def = 20 L + 48 P + 104 I G with the I G of the lattices that were really built) over the
+    # timed region's wall time.  `..._walked` prices the half-links at the ones the sweeps walked.
+    i_own = own_e - own_b
+    b_lin = 20.0 * l_own + 36.0 * p_own
+    def_iters = [(la["control_points"], la["iterations"]) for la in grp.lattices]
+    b_total = n_lin * b_lin + sum(n * (20.0 * l_own + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
+    lin_cull = engine.cull_stats_kind("sweep_linear")
+    walked_lin = float(lin_cull[1]) if lin_cull[0] else float(l_own)
+    walked_def = float(engine.cull_stats_kind("sweep_deformable")[1]) if engine.cull_stats_kind("sweep_deformable")[0] else float(l_own)
+    b_walked = n_lin * (20.0 * walked_lin + 36.0 * p_own) + sum(n * (20.0 * walked_def + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
+    iteration = {"algorithmic_bytes": b_total, "elapsed_s": elapsed, "iteration_frac": b_total / elapsed / 8e12,
+                 "iteration_frac_walked": b_walked / elapsed / 8e12,
+                 "lattices": [{"level": la["level"], "dims": la["dims"], "iterations": la["iterations"]} for la in grp.lattices],
+                 "formula": "(n_lin (20 L + 36 P) + sum over lattices n (20 L + 48 P + 104 I G)) / elapsed / 8 TB/s, per rank"}
     # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE collected in their own
     # rocprofv3 passes by scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
     # doubled on gfx950).  Counters cannot be read from inside this process, so the committed measurement of
     # the same workload is reported; null when there is none for this workload / shard size, or when the device
     # sources have changed since it was taken (profiles/hbm_traffic.json "measured_at").
+    src_hash = _abi.device_source_hash()
+    roofline["device_source_hash"] = src_hash
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tr = json.load(fh)
         # keyed on the workload AND on the device sources the counters were collected with: stale after any kernel change
         if (tr.get("kernel") == dom and tr.get("half_links_per_launch") == l_own
-                and tr.get("measured_at") == _abi.device_source_hash()):
+                and tr.get("measured_at") == src_hash):
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
             roofline["traffic_source"] = tr.get("source")
+            roofline["traffic_measured_at"] = tr.get("measured_at")
     except (OSError, ValueError, KeyError):
         pass
 
@@ -324,6 +383,7 @@ def main():
                        "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
                        "final_E": e},
             "roofline": roofline,
+            "iteration": iteration,
             "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items() if v[1]},
             "kernels_ms_by_phase": phase_k,
             "phase_iterations_per_s": {
@@ -346,6 +406,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if replicas_identical is False:
+        # the line above says so; a run whose ranks disagree about the coordinates is not a measurement
+        raise SystemExit("replicas_identical is false: the ranks' replicas of xyz2 / the EM table differ")
 
 
 if __name__ == "__main__":

@@ -194,6 +194,16 @@ class HipEngine:
         check(self._lib.frog_cull_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats")
         return a.value, b.value, c.value
 
+    def cull_stats_kind(self, kind):
+        """cull_stats() of the list the sweep `kind` ("sweep_deformable" / "sweep_linear") walks."""
+        if kind == "sweep_deformable":
+            return self.cull_stats()
+        if kind == "sweep_linear" and hasattr(self._lib, "frog_cull_stats_linear"):
+            a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            check(self._lib.frog_cull_stats_linear(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats_linear")
+            return a.value, b.value, c.value
+        return 0, 0, self.cull_stats()[2]
+
     def profile_enable(self, on=True):
         """True/1: every kernel group; 2: the half-link sweeps only (cheap); False/0: off."""
         check(self._lib.frog_profile_enable(self._ctx, int(on)), "frog_profile_enable")
@@ -208,8 +218,12 @@ class NativeComm:
     """The collectives of include/frog_comm.h (libfrog_comm.so: RCCL called from C, on the context's stream) for one
     rank of a one-process-per-GPU run.  The unique id travels over ``torch.distributed``; afterwards an iteration costs a
     handful of ctypes calls instead of three ``torch.distributed`` collectives (tens of microseconds of host time each --
-    more than a rank's kernels take at 8 GPUs).  ``create`` returns None when any rank could not set it up: the caller
-    then keeps the ``torch.distributed`` collectives."""
+    more than a rank's kernels take at 8 GPUs).  ``create`` returns None when any rank could not set it up or when the
+    new communicator fails a known-answer all-reduce / all-gather: the caller then keeps the ``torch.distributed``
+    collectives.  Opt-in (``FROG_NATIVE_COMM=1``) until a run with two or more GPUs has validated it: libfrog_comm.so
+    names librccl.so.1, the SONAME of the RCCL torch ships and has already mapped, so inside a torch process the calls
+    land in torch's RCCL build (one instance) with the image's rccl.h (the entry points used -- unique id, init rank,
+    all-reduce, broadcast, group start/end, destroy -- have had one ABI since NCCL 2.4)."""
 
     def __init__(self, lib, handle):
         self._lib, self._h = lib, handle
@@ -260,7 +274,49 @@ class NativeComm:
                 arr = (C.c_void_p * 1)(h)
                 lib.frog_comm_destroy_all(1, arr)
             return None
-        return cls(lib, h)
+        self = cls(lib, h)
+        # Known-answer check of the two collectives the iterations depend on, before they are adopted: a communicator that
+        # comes up but moves wrong data (two RCCL builds in one process, a header / library skew) must not carry a run.
+        good = 1
+        try:
+            good = int(self._known_answers(engine, shards, point_offset, rank, world_size, torch))
+        except Exception:                                   # noqa: BLE001 -- any failure here means "do not adopt"
+            good = 0
+        flag = torch.tensor([good], dtype=torch.int32, device=f"cuda:{device}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            import sys
+            print(f"[frog] rank {rank}: libfrog_comm collectives failed their known-answer check; "
+                  f"staying with torch.distributed", file=sys.stderr, flush=True)
+            self.close()
+            return None
+        return self
+
+    def _known_answers(self, engine, shards, point_offset, rank, world_size, torch):
+        """all-reduce(sum) of (rank + 1, 2^rank, -rank, 0.5) over the energy buffer and an all-gather in which rank r's
+        rows hold r + 1: both results are known in closed form.  Buffers are restored afterwards."""
+        keep = engine.energy.clone()
+        engine.energy.copy_(torch.tensor([rank + 1.0, 2.0 ** rank, -float(rank), 0.5], dtype=torch.float64,
+                                         device=engine.energy.device)[:engine.energy.numel()])
+        self.all_reduce(_abi.FROG_BUF_ENERGY)
+        n = world_size
+        want = torch.tensor([n * (n + 1) / 2.0, 2.0 ** n - 1.0, -n * (n - 1) / 2.0, 0.5 * n], dtype=torch.float64,
+                            device=engine.energy.device)[:engine.energy.numel()]
+        ok = bool(torch.equal(engine.energy, want))
+        engine.energy.copy_(keep)
+        if engine.xyz2 is not None:
+            po = np.asarray(point_offset, dtype=np.int64)
+            rows = [(int(po[b]), int(po[e])) for b, e in shards]
+            keep = engine.xyz2.clone()
+            engine.xyz2.zero_()
+            b, e = rows[rank]
+            engine.xyz2[b:e] = float(rank + 1)
+            self.all_gather_xyz2()
+            for r, (rb, re_) in enumerate(rows):
+                ok = ok and bool((engine.xyz2[rb:re_] == float(r + 1)).all())
+            engine.xyz2.copy_(keep)
+        torch.cuda.synchronize()
+        return ok
 
     def _check(self, rc, what):
         if rc:
@@ -312,6 +368,7 @@ class ShardedImageGroup:
         self.measures = []
         self.gridsPerLevel = []
         self.setup_seconds = []
+        self.lattices = []
         # device time of every collective (events on the stream the collectives are ordered against), summed per kind by
         # comm_summary(); costs two event records per collective, so only on request
         self.time_comm = False
@@ -421,6 +478,10 @@ class ShardedImageGroup:
         t0 = time.perf_counter()
         info = self._setup(level)
         self.setup_seconds.append(time.perf_counter() - t0)      # host side only: the device work is queued, not awaited
+        # one entry per lattice: its size and the accepted iterations taken on it (bench.py prices an iteration's
+        # algorithmic bytes with the lattices that were really built)
+        self.lattices.append({"level": int(level), "dims": [int(d) for d in info.dims],
+                              "control_points": int(info.dims[0]) * int(info.dims[1]) * int(info.dims[2]), "iterations": 0})
         return info
 
     def _setup(self, level):
@@ -490,6 +551,7 @@ class ShardedImageGroup:
             n_diffeo += 1
             self.transformPoints()
             self.measures.append(float(np.float32(e)))
+            self.lattices[-1]["iterations"] += 1
             it += 1
         self.transformPoints(True)
         return n_grids

@@ -27,7 +27,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum -d $O/nocull_lat -o p --output-format csv -- python3 $ARGS > /dev/null 2> $O/nocull_lat.log
 unset FROG_CULL
 python3 scripts/summarize_profile.py gpurun_out/${TAG}_nocull_n1.txt $O/nocull_trace $O/nocull_sq $O/nocull_ta $O/nocull_lat > /dev/null
-python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat $(python3 -c "import json; print(json.load(open('$O/bench.json'))['roofline']['half_links_per_launch'])") > /dev/null
+python3 scripts/summarize_profile.py gpurun_out/${TAG}_bench_n1.txt $O/trace $O/fetch $O/write $O/tcc $O/tcp $O/sq $O/ta $O/lat $(python3 -c "import json; print(json.load(open('$O/bench.json'))['roofline']['half_links_owned'])") > /dev/null
 cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
 cp $O/bench_kernel_times.json gpurun_out/${TAG}_bench_n1_kernel_times.json
 cp $O/bench_steps20.json gpurun_out/${TAG}_bench_n1_steps20.json
