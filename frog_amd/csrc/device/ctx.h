@@ -292,6 +292,7 @@ struct frog_ctx {
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 
     // certified outlier culling of the deformable sweep (k_cull.hip.h)
+    bool exact_weights = false;               // FROG_WEIGHT_EXACT=1 (test hook): inlier_probability_exact for every weight
     bool cull_enabled = true;                 // FROG_CULL=0 turns it off (every sweep walks all records)
     bool cull_need_build = true;              // host side: (re)build the list before the next deformable sweep
     float cull_scale = 2.0f, cull_pad = 25.0f; // list cutoff = scale * certified cutoff + pad (the skin)

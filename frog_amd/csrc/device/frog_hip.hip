@@ -89,6 +89,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
     a.img_bits = ctx->rec_format.img_bits; a.lds_images = sweep_lds_images(ctx); a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
+    a.band = ctx->exact_weights ? __builtin_inff() : THRESHOLD_BAND;
     a.tile_partial = ctx->tile_partial.p; a.tile_counts = ctx->tile_counts.p; a.group_sums = ctx->group_sums.p;
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
     a.act_recs = nullptr; a.act_cnt = nullptr; a.cull_state = nullptr;
@@ -378,6 +379,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipGetLastError());
     // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
     if (const char *e = getenv("FROG_CULL")) c->cull_enabled = atoi(e) != 0;
+    // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
+    if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
     if (const char *e = getenv("FROG_CULL_SKIN")) {
         float a = 0, b = 0;
         if (sscanf(e, "%f,%f", &a, &b) == 2 && a >= 1.0f && b >= 0.0f) { c->cull_scale = a; c->cull_pad = b; }

@@ -61,6 +61,8 @@ struct SweepArgs {
     uint32_t n_tiles;
     uint32_t rec2_last;         // index of the last record PAIR (16 bytes) of the context (prefetch clamp)
     float threshold;
+    float band;                 // weights within this of the threshold are recomputed with the reference's arithmetic (THRESHOLD_BAND;
+                                // +inf with FROG_WEIGHT_EXACT=1, a test hook: every weight, also the linear sweep's)
     double *tile_partial;       // [n_tiles][n_groups][18] (linear) or [..][2] (deformable)
     long long *tile_counts;     // [n_tiles][n_groups][2]  (count)
     float4 *group_sums;         // [N_XCD][own points]  (deformable)
@@ -355,11 +357,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         float w = fminf(inlier_probability(d2, eA), inlier_probability(d2, eB));
         if constexpr (MODE != SWEEP_LINEAR) {
             // the threshold decision is taken on the reference's own arithmetic when it is close
-            if (fabsf(w - a.threshold) < THRESHOLD_BAND) {
+            if (fabsf(w - a.threshold) < a.band) {
                 const uint32_t imgB = img_of(rq) + (WIDE && !EMD_LDS ? 0u : g_first);
                 const float d = sqrt_rn(d2);
                 w = fminf(inlier_probability_exact(d, a.em[image]), inlier_probability_exact(d, a.em[imgB]));
             }
+        } else if (a.band > 1.0f) {                         // test hook only (wave-uniform)
+            const uint32_t imgB = img_of(rq) + (WIDE && !EMD_LDS ? 0u : g_first);
+            const float d = sqrt_rn(d2);
+            w = fminf(inlier_probability_exact(d, a.em[image]), inlier_probability_exact(d, a.em[imgB]));
         }
 
         if constexpr (MODE == SWEEP_LINEAR) {

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
@@ -185,6 +186,7 @@ void ImageGroup::runSharded()
 {
     using clk = std::chrono::steady_clock;
     const int N = nGpus;
+    std::vector<uint64_t> replicaHashes(N, 0);
     #pragma omp parallel num_threads(N)
     {
         const int r = omp_get_thread_num();
@@ -313,6 +315,30 @@ void ImageGroup::runSharded()
         }
         ck(frog_synchronize(c), "frog_synchronize");
         g_comm.barrier(cm);
+        if (std::getenv("FROG_CHECK_REPLICAS")) {
+            // every rank holds a replica of all transformed coordinates (the all-gather's product) and of the mixture table:
+            // they must be the same bits everywhere, whatever carried the collectives
+            const uint64_t nP = frog_num_points(c);
+            const uint32_t nI = frog_num_images(c);
+            std::vector<float> xyz(3 * nP), xyz2(3 * nP), em(3 * (size_t)nI);
+            ck(frog_get_points(c, xyz.data(), xyz2.data()), "frog_get_points");
+            for (uint32_t i = 0; i < nI; i++) ck(frog_get_em(c, i, &em[3 * (size_t)i]), "frog_get_em");
+            uint64_t h = 1469598103934665603ull;            // FNV-1a over the bit patterns
+            auto eat = [&](const std::vector<float> &v) {
+                for (float f : v) { uint32_t b; std::memcpy(&b, &f, 4); h = (h ^ b) * 1099511628211ull; }
+            };
+            eat(xyz2); eat(em);
+            #pragma omp critical
+            replicaHashes[r] = h;
+            g_comm.barrier(cm);
+            if (root) {
+                bool same = true;
+                for (int k = 1; k < N; k++) same = same && replicaHashes[k] == replicaHashes[0];
+                cout << "Replicas identical : " << (same ? "yes" : "NO") << " (" << N << " contexts, xyz2 of " << nP << " points + " << nI << " mixtures)" << endl;
+                if (!same) exit(1);
+            }
+            g_comm.barrier(cm);
+        }
     }
 }
 
