@@ -219,6 +219,11 @@ struct frog_ctx {
     frog::DevBuf<long long> tile_counts;      // [n_tiles][n_groups][2]
     frog::DevBuf<float4> group_sums;          // [N_XCD][ownP] per-point partial sums (one buffer per XCD, continued across sub-passes)
     frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
+    // fused deformable sweep (k_links.hip.h FUSED): block -> tile table and whether this context uses it
+    frog::DevBuf<uint32_t> tile_order;        // [n_order_blocks] tile of every block, 0xFFFFFFFF = none; block % 8 = the tile's eighth of its image
+    uint32_t n_order_blocks = 0;
+    bool fused_sweep = false;
+    bool fused_forced = false;                // FROG_SWEEP_FUSED=1 / 2: also without a culling list
 
     // statistics
     frog::DevBuf<float4> em;                  // [nI] c1,c2,ratio,0

@@ -94,6 +94,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
     a.act_recs = nullptr; a.act_cnt = nullptr; a.cull_state = nullptr;
     a.cut_list = nullptr; a.build_recs = nullptr; a.build_cnt = nullptr;
+    a.point_sums = ctx->point_sums.p; a.tile_order = ctx->tile_order.p;
     return a;
 }
 
@@ -105,6 +106,16 @@ static bool cull_active(const frog_ctx *ctx)
 
 // the narrow deformable sweep can write the culling list while it walks every record (k_links.hip.h BUILD)
 static bool sweep_builds_list(const frog_ctx *ctx) { return ctx->rec_format.narrow != 0; }
+
+// Does this deformable sweep run in its fused form (k_links.hip.h FUSED)?  The one launch per list that walks EVERY record
+// (and writes the list) does not: its false matches gather from uniformly random places of their partner image, which the
+// per-group form keeps inside one XCD's 3 MB slice of the coordinates and the fused form does not (measured on cfg 3:
+// 0.62 against 0.76 ms; the steady-state launches 0.300 against 0.254 ms).  FROG_SWEEP_FUSED=2 fuses that launch too.
+static bool sweep_fused_now(const frog_ctx *ctx, bool build)
+{
+    static const bool fuse_build = [] { const char *e = getenv("FROG_SWEEP_FUSED"); return e && e[0] == '2'; }();
+    return ctx->fused_sweep && (!build || fuse_build);
+}
 
 template <int MODE>
 static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr,
@@ -124,9 +135,21 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
     const dim3 grid(sweep_blocks(ctx)), block(256);
     const size_t lds = (size_t)args.lds_images * (sizeof(EmDerived) + sizeof(uint32_t) + sizeof(float));
     if constexpr (MODE == SWEEP_DEFORMABLE) {
-        if (build_list && sweep_builds_list(ctx)) {
+        const bool build = build_list && sweep_builds_list(ctx);
+        if (build) {
             args.act_recs = nullptr; args.act_cnt = nullptr;         // walks every record
             args.cut_list = ctx->cut_list.p; args.build_recs = ctx->act_recs32.p; args.build_cnt = ctx->act_cnt.p;
+        }
+        if (sweep_fused_now(ctx, build)) {
+            // one block per tile, wavefront = partner group, ONE float4 of sums per point out (k_links.hip.h FUSED)
+            const dim3 fgrid(ctx->n_order_blocks), fblock(512);
+            const size_t flds = lds * N_XCD;
+            if (build) hipExtLaunchKernelGGL((sweep_kernel<SWEEP_DEFORMABLE, true, false, true, true>), fgrid, fblock, flds, s, ea, eb, 0, args);
+            else if (ctx->rec_format.narrow) hipExtLaunchKernelGGL((sweep_kernel<SWEEP_DEFORMABLE, true, false, false, true>), fgrid, fblock, flds, s, ea, eb, 0, args);
+            else hipExtLaunchKernelGGL((sweep_kernel<SWEEP_DEFORMABLE, true, true, false, true>), fgrid, fblock, flds, s, ea, eb, 0, args);
+            return;
+        }
+        if (build) {
             hipExtLaunchKernelGGL((sweep_kernel<SWEEP_DEFORMABLE, true, false, true>), grid, block, lds, s, ea, eb, 0, args);
             return;
         }
@@ -317,6 +340,31 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (lay.format.narrow) { CREATE_CHECK(c->recs32.upload(lay.recs32, s)); }
     else { CREATE_CHECK(c->recs.upload(lay.recs, s)); }
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
+    {
+        // Fused deformable sweep (k_links.hip.h FUSED): block b works on tile order[b], and b % 8 -- the XCD the block lands on
+        // under round-robin dispatch -- is the tile's eighth of its image along the Morton curve, so that an XCD's L2 sees the
+        // same eighth of every image: its own tiles' and, since true matches are spatial neighbours, nearly all their partners'.
+        std::vector<uint32_t> lists[N_XCD];
+        for (uint32_t i = c->ib; i < c->ie; i++) {
+            const uint32_t tb = lay.img_tile_ptr[i], nt = lay.img_tile_ptr[i + 1] - tb;
+            for (uint32_t j = 0; j < nt; j++) lists[(size_t)j * N_XCD / nt].push_back(tb + j);
+        }
+        size_t rounds = 0;
+        for (auto &l : lists) rounds = std::max(rounds, l.size());
+        std::vector<uint32_t> order(std::max<size_t>(1, rounds * N_XCD), 0xFFFFFFFFu);
+        for (int x = 0; x < N_XCD; x++)
+            for (size_t r = 0; r < lists[x].size(); r++) order[r * N_XCD + x] = lists[x][r];
+        c->n_order_blocks = (uint32_t)(rounds * N_XCD);
+        CREATE_CHECK(c->tile_order.upload(order, s));
+        CREATE_CHECK(hipStreamSynchronize(s));
+        // static + dynamic LDS of the fused block must stay under the 64 KB a block gets without asking for more
+        uint32_t widest = 0;
+        for (uint32_t g = 0; g < c->n_groups; g++) widest = std::max(widest, c->group_begin[g + 1] - c->group_begin[g]);
+        const char *fe = getenv("FROG_SWEEP_FUSED");
+        c->fused_sweep = c->n_sub == 1 && c->n_tiles > 0 && widest <= (uint32_t)EMD_LDS_IMAGES && sweep_lds_images(c) <= 64u
+                         && !(fe && fe[0] == '0');
+        c->fused_forced = fe && (fe[0] == '1' || fe[0] == '2');
+    }
     CREATE_CHECK(c->tile_partial.alloc((size_t)std::max(1u, c->n_tiles) * c->n_groups * LINEAR_SUMS));
     CREATE_CHECK(c->tile_counts.alloc((size_t)std::max(1u, c->n_tiles) * c->n_groups * 2));
     CREATE_CHECK(c->group_sums.alloc((size_t)N_XCD * std::max(1u, c->own_pt_end - c->own_pt_begin)));
@@ -379,6 +427,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipGetLastError());
     // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
     if (const char *e = getenv("FROG_CULL")) c->cull_enabled = atoi(e) != 0;
+    // without the culling list a third of a typical group's gathers are false matches with random partners: the fused sweep's
+    // spatial XCD mapping does nothing for them, the per-group form keeps them in L2 (unless FROG_SWEEP_FUSED=1 insists)
+    if (!(c->cull_enabled && c->opt.inlier_threshold >= 1e-3f) && !c->fused_forced) c->fused_sweep = false;
     // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
     if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
     if (const char *e = getenv("FROG_CULL_SKIN")) {
@@ -1138,8 +1189,9 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         // the per-point sums are only materialised when something other than the scatter reads them (landmark
         // constraints here, frog_get_point_sums later): the scatter adds the N_XCD partial sums itself
         static const bool always_combine = getenv("FROG_COMBINE") != nullptr;      // test hook
-        ctx->point_sums_stale = !(ctx->n_hard || always_combine);
-        if (!ctx->point_sums_stale)
+        const bool fused = sweep_fused_now(ctx, ctx->build_in_sweep && sweep_builds_list(ctx));
+        ctx->point_sums_stale = !(ctx->n_hard || always_combine || fused);     // the fused sweep writes the points' sums itself
+        if (!ctx->point_sums_stale && !fused)
             combine_groups_kernel<<<div_up(ctx->own_pt_end - ctx->own_pt_begin, 256), 256, 0, s>>>(
                 ctx->group_sums.p, ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->point_sums.p);
         // the energy sums: by the first blocks of the scatter's launch (k_grid.hip.h), unless something between here and the
@@ -1464,7 +1516,8 @@ int frog_residual_sums(frog_ctx *ctx)
     hipStream_t s = ctx->stream;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     for (uint32_t sub = 0; sub < ctx->n_sub; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
-    if (n) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
+    if (n && !sweep_fused_now(ctx, false)) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
+    ctx->point_sums_stale = false;
     if (ctx->n_hard)                                            // :520-533
         hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
                                                                 ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, nullptr);

@@ -65,7 +65,9 @@ struct SweepArgs {
                                 // +inf with FROG_WEIGHT_EXACT=1, a test hook: every weight, also the linear sweep's)
     double *tile_partial;       // [n_tiles][n_groups][18] (linear) or [..][2] (deformable)
     long long *tile_counts;     // [n_tiles][n_groups][2]  (count)
-    float4 *group_sums;         // [N_XCD][own points]  (deformable)
+    float4 *group_sums;         // [N_XCD][own points]  (deformable, one block per (4 tiles, group))
+    float4 *point_sums;         // [P]  (deformable, FUSED: one block per tile adds its 8 group sums itself)
+    const uint32_t *tile_order; // FUSED: block -> tile (0xFFFFFFFF: no tile), dealt so that block % 8 = the tile's octant of its image
     uint32_t own_pt_begin, own_points;
     uint32_t sub;               // sub-pass of this launch
     uint32_t n_groups;
@@ -194,42 +196,57 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // BUILD (deformable sweep, narrow records): while walking EVERY record of its range the wavefront also writes the culling
 // list for the coordinates it reads -- what cull_build_kernel does in a pass of its own (0.6 ms for 1e8 records: a record,
 // two coordinates and a distance per half-link, all of which this kernel has in hand anyway).
-template <int MODE, bool EMD_LDS, bool WIDE, bool BUILD = false>
-__global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
+// FUSED (deformable sweep, one launch per pass): a block is ONE tile and all 8 partner groups, wavefront w = group w.  The
+// eight per-group sums of a point are then in one block's LDS when the walk ends: they are added there, in group order --
+// the same additions in the same order as combine_groups_kernel / the scatter's point phase, i.e. the same bits -- and ONE
+// float4 per point goes to memory (32 MB instead of the 252 MB of per-group partial sums that the scatter then reads
+// back, half of every line unused: 0.85 of an iteration's 2.0 GB of fabric traffic).  What it gives
+// up is "one partner group per XCD": a block gathers from all partner images.  The coordinates an XCD touches are kept
+// small the other way instead: blocks are dealt so that block % 8 = the tile's eighth of its image along the Morton curve
+// (tile_order), and a true match's partner lies in the same eighth of the partner image -- with the certified outliers
+// gone from the list (k_cull.hip.h) nearly every gather is a true match.
+template <int MODE, bool EMD_LDS, bool WIDE, bool BUILD = false, bool FUSED = false>
+__global__ __launch_bounds__(FUSED ? 512 : 256) void sweep_kernel(const SweepArgs a)
 {
     static_assert(!BUILD || (MODE == SWEEP_DEFORMABLE && EMD_LDS && !WIDE), "the list is built by the narrow deformable sweep");
+    static_assert(!FUSED || (MODE == SWEEP_DEFORMABLE && EMD_LDS), "the fused form is the deformable sweep's");
+    constexpr int WAVES = FUSED ? 8 : 4;                // wavefronts per block
+    constexpr int OWN_TILES = FUSED ? 1 : 4;            // tiles whose own points the block stages
     // per-wave accumulators: (sDisp xyz, sWeight) of every point of the tile, f32 like the
     // reference's (imageGroup.cxx:256-257), plus one ownership word per point
-    __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? 4 * TILE_POINTS : 1];
+    __shared__ float4 acc[(MODE == SWEEP_DEFORMABLE) ? WAVES * TILE_POINTS : 1];
     // one election word per pair of points (k, k + TILE_POINTS / 2): the lanes of a step hold a stretch of about
     // half a tile's points (records are partner-major, then point order), so the two rarely meet -- and when they do,
     // the higher lane waits one more round, nothing else
-    __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? 4 * OWNER_WORDS : 1];
+    __shared__ unsigned int owner[(MODE == SWEEP_DEFORMABLE) ? WAVES * OWNER_WORDS : 1];
     // Scattered vector loads cost ~48 CU-cycles per wave-instruction through the texture
     // path even when they hit L1 (measured: the sweep takes 0.26 ms without its three
     // gathers per step, 0.68 ms with them), so everything that can be staged is: the xyz2
-    // of the tile's own points (per wave) and the EM constants of the partner group's
-    // images (per block) live in LDS; only the partner point is gathered from memory.
-    // one array, x / y / z planes a constant 4 KB apart: one address computation per step, the planes are DS offsets
-    __shared__ float own_xyz[3 * 4 * TILE_POINTS];
+    // of the tile's own points (per wave; per block when FUSED) and the EM constants of the partner group's
+    // images (per block; per wave when FUSED) live in LDS; only the partner point is gathered from memory.
+    // one array, x / y / z planes a constant distance apart: one address computation per step, the planes are DS offsets
+    __shared__ float own_xyz[3 * OWN_TILES * TILE_POINTS];
     // a.lds_images entries each, sized at launch (sweep_lds_images: a power of two >= the largest group): with the
     // 30 KB above, a block stays under 32 KB and FIVE blocks share a CU's 160 KB -- the sweep's time follows its
-    // resident wavefronts almost in proportion (measured: 12 instead of 16 per CU, +21 %)
+    // resident wavefronts almost in proportion (measured: 12 instead of 16 per CU, +21 %).  FUSED: one set of tables per
+    // wavefront (its group's), 41 KB per block of eight wavefronts, three blocks per CU.
     extern __shared__ __align__(16) unsigned char sweep_dyn_lds[];
-    EmDerived *emd_s = reinterpret_cast<EmDerived *>(sweep_dyn_lds);
-    uint32_t *img_base_s = reinterpret_cast<uint32_t *>(sweep_dyn_lds + (size_t)a.lds_images * sizeof(EmDerived));   // narrow records: first point of the group's images
-    float *cut_s = reinterpret_cast<float *>(img_base_s + a.lds_images);      // BUILD: list cutoff of the group's images
-    __shared__ uint32_t last_step_s[BUILD ? 4 * TILE_POINTS : 1];             // BUILD: see cull_build_kernel
-
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    unsigned char *tables = sweep_dyn_lds + (FUSED ? (size_t)wave * a.lds_images * (sizeof(EmDerived) + 2 * sizeof(uint32_t)) : (size_t)0);
+    EmDerived *emd_s = reinterpret_cast<EmDerived *>(tables);
+    uint32_t *img_base_s = reinterpret_cast<uint32_t *>(tables + (size_t)a.lds_images * sizeof(EmDerived));   // narrow records: first point of the group's images
+    float *cut_s = reinterpret_cast<float *>(img_base_s + a.lds_images);      // BUILD: list cutoff of the group's images
+    __shared__ uint32_t last_step_s[BUILD ? WAVES * TILE_POINTS : 1];         // BUILD: see cull_build_kernel
+
     // One launch per sub-pass.  block -> (4 consecutive tiles, XCD): block % 8 is the XCD the
     // block lands on under round-robin dispatch (a performance assumption only) and selects
     // the partner group sub*8 + xcd it reads, so during a launch an XCD's L2 only has to hold
     // 1/n_groups of the coordinate table.  Later sub-passes continue the per-XCD partial sums.
-    const uint32_t xcd = blockIdx.x % N_XCD;
-    const uint32_t grp = a.sub * N_XCD + xcd;
-    const uint32_t t = (blockIdx.x / N_XCD) * 4 + wave;
+    // FUSED: block -> one tile (tile_order), wavefront -> partner group.
+    const uint32_t xcd = FUSED ? (uint32_t)wave : blockIdx.x % N_XCD;
+    const uint32_t grp = FUSED ? (uint32_t)wave : a.sub * N_XCD + xcd;
+    const uint32_t t = FUSED ? a.tile_order[blockIdx.x] : (blockIdx.x / N_XCD) * 4 + wave;
     const bool live = t < a.n_tiles;
 
     uint32_t pt_begin = 0, pt_count = 0, rec_lo = 0, rec_n = 0, image = 0;
@@ -264,20 +281,29 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
             if (k < OWNER_WORDS) own[k] = 0xFFFFFFFFu;
         }
     }
-    float *px = own_xyz + wave * TILE_POINTS;
-    constexpr int PLANE = 4 * TILE_POINTS;
-    for (uint32_t k = lane; k < pt_count; k += 64) {
-        const P3 p = a.pos2[pt_begin + k];
-        px[k] = p.x; px[k + PLANE] = p.y; px[k + 2 * PLANE] = p.z;
+    float *px = own_xyz + (FUSED ? 0 : wave * TILE_POINTS);
+    constexpr int PLANE = OWN_TILES * TILE_POINTS;
+    if constexpr (FUSED) {
+        for (uint32_t k = threadIdx.x; k < pt_count; k += 64 * WAVES) {     // the block's one tile, by all its wavefronts
+            const P3 p = a.pos2[pt_begin + k];
+            px[k] = p.x; px[k + PLANE] = p.y; px[k + 2 * PLANE] = p.z;
+        }
+    } else {
+        for (uint32_t k = lane; k < pt_count; k += 64) {
+            const P3 p = a.pos2[pt_begin + k];
+            px[k] = p.x; px[k + PLANE] = p.y; px[k + 2 * PLANE] = p.z;
+        }
     }
     const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
+    // the group's tables: filled by the block (one group per block) or by the wavefront (FUSED: one group per wavefront)
+    const uint32_t fill_id = FUSED ? (uint32_t)lane : threadIdx.x, fill_stride = FUSED ? 64u : 256u;
     if (EMD_LDS)
-        for (uint32_t k = threadIdx.x; k < g_count; k += 256) emd_s[k] = a.emd[g_first + k];
+        for (uint32_t k = fill_id; k < g_count; k += fill_stride) emd_s[k] = a.emd[g_first + k];
     if (!WIDE)
-        for (uint32_t k = threadIdx.x; k < a.lds_images; k += 256) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
+        for (uint32_t k = fill_id; k < a.lds_images; k += fill_stride) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
     uint32_t *last_step = last_step_s + (BUILD ? wave * TILE_POINTS : 0);
     if constexpr (BUILD) {
-        for (uint32_t k = threadIdx.x; k < a.lds_images; k += 256) cut_s[k] = k < g_count ? a.cut_list[g_first + k] : 0.f;
+        for (uint32_t k = fill_id; k < a.lds_images; k += fill_stride) cut_s[k] = k < g_count ? a.cut_list[g_first + k] : 0.f;
         for (int k = lane; k < TILE_POINTS; k += 64) last_step[k] = 0xFFFFFFFFu;
     }
     __syncthreads();
@@ -459,11 +485,24 @@ __global__ __launch_bounds__(256) void sweep_kernel(const SweepArgs a)
         }
         __syncthreads();
         typedef float v4f __attribute__((ext_vector_type(4)));
-        for (uint32_t k = lane; k < pt_count; k += 64) {                 // written once, read once: non-temporal
-            const float4 v = my[k];
-            float4 *dst = a.group_sums + group_sum_index(xcd, pt_begin - a.own_pt_begin + k, a.own_points);
-            if (SUMS_POINT_MAJOR) *dst = v;                              // pieces of a line other XCDs complete: let the caches merge them
-            else __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f *>(dst));
+        if constexpr (FUSED) {
+            // the point's sums = its eight group sums added in group order (combine_groups_kernel's order: same bits)
+            for (uint32_t k = threadIdx.x; k < pt_count; k += 64 * WAVES) {
+                float4 v = acc[k];
+                #pragma unroll
+                for (int g = 1; g < N_XCD; g++) {
+                    const float4 u = acc[g * TILE_POINTS + k];
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                a.point_sums[pt_begin + k] = v;
+            }
+        } else {
+            for (uint32_t k = lane; k < pt_count; k += 64) {                 // written once, read once: non-temporal
+                const float4 v = my[k];
+                float4 *dst = a.group_sums + group_sum_index(xcd, pt_begin - a.own_pt_begin + k, a.own_points);
+                if (SUMS_POINT_MAJOR) *dst = v;                              // pieces of a line other XCDs complete: let the caches merge them
+                else __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f *>(dst));
+            }
         }
     } else {
         long long v0 = wave_sum_ll(n_in), v1 = wave_sum_ll(n_out);

@@ -200,3 +200,50 @@ def test_config4_eight_contexts_on_the_config3_group(tmp_path):
     assert worst_m < 1e-6 and worst_c < 1e-5
     ba, bb = json.load(open(one / "bbox.json")), json.load(open(eight / "bbox.json"))
     assert ba["halfPairs"] == bb["halfPairs"] and abs(ba["inliers"] - bb["inliers"]) <= 2
+
+
+def _short_run(pairs, **opt):
+    g = ImageGroup(pairs, **opt)
+    g.setupLinearTransforms(); g.transformPoints()
+    es = []
+    for it in range(6):
+        if it % 10 == 0:
+            g.updateStats()
+        es.append(g.updateLinearTransforms()); g.transformPoints()
+    g.transformPoints(True)
+    sums = []
+    for level in range(2):
+        g.setupDeformableTransforms(level); g.transformPoints()
+        for it in range(12):
+            if it % 10 == 0:
+                g.updateStats()
+            e = g.updateDeformableTransforms(0.02)
+            assert e >= 0
+            es.append(e); g.transformPoints()
+            if it in (0, 11):
+                sums.append(g.point_sums().copy())
+        g.transformPoints(True)
+    grids = [g.grid(i, k)[1].copy() for k in range(g.num_grids()) for i in range(pairs.n_images)]
+    return np.array(es), sums, grids, g.points()[0].copy()
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_fused_sweep_equals_the_per_group_sweep_bit_for_bit(monkeypatch, wide):
+    """The deformable sweep as one block per tile with the eight group sums added in LDS (k_links.hip.h FUSED: one float4
+    per point to memory) against one block per (4 tiles, partner group) + the scatter adding the eight partial sums: the
+    same additions in the same order -- energies, per-point sums, lattices and coordinates identical bits, with narrow
+    and wide records, with the culling list (built in the sweep) and without it."""
+    pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+    monkeypatch.setenv("FROG_WIDE_RECORDS", wide)
+    for cull in ("1", "0"):
+        monkeypatch.setenv("FROG_CULL", cull)
+        monkeypatch.setenv("FROG_SWEEP_FUSED", "0")
+        e0, s0, g0, x0 = _short_run(pairs)
+        monkeypatch.setenv("FROG_SWEEP_FUSED", "1")
+        e1, s1, g1, x1 = _short_run(pairs)
+        assert np.array_equal(e0, e1)
+        for a, b in zip(s0, s1):
+            assert np.array_equal(a, b)
+        for a, b in zip(g0, g1):
+            assert np.array_equal(a, b)
+        assert np.array_equal(x0, x1)
