@@ -230,19 +230,25 @@ struct frog_ctx {
     frog::DevBuf<frog::EmDerived> emd;        // [nI]
     frog::DevBuf<float> samples;              // [nOwned][cap]
     frog::DevBuf<unsigned char> em_guess;     // [nOwned][4][EM_GUESS_BATCHES] exponents of the EM sums' trajectories, last fit (k_stats.hip.h)
-    // Which ordinals a refresh keeps does not depend on the data (k_stats.hip.h), so the
-    // selection for the NEXT refresh is computed ahead of time on a side stream into the
-    // other buffer of this pair.
-    frog::DevBuf<uint32_t> sample_ord[2];     // [nOwned][cap]
-    frog::DevBuf<uint32_t> sample_count[2];   // [nOwned]
-    frog::DevBuf<uint2> sample_ends[2];       // [nOwned][cap] (own point, partner point) of every kept half-link, internal numbering
-    int sel_ready = 0;                        // buffer the pending/ready selection is written to
+    // Which ordinals a refresh keeps does not depend on the data (k_stats.hip.h: only on virtualSize, the capacity and the
+    // number of earlier refreshes), so the selections of the NEXT refreshes -- and the end points of the kept half-links --
+    // are computed ahead of time on a side stream into a ring of sel_ring buffers: sel_ring - 1 of them are filled when
+    // the context is created, every refresh consumes one and queues the production of one more.  (Two buffers, i.e. one
+    // refresh ahead, put the 2.4 ms replay of the generator on the critical path of a context whose ten iterations take
+    // less than that: one rank of eight.)
+    static constexpr int SEL_RING_MAX = 16;
+    int sel_ring = 2;
+    frog::DevBuf<uint32_t> sample_ord[SEL_RING_MAX];     // [nOwned][cap]
+    frog::DevBuf<uint32_t> sample_count[SEL_RING_MAX];   // [nOwned]
+    frog::DevBuf<uint2> sample_ends[SEL_RING_MAX];       // [nOwned][cap] (own point, partner point) of every kept half-link, internal numbering
+    uint64_t sel_consumed = 0;                // refreshes done
+    uint64_t sel_produced = 0;                // selections queued on the side stream (refresh k lives in buffer k % sel_ring)
     int sel_used = 0;                         // buffer the last refresh consumed
     hipStream_t side = nullptr;
     hipEvent_t energy_copied = nullptr;       // the four scalars of the last step are in h_energy
     bool xyz2_exported = false;               // frog_comm_buffer handed out pos2: its address must not change
-    hipEvent_t sel_done = nullptr;            // selection `sel_ready` complete (side stream)
-    hipEvent_t ord_read[2] = { nullptr, nullptr };   // last reader of sample_ord[b] done (main stream)
+    hipEvent_t sel_done[SEL_RING_MAX] = {};   // selection in buffer b complete (side stream)
+    hipEvent_t ord_read[SEL_RING_MAX] = {};   // last reader of buffer b done (main stream)
     frog::DevBuf<uint32_t> mt_state;          // [nOwned][625] (624 words + index)
     std::vector<uint32_t> h_virtual;          // per owned image: virtualSize (clamped to 2^32-1)
     frog::DevBuf<uint32_t> d_virtual;         // [nOwned]

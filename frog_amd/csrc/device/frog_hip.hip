@@ -166,6 +166,36 @@ static int cull_allocate(frog_ctx *ctx);
 static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], const double maxs[3], GridGeom &g, frog_grid_info &info);
 static int lattice_alloc(frog_ctx *ctx, const GridGeom &g);
 
+// The runtime gives a queue its scratch memory at the first dispatch that asks for any -- a stall of 0.13 ms in front of the
+// first tiled B-spline transform of a run (the one kernel here with spills: 12 bytes per lane; rocprofv3 kernel trace).
+// This kernel asks for more than that, once, on every stream a context is put on.
+__global__ void scratch_warm_kernel(unsigned int *out, int n)
+{
+    volatile unsigned int a[16];
+    for (int k = 0; k < 16; k++) a[k] = (unsigned int)(k * n);
+    unsigned int v = 0;
+    for (int k = 0; k < 16; k++) v += a[(k + n) & 15];
+    if (n < 0) out[0] = v;              // never: n >= 0
+}
+
+// Queues, on the side stream, the selection of the next refresh not yet selected (k_stats.hip.h select_kernel: the
+// generator's state carries over, so selections are produced in refresh order) and the end points of its half-links.
+static int produce_selection(frog_ctx *c)
+{
+    const int b = (int)(c->sel_produced % (uint64_t)c->sel_ring);
+    const uint32_t nO = c->n_owned(), cap = (uint32_t)c->sample_cap;
+    if (c->sel_produced >= (uint64_t)c->sel_ring)                       // the buffer has been consumed before: wait for its readers
+        FROG_HIP_CHECK(hipStreamWaitEvent(c->side, c->ord_read[b], 0));
+    select_kernel<<<nO, SELECT_THREADS, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[b].p, c->sample_count[b].p);
+    sample_resolve_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, c->side>>>(
+        c->sample_ord[b].p, c->sample_count[b].p, cap, c->d_poff.p, c->ib, c->own_pt_begin,
+        c->ref_rowptr.p, c->ref_link.p, c->new_of_old.p, c->sample_ends[b].p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipEventRecord(c->sel_done[b], c->side));
+    c->sel_produced++;
+    return FROG_OK;
+}
+
 extern "C" {
 
 int frog_device_count(void)
@@ -191,9 +221,9 @@ void frog_destroy(frog_ctx *ctx)
     }
 #endif
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    if (ctx->sel_done) (void)hipEventDestroy(ctx->sel_done);
+    for (hipEvent_t e : ctx->sel_done) if (e) (void)hipEventDestroy(e);
     if (ctx->energy_copied) (void)hipEventDestroy(ctx->energy_copied);
-    for (int b = 0; b < 2; b++) if (ctx->ord_read[b]) (void)hipEventDestroy(ctx->ord_read[b]);
+    for (hipEvent_t e : ctx->ord_read) if (e) (void)hipEventDestroy(e);
     for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->h_energy) (void)hipHostFree(ctx->h_energy);
@@ -386,20 +416,31 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->samples.alloc((size_t)c->n_owned() * cap));
     CREATE_CHECK(c->em_guess.alloc((size_t)c->n_owned() * 4 * EM_GUESS_BATCHES));
     CREATE_CHECK(hipMemsetAsync(c->em_guess.p, 0, c->em_guess.bytes(), s));
-    for (int b = 0; b < 2; b++) {
+    // ring of pre-computed selections (ctx.h): FROG_SELECT_RING buffers (default 6: five refreshes ahead), fewer when they
+    // would take more than 1 GB
+    c->sel_ring = 6;
+    if (const char *e = getenv("FROG_SELECT_RING")) c->sel_ring = atoi(e);
+    c->sel_ring = std::max(2, std::min(c->sel_ring, (int)frog_ctx::SEL_RING_MAX));
+    while (c->sel_ring > 2 && (size_t)c->sel_ring * c->n_owned() * cap * 12 > ((size_t)1 << 30)) c->sel_ring--;
+    for (int b = 0; b < c->sel_ring; b++) {
         CREATE_CHECK(c->sample_ord[b].alloc((size_t)c->n_owned() * cap));
         CREATE_CHECK(c->sample_ends[b].alloc((size_t)c->n_owned() * cap));
         CREATE_CHECK(c->sample_count[b].alloc(c->n_owned()));
         CREATE_CHECK(hipMemsetAsync(c->sample_count[b].p, 0, c->sample_count[b].bytes(), s));
         CREATE_CHECK(hipEventCreateWithFlags(&c->ord_read[b], hipEventDisableTiming));
+        CREATE_CHECK(hipEventCreateWithFlags(&c->sel_done[b], hipEventDisableTiming));
     }
     {
-        // the selection kernel is one wavefront per image and must not starve behind the sweeps
+        // The replay is a latency chain on a few wavefronts per image.  With one selection ahead it had to finish within ten
+        // iterations and ran at high priority -- where its wavefronts take issue slots from the kernels of the iteration
+        // (measured on cfg 3 while it runs: sweeps +4 %, the one-block-per-CU lattice step +60 %).  With a ring it has
+        // (sel_ring - 1) x ten iterations and runs at LOW priority (FROG_SELECT_PRIORITY=high restores the old choice).
         int lo = 0, hi = 0;
         CREATE_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        CREATE_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+        const char *pe = getenv("FROG_SELECT_PRIORITY");
+        const bool high = pe ? pe[0] == 'h' : c->sel_ring < 3;
+        CREATE_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, high ? hi : lo));
     }
-    CREATE_CHECK(hipEventCreateWithFlags(&c->sel_done, hipEventDisableTiming));
     CREATE_CHECK(hipEventCreateWithFlags(&c->energy_copied, hipEventDisableTiming));
     {
         // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
@@ -467,14 +508,30 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             c->retired_used = 0;
         }
     }
-    // selection of the first refresh, ahead of time
-    c->sel_ready = 0; c->sel_used = 1;
-    select_kernel<<<c->n_owned(), SELECT_THREADS, 0, c->side>>>(c->mt_state.p, c->d_virtual.p, cap, c->sample_ord[0].p, c->sample_count[0].p);
-    sample_resolve_kernel<<<dim3(div_up(cap, 256), c->n_owned()), 256, 0, c->side>>>(
-        c->sample_ord[0].p, c->sample_count[0].p, cap, c->d_poff.p, c->ib, c->own_pt_begin,
-        c->ref_rowptr.p, c->ref_link.p, c->new_of_old.p, c->sample_ends[0].p);
-    CREATE_CHECK(hipGetLastError());
-    CREATE_CHECK(hipEventRecord(c->sel_done, c->side));
+    {
+        // Resolve the kernels of the deformable stage now: the runtime creates a kernel's function object at its first
+        // launch, which cost the first deformable step of a run 0.1-0.15 ms of host time with the GPU idle (rocprofv3
+        // kernel trace: a gap in front of the first transform through a lattice).  Asking for the attributes does the same work.
+        const void *kernels[] = {
+            (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, false>, (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, true, false>,
+            (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, true>, (const void *)sweep_kernel<SWEEP_COUNT, true, false, false, false>,
+            (const void *)scatter_kernel, (const void *)lattice_step_kernel<true>, (const void *)lattice_step_kernel<false>,
+            (const void *)transform_bspline_tile_kernel, (const void *)transform_bspline_kernel, (const void *)transform_zero_lattice_kernel,
+            (const void *)cp_center_kernel, (const void *)bounds_kernel, (const void *)bounds_final_kernel, (const void *)zero_buffers_kernel,
+            (const void *)brick_count_kernel, (const void *)brick_place_kernel, (const void *)cell_order_kernel, (const void *)brick_chunks_kernel,
+            (const void *)scan_block_sums_kernel, (const void *)scan_of_sums_kernel, (const void *)scan_apply_kernel,
+            (const void *)block_fill_kernel, (const void *)block_len_base_kernel, (const void *)block_sort_kernel,
+            (const void *)cull_list_cutoff_kernel, (const void *)cull_allow_kernel, (const void *)cull_validate_kernel, (const void *)cull_disp_kernel,
+            (const void *)count_reduce_kernel, (const void *)combine_groups_kernel, (const void *)energy_reduce_kernel,
+        };
+        for (const void *k : kernels) { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, k); }
+        (void)hipGetLastError();
+    }
+    scratch_warm_kernel<<<1, 64, 0, s>>>(c->stray.p, 0);
+    (void)hipGetLastError();
+    // selections of the first sel_ring - 1 refreshes, ahead of time
+    for (int k = 0; k + 1 < c->sel_ring; k++)
+        if (int rc_ = produce_selection(c)) { frog_destroy(c); return rc_; }
 #undef CREATE_CHECK
     *out = c;
     return FROG_OK;
@@ -487,6 +544,8 @@ int frog_set_stream(frog_ctx *ctx, void *hip_stream)
     if (ctx->own_stream) FROG_HIP_CHECK(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    scratch_warm_kernel<<<1, 64, 0, ctx->stream>>>(ctx->stray.p, 0);
+    (void)hipGetLastError();
     if (ctx->helper) return frog_set_stream(ctx->helper, hip_stream);
     return FROG_OK;
 }
@@ -624,9 +683,9 @@ int frog_update_stats_local(frog_ctx *ctx)
     const uint32_t nO = ctx->n_owned();
     const uint32_t cap = (uint32_t)ctx->sample_cap;
     hipStream_t s = ctx->stream;
-    // consume the selection prepared on the side stream
-    const int cur = ctx->sel_ready;
-    FROG_HIP_CHECK(hipStreamWaitEvent(s, ctx->sel_done, 0));
+    // consume the oldest selection prepared on the side stream
+    const int cur = (int)(ctx->sel_consumed % (uint64_t)ctx->sel_ring);
+    FROG_HIP_CHECK(hipStreamWaitEvent(s, ctx->sel_done[cur], 0));
     {
         Span span(ctx, FROG_K_STATS);
         sample_distance_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, s>>>(
@@ -643,16 +702,9 @@ int frog_update_stats_local(frog_ctx *ctx)
     }
     FROG_HIP_CHECK(hipEventRecord(ctx->ord_read[cur], s));
     ctx->sel_used = cur;
-    // prepare the next refresh's selection into the other buffer, behind its last reader
-    const int nxt = cur ^ 1;
-    FROG_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ord_read[nxt], 0));
-    select_kernel<<<nO, SELECT_THREADS, 0, ctx->side>>>(ctx->mt_state.p, ctx->d_virtual.p, cap, ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p);
-    sample_resolve_kernel<<<dim3(div_up(cap, 256), nO), 256, 0, ctx->side>>>(
-        ctx->sample_ord[nxt].p, ctx->sample_count[nxt].p, cap, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin,
-        ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, ctx->sample_ends[nxt].p);
-    FROG_HIP_CHECK(hipGetLastError());
-    FROG_HIP_CHECK(hipEventRecord(ctx->sel_done, ctx->side));
-    ctx->sel_ready = nxt;
+    ctx->sel_consumed++;
+    // one more selection for the ring: into the buffer the PREVIOUS refresh consumed (this one's stays readable: getters)
+    { const int rc = produce_selection(ctx); if (rc) return rc; }
     // rows of other ranks' images: zero, so that an all-reduce(sum) completes the table
     if (ctx->ib > 0) FROG_HIP_CHECK(hipMemsetAsync(ctx->em.p, 0, (size_t)ctx->ib * sizeof(float4), s));
     if (ctx->ie < ctx->nI)

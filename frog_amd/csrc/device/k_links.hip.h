@@ -206,7 +206,10 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // (tile_order), and a true match's partner lies in the same eighth of the partner image -- with the certified outliers
 // gone from the list (k_cull.hip.h) nearly every gather is a true match.
 template <int MODE, bool EMD_LDS, bool WIDE, bool BUILD = false, bool FUSED = false>
-__global__ __launch_bounds__(FUSED ? 512 : 256) void sweep_kernel(const SweepArgs a)
+#ifndef FROG_FUSED_MIN_WAVES
+#define FROG_FUSED_MIN_WAVES 1      // 7 caps the kernel at 72 VGPRs (six wavefronts per SIMD and room for the side stream's selection kernel beside them): measured slower, 0.260 against 0.254 ms
+#endif
+__global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1) void sweep_kernel(const SweepArgs a)
 {
     static_assert(!BUILD || (MODE == SWEEP_DEFORMABLE && EMD_LDS && !WIDE), "the list is built by the narrow deformable sweep");
     static_assert(!FUSED || (MODE == SWEEP_DEFORMABLE && EMD_LDS), "the fused form is the deformable sweep's");

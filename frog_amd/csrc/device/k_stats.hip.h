@@ -25,27 +25,32 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Regenerates all 624 state words in place (std::mt19937's _M_gen_rand), one block of
-// SELECT_THREADS threads, state in LDS.  Four dependency phases: [0,227) [227,454) [454,623) {623};
-// each fits one pass of the block.
+// Regenerates all 624 state words in place (std::mt19937's _M_gen_rand), one block of SELECT_THREADS threads, state in
+// LDS.  The recurrence has lag 227 (= N - M): new[k] needs old[k], old[k+1] and, for k >= 227, new[k-227].  So thread
+// t < 227 forms the chain new[t] -> new[t+227] -> new[t+454] in its own registers from OLD words only (the last word,
+// new[623] = f(old[623], new[0], new[396]), falls to thread 169, which holds new[396] and recomputes new[0]): ONE
+// barrier between the reads and the writes instead of the four dependency phases [0,227) [227,454) [454,623) {623} with
+// two barriers each that the first version took -- the replay is a latency chain of 1 600 regenerations per image and
+// refresh, and barriers were most of it.
 constexpr int SELECT_THREADS = 256;
 
 __device__ __forceinline__ void mt_regenerate(uint32_t *x, int tid)
 {
-    const int starts[5] = { 0, 227, 454, 623, 624 };
-    #pragma unroll
-    for (int ph = 0; ph < 4; ph++) {
-        const int k = starts[ph] + tid;
-        uint32_t v = 0;
-        if (k < starts[ph + 1]) {
-            const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
-            const int km = (k + MT_M >= MT_N) ? k + MT_M - MT_N : k + MT_M;
-            v = mt_twist(x[k], x[k1], x[km]);
-        }
-        __syncthreads();
-        if (k < starts[ph + 1]) x[k] = v;
-        __syncthreads();
+    constexpr int LAG = MT_N - MT_M;            // 227
+    uint32_t a = 0, b = 0, c = 0;
+    if (tid < LAG) {
+        a = mt_twist(x[tid], x[tid + 1], x[tid + MT_M]);
+        b = mt_twist(x[tid + LAG], x[tid + LAG + 1], a);
+        if (tid + 2 * LAG < MT_N - 1) c = mt_twist(x[tid + 2 * LAG], x[tid + 2 * LAG + 1], b);
+        else if (tid + 2 * LAG == MT_N - 1) c = mt_twist(x[MT_N - 1], mt_twist(x[0], x[1], x[MT_M]), b);
     }
+    __syncthreads();
+    if (tid < LAG) {
+        x[tid] = a;
+        x[tid + LAG] = b;
+        if (tid + 2 * LAG < MT_N) x[tid + 2 * LAG] = c;
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
@@ -63,14 +68,18 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 //                            image's half-links are exhausted.
 // The replay of one image is a chain (every block of 624 outputs needs the previous one) and the
 // kernel is pure latency: with a single wavefront per image a refresh of 10^6 draws took 8 ms,
-// more than ten iterations last once the images are spread over several GPUs.  With 256 threads a
-// regeneration phase is one pass, and 256 draws are tested, ranked (ballot + a 4-entry prefix) and
-// stored per round.
+// more than ten iterations last once the images are spread over several GPUs.  A round consumes ALL
+// the words left in the state (up to 624: three per thread, word index = ordinal order), tests them,
+// ranks the kept ones (ballots + a 12-entry prefix over (row, wavefront)) and stores them: two barriers
+// per round and two per regeneration (2.4 ms per refresh with rounds of 256 draws and the four-phase
+// regeneration; the kept ordinals are the same, bit for bit: tests compare them with the oracle's).
+constexpr int SELECT_ROWS = (MT_N + SELECT_THREADS - 1) / SELECT_THREADS;     // 3
+
 __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_state, const uint32_t *virtual_size,
                                                                 uint32_t cap, uint32_t *sample_ord, uint32_t *sample_count)
 {
     __shared__ uint32_t x[MT_N];
-    __shared__ uint32_t wave_cnt[SELECT_THREADS / 64];
+    __shared__ uint32_t row_cnt[SELECT_ROWS][SELECT_THREADS / 64];
     __shared__ int jstar_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t img = blockIdx.x;
@@ -94,31 +103,49 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
     bool done = false;
     while (!done && ordinal < vs) {
         if (idx >= (uint32_t)MT_N) { mt_regenerate(x, tid); idx = 0; }
-        // consume up to 256 words [idx, idx+256) of the current block
-        const uint32_t avail = min((uint32_t)MT_N - idx, vs - ordinal);
-        const uint32_t n = min(avail, (uint32_t)SELECT_THREADS);
-        bool keep = false;
-        if ((uint32_t)tid < n) {
-            const uint32_t y = mt_temper(x[idx + tid]);
-            const float r = (float)y / 4294967296.0f;   // (float) rng() / rng.max(); (float)0xFFFFFFFF == 2^32
-            keep = !(r > thresh);
+        // consume the words [idx, idx + n) of the current state: position q = tid + 256 row <-> ordinal + q
+        const uint32_t n = min((uint32_t)MT_N - idx, vs - ordinal);
+        // per row: kept? (bit r of keep_bits) and how many lower lanes of this wavefront kept theirs (byte r of below_pk)
+        uint32_t keep_bits = 0, below_pk = 0;
+        #pragma unroll
+        for (int r = 0; r < SELECT_ROWS; r++) {
+            const uint32_t q = (uint32_t)tid + (uint32_t)(SELECT_THREADS * r);
+            bool keep = false;
+            if (q < n) {
+                const uint32_t y = mt_temper(x[idx + q]);
+                const float u = (float)y / 4294967296.0f;   // (float) rng() / rng.max(); (float)0xFFFFFFFF == 2^32
+                keep = !(u > thresh);
+            }
+            const unsigned long long mask = __ballot(keep);
+            keep_bits |= (keep ? 1u : 0u) << r;
+            below_pk |= (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) << (8 * r);
+            if (lane == 0) row_cnt[r][wave] = (uint32_t)__popcll(mask);
         }
-        const unsigned long long mask = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
         if (tid == 0) jstar_s = -1;
         __syncthreads();
-        uint32_t kept = 0, rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t kept = 0;
         #pragma unroll
-        for (int w = 0; w < SELECT_THREADS / 64; w++) {
-            const uint32_t c = wave_cnt[w];
-            kept += c;
-            if (w < wave) rank += c;
+        for (int r = 0; r < SELECT_ROWS; r++)
+            #pragma unroll
+            for (int w = 0; w < SELECT_THREADS / 64; w++) kept += row_cnt[r][w];
+        // the buffer fills inside this round: keep the first (cap - count); the need-th kept draw is the last one consumed
+        const bool fills = count + kept >= cap;
+        const uint32_t need = fills ? cap - count : 0xFFFFFFFFu;
+        uint32_t before = 0;                       // kept draws of the rows and wavefronts before this thread's (row, wavefront)
+        #pragma unroll
+        for (int r = 0; r < SELECT_ROWS; r++) {
+            uint32_t rank = before + ((below_pk >> (8 * r)) & 0xFFu);
+            #pragma unroll
+            for (int w = 0; w < SELECT_THREADS / 64; w++) {
+                const uint32_t c = row_cnt[r][w];
+                if (w < wave) rank += c;
+                before += c;
+            }
+            const uint32_t q = (uint32_t)tid + (uint32_t)(SELECT_THREADS * r);
+            if (((keep_bits >> r) & 1u) && rank < need) ord[count + rank] = ordinal + q;
+            if (((keep_bits >> r) & 1u) && fills && rank == need - 1) jstar_s = (int)q;
         }
-        if (count + kept >= cap) {
-            // the buffer fills inside this round: keep the first (cap - count)
-            const uint32_t need = cap - count;
-            if (keep && rank < need) ord[count + rank] = ordinal + tid;
-            if (keep && rank == need - 1) jstar_s = tid;            // the need-th kept draw = last draw consumed
+        if (fills) {
             __syncthreads();
             const uint32_t jstar = (uint32_t)jstar_s;
             idx += jstar + 1;
@@ -126,12 +153,11 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
             count = cap;
             done = true;
         } else {
-            if (keep) ord[count + rank] = ordinal + tid;
             count += kept;
             idx += n;
             ordinal += n;
         }
-        __syncthreads();                           // wave_cnt / jstar_s are reused, the state may be regenerated
+        __syncthreads();                           // row_cnt / jstar_s are reused, the state may be regenerated
     }
     for (int k = tid; k < MT_N; k += SELECT_THREADS) st[k] = x[k];
     if (tid == 0) { st[MT_N] = idx; sample_count[img] = count; }
