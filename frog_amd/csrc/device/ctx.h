@@ -245,6 +245,14 @@ struct frog_ctx {
     uint64_t sel_produced = 0;                // selections queued on the side stream (refresh k lives in buffer k % sel_ring)
     int sel_used = 0;                         // buffer the last refresh consumed
     hipStream_t side = nullptr;
+    // The device work of a lattice set-up (zeroing, the sort of the points by (image, brick, cell), the scatter's block table)
+    // runs on a stream of its own: nothing needs its products before the first scatter on the new lattice, so it overlaps
+    // with the statistics refresh and the half-link sweep that open the level (frog_deformable_setup_bounds, join_setup)
+    hipStream_t setup_stream = nullptr;
+    hipEvent_t setup_fork = nullptr, setup_join = nullptr;
+    bool setup_pending = false;               // host side: setup_join not yet waited for on `stream`
+    bool setup_deferred = false;              // host side: the set-up's kernels are not queued yet (join_setup queues them)
+    bool setup_async = true;                  // FROG_SETUP_STREAM=0: everything on `stream`
     hipEvent_t energy_copied = nullptr;       // the four scalars of the last step are in h_energy
     bool xyz2_exported = false;               // frog_comm_buffer handed out pos2: its address must not change
     hipEvent_t sel_done[SEL_RING_MAX] = {};   // selection in buffer b complete (side stream)

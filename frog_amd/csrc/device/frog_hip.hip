@@ -178,6 +178,113 @@ __global__ void scratch_warm_kernel(unsigned int *out, int n)
     if (n < 0) out[0] = v;              // never: n >= 0
 }
 
+// upper bound of the scatter's block count: every non-empty brick ends with at most one partial block
+static uint32_t scatter_max_blocks(uint32_t n_bricks_total, uint32_t n_points)
+{
+    return std::min(n_bricks_total, n_points) + n_points / SCATTER_CHUNK;
+}
+
+// Device work of a lattice set-up (frog_deformable_setup_bounds) for the geometry in ctx->geom, on stream s.
+static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
+{
+    const GridGeom &g = ctx->geom;
+    const uint32_t nO = ctx->n_owned();
+    const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
+    const size_t nb = (size_t)g.n_bricks;
+    int rc = FROG_OK;
+    {
+        // gradient lattice, coefficients, proposals, their sums, the sort's counters, the block-length histogram: one launch
+        ZeroList z{};
+        auto add = [&](void *p, size_t bytes) {
+            if (!p || !bytes) return;
+            z.p[z.n] = (uint32_t *)p; z.bytes[z.n] = bytes;
+            z.first_block[z.n + 1] = z.first_block[z.n] + (unsigned)((bytes + ZERO_BLOCK_BYTES - 1) / ZERO_BLOCK_BYTES);
+            z.n++;
+        };
+        add(ctx->gradf.p, ctx->gradf.bytes()); add(ctx->coeff.p, ctx->coeff.bytes()); add(ctx->grad.p, ctx->grad.bytes());
+        add(ctx->gridsum.p, ctx->gridsum.bytes()); add(ctx->key_counts.p, ctx->key_counts.bytes());
+        add(ctx->len_hist.p, ctx->len_hist.bytes());
+        if (z.n) {
+            zero_buffers_kernel<<<z.first_block[z.n], 256, 0, s>>>(z);
+            FROG_HIP_CHECK(hipGetLastError());
+        }
+    }
+
+    // sort the owned points by (image, brick, cell) and build the scatter's block table -- all on the device, nothing
+    // comes back to the host (the first version read the brick sizes back, built and sorted the table on the host and
+    // uploaded it: 1.0-2.5 ms per lattice, most of it two round trips and the host loop)
+    const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
+    const uint32_t n_keys = (uint32_t)((size_t)nO * nb * keys_per_brick);
+    const uint32_t n_bricks_total = nO * (uint32_t)nb;
+    frog::DevBuf<uint32_t> &counts = ctx->key_counts, &chunks = ctx->brick_ptr_scratch;
+    const GeomDev gd = to_dev(g);
+    uint32_t max_img_pts = 0;
+    for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
+    const dim3 bgrid(std::max(1u, div_up(max_img_pts, BRICK_BLOCK_POINTS)), nO);
+    if (nPts) {
+        brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
+        FROG_HIP_CHECK(hipGetLastError());
+    }
+    auto exclusive_scan = [&](const uint32_t *in, uint32_t n, uint32_t *ptr, uint32_t *cursor) -> int {
+        const uint32_t n_scan_blocks = div_up(n, SCAN_BLOCK_ITEMS);
+        frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;      // sized for the longer of the two scans by lattice_alloc
+        scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p);
+        scan_of_sums_kernel<<<1, 1024, 0, s>>>(bsums.p, n_scan_blocks, bsums.p + n_scan_blocks);
+        scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p, bsums.p + n_scan_blocks, ptr, cursor);
+        FROG_HIP_CHECK(hipGetLastError());
+        return FROG_OK;
+    };
+    rc = exclusive_scan(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
+    if (rc) return rc;
+    if (nPts) {
+        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p, ctx->perm_key.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        // canonical order inside every cell (the placement's atomics make it arbitrary): reproducible sums
+        cell_order_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->perm_key.p, nPts, ctx->perm.p, ctx->perm_tmp.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        std::swap(ctx->perm.p, ctx->perm_tmp.p);
+        std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
+        std::swap(ctx->perm.n, ctx->perm_tmp.n);
+    }
+    // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
+    // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
+    // every non-empty brick ends with at most one partial block
+    const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts);
+    brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
+    if (rc) return rc;
+    ScatterBlock *blk_tmp = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks_tmp.p);
+    ScatterBlock *blk = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks.p);
+    uint32_t *len_hist = ctx->len_hist.p, *len_cursor = ctx->len_hist.p + (SCATTER_CHUNK + 1);
+    const uint32_t *n_blocks_dev = ctx->brick_slot_ptr.p + n_bricks_total;
+    block_fill_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->brick_slot_ptr.p, n_bricks_total, keys_per_brick,
+                                                                 blk_tmp, len_hist);
+    block_len_base_kernel<<<1, 512, 0, s>>>(len_hist, len_cursor);
+    if (max_blocks)
+        block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+// Makes `stream` wait for the lattice set-up (once per set-up; a no-op otherwise).  A set-up whose device work has not
+// been queued yet (frog_deformable_setup_bounds) is queued now, on the set-up stream, behind the fork event.
+static int join_setup(frog_ctx *ctx)
+{
+    if (ctx->setup_deferred) {
+        ctx->setup_deferred = false;
+        FROG_HIP_CHECK(hipStreamWaitEvent(ctx->setup_stream, ctx->setup_fork, 0));
+        const int rc = queue_setup_kernels(ctx, ctx->setup_stream);
+        if (rc) return rc;
+        FROG_HIP_CHECK(hipEventRecord(ctx->setup_join, ctx->setup_stream));
+        ctx->setup_pending = true;
+    }
+    if (!ctx->setup_pending) return FROG_OK;
+    FROG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->setup_join, 0));
+    ctx->setup_pending = false;
+    return FROG_OK;
+}
+
 // Queues, on the side stream, the selection of the next refresh not yet selected (k_stats.hip.h select_kernel: the
 // generator's state carries over, so selections are produced in refresh order) and the end points of its half-links.
 static int produce_selection(frog_ctx *c)
@@ -221,6 +328,9 @@ void frog_destroy(frog_ctx *ctx)
     }
 #endif
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->setup_stream) { (void)hipStreamSynchronize(ctx->setup_stream); (void)hipStreamDestroy(ctx->setup_stream); }
+    if (ctx->setup_fork) (void)hipEventDestroy(ctx->setup_fork);
+    if (ctx->setup_join) (void)hipEventDestroy(ctx->setup_join);
     for (hipEvent_t e : ctx->sel_done) if (e) (void)hipEventDestroy(e);
     if (ctx->energy_copied) (void)hipEventDestroy(ctx->energy_copied);
     for (hipEvent_t e : ctx->ord_read) if (e) (void)hipEventDestroy(e);
@@ -442,6 +552,10 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, high ? hi : lo));
     }
     CREATE_CHECK(hipEventCreateWithFlags(&c->energy_copied, hipEventDisableTiming));
+    CREATE_CHECK(hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking));
+    CREATE_CHECK(hipEventCreateWithFlags(&c->setup_fork, hipEventDisableTiming));
+    CREATE_CHECK(hipEventCreateWithFlags(&c->setup_join, hipEventDisableTiming));
+    if (const char *e = getenv("FROG_SETUP_STREAM")) c->setup_async = atoi(e) != 0;
     {
         // std::mt19937::seed(0); index 624 forces a regeneration at the first draw
         std::vector<uint32_t> st((size_t)c->n_owned() * MT_WORDS);
@@ -540,7 +654,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
 int frog_set_stream(frog_ctx *ctx, void *hip_stream)
 {
     CTX_GUARD(ctx);
+    { const int rc = join_setup(ctx); if (rc) return rc; }
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->setup_stream) FROG_HIP_CHECK(hipStreamSynchronize(ctx->setup_stream));
     if (ctx->own_stream) FROG_HIP_CHECK(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
@@ -561,6 +677,7 @@ int frog_get_stream(frog_ctx *ctx, void **hip_stream, int *device)
 int frog_synchronize(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
+    { const int rc = join_setup(ctx); if (rc) return rc; }
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
 }
@@ -613,6 +730,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         if (out != ctx->pos2.p) ctx->disp_spec = false;
         transform_zero_lattice_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->own_pt_begin, ctx->own_pt_end, apply);
     } else {
+        { const int rc = join_setup(ctx); if (rc) return rc; }
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
         const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
@@ -909,11 +1027,6 @@ int frog_bounds_local(frog_ctx *ctx, double mins[3], double maxs[3])
     return FROG_OK;
 }
 
-// upper bound of the scatter's block count: every non-empty brick ends with at most one partial block
-static uint32_t scatter_max_blocks(uint32_t n_bricks_total, uint32_t n_points)
-{
-    return std::min(n_bricks_total, n_points) + n_points / SCATTER_CHUNK;
-}
 
 // box.ScaleAboutCenter(1 + 2*margin) then the lattice (imageGroup.cxx:161-179), and the brick partition of its cells
 static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], const double maxs[3], GridGeom &g, frog_grid_info &info)
@@ -1015,7 +1128,9 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     CTX_GUARD(ctx);
     if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
     ctx->xyz2_fresh = false; ctx->res_valid = false;
-    int rc = retire_current_grid(ctx);
+    int rc = join_setup(ctx);                   // a set-up right behind a set-up
+    if (rc) return rc;
+    rc = retire_current_grid(ctx);
     if (rc) return rc;
 
     GridGeom g{};
@@ -1028,85 +1143,26 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     ctx->geom = g;
     info.n_grid = (int)ctx->grids.size();
 
-    hipStream_t s = ctx->stream;
     rc = lattice_alloc(ctx, g);                 // within the head-room reserved earlier, as a rule: no hipMalloc here
     if (rc) return rc;
-    {
-        // gradient lattice, coefficients, proposals, their sums, the sort's counters, the block-length histogram: one launch
-        ZeroList z{};
-        auto add = [&](void *p, size_t bytes) {
-            if (!p || !bytes) return;
-            z.p[z.n] = (uint32_t *)p; z.bytes[z.n] = bytes;
-            z.first_block[z.n + 1] = z.first_block[z.n] + (unsigned)((bytes + ZERO_BLOCK_BYTES - 1) / ZERO_BLOCK_BYTES);
-            z.n++;
-        };
-        add(ctx->gradf.p, ctx->gradf.bytes()); add(ctx->coeff.p, ctx->coeff.bytes()); add(ctx->grad.p, ctx->grad.bytes());
-        add(ctx->gridsum.p, ctx->gridsum.bytes()); add(ctx->key_counts.p, ctx->key_counts.bytes());
-        add(ctx->len_hist.p, ctx->len_hist.bytes());
-        if (z.n) {
-            zero_buffers_kernel<<<z.first_block[z.n], 256, 0, s>>>(z);
-            FROG_HIP_CHECK(hipGetLastError());
-        }
-        ctx->coeff_zero = true;
-    }
-
-    // sort the owned points by (image, brick, cell) and build the scatter's block table -- all on the device, nothing
-    // comes back to the host (the first version read the brick sizes back, built and sorted the table on the host and
-    // uploaded it: 1.0-2.5 ms per lattice, most of it two round trips and the host loop)
+    // sizes the kernels below rely on, checked here where an error can still be returned to the caller
     const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
     const size_t n_keys64 = (size_t)nO * nb * keys_per_brick;
     if (n_keys64 >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
-    const uint32_t n_keys = (uint32_t)n_keys64;
-    const uint32_t n_bricks_total = nO * (uint32_t)nb;
-    frog::DevBuf<uint32_t> &counts = ctx->key_counts, &chunks = ctx->brick_ptr_scratch;
-    const GeomDev gd = to_dev(g);
-    uint32_t max_img_pts = 0;
-    for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
-    const dim3 bgrid(std::max(1u, div_up(max_img_pts, BRICK_BLOCK_POINTS)), nO);
-    if (nPts) {
-        brick_count_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, counts.p);
-        FROG_HIP_CHECK(hipGetLastError());
+    ctx->n_scatter_blocks = scatter_max_blocks(nO * (uint32_t)nb, nPts);
+    ctx->coeff_zero = true;
+    // The device work of the set-up -- zeroing, the sort of the points, the block table -- is queued on the set-up stream,
+    // behind what `stream` holds NOW (the re-based coordinates, the copy of the finished lattice, the last readers of the old
+    // sort: the fork event), but not yet: the host queues it when the first consumer asks (join_setup: as a rule the step's
+    // scatter, right after its half-link sweep has been launched), so that the transform, the statistics refresh and the
+    // sweep that open the level are in the queue first and the set-up runs beside them instead of in front of them.
+    if (ctx->setup_async && ctx->setup_stream) {
+        FROG_HIP_CHECK(hipEventRecord(ctx->setup_fork, ctx->stream));
+        ctx->setup_deferred = true;
+    } else {
+        rc = queue_setup_kernels(ctx, ctx->stream);
+        if (rc) return rc;
     }
-    auto exclusive_scan = [&](const uint32_t *in, uint32_t n, uint32_t *ptr, uint32_t *cursor) -> int {
-        const uint32_t n_scan_blocks = div_up(n, SCAN_BLOCK_ITEMS);
-        frog::DevBuf<uint32_t> &bsums = ctx->scan_sums;      // sized for the longer of the two scans by lattice_alloc
-        scan_block_sums_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p);
-        scan_of_sums_kernel<<<1, 1024, 0, s>>>(bsums.p, n_scan_blocks, bsums.p + n_scan_blocks);
-        scan_apply_kernel<<<n_scan_blocks, 1024, 0, s>>>(in, n, bsums.p, bsums.p + n_scan_blocks, ptr, cursor);
-        FROG_HIP_CHECK(hipGetLastError());
-        return FROG_OK;
-    };
-    rc = exclusive_scan(counts.p, n_keys, ctx->key_ptr.p, ctx->key_cursor.p);
-    if (rc) return rc;
-    if (nPts) {
-        brick_place_kernel<<<bgrid, 256, 0, s>>>(ctx->pos.p, ctx->d_poff.p, ctx->ib, gd, ctx->key_cursor.p, ctx->perm.p, ctx->perm_key.p);
-        FROG_HIP_CHECK(hipGetLastError());
-        // canonical order inside every cell (the placement's atomics make it arbitrary): reproducible sums
-        cell_order_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->perm_key.p, nPts, ctx->perm.p, ctx->perm_tmp.p);
-        FROG_HIP_CHECK(hipGetLastError());
-        std::swap(ctx->perm.p, ctx->perm_tmp.p);
-        std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
-        std::swap(ctx->perm.n, ctx->perm_tmp.n);
-    }
-    // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
-    // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
-    // every non-empty brick ends with at most one partial block
-    const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts);
-    brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
-    FROG_HIP_CHECK(hipGetLastError());
-    rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
-    if (rc) return rc;
-    ScatterBlock *blk_tmp = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks_tmp.p);
-    ScatterBlock *blk = reinterpret_cast<ScatterBlock *>(ctx->scatter_blocks.p);
-    uint32_t *len_hist = ctx->len_hist.p, *len_cursor = ctx->len_hist.p + (SCATTER_CHUNK + 1);
-    const uint32_t *n_blocks_dev = ctx->brick_slot_ptr.p + n_bricks_total;
-    block_fill_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->brick_slot_ptr.p, n_bricks_total, keys_per_brick,
-                                                                 blk_tmp, len_hist);
-    block_len_base_kernel<<<1, 512, 0, s>>>(len_hist, len_cursor);
-    if (max_blocks)
-        block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
-    FROG_HIP_CHECK(hipGetLastError());
-    ctx->n_scatter_blocks = max_blocks;
 
     GridRecord rec;
     rec.info = info;
@@ -1236,6 +1292,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
                                            ctx->build_in_sweep);
     }
     FROG_HIP_CHECK(hipGetLastError());
+    { const int rc = join_setup(ctx); if (rc) return rc; }     // the scatter is the first kernel that needs the new lattice's sort
     {
         Span span(ctx, FROG_K_COMBINE);
         // the per-point sums are only materialised when something other than the scatter reads them (landmark
@@ -1515,6 +1572,7 @@ int frog_num_grids(const frog_ctx *ctx) { return ctx ? (int)ctx->grids.size() : 
 int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, float *coeffs, size_t cap)
 {
     CTX_GUARD(ctx);
+    { const int rc_ = join_setup(ctx); if (rc_) return rc_; }
     if (k < 0 || k >= (int)ctx->grids.size()) return fail(FROG_E_INVALID, "bad lattice index");
     GridRecord &gr = ctx->grids[k];
     if (info) *info = gr.info;
@@ -1564,6 +1622,7 @@ int frog_set_hard_links(frog_ctx *ctx, const uint64_t *point, const uint64_t *pa
 int frog_residual_sums(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
+    { const int rc_ = join_setup(ctx); if (rc_) return rc_; }
     if (ctx->phase != 0) return fail(FROG_E_STATE, "residual sums inside a deformable step");
     hipStream_t s = ctx->stream;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
@@ -1589,6 +1648,7 @@ int frog_residual_sums(frog_ctx *ctx)
 int frog_get_error_map(frog_ctx *ctx, uint32_t image, frog_grid_info *info, float *out, size_t cap)
 {
     CTX_GUARD(ctx);
+    { const int rc_ = join_setup(ctx); if (rc_) return rc_; }
     if (!ctx->deformable || ctx->grids.empty()) return fail(FROG_E_STATE, "no lattice");
     if (!ctx->res_valid) return fail(FROG_E_STATE, "frog_get_error_map without frog_residual_sums");
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
@@ -1639,6 +1699,7 @@ int frog_get_point_sums(frog_ctx *ctx, float *out)
 int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
 {
     CTX_GUARD(ctx);
+    { const int rc_ = join_setup(ctx); if (rc_) return rc_; }
     if (!ctx->deformable) return fail(FROG_E_STATE, "no lattice");
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
     const size_t G = (size_t)ctx->geom.n_cp;
@@ -1711,6 +1772,7 @@ int frog_test_cull_ranges(frog_ctx *ctx, uint64_t *ranges, uint64_t *with_electi
 int frog_test_stray_points(frog_ctx *ctx, uint64_t *n)
 {
     CTX_GUARD(ctx);
+    { const int rc_ = join_setup(ctx); if (rc_) return rc_; }
     if (!n) return fail(FROG_E_INVALID, "null output");
     unsigned int v = 0;
     FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->stray.p + 2, sizeof v, hipMemcpyDeviceToHost, ctx->stream));

@@ -43,7 +43,10 @@ def main():
             tot = collections.defaultdict(lambda: [0.0, 0])
             for r in csv.DictReader(open(f)):
                 # the launch that also writes the culling list (last template argument true: once per list) is not the steady state
-                if (short(r["Kernel_Name"]).startswith("sweep_kernel<1") and not short(r["Kernel_Name"]).rstrip().endswith(", true>")
+                # (template arguments: MODE, EMD_LDS, WIDE, BUILD, FUSED)
+                nm = short(r["Kernel_Name"]).strip()
+                targs = [a.strip() for a in nm[nm.find("<") + 1:nm.rfind(">")].split(",")] if "<" in nm else []
+                if (nm.startswith("sweep_kernel<1") and not (len(targs) > 3 and targs[3] == "true")
                         and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")):
                     tot[r["Counter_Name"]][0] += float(r["Counter_Value"]); tot[r["Counter_Name"]][1] += 1
             if "FETCH_SIZE" in tot: fetch = tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1]
