@@ -833,10 +833,9 @@ int frog_update_stats_local(frog_ctx *ctx)
 int frog_stats_publish(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
-    em_derive_kernel<<<div_up(ctx->nI, 256), 256, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI);
-    // the certified outlier cutoffs follow the mixtures (k_cull.hip.h); the check before the next sweep compares them
-    // with the list's
-    cull_cutoff_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p);
+    // the weight constants of the new mixtures and, with them, the certified outlier cutoffs (k_cull.hip.h); the check before
+    // the next sweep compares the cutoffs with the list's
+    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p);
     ctx->cull_check_due = true;         // the next cull_prepare recomputes the allowed displacement and runs the stand-alone check
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -1258,8 +1257,10 @@ static int cull_prepare(frog_ctx *ctx)
     // have changed since, or when the displacement was measured here.  While the flag is up the host rebuilds anyway.
     if (ctx->cull_check_due || !measured) {
         if (ctx->cull_check_due)
-            cull_allow_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, nI, ctx->disp_allow.p);
-        cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI, ctx->cull_state.p);
+            cull_allow_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI,
+                                                         ctx->disp_allow.p, ctx->cull_state.p);
+        else
+            cull_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI, ctx->cull_state.p);
         ctx->cull_check_due = false;
     }
     FROG_HIP_CHECK(hipGetLastError());

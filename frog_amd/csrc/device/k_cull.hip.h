@@ -31,6 +31,7 @@
 
 #include "ctx.h"
 #include "k_links.hip.h"
+#include "k_stats.hip.h"
 
 namespace frog {
 
@@ -52,11 +53,28 @@ __device__ inline double mixture_probability(double d, double c1, double c2, dou
 // evaluation is within 1e-5 of the real value (k_links.hip.h, bound at inlier_probability), far inside the margin
 // between threshold/2 and threshold - THRESHOLD_BAND for any threshold >= 1e-3.  No cutoff (+inf: the image's links
 // are always listed) when the mixture is degenerate (c1 >= c2, ratio outside (0,1), non-finite) or the threshold tiny.
+__device__ inline float cull_cutoff_of(const float4 e, float threshold);
+
 __global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float threshold, float *cut_now)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_images) return;
+    cut_now[i] = cull_cutoff_of(em[i], threshold);
+}
+
+// what frog_stats_publish does per image in ONE launch: the weight constants of the new mixture (k_stats.hip.h em_derive_kernel)
+// and its certified cutoff (two launches of 5 + 12 us each with a gap between them, at every statistics refresh)
+__global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, uint32_t n_images, float threshold, float *cut_now)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
     const float4 e = em[i];
+    emd[i] = em_derived_of(e);
+    cut_now[i] = cull_cutoff_of(e, threshold);
+}
+
+__device__ inline float cull_cutoff_of(const float4 e, float threshold)
+{
     const double c1 = e.x, c2 = e.y, r = e.z;
     float out = __builtin_inff();
     if (threshold >= 1e-3f && c1 > 0.0 && c2 > c1 && r > 0.0 && r < 1.0 && c2 < 1e30) {
@@ -82,7 +100,7 @@ __global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float th
         // round up: (float) may have rounded down
         if (out < __builtin_inff()) out = out * 1.000001f + 1e-6f;
     }
-    cut_now[i] = out;
+    return out;
 }
 
 __global__ void cull_list_cutoff_kernel(const float *cut_now, uint32_t n_images, float scale, float pad, float *cut_list)
@@ -224,6 +242,11 @@ __global__ __launch_bounds__(256) void cull_allow_kernel(const float *cut_now, c
     if (threadIdx.x == 0) allow[0] = sh[0] - fabsf(sh[0]) * 1e-6f;
 }
 
+// cull_allow_kernel followed by cull_validate_kernel in one launch (one block): what cull_prepare runs whenever the cutoffs
+// or the list have changed -- at every statistics refresh.
+__global__ __launch_bounds__(256) void cull_allow_validate_kernel(const float *cut_now, const float *cut_list, const uint32_t *disp_part,
+                                                                  uint32_t n_part, uint32_t n_images, float *allow, uint32_t *state);
+
 // state[0] = 1 when some left-out link could have come within its images' cutoff (the sweep then walks all records
 // and the host rebuilds the list), else 0.  With D = the largest displacement of any point since the build, a left-out
 // link (d_build >= cut_list[k] for k = A or B) is now at d >= cut_list[k] - 2 D, so the list is good while
@@ -250,6 +273,46 @@ __global__ __launch_bounds__(256) void cull_validate_kernel(const float *cut_now
         const float need = cut_now[i] * 1.0001f + 0.01f + 2.0f * dispmax;        // inf when the image has no cutoff
         const float have = cut_list[i] * 0.99999f;
         if (!(need <= have)) bad = 1;                                           // also catches NaN
+    }
+    if (bad) atomicOr(&bad_s, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) state[0] = bad_s ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void cull_allow_validate_kernel(const float *cut_now, const float *cut_list, const uint32_t *disp_part,
+                                                                  uint32_t n_part, uint32_t n_images, float *allow, uint32_t *state)
+{
+    // the two kernels' bodies, one after the other, on the same 256 threads (their expressions unchanged: same bits)
+    __shared__ float sh[256];
+    __shared__ uint32_t shm[256];
+    __shared__ int bad_s;
+    float a = __builtin_inff();
+    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
+        const float now = cut_now[i], list = cut_list[i];
+        if (now == __builtin_inff() && list == __builtin_inff()) continue;
+        const float v = 0.5f * (list * 0.99999f - (now * 1.0001f + 0.01f));
+        a = (v < a) ? v : (v == v ? a : -1.0f);
+    }
+    uint32_t mx = 0;
+    for (uint32_t i = threadIdx.x; i < n_part; i += 256) mx = max(mx, disp_part[i]);
+    sh[threadIdx.x] = a;
+    shm[threadIdx.x] = mx;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            sh[threadIdx.x] = fminf(sh[threadIdx.x], sh[threadIdx.x + h]);
+            shm[threadIdx.x] = max(shm[threadIdx.x], shm[threadIdx.x + h]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) allow[0] = sh[0] - fabsf(sh[0]) * 1e-6f;
+    const float dispmax = __uint_as_float(shm[0]);
+    int bad = 0;
+    for (uint32_t i = threadIdx.x; i < n_images; i += 256) {
+        const float need = cut_now[i] * 1.0001f + 0.01f + 2.0f * dispmax;
+        const float have = cut_list[i] * 0.99999f;
+        if (!(need <= have)) bad = 1;
     }
     if (bad) atomicOr(&bad_s, 1);
     __syncthreads();
