@@ -106,7 +106,7 @@ class FrogKernelTime(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
 
 
-FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull", "sweep_build"]
+FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull", "sweep_build", "sweep_linear_build"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM, FROG_E_IO = range(7)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
 
@@ -209,6 +209,7 @@ HIP_SYMBOLS = {
     "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
     "frog_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "frog_cull_stats_linear": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_stray_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "frog_test_cull_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_em_refit": (C.c_int, [C.c_void_p, C.c_int]),

@@ -315,6 +315,12 @@ struct frog_ctx {
     bool cull_enabled = true;                 // FROG_CULL=0 turns it off (every sweep walks all records)
     bool cull_need_build = true;              // host side: (re)build the list before the next deformable sweep
     float cull_scale = 2.0f, cull_pad = 25.0f; // list cutoff = scale * certified cutoff + pad (the skin)
+    // the same machinery for the LINEAR stage (weights that are exactly zero, k_cull.hip.h cull_cutoff_linear_of): on unless
+    // FROG_CULL_LINEAR=0; its own skin (the cutoffs are 14.5 c1: far out, where a tighter skin still lasts for iterations)
+    bool cull_linear = true;
+    float cull_lin_scale = 1.25f, cull_lin_pad = 10.0f;
+    uint64_t cull_lin_builds = 0;             // statistics: lists built during the linear stage
+    frog::DevBuf<unsigned long long> lin_listed;   // [0] half-links in the last list of the linear stage
     frog::DevBuf<uint32_t> act_recs32;        // listed records (narrow form), or ...
     frog::DevBuf<frog::LinkRec> act_recs;     // ... wide form; same offsets as recs32 / recs
     frog::DevBuf<uint32_t> act_cnt;           // [n_tiles][n_groups]

@@ -41,7 +41,7 @@ struct Span {
                             // recorded around it: no marker packets, so no bubbles before and after the kernel
     Span(frog_ctx *ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach)
     {
-        if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE && s != FROG_K_SWEEP_BUILD)) return;
+        if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE && s != FROG_K_SWEEP_BUILD && s != FROG_K_SWEEP_LINEAR_BUILD)) return;
         if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         if (!attached) (void)hipEventRecord(a, c->stream);
@@ -104,6 +104,13 @@ static bool cull_active(const frog_ctx *ctx)
     return ctx->cull_enabled && ctx->deformable && ctx->opt.inlier_threshold >= 1e-3f && ctx->n_tiles > 0;
 }
 
+// ... and to the linear sweeps (weights that are exactly zero: k_cull.hip.h cull_cutoff_linear_of), whose zero set belongs
+// to the fast weight: not with FROG_WEIGHT_EXACT
+static bool cull_active_linear(const frog_ctx *ctx)
+{
+    return ctx->cull_enabled && ctx->cull_linear && !ctx->exact_weights && !ctx->deformable && ctx->n_tiles > 0 && ctx->n_sub == 1;
+}
+
 // the narrow deformable sweep can write the culling list while it walks every record (k_links.hip.h BUILD)
 static bool sweep_builds_list(const frog_ctx *ctx) { return ctx->rec_format.narrow != 0; }
 
@@ -134,6 +141,14 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
     }
     const dim3 grid(sweep_blocks(ctx)), block(256);
     const size_t lds = (size_t)args.lds_images * (sizeof(EmDerived) + sizeof(uint32_t) + sizeof(float));
+    if constexpr (MODE == SWEEP_LINEAR) {
+        if (build_list && sweep_builds_list(ctx)) {
+            args.act_recs = nullptr; args.act_cnt = nullptr;         // walks every record, writes the list
+            args.cut_list = ctx->cut_list.p; args.build_recs = ctx->act_recs32.p; args.build_cnt = ctx->act_cnt.p;
+            hipExtLaunchKernelGGL((sweep_kernel<SWEEP_LINEAR, true, false, true>), grid, block, lds, s, ea, eb, 0, args);
+            return;
+        }
+    }
     if constexpr (MODE == SWEEP_DEFORMABLE) {
         const bool build = build_list && sweep_builds_list(ctx);
         if (build) {
@@ -163,6 +178,7 @@ static void launch_sweep(frog_ctx *ctx, uint32_t sub, hipStream_t s, hipEvent_t 
 }
 
 static int cull_allocate(frog_ctx *ctx);
+static int cull_prepare(frog_ctx *ctx);
 static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], const double maxs[3], GridGeom &g, frog_grid_info &info);
 static int lattice_alloc(frog_ctx *ctx, const GridGeom &g);
 
@@ -587,15 +603,22 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!(c->cull_enabled && c->opt.inlier_threshold >= 1e-3f) && !c->fused_forced) c->fused_sweep = false;
     // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
     if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
+    if (const char *e = getenv("FROG_CULL_LINEAR")) c->cull_linear = atoi(e) != 0;
+    if (const char *e = getenv("FROG_CULL_SKIN_LINEAR")) {
+        float a = 0, b = 0;
+        if (sscanf(e, "%f,%f", &a, &b) == 2 && a >= 1.0f && b >= 0.0f) { c->cull_lin_scale = a; c->cull_lin_pad = b; }
+    }
     if (const char *e = getenv("FROG_CULL_SKIN")) {
         float a = 0, b = 0;
         if (sscanf(e, "%f,%f", &a, &b) == 2 && a >= 1.0f && b >= 0.0f) { c->cull_scale = a; c->cull_pad = b; }
     }
     CREATE_CHECK(c->cut_now.alloc(c->nI));
-    if (c->cull_enabled && c->opt.inlier_threshold >= 1e-3f && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
+    CREATE_CHECK(c->lin_listed.alloc(1));
+    CREATE_CHECK(hipMemsetAsync(c->lin_listed.p, 0, sizeof(unsigned long long), s));
+    if (c->cull_enabled && (c->opt.inlier_threshold >= 1e-3f || c->cull_linear) && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
         if (int rc_ = cull_allocate(c)) { frog_destroy(c); return rc_; }
     }
-    cull_cutoff_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->nI, c->opt.inlier_threshold, c->cut_now.p);
+    stats_publish_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->emd.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     if (!getenv("FROG_LATTICE_LAZY")) {
@@ -835,7 +858,13 @@ int frog_stats_publish(frog_ctx *ctx)
     CTX_GUARD(ctx);
     // the weight constants of the new mixtures and, with them, the certified outlier cutoffs (k_cull.hip.h); the check before
     // the next sweep compares the cutoffs with the list's
-    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p);
+    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
+                                                                       ctx->deformable ? 0 : 1);
+    // Linear stage: the mixtures tighten from refresh to refresh as the images come together, and with them the distance
+    // from which a weight is exactly zero -- a list built for the old cutoffs stays VALID but holds links it no longer
+    // needs to.  A new list per refresh (one sweep in ten writes it as it goes: +0.15 ms).  The deformable stage keeps its
+    // list while it is valid: its mixtures hardly move.
+    if (!ctx->deformable) ctx->cull_need_build = true;
     ctx->cull_check_due = true;         // the next cull_prepare recomputes the allowed displacement and runs the stand-alone check
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -978,17 +1007,26 @@ int frog_linear_step_local(frog_ctx *ctx)
     CTX_GUARD(ctx);
     if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
     hipStream_t s = ctx->stream;
+    // half-links whose weight is exactly zero are left to a list, as the deformable stage's certain outliers are (k_cull.hip.h)
+    const bool culled = cull_active_linear(ctx);
+    ctx->build_in_sweep = false;
+    if (culled) {
+        Span span(ctx, FROG_K_CULL);
+        const int rc = cull_prepare(ctx);
+        if (rc) return rc;
+    }
     {
-        Span span(ctx, FROG_K_SWEEP_LINEAR, ctx->n_sub == 1);
+        Span span(ctx, ctx->build_in_sweep ? FROG_K_SWEEP_LINEAR_BUILD : FROG_K_SWEEP_LINEAR, ctx->n_sub == 1);
         for (uint32_t sub = 0; sub < ctx->n_sub; sub++)
-            launch_sweep<SWEEP_LINEAR>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr);
+            launch_sweep<SWEEP_LINEAR>(ctx, sub, s, span.attached ? span.a : nullptr, span.attached ? span.b : nullptr, culled,
+                                       ctx->build_in_sweep);
     }
     FROG_HIP_CHECK(hipGetLastError());
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, ctx->mat.p,
                                                       ctx->opt.linear_alpha, ctx->opt.use_scale);
     FROG_HIP_CHECK(hipGetLastError());
     energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, LINEAR_SUMS, 16, ctx->energy_blocks.p,
-                                                       ctx->energy_ticket.p, ctx->energy.p);
+                                                       ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -998,6 +1036,7 @@ int frog_energy_read(frog_ctx *ctx, double *E, double *n_oversize)
     CTX_GUARD(ctx);
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // the sweep found its list out of date (it walked every record)
     if (E) *E = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]);
     if (n_oversize) *n_oversize = ctx->h_energy[2];
     return FROG_OK;
@@ -1163,6 +1202,16 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         if (rc) return rc;
     }
 
+    if (!ctx->deformable && ctx->act_cnt.p) {
+        // end of the linear stage: its list (if any) is counted for frog_cull_stats_linear, and the deformable stage starts
+        // with cutoffs of its own criterion and a list of its own
+        if (ctx->cull_lin_builds)
+            cull_count_kernel<<<1, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+        stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
+        FROG_HIP_CHECK(hipGetLastError());
+        ctx->cull_need_build = true;
+        ctx->cull_check_due = true;
+    }
     GridRecord rec;
     rec.info = info;
     ctx->grids.push_back(std::move(rec));
@@ -1222,7 +1271,8 @@ static int cull_prepare(frog_ctx *ctx)
     int rc = cull_allocate(ctx);
     if (rc) return rc;
     if (ctx->cull_need_build) {
-        cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->cull_scale, ctx->cull_pad, ctx->cut_list.p);
+        cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->deformable ? ctx->cull_scale : ctx->cull_lin_scale,
+                                                              ctx->deformable ? ctx->cull_pad : ctx->cull_lin_pad, ctx->cut_list.p);
         FROG_HIP_CHECK(hipMemcpyAsync(ctx->pos2_snap.p, ctx->pos2.p, ctx->P * sizeof(P3), hipMemcpyDeviceToDevice, s));
         // the list itself: written by the sweep this call prepares (it walks every record anyway: k_links.hip.h BUILD), or,
         // for the record formats that sweep does not cover, by a pass of its own
@@ -1237,7 +1287,7 @@ static int cull_prepare(frog_ctx *ctx)
             FROG_HIP_CHECK(hipGetLastError());
         }
         ctx->cull_need_build = false;
-        ctx->cull_builds++;
+        if (ctx->deformable) ctx->cull_builds++; else ctx->cull_lin_builds++;
         ctx->disp_n = 0;                    // the points are where the snapshot has them: no displacement to look at
         ctx->disp_current = true;
         ctx->cull_check_due = true;
@@ -1707,6 +1757,25 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
     const size_t n = std::min(cap, 4 * G);
     FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->gradf.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FROG_OK;
+}
+
+int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed, uint64_t *owned)
+{
+    CTX_GUARD(ctx);
+    if (lists_built) *lists_built = ctx->cull_lin_builds;
+    if (owned) *owned = ctx->L_own;
+    if (listed) {
+        *listed = 0;
+        if (ctx->cull_lin_builds && ctx->act_cnt.n) {
+            if (!ctx->deformable)                   // still in the linear stage: count the current list
+                cull_count_kernel<<<1, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+            unsigned long long v = 0;
+            FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->lin_listed.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+            FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            *listed = v;
+        }
+    }
     return FROG_OK;
 }
 

@@ -64,13 +64,32 @@ __global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float th
 
 // what frog_stats_publish does per image in ONE launch: the weight constants of the new mixture (k_stats.hip.h em_derive_kernel)
 // and its certified cutoff (two launches of 5 + 12 us each with a gap between them, at every statistics refresh)
-__global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, uint32_t n_images, float threshold, float *cut_now)
+// `linear`: the cutoff of the LINEAR stage's list instead (cull_cutoff_linear_of below)
+__device__ inline float cull_cutoff_linear_of(const EmDerived d);
+__global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, uint32_t n_images, float threshold, float *cut_now, int linear)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_images) return;
     const float4 e = em[i];
-    emd[i] = em_derived_of(e);
-    cut_now[i] = cull_cutoff_of(e, threshold);
+    const EmDerived d = em_derived_of(e);
+    emd[i] = d;
+    cut_now[i] = linear ? cull_cutoff_linear_of(d) : cull_cutoff_of(e, threshold);
+}
+
+// The linear stage has no threshold (imageGroup.cxx:1100-1117: every half-link enters the 18 sums with its weight), but the
+// sweep's weight (k_links.hip.h inlier_probability) is EXACTLY zero from some distance on: x1 = kq1 (d2 2^(s1 d2)) with
+// v_exp_f32, whose result is +0 once the true value is below half the smallest denormal, i.e. for s1 d2 <= -150; then
+// p = div_fast(0, x2 + 1e-10) = +0 and w = min(pA, pB) = +0 (the other probability is >= 0 or NaN, and fminf returns the
+// number), and the link adds +-0.0 to sums that are never -0.0: nothing.  The cutoff takes s1 d2 <= -160 (2^-160 is 2^-11
+// smallest denormals: no rounding of the instruction's last bit reaches it; the f32 product d2 s1 is within 2^-24 of -160) and
+// is at least 0.2 (d < 0.1 gives weight 1, stats.h:87).  weight = min over the two images, so the smaller cutoff decides,
+// as in the deformable stage.  Not used with FROG_WEIGHT_EXACT (another arithmetic, another zero set).
+__device__ inline float cull_cutoff_linear_of(const EmDerived d)
+{
+    const double s1 = -(double)d.s1;
+    if (!(s1 > 0.0) || !(s1 < 1e30)) return __builtin_inff();          // no usable exponent: every link stays listed
+    const float c = (float)sqrt(160.0 / s1);
+    return fmaxf(c * 1.00001f + 1e-6f, 0.2f);
 }
 
 __device__ inline float cull_cutoff_of(const float4 e, float threshold)
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, cons
             const float dx = pb[u].x - pa[u].x, dy = pb[u].y - pa[u].y, dz = pb[u].z - pa[u].z;
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float cut = have[u] ? fminf(cutA, cut_list[imgB[u]]) : 0.f;
-            const bool keep = have[u] && d2 < cut * cut;      // NaN or inf distance: left out, and an outlier in the full sweep too
+            const bool keep = have[u] && !(d2 >= cut * cut);  // as the sweep's own list-writing form (k_links.hip.h BUILD)
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const uint32_t to = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -188,6 +207,10 @@ __global__ __launch_bounds__(256) void cull_build_kernel(const SweepArgs a, cons
     }
     const bool any_dup = __ballot(dup) != 0ull;
     if (lane == 0) act_cnt[(size_t)t * a.n_groups + grp] = base | (any_dup ? CULL_DUP_BIT : 0u);
+    // null records as far as a listed sweep's run-ahead reaches behind the list (k_links.hip.h, the sweep's own list-writing form)
+    const uint32_t cap = (rec_n + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK;
+    const uint32_t reach = (((base + 63u) / 64u + BODY_STEPS - 1u) / BODY_STEPS * BODY_STEPS + PT_AHEAD) * 64u;
+    for (uint32_t k = base + lane; k < min(cap, reach); k += 64) dst[phys(k)] = (Rec)0;
 }
 
 // Largest distance of a point from where it was at build time, as per-block maxima (f32 bits: non-negative floats order
@@ -317,6 +340,21 @@ __global__ __launch_bounds__(256) void cull_allow_validate_kernel(const float *c
     if (bad) atomicOr(&bad_s, 1);
     __syncthreads();
     if (threadIdx.x == 0) state[0] = bad_s ? 1u : 0u;
+}
+
+// total of the listed records of a list (act_cnt without the flag bit) -> out[0] (u64); one block
+__global__ __launch_bounds__(256) void cull_count_kernel(const uint32_t *act_cnt, uint32_t n, unsigned long long *out)
+{
+    __shared__ unsigned long long sh[256];
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) v += act_cnt[i] & ~CULL_DUP_BIT;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 } // namespace frog

@@ -211,7 +211,7 @@ template <int MODE, bool EMD_LDS, bool WIDE, bool BUILD = false, bool FUSED = fa
 #endif
 __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1) void sweep_kernel(const SweepArgs a)
 {
-    static_assert(!BUILD || (MODE == SWEEP_DEFORMABLE && EMD_LDS && !WIDE), "the list is built by the narrow deformable sweep");
+    static_assert(!BUILD || (MODE != SWEEP_COUNT && EMD_LDS && !WIDE), "the list is built by the narrow linear / deformable sweeps");
     static_assert(!FUSED || (MODE == SWEEP_DEFORMABLE && EMD_LDS), "the fused form is the deformable sweep's");
     constexpr int WAVES = FUSED ? 8 : 4;                // wavefronts per block
     constexpr int OWN_TILES = FUSED ? 1 : 4;            // tiles whose own points the block stages
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     }
     // the listed records only, when there is a list and the check before this launch found it valid (k_cull.hip.h)
     bool listed = false;
-    if constexpr (MODE == SWEEP_DEFORMABLE) listed = a.act_cnt != nullptr && a.cull_state[0] == 0u;
+    if constexpr (MODE != SWEEP_COUNT) listed = a.act_cnt != nullptr && a.cull_state[0] == 0u;
     bool elect = true;          // wave-uniform: lanes of one step may meet on a point (always assumed for unlisted ranges)
     if (listed && live) {
         const uint32_t c = a.act_cnt[(size_t)t * a.n_groups + grp];
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
             // cull_build_kernel's criterion and compaction, on the distance this step has just formed (all 64 lanes are here:
             // `valid` = the lane holds a record of the range)
             const float cut = fminf(cutA, cut_s[img_of(rq)]);
-            const bool keep = valid && d2 < cut * cut;      // NaN or inf distance: left out, and an outlier below too
+            const bool keep = valid && !(d2 >= cut * cut);  // a NaN distance is listed (the linear sweep's sums must see it, as the full sweep's do)
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const uint32_t to = built + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -470,11 +470,24 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     if (MODE != SWEEP_DEFORMABLE || elect) walk(std::true_type{});
     else walk(std::false_type{});
 
+    if constexpr (BUILD) {
+        // Null records behind the list's last record, as far as a listed sweep's run-ahead gathers reach (its walk goes in
+        // trips of BODY_STEPS steps and gathers PT_AHEAD steps ahead): what lies there otherwise are records of an EARLIER,
+        // longer list -- left-out false matches whose partners are anywhere --, and every range would pay a few steps of
+        // random gathers for them (measured: the deformable sweep 0.258 -> 0.294 ms behind the linear stage's lists).
+        const uint32_t cap = (rec_n + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK;
+        const uint32_t reach = (((built + 63u) / 64u + BODY_STEPS - 1u) / BODY_STEPS * BODY_STEPS + PT_AHEAD) * 64u;
+        for (uint32_t k = built + lane; k < min(cap, reach); k += 64)
+            reinterpret_cast<Rec *>(a.build_recs)[(size_t)rec_lo + (k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u] = (Rec)0;
+    }
     if constexpr (MODE == SWEEP_LINEAR) {
         #pragma unroll
         for (int k = 0; k < LINEAR_SUMS; k++) {
             double v = wave_sum(s[k]);
             if (lane == 0 && live) a.tile_partial[((size_t)t * a.n_groups + grp) * LINEAR_SUMS + k] = v;
+        }
+        if constexpr (BUILD) {
+            if (lane == 0 && live) a.build_cnt[(size_t)t * a.n_groups + grp] = built | CULL_DUP_BIT;    // the linear sweep has no election to skip
         }
     } else if constexpr (MODE == SWEEP_DEFORMABLE) {
         double v0 = wave_sum(s[0]), v1 = wave_sum(s[1]);

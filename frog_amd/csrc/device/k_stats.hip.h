@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 // the words left in the state (up to 624: three per thread, word index = ordinal order), tests them,
 // ranks the kept ones (ballots + a 12-entry prefix over (row, wavefront)) and stores them: two barriers
 // per round and two per regeneration (2.4 ms per refresh with rounds of 256 draws and the four-phase
-// regeneration; the kept ordinals are the same, bit for bit: tests compare them with the oracle's).
+// regeneration; the kept ordinals are the same, bit for bit: the parity tests compare them).
 constexpr int SELECT_ROWS = (MT_N + SELECT_THREADS - 1) / SELECT_THREADS;     // 3
 
 __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_state, const uint32_t *virtual_size,

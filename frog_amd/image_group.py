@@ -256,6 +256,12 @@ class ImageGroup:
         check(self._lib.frog_set_hard_links(self._ctx, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), len(a), float(weight2)),
               "frog_set_hard_links")
 
+    def cull_stats_linear(self):
+        """(lists built during the linear stage, half-links in the last of them, half-links owned): frog_cull_stats_linear."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.frog_cull_stats_linear(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frog_cull_stats_linear")
+        return a.value, b.value, c.value
+
     def cull_stats(self):
         """(lists built, half-links in the last list, half-links owned) of the outlier-culling list
         (frog_hip.h: frog_cull_stats)."""

@@ -200,6 +200,11 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E);
  * it off.  frog_cull_stats reports what it did: lists built so far, half-links in the last list and
  * half-links owned (0 listed = no list yet). */
 int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
+/* The same for the LINEAR stage (updateLinearTransforms has no threshold, imageGroup.cxx:1100-1117, but a half-link whose
+ * weight is exactly zero adds nothing to its 18 sums either: the list leaves out the half-links whose distance puts the
+ * sweep's weight at exactly zero; FROG_CULL_LINEAR=0 turns it off): lists built during the linear stage, half-links in the
+ * last of them, half-links owned. */
+int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
 
 /* ---- test hook: the sweep's inlier weight -------------------------------------------
  * Evaluates, on `device`, Stats::getInlierProbability (stats.h:84-92) for n SQUARED distances d2 (what a sweep step
@@ -234,6 +239,7 @@ enum {
     FROG_K_COMBINE,            /* per-point sums of the partner groups added up, energy reduction */
     FROG_K_CULL,               /* outlier-culling list: validity check before a deformable sweep, rebuilds */
     FROG_K_SWEEP_BUILD,        /* the deformable sweep that walks EVERY half-link and writes the next culling list (once per list) */
+    FROG_K_SWEEP_LINEAR_BUILD, /* the linear sweep that does the same for the linear stage's list (once per statistics refresh) */
     FROG_K_COUNT_
 };
 typedef struct frog_kernel_time {

@@ -247,3 +247,37 @@ def test_fused_sweep_equals_the_per_group_sweep_bit_for_bit(monkeypatch, wide):
         for a, b in zip(g0, g1):
             assert np.array_equal(a, b)
         assert np.array_equal(x0, x1)
+
+
+def _linear_run(pairs, n_it, **opt):
+    g = ImageGroup(pairs, **opt)
+    g.setupLinearTransforms(); g.transformPoints()
+    es = []
+    for it in range(n_it):
+        if it % 10 == 0:
+            g.updateStats()
+        es.append(g.updateLinearTransforms()); g.transformPoints()
+    mats = np.stack([g.matrix(i) for i in range(pairs.n_images)])
+    stats = g.cull_stats_linear()
+    return np.array(es), mats, g.points()[1].copy(), stats
+
+
+@pytest.mark.parametrize("skin", ["1.25,10", "1.0,0"])
+def test_linear_stage_with_the_zero_weight_list_is_bit_identical(monkeypatch, skin):
+    """updateLinearTransforms has no threshold (imageGroup.cxx:1100-1117), but a half-link whose weight is exactly zero
+    adds nothing to the 18 sums: the linear sweep walks a list that leaves out the half-links whose distance puts the
+    sweep's weight at exactly +0 (k_cull.hip.h cull_cutoff_linear_of).  40 linear iterations with the list (default skin,
+    and a zero skin that invalidates the list at every step so that every sweep walks all records and rewrites it) against
+    FROG_CULL_LINEAR=0: energies, matrices and coordinates identical bits; and the list really leaves links out once the
+    images have come together."""
+    pairs = Pairs.synthetic(8, 3000, 1200, seed=5)
+    monkeypatch.setenv("FROG_CULL_LINEAR", "0")
+    e0, m0, x0, st0 = _linear_run(pairs, 40)
+    assert st0[0] == 0
+    monkeypatch.setenv("FROG_CULL_LINEAR", "1")
+    monkeypatch.setenv("FROG_CULL_SKIN_LINEAR", skin)
+    e1, m1, x1, st1 = _linear_run(pairs, 40)
+    assert np.array_equal(e0, e1) and np.array_equal(m0, m1) and np.array_equal(x0, x1)
+    lists, listed, owned = st1
+    note(f"linear_list_skin_{skin}", f"lists {lists} listed {listed} of {owned} half-links")
+    assert lists >= 4 and 0 < listed < owned
