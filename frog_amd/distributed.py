@@ -480,8 +480,9 @@ class ShardedImageGroup:
         self.setup_seconds.append(time.perf_counter() - t0)      # host side only: the device work is queued, not awaited
         # one entry per lattice: its size and the accepted iterations taken on it (bench.py prices an iteration's
         # algorithmic bytes with the lattices that were really built)
-        self.lattices.append({"level": int(level), "dims": [int(d) for d in info.dims],
-                              "control_points": int(info.dims[0]) * int(info.dims[1]) * int(info.dims[2]), "iterations": 0})
+        dims = [int(d) for d in getattr(info, "dims", ())]       # (test engines return their own kind of record)
+        self.lattices.append({"level": int(level), "dims": dims,
+                              "control_points": dims[0] * dims[1] * dims[2] if len(dims) == 3 else 0, "iterations": 0})
         return info
 
     def _setup(self, level):
