@@ -268,7 +268,9 @@ struct frog_ctx {
     frog::DevBuf<double> energy;              // [4]
     frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
     frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel
-    double *h_energy = nullptr;               // pinned [4]
+    double *h_energy = nullptr;               // pinned [8]
+    double *h_energy_dev = nullptr;           // the same memory as the device sees it (null: scalars come by copy)
+    uint64_t scalar_seq = 0;                  // steps whose scalars were handed over through h_energy[7]
 
     // deformable
     bool deformable = false;

@@ -12,6 +12,8 @@
 #include "k_ransac.hip.h"
 #include "similarity.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <random>
@@ -454,7 +456,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         }
         (void)hipGetLastError();
     }
-    CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 8 * sizeof(double)));     // [0..3] energy scalars, [4..6] bounding box (6 floats)
+    // [0..3] energy scalars, [4..6] bounding box (6 floats), [7] sequence number of the step whose scalars a kernel wrote here
+    CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 8 * sizeof(double), hipHostMallocMapped));
+    std::memset(c->h_energy, 0, 8 * sizeof(double));
+    if (hipHostGetDevicePointer((void **)&c->h_energy_dev, c->h_energy, 0) != hipSuccess) { (void)hipGetLastError(); c->h_energy_dev = nullptr; }
+    if (getenv("FROG_SCALARS_COPY")) c->h_energy_dev = nullptr;      // the copy + event hand-off (A/B, fallback)
     hipStream_t s = c->stream;
 
     // points: xyz | image id
@@ -737,8 +743,9 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
 }
 
 // ---- transformPoints (imageGroup.cxx:910-916, image.cxx:3-13) -----------------------
-static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step = false)
+static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step = false, double scalar_seq = 0.0)
 {
+    double *host_scalars = scalar_seq != 0.0 ? ctx->h_energy_dev : nullptr;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
     if (!n) return FROG_OK;                     // a context whose images are all empty: nothing to launch
     Span span(ctx, FROG_K_TRANSFORM);
@@ -774,7 +781,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                 after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
-                ctx->disp_allow.p, ctx->cull_state.p);
+                ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
             if (with_disp) ctx->disp_n = ctx->n_scatter_blocks;
         } else {
             transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
@@ -782,7 +789,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
                                                                              ctx->opt.guarantee_diffeomorphism,
-                                                                             ctx->disp_allow.p, ctx->cull_state.p);
+                                                                             ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
             if (with_disp) ctx->disp_n = div_up(n, 256);
         }
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
@@ -1435,13 +1442,37 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     // with the proposal lattice; rejected: with the standing coefficients), into a shadow buffer -- the GPU keeps working
     // while the host waits for the four scalars, which are copied out first; the wait below is for that copy alone.
     // The commit itself (:441-468) costs nothing: once the host has the decision it exchanges the two buffers.
-    FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    FROG_HIP_CHECK(hipEventRecord(ctx->energy_copied, ctx->stream));
+    // The scalars reach the host without a copy of their own when a transform through the lattice follows (it does unless the
+    // context owns no point): its first thread writes them, then the step's sequence number, into pinned memory the host
+    // spins on (k_grid.hip.h publish_step_scalars).
+    const bool direct = ctx->h_energy_dev && ctx->own_pt_end > ctx->own_pt_begin;
+    double seq = 0.0;
+    if (direct) {
+        seq = (double)(++ctx->scalar_seq);
+    } else {
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FROG_HIP_CHECK(hipEventRecord(ctx->energy_copied, ctx->stream));
+    }
     // the transformPoints() that run() calls next, from the lattice the guard's decision selects (on the device)
-    int rc = launch_transform(ctx, ctx->pos2_spec.p, 0, true);  // xyz2 itself changes only when the caller asks
+    int rc = launch_transform(ctx, ctx->pos2_spec.p, 0, true, seq);  // xyz2 itself changes only when the caller asks
     if (rc) return rc;
     ctx->xyz2_fresh = true;
-    FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
+    if (direct) {
+        volatile double *h = ctx->h_energy;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (h[7] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                // the kernel never ran (a launch failure shows here): wait for the stream and report
+                FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (h[7] != seq) return fail(FROG_E_HIP, "the step's scalars never arrived");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
+    }
     const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
     if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // this step's sweep found the culling list out of date
     if (!(ctx->opt.guarantee_diffeomorphism && nbig > 0)) {

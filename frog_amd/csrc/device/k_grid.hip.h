@@ -44,6 +44,20 @@ __device__ __forceinline__ void bspline_weights(double F[4], double f)
     F[1] = 1 - F[0] - F[2] - F[3];
 }
 
+// The four scalars a deformable step hands to the host (energy sums, oversize count, list flag), written straight into
+// pinned host memory by the first thread of the transform that is queued behind the step -- the kernel that starts once
+// the scalars are final -- followed by the step's sequence number, which the host spins on.  A copy kernel + event between
+// the lattice step and the transform cost every iteration 4 us of copy, a dependent-launch gap and the event's wake-up.
+__device__ __forceinline__ void publish_step_scalars(const double *energy, double *host, double seq)
+{
+    if (host && blockIdx.x == 0 && threadIdx.x == 0) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&host[k], energy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- K5: linear transform (vtkLinearTransformPoint, f64 row products -> f32) ----
 __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *pos2, const double *mat,
                                                                uint32_t pt_begin, uint32_t pt_end, int apply)
@@ -73,8 +87,10 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
                                                                 uint32_t image_begin, const GeomDev g, int apply,
                                                                 const P3 *snap, uint32_t *disp_part,
                                                                 const float4 *proposal, const double *energy, int guarantee,
-                                                                const float *disp_allow, uint32_t *cull_state)
+                                                                const float *disp_allow, uint32_t *cull_state,
+                                                                double *host_scalars, double seq)
 {
+    publish_step_scalars(energy, host_scalars, seq);
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
     // reduction at the end is wave-wide
@@ -209,7 +225,8 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                                                                     const uint32_t *n_blocks, const GeomDev g, int apply,
                                                                     const P3 *snap, uint32_t *disp_part,
                                                                     const float4 *proposal, const double *energy, int guarantee,
-                                                                    const float *disp_allow, uint32_t *cull_state);
+                                                                    const float *disp_allow, uint32_t *cull_state,
+                                                                    double *host_scalars, double seq);
 
 // Zeroes up to ZERO_MAX device buffers in ONE launch (a lattice set-up clears six: every hipMemsetAsync is a launch
 // of its own with a few microseconds of idle stream in front of it).  A block clears ZERO_BLOCK_BYTES of one buffer with
@@ -584,8 +601,10 @@ void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
                                    const uint32_t *n_blocks, const GeomDev g, int apply,
                                    const P3 *snap, uint32_t *disp_part,
                                    const float4 *proposal, const double *energy, int guarantee,
-                                   const float *disp_allow, uint32_t *cull_state)
+                                   const float *disp_allow, uint32_t *cull_state,
+                                   double *host_scalars, double seq)
 {
+    publish_step_scalars(energy, host_scalars, seq);
     // the brick's (B+3)^3 coefficients as they are in memory (f32 x, y, z, pad): one ds_read_b128 per tap.  The first
     // version kept them as three f64 arrays ("converted once"): 192 ds_read_b64 per point, and the kernel ran at the LDS's
     // bandwidth (1.5 KB per point; 81 us).  Converting each tap again costs three v_cvt per tap on a vector unit that had
