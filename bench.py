@@ -111,7 +111,14 @@ def self_launch(n, argv):
     if os.environ.get("FROG_BENCH_LAUNCH_DRY_RUN") == "1":
         print(json.dumps({"launch": cmd, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}), flush=True)
         return 0
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries ONE line: rank 0's metric line.  Whatever else the children print there (gloo's connection notices in
+    # rehearsals, library banners) goes to stderr.
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        out = sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr
+        out.write(line)
+        out.flush()
+    return proc.wait()
 
 
 def main():
