@@ -1212,8 +1212,10 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     if (!ctx->deformable && ctx->act_cnt.p) {
         // end of the linear stage: its list (if any) is counted for frog_cull_stats_linear, and the deformable stage starts
         // with cutoffs of its own criterion and a list of its own
-        if (ctx->cull_lin_builds)
-            cull_count_kernel<<<1, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+        if (ctx->cull_lin_builds) {
+            FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
+            cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+        }
         stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->cull_need_build = true;
@@ -1799,8 +1801,10 @@ int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *liste
     if (listed) {
         *listed = 0;
         if (ctx->cull_lin_builds && ctx->act_cnt.n) {
-            if (!ctx->deformable)                   // still in the linear stage: count the current list
-                cull_count_kernel<<<1, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+            if (!ctx->deformable) {                 // still in the linear stage: count the current list
+                FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
+                cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
+            }
             unsigned long long v = 0;
             FROG_HIP_CHECK(hipMemcpyAsync(&v, ctx->lin_listed.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
             FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));

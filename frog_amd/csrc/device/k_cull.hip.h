@@ -342,19 +342,21 @@ __global__ __launch_bounds__(256) void cull_allow_validate_kernel(const float *c
     if (threadIdx.x == 0) state[0] = bad_s ? 1u : 0u;
 }
 
-// total of the listed records of a list (act_cnt without the flag bit) -> out[0] (u64); one block
+// total of the listed records of a list (act_cnt without the flag bit) added to out[0] (u64, zeroed by the caller); every block
+// takes a slice and adds its sum with one atomic (integers: the order does not matter)
+constexpr int CULL_COUNT_BLOCKS = 64;
 __global__ __launch_bounds__(256) void cull_count_kernel(const uint32_t *act_cnt, uint32_t n, unsigned long long *out)
 {
     __shared__ unsigned long long sh[256];
     unsigned long long v = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) v += act_cnt[i] & ~CULL_DUP_BIT;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) v += act_cnt[i] & ~CULL_DUP_BIT;
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0 && sh[0]) atomicAdd(out, sh[0]);
 }
 
 } // namespace frog

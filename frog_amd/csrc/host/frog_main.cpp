@@ -78,9 +78,15 @@ int main(int argc, char *argv[])
         cout << "-rs maxScale  : maximum allowed scale for RANSAC iterations. Default : " << group.RANSACMaxScale << endl;
         cout << "-rid value    : RANSAC inlier distance. Default : " << group.RANSACInlierDistance << endl;
         cout << "-rb number    : RANSAC candidate batches (seeds 0, 1000, ...). Default : number of cores, as upstream" << endl;
+        cout << endl << "*Reference landmarks:" << endl;
+        cout << "-l path       : path containing reference landmarks." << endl;
+        cout << "-lc path      : path containing constraint landmarks." << endl;
+        cout << "-il 0/1       : invert landmarks x and y coordinates. Default : " << group.invertLandmarksCoordinates << endl;
+        cout << "-lcw path     : landmarks constraints weight. Default: " << group.landmarksConstraintsWeight << endl;
         cout << endl << "*Other parameters:" << endl;
         cout << "-nt number    : set number of host threads. Default : number of cores" << endl;
         cout << "-mf file      : path+name of measure.csv file." << endl;
+        cout << "-wp 0/1       : write pairs, distances and probabilities. Default : " << group.writePairs << endl;
         cout << "-j            : outputs a single big JSON file for each transform. Default : " << group.writeSingleFileTransforms << endl;
         cout << "-ts subdir    : subdirectory where transforms will be written. Default : " << group.transformSubdirectory << endl;
         cout << "-dev number   : HIP device. Default : " << group.device << endl;
