@@ -132,7 +132,7 @@ int frog_comm_unique_id(unsigned char id_out[128])
 
 int frog_comm_create_rank(int n, int rank, const unsigned char id_in[128], int device, frog_comm **out)
 {
-    if (n < 1 || rank < 0 || rank >= n || !id_in || !out) return comm_fail(FROG_E_INVALID, "bad communicator arguments");
+    if (n < 1 || n > 4096 || rank < 0 || rank >= n || !id_in || !out) return comm_fail(FROG_E_INVALID, "bad communicator arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return comm_fail(FROG_E_NODEVICE, "no HIP device");
     if (device < 0 || device >= ndev) return comm_fail(FROG_E_INVALID, "device index out of range");
@@ -188,7 +188,10 @@ int frog_comm_bind(frog_comm *c, frog_ctx *ctx, const uint32_t *image_begin)
     rc = frog_comm_buffer(ctx, FROG_BUF_XYZ2, nullptr, nullptr, &rb, &re);
     if (rc) return rc;
     c->sh->row_begin[c->rank] = rb; c->sh->row_end[c->rank] = re;
-    if (!c->d_box) COMM_HIP(hipMalloc((void **)&c->d_box, 6 * sizeof(double)));
+    if (!c->d_box) {
+        COMM_HIP(hipMalloc((void **)&c->d_box, 6 * sizeof(double)));
+        COMM_HIP(hipMemset(c->d_box, 0, 6 * sizeof(double)));       // frog_comm_barrier all-reduces its first word
+    }
     if (!c->h_box) COMM_HIP(hipHostMalloc((void **)&c->h_box, 6 * sizeof(double)));
     if (c->sh->one_rank_per_process) return FROG_OK;    // the other ranks' rows come through frog_comm_set_rows
     c->sh->barrier.wait();          // every rank's rows are known to all

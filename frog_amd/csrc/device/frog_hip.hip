@@ -1015,12 +1015,13 @@ int frog_linear_step_local(frog_ctx *ctx)
     if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
     hipStream_t s = ctx->stream;
     // half-links whose weight is exactly zero are left to a list, as the deformable stage's certain outliers are (k_cull.hip.h)
-    const bool culled = cull_active_linear(ctx);
+    bool culled = cull_active_linear(ctx);
     ctx->build_in_sweep = false;
     if (culled) {
         Span span(ctx, FROG_K_CULL);
         const int rc = cull_prepare(ctx);
         if (rc) return rc;
+        culled = cull_active_linear(ctx);   // no room for the list's buffers: the context goes on without one
     }
     {
         Span span(ctx, ctx->build_in_sweep ? FROG_K_SWEEP_LINEAR_BUILD : FROG_K_SWEEP_LINEAR, ctx->n_sub == 1);
@@ -1242,9 +1243,25 @@ int frog_deformable_setup(frog_ctx *ctx, int level, frog_grid_info *out)
 
 // buffers of the culling list (4 bytes per half-link for the listed records); at frog_create, so that the first deformable
 // step does not pay for them
+static int cull_allocate_buffers(frog_ctx *ctx);
+
+// The list is an optimisation: when its buffers do not fit (4-8 bytes per half-link, a second coordinate table) the context
+// runs without one -- every sweep walks all records -- instead of failing.
 static int cull_allocate(frog_ctx *ctx)
 {
-    if (ctx->act_cnt.p) return FROG_OK;
+    if (ctx->act_cnt.p || !ctx->cull_enabled) return FROG_OK;
+    const int rc = cull_allocate_buffers(ctx);
+    if (rc == FROG_OK) return rc;
+    (void)hipGetLastError();
+    ctx->act_recs32.release(); ctx->act_recs.release(); ctx->act_cnt.release(); ctx->pos2_snap.release();
+    ctx->cut_list.release(); ctx->disp_part.release(); ctx->cull_state.release(); ctx->disp_allow.release();
+    ctx->cull_enabled = false;
+    ctx->fused_sweep = ctx->fused_sweep && ctx->fused_forced;
+    return FROG_OK;
+}
+
+static int cull_allocate_buffers(frog_ctx *ctx)
+{
     hipStream_t s = ctx->stream;
     if (ctx->rec_format.narrow) {
         FROG_HIP_CHECK(ctx->act_recs32.alloc(ctx->L_recs));
@@ -1279,6 +1296,7 @@ static int cull_prepare(frog_ctx *ctx)
     const uint32_t nI = ctx->nI;
     int rc = cull_allocate(ctx);
     if (rc) return rc;
+    if (!ctx->cull_enabled) return FROG_OK;     // the buffers did not fit
     if (ctx->cull_need_build) {
         cull_list_cutoff_kernel<<<div_up(nI, 64), 64, 0, s>>>(ctx->cut_now.p, nI, ctx->deformable ? ctx->cull_scale : ctx->cull_lin_scale,
                                                               ctx->deformable ? ctx->cull_pad : ctx->cull_lin_pad, ctx->cut_list.p);
@@ -1336,13 +1354,14 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
     // the gradient lattice proper lives in the staged tiles of the scatter; `gradf` only receives stray points (Fill(0), :249)
-    const bool culled = cull_active(ctx);
+    bool culled = cull_active(ctx);
     bool fused_energy = false;
     ctx->build_in_sweep = false;
     if (culled) {
         Span span(ctx, FROG_K_CULL);
         int rc = cull_prepare(ctx);
         if (rc) return rc;
+        culled = cull_active(ctx);          // no room for the list's buffers: the context goes on without one
     }
     {
         // a launch that also writes the culling list is timed as a group of its own: it is not the steady-state kernel

@@ -23,10 +23,12 @@
 //                records.  Otherwise the flag tells the sweep (on the device, same launch) to walk all records,
 //                and the host (through the fourth scalar it reads back per iteration anyway) to rebuild the list.
 //
-// The listed records keep their relative order, the skipped ones would have added +0.0 to f64 sums and nothing
-// to f32 sums: every output is bit-identical to the full sweep (tests/test_gpu_round2.py compares whole runs with
-// FROG_CULL=0 and 1, and with a zero skin that invalidates the list at every step).  Nothing is approximated and
-// no decision is cached: a listed link is evaluated from scratch each iteration.
+// The listed records keep their relative order and the skipped ones would have added nothing: the f32 per-point sums --
+// and with them lattices, coordinates, the census -- are bit-identical to the full sweep's.  The energy's two f64 sums are
+// accumulated per lane and then over the wavefront; compaction moves records to other lanes, so their association
+// changes: equal up to f64 re-association of f32 terms (identical bits in every run compared so far:
+// tests/test_gpu_round2.py compares whole runs with FROG_CULL=0 and 1, and with a zero skin that invalidates the list at
+// every step).  Nothing is approximated and no decision is cached: a listed link is evaluated from scratch each iteration.
 #pragma once
 
 #include "ctx.h"
