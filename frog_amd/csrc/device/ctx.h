@@ -267,6 +267,7 @@ struct frog_ctx {
     // energy / counters
     frog::DevBuf<double> energy;              // [4]
     frog::DevBuf<double> energy_blocks;       // [ENERGY_BLOCKS][2] stage-1 sums
+    frog::DevBuf<double> img_energy;          // [nOwned][2] per-image (sDistances, sWeights) of the last linear step
     frog::DevBuf<unsigned int> energy_ticket; // [0] blocks done in energy_reduce_kernel
     double *h_energy = nullptr;               // pinned [8]
     double *h_energy_dev = nullptr;           // the same memory as the device sees it (null: scalars come by copy)

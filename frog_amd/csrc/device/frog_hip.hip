@@ -303,6 +303,24 @@ static int join_setup(frog_ctx *ctx)
     return FROG_OK;
 }
 
+// Spins until the kernel that carries a step's scalars (publish_step_scalars) has written sequence number `seq` to pinned memory.
+static int wait_step_scalars(frog_ctx *ctx, double seq)
+{
+    volatile double *h = ctx->h_energy;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (h[7] != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            // the kernel never ran (a launch failure shows here): wait for the stream and report
+            FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (h[7] != seq) return fail(FROG_E_HIP, "the step's scalars never arrived");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return FROG_OK;
+}
+
 // Queues, on the side stream, the selection of the next refresh not yet selected (k_stats.hip.h select_kernel: the
 // generator's state carries over, so selections are produced in refresh order) and the end points of its half-links.
 static int produce_selection(frog_ctx *c)
@@ -594,6 +612,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->mat.upload(hm, s));
     CREATE_CHECK(c->energy.alloc(4));
     CREATE_CHECK(c->energy_blocks.alloc(2 * ENERGY_BLOCKS));
+    CREATE_CHECK(c->img_energy.alloc(2 * (size_t)std::max(1u, c->n_owned())));
     CREATE_CHECK(c->energy_ticket.alloc(2));
     CREATE_CHECK(hipMemsetAsync(c->energy_ticket.p, 0, 2 * sizeof(unsigned int), s));
     CREATE_CHECK(hipMemsetAsync(c->energy.p, 0, c->energy.bytes(), s));
@@ -750,9 +769,17 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
     if (!n) return FROG_OK;                     // a context whose images are all empty: nothing to launch
     Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
-        ctx->disp_current = false;
+        // a context that owns every moving point measures the displacement against the linear stage's list in the same pass
+        const bool with_disp = cull_active_linear(ctx) && ctx->whole_group() && ctx->cull_lin_builds > 0 && !ctx->cull_need_build
+                               && ctx->pos2_snap.p;
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->mat.p,
-                                                                        ctx->own_pt_begin, ctx->own_pt_end, apply);
+                                                                        ctx->own_pt_begin, ctx->own_pt_end, apply,
+                                                                        with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
+                                                                        ctx->disp_allow.p, ctx->cull_state.p, ctx->energy.p,
+                                                                        host_scalars, scalar_seq);
+        if (with_disp) ctx->disp_n = div_up(n, 256);
+        if (out == ctx->pos2.p) ctx->disp_current = with_disp;
+        else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
     } else if (ctx->coeff_zero && !after_step) {
         // a fresh lattice: identity (k_grid.hip.h); the displacement against the culling list's snapshot is measured by
         // the check before the next sweep instead
@@ -1030,12 +1057,13 @@ int frog_linear_step_local(frog_ctx *ctx)
                                        ctx->build_in_sweep);
     }
     FROG_HIP_CHECK(hipGetLastError());
+    // the per-image update; its blocks also leave the image's energy terms, which the last of them adds up in image order
+    // (energy_reduce_kernel, a launch of its own over the tile partials, until round 3)
     linear_update_kernel<<<ctx->n_owned(), 256, 0, s>>>(ctx->tile_partial.p, ctx->img_tile_ptr.p, ctx->n_groups, ctx->ib, ctx->mat.p,
-                                                      ctx->opt.linear_alpha, ctx->opt.use_scale);
+                                                      ctx->opt.linear_alpha, ctx->opt.use_scale, ctx->img_energy.p, ctx->energy_ticket.p + 1,
+                                                      ctx->energy.p, culled ? ctx->cull_state.p : nullptr);
     FROG_HIP_CHECK(hipGetLastError());
-    energy_reduce_kernel<<<ENERGY_BLOCKS, 256, 0, s>>>(ctx->tile_partial.p, ctx->n_tiles * ctx->n_groups, LINEAR_SUMS, 16, ctx->energy_blocks.p,
-                                                       ctx->energy_ticket.p, ctx->energy.p, culled ? ctx->cull_state.p : nullptr);
-    FROG_HIP_CHECK(hipGetLastError());
+    ctx->xyz2_fresh = false;
     return FROG_OK;
 }
 
@@ -1054,7 +1082,22 @@ int frog_linear_step(frog_ctx *ctx, double *E)
 {
     int rc = frog_linear_step_local(ctx);
     if (rc) return rc;
-    return frog_energy_read(ctx, E, nullptr);
+    // A context that owns the whole group: the transformPoints() that run() calls next (imageGroup.cxx:63) is queued here,
+    // into the shadow buffer, and its first thread hands the step's scalars to the host through pinned memory -- the host used
+    // to wait for a copy of the scalars, return, and only then queue the transform: 20 us of idle GPU per linear iteration.
+    const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    if (!(ctx->whole_group() && ctx->h_energy_dev && n && !ctx->helper && !getenv("FROG_LINEAR_NO_SPECULATION")))
+        return frog_energy_read(ctx, E, nullptr);
+    if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
+    const double seq = (double)(++ctx->scalar_seq);
+    rc = launch_transform(ctx, ctx->pos2_spec.p, 0, false, seq);
+    if (rc) return rc;
+    ctx->xyz2_fresh = true;
+    rc = wait_step_scalars(ctx, seq);
+    if (rc) return rc;
+    if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // the sweep found its list out of date (it walked every record)
+    if (E) *E = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]);
+    return FROG_OK;
 }
 
 // ---- setupDeformableTransforms (imageGroup.cxx:159-218) ----------------------------------
@@ -1479,18 +1522,8 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
     if (rc) return rc;
     ctx->xyz2_fresh = true;
     if (direct) {
-        volatile double *h = ctx->h_energy;
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (h[7] != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                // the kernel never ran (a launch failure shows here): wait for the stream and report
-                FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                if (h[7] != seq) return fail(FROG_E_HIP, "the step's scalars never arrived");
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        rc = wait_step_scalars(ctx, seq);
+        if (rc) return rc;
     } else {
         FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied));
     }

@@ -59,20 +59,45 @@ __device__ __forceinline__ void publish_step_scalars(const double *energy, doubl
 }
 
 // ---- K5: linear transform (vtkLinearTransformPoint, f64 row products -> f32) ----
+// `snap` (null: no list): the kernel also measures how far its block's points are from the culling list's snapshot and
+// compares with the list's allowance, as the B-spline transforms do (k_cull.hip.h); `host_scalars`: the launch queued behind a
+// linear step hands the step's scalars to the host (publish_step_scalars).
 __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *pos2, const double *mat,
-                                                               uint32_t pt_begin, uint32_t pt_end, int apply)
+                                                               uint32_t pt_begin, uint32_t pt_end, int apply,
+                                                               const P3 *snap, uint32_t *disp_part, const float *disp_allow,
+                                                               uint32_t *cull_state, const double *energy, double *host_scalars, double seq)
 {
-    uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pt_end) return;
-    float4 v = pos[p];
-    const double *M = mat + (size_t)__float_as_int(v.w) * 16;
-    float4 o;
-    o.x = (float)(M[0] * v.x + M[1] * v.y + M[2] * v.z + M[3]);
-    o.y = (float)(M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7]);
-    o.z = (float)(M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11]);
-    o.w = v.w;
-    pos2[p] = P3{ o.x, o.y, o.z };
-    if (apply) pos[p] = o;
+    publish_step_scalars(energy, host_scalars, seq);
+    __shared__ uint32_t dmax_s[4];
+    const uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t dmax = 0;
+    if (p < pt_end) {
+        float4 v = pos[p];
+        const double *M = mat + (size_t)__float_as_int(v.w) * 16;
+        float4 o;
+        o.x = (float)(M[0] * v.x + M[1] * v.y + M[2] * v.z + M[3]);
+        o.y = (float)(M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7]);
+        o.z = (float)(M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11]);
+        o.w = v.w;
+        pos2[p] = P3{ o.x, o.y, o.z };
+        if (apply) pos[p] = o;
+        if (snap) {
+            const P3 q = snap[p];
+            const float ex = o.x - q.x, ey = o.y - q.y, ez = o.z - q.z;
+            dmax = __float_as_uint(__builtin_sqrtf(ex * ex + ey * ey + ez * ez)) & 0x7FFFFFFFu;
+        }
+    }
+    if (snap) {                                 // block-uniform
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+        if ((threadIdx.x & 63) == 0) dmax_s[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t m = max(max(dmax_s[0], dmax_s[1]), max(dmax_s[2], dmax_s[3]));
+            disp_part[blockIdx.x] = m;
+            if (!(__uint_as_float(m) <= *disp_allow)) atomicOr(cull_state, 1u);      // NaN included: see transform_bspline_kernel
+        }
+    }
 }
 
 // ---- K11: cubic B-spline forward transform (vtkBSplineTransform, BorderModeZero) --

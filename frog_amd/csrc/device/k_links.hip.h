@@ -633,18 +633,33 @@ __global__ __launch_bounds__(256) void energy_reduce_kernel(const double *partia
 // K4: per-image scale / translation update (imageGroup.cxx:1123-1143).  One block per owned
 // image: 8 slices x 18 sums add the image's (tile, group) partials in a fixed order, the
 // slices are combined in order, then lanes 0..2 update one axis each.
+// `img_energy` (null: the energy is reduced by energy_reduce_kernel): the block also leaves its image's (sDistances, sWeights)
+// -- sums 16 and 17, which it forms anyway -- in img_energy[image - image_begin], and the block that finishes last adds them
+// over the owned images in image order -> energy[0..1] (fixed order: deterministic), energy[2] = 0, energy[3] = the culling
+// list's flag.  One launch and one dependent-launch gap less per linear iteration.
 __global__ __launch_bounds__(256) void linear_update_kernel(const double *partial, const uint32_t *img_tile_ptr,
                                                             uint32_t n_groups, uint32_t image_begin, double *mat,
-                                                            float linear_alpha, int use_scale)
+                                                            float linear_alpha, int use_scale,
+                                                            double *img_energy = nullptr, unsigned int *ticket = nullptr,
+                                                            double *energy = nullptr, const uint32_t *list_invalid = nullptr)
 {
     __shared__ double part[8][32];
     __shared__ double sums[LINEAR_SUMS];
+    __shared__ bool last_s;
     const uint32_t image = image_begin + blockIdx.x;
     const uint32_t t0 = img_tile_ptr[image] * n_groups, t1 = img_tile_ptr[image + 1] * n_groups;
     const int comp = threadIdx.x & 31, slice = threadIdx.x >> 5;
     if (comp < LINEAR_SUMS) {
+        // a slice's partials in its order, eight loads at a time (a load per add made this a chain of ~80 memory round trips:
+        // 25 us for a kernel of a hundred blocks); a slot past the end adds +0.0: the same sums
         double v = 0;
-        for (uint32_t t = t0 + slice; t < t1; t += 8) v += partial[(size_t)t * LINEAR_SUMS + comp];
+        for (uint32_t t = t0 + slice; t < t1; t += 64) {
+            double w[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = (t + 8u * u < t1) ? partial[(size_t)(t + 8u * u) * LINEAR_SUMS + comp] : 0.0;
+            #pragma unroll
+            for (int u = 0; u < 8; u++) v += w[u];
+        }
         part[slice][comp] = v;
     }
     __syncthreads();
@@ -671,6 +686,35 @@ __global__ __launch_bounds__(256) void linear_update_kernel(const double *partia
                 M[4 * k + 3] = (double)translation + (double)linear_alpha * sDisp / sWeight
                              + sPosA * (double)(1 - newScale) / sWeight;
         }
+    }
+    if (!img_energy) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&img_energy[2 * blockIdx.x], sums[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&img_energy[2 * blockIdx.x + 1], sums[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_s = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    // the last block: every image's pair fetched side by side, then added in image order by one thread
+    __shared__ double pairs_s[2][256];
+    double s0 = 0, s1 = 0;
+    for (uint32_t base = 0; base < gridDim.x; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < gridDim.x) {
+            pairs_s[0][threadIdx.x] = __hip_atomic_load(&img_energy[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pairs_s[1][threadIdx.x] = __hip_atomic_load(&img_energy[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t k = 0; k < min(256u, gridDim.x - base); k++) { s0 += pairs_s[0][k]; s1 += pairs_s[1][k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        energy[0] = s0; energy[1] = s1; energy[2] = 0.0;
+        energy[3] = list_invalid ? (double)list_invalid[0] : 0.0;
+        *ticket = 0u;                                       // ready for the next launch (same stream: ordered)
     }
 }
 

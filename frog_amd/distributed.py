@@ -125,6 +125,12 @@ class HipEngine:
     def linear_step_local(self):
         check(self._lib.frog_linear_step_local(self._ctx), "frog_linear_step_local")
 
+    def linear_step(self):
+        """The whole step for a context that owns the whole group (frog_linear_step): returns E."""
+        e = C.c_double()
+        check(self._lib.frog_linear_step(self._ctx, C.byref(e)), "frog_linear_step")
+        return e.value
+
     def energy_read(self):
         e, nb = C.c_double(), C.c_double()
         check(self._lib.frog_energy_read(self._ctx, C.byref(e), C.byref(nb)), "frog_energy_read")
@@ -462,6 +468,8 @@ class ShardedImageGroup:
         self.engine.stats_publish()
 
     def updateLinearTransforms(self):
+        if not self.multi and hasattr(self.engine, "linear_step") and (self.engine.image_begin, self.engine.image_end) == (0, self.engine.n_images):
+            return self.engine.linear_step()        # one rank, every image: the entry point that also queues the transform
         self.engine.linear_step_local()
         if self.multi:
             self._reduce_energy()
