@@ -281,3 +281,23 @@ def test_linear_stage_with_the_zero_weight_list_is_bit_identical(monkeypatch, sk
     lists, listed, owned = st1
     note(f"linear_list_skin_{skin}", f"lists {lists} listed {listed} of {owned} half-links")
     assert lists >= 4 and 0 < listed < owned
+
+
+def test_config5_shaped_group_five_levels_against_the_oracle():
+    """BASELINE.json configs[4] has 500 images; the oracle cannot follow that, so its deformable levels are only checked by
+    properties there (tests/test_gpu_config5.py).  This is the same KIND of group at a size the oracle walks in seconds --
+    40 images x 20 000 keypoints, ~20 partner images each, five levels, -gd 1 -- free-running on both sides: levels 3 and 4
+    have under 24 points per brick of 4^3 cells and take the bricks of 8^3 cells (11^3-node tiles, the point-by-point
+    B-spline transform), which the small parity cases never reach by themselves.  E series, guard decisions and lattices per
+    level equal; displacement field and support-weighted coefficients 1e-4; raw coefficients reported."""
+    pairs = Pairs.synthetic(40, 20000, 16667, seed=2, partners_per_image=20)
+    assert pairs.n_half_links > 1.0e7
+    r = free_run(pairs, 10, 5, 3, images=range(0, 40, 7))
+    note("cfg5_shaped_free_run", f"E {r['E']:.2e} matrices {r['matrices']:.2e} grids {r['grids_per_level']} half_links {pairs.n_half_links}")
+    for k, d in enumerate(r["lattices"]):
+        note(f"cfg5_shaped_lattice_{k}", f"level {d['level']} raw {d['raw']:.2e} weighted {d['weighted']:.2e} field {d['field']:.2e} "
+                                          f"weak_nodes {d['weak']}/{d['nodes']}")
+    assert len(r["grids_per_level"]) == 5 and r["E"] < REL and r["matrices"] < 1e-6
+    assert max(d["nodes"] for d in r["lattices"]) > 500000            # the fine lattice really is fine
+    for k, d in enumerate(r["lattices"]):
+        assert d["field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
