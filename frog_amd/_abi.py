@@ -208,6 +208,7 @@ HIP_SYMBOLS = {
     "frog_deformable_phase_b": (C.c_int, [C.c_void_p]),
     "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
     "frog_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "frog_comm_unpack_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32]),
     "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_cull_stats_linear": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_stray_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

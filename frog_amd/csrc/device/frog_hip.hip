@@ -1979,6 +1979,40 @@ int frog_profile_read(frog_ctx *ctx, frog_kernel_time *out, int reset)
     return FROG_OK;
 }
 
+// rows [row_begin[r], row_begin[r + 1]) of every rank r != self: slab slot r -> the coordinate table
+constexpr int UNPACK_MAX_RANKS = 64;
+struct UnpackArgs { uint64_t row_begin[UNPACK_MAX_RANKS + 1]; uint64_t slot_rows; uint32_t world, self; };
+__global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *pos2, const UnpackArgs a)
+{
+    const uint32_t r = blockIdx.y;
+    if (r == a.self) return;
+    const uint64_t n = a.row_begin[r + 1] - a.row_begin[r];
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u)
+        pos2[a.row_begin[r] + k] = slab[(uint64_t)r * a.slot_rows + k];
+}
+
+int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size, const uint64_t *row_begin, uint32_t self)
+{
+    CTX_GUARD(ctx);
+    if (!slab || !row_begin || world_size < 1 || world_size > (uint32_t)UNPACK_MAX_RANKS || self >= world_size)
+        return fail(FROG_E_INVALID, "bad slab arguments");
+    UnpackArgs a{};
+    uint64_t longest = 0;
+    for (uint32_t r = 0; r <= world_size; r++) a.row_begin[r] = row_begin[r];
+    for (uint32_t r = 0; r < world_size; r++) {
+        if (row_begin[r + 1] < row_begin[r] || row_begin[r + 1] > ctx->P) return fail(FROG_E_INVALID, "rows must be ascending and inside the table");
+        longest = std::max(longest, row_begin[r + 1] - row_begin[r]);
+    }
+    if (longest > slot_rows) return fail(FROG_E_INVALID, "slot shorter than the longest shard");
+    a.slot_rows = slot_rows; a.world = world_size; a.self = self;
+    if (longest == 0) return FROG_OK;
+    const dim3 grid((unsigned)std::min<uint64_t>(div_up(longest, 256), 1024), world_size);
+    unpack_slab_kernel<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const P3 *>(slab), ctx->pos2.p, a);
+    FROG_HIP_CHECK(hipGetLastError());
+    ctx->disp_current = false;          // coordinates from elsewhere: the list's displacement is measured by the next check
+    return FROG_OK;
+}
+
 int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t *row_begin, size_t *row_end)
 {
     CTX_GUARD(ctx);

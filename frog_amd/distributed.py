@@ -149,6 +149,15 @@ class HipEngine:
         self.gridsum, _ = self._buffer(_abi.FROG_BUF_GRIDSUM, "<f8", 1)
         return info
 
+    def unpack_slab(self, slab, slot_rows, rows, self_rank):
+        """frog_comm_unpack_slab: the other ranks' rows of a gathered slab (a torch tensor on this device) into xyz2."""
+        if getattr(self, "_row_begin_key", None) != tuple(rows):
+            rb = [r[0] for r in rows] + [rows[-1][1]]
+            self._row_begin = (C.c_uint64 * len(rb))(*rb)
+            self._row_begin_key = tuple(rows)
+        check(self._lib.frog_comm_unpack_slab(self._ctx, C.c_void_p(slab.data_ptr()), int(slot_rows), len(rows), self._row_begin,
+                                              int(self_rank)), "frog_comm_unpack_slab")
+
     def phase_a(self, alpha):
         check(self._lib.frog_deformable_phase_a(self._ctx, alpha), "frog_deformable_phase_a")
 
@@ -455,6 +464,11 @@ class ShardedImageGroup:
         b, e = rows[self.rank]
         self._gather_in[:e - b].copy_(xyz2[b:e])
         self._collective("all_gather_xyz2", lambda: self._dist.all_gather_into_tensor(self._gather_out, self._gather_in, group=self.group))
+        if hasattr(self.engine, "unpack_slab") and self.world_size <= 64:
+            # one launch for all the other ranks' rows (a copy per rank is world_size - 1 launches and as many trips
+            # through the Python / torch dispatch per iteration: at 8 ranks more host time than a rank's kernels take)
+            self.engine.unpack_slab(self._gather_out, longest, rows, self.rank)
+            return
         for r, (rb, re_) in enumerate(rows):
             if r != self.rank and re_ > rb:
                 xyz2[rb:re_].copy_(self._gather_out[r * longest:r * longest + (re_ - rb)])

@@ -168,6 +168,13 @@ enum {
 int frog_comm_buffer(frog_ctx *ctx, int which, void **device_ptr, size_t *bytes,
                      size_t *row_begin, size_t *row_end);
 
+/* Ragged shards gathered with ONE equal-size all-gather: every rank contributes its owned xyz2 rows at the start of a slot of
+ * `slot_rows` rows (>= the longest shard); `slab` holds the world_size slots in rank order.  This call copies the other
+ * ranks' rows (row_begin[r] .. row_begin[r + 1], r != self) from the slab into FROG_BUF_XYZ2, in one launch on the context's
+ * stream (a host that unpacks with one copy per rank pays world_size - 1 launches per iteration). */
+int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size,
+                          const uint64_t *row_begin, uint32_t self);
+
 /* updateStats, owned images only; afterwards all-reduce(sum) FROG_BUF_EM
  * (non-owned rows are zero) and call frog_stats_publish. */
 int frog_update_stats_local(frog_ctx *ctx);
