@@ -172,7 +172,7 @@ from frog_amd.distributed import HipEngine, ShardedImageGroup, plan_shards
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share GPU 0; gloo moves the tensors
-pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+pairs = Pairs.synthetic(int(os.environ.get("FROG_TEST_IMAGES", "6")), 3000, 1500, seed=7)
 shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
 eng = HipEngine(pairs, _abi.FrogOptions.default(), 0, shards[rank])
 g = ShardedImageGroup(eng, shards, pairs.point_offset, rank, world)
@@ -190,13 +190,14 @@ if world > 1:
 '''
 
 
-def _launch(tmp_path, world, tag):
+def _launch(tmp_path, world, tag, images=6):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FROG_TEST_IMAGES=str(images))
         procs.append(subprocess.Popen(["python", str(script), ROOT, str(tmp_path / tag)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -217,6 +218,25 @@ def test_two_ranks_match_one_rank(tmp_path):
     for res in two:
         for i, m in res["matrix"].items():
             assert relerr(m, one["matrix"][i]) < 1e-6
+        for i, grids in res["coeff"].items():
+            for k, c in enumerate(grids):
+                assert relerr(c, one["coeff"][i][k]) < 1e-5
+
+
+def test_three_ranks_with_ragged_shards_match_one_rank(tmp_path):
+    """Seven images over three ranks: shards of 2 / 2 / 3 images, i.e. unequal row counts -- the all-gather of the coordinates
+    goes through the padded slab and frog_comm_unpack_slab (one launch for all the other ranks' rows), as the 100 images of
+    cfg 3 do over 8 ranks."""
+    one = _launch(tmp_path, 1, "one7", images=7)[0]
+    three = _launch(tmp_path, 3, "three7", images=7)
+    sizes = sorted(r["range"][1] - r["range"][0] for r in three)
+    assert sizes == [2, 2, 3]
+    assert three[0]["E"] == three[1]["E"] == three[2]["E"] and three[0]["grids"] == one["grids"]
+    assert np.max(np.abs(np.array(three[0]["E"]) - np.array(one["E"])) / np.array(one["E"])) < 1e-6
+    assert np.array_equal(np.array(three[0]["xyz2"]), np.array(three[1]["xyz2"]))
+    assert np.array_equal(np.array(three[0]["xyz2"]), np.array(three[2]["xyz2"]))
+    assert relerr(three[0]["xyz2"], one["xyz2"]) < 1e-6
+    for res in three:
         for i, grids in res["coeff"].items():
             for k, c in enumerate(grids):
                 assert relerr(c, one["coeff"][i][k]) < 1e-5
