@@ -1470,8 +1470,17 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
         la.energy = ctx->energy.p;
         ctx->centered_in_a = ctx->whole_group();
-        if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
-        else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
+        // a coarse lattice takes the narrow block shape: four times the blocks (k_grid.hip.h LS_CPB_SMALL)
+        static const int force_shape = [] { const char *e = getenv("FROG_LS_SHAPE"); return e ? atoi(e) : 0; }();      // 16 / 4: A/B
+        const bool narrow = force_shape ? force_shape == LS_CPB_SMALL : gd.n_cp < LS_SMALL_NODES;
+        if (narrow) {
+            const dim3 lgrid(div_up(gd.n_cp, LS_CPB_SMALL));
+            if (ctx->centered_in_a) lattice_step_kernel<true, LS_CPB_SMALL><<<lgrid, LS_CPB_SMALL * LS_IC, 0, s>>>(la, gd);
+            else lattice_step_kernel<false, LS_CPB_SMALL><<<lgrid, LS_CPB_SMALL * LS_IC, 0, s>>>(la, gd);
+        } else {
+            if (ctx->centered_in_a) lattice_step_kernel<true><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
+            else lattice_step_kernel<false><<<div_up(gd.n_cp, LS_CPB), LS_THREADS, 0, s>>>(la, gd);
+        }
     }
     FROG_HIP_CHECK(hipGetLastError());
     ctx->pending_alpha = alpha;

@@ -1091,6 +1091,8 @@ constexpr int LS_CPB = 16;          // control points per block
 constexpr int LS_IC = 64;           // images per pass (with 16 a group of 100 images took 7 dependent rounds of
                                     // slot-pointer -> tile loads per block: 130 us where the three kernels took 77)
 constexpr int LS_THREADS = LS_CPB * LS_IC;
+constexpr int LS_CPB_SMALL = 4;      // block shape for lattices below LS_SMALL_NODES control points: 4 x 64 = 256 threads
+constexpr int LS_SMALL_NODES = 2048;     // measured on cfg 3: 704 nodes 35.7 -> 31.8 us with the narrow shape, 3 042 nodes 28.8 -> 34.6 us (slower)
 constexpr int LS_KEEP = 8;          // passes whose proposals stay in registers until the mean is known
 static_assert(LS_THREADS <= 1024 && 3 * LS_CPB <= LS_THREADS, "lattice_step_kernel thread mapping");
 
@@ -1108,14 +1110,16 @@ struct LatticeStepArgs {
     double *energy;
 };
 
-template <bool CENTER>
-__global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeStepArgs a, const GeomDev g)
+// CPB: control points per block (LS_CPB, or LS_CPB_SMALL for lattices of so few nodes that blocks of LS_CPB would leave most
+// of the chip idle: 704 nodes of a coarse level are 44 blocks of 16 -- 17 % of the CUs, each waiting on its own loads).
+template <bool CENTER, int CPB = LS_CPB>
+__global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const LatticeStepArgs a, const GeomDev g)
 {
-    __shared__ float prop[LS_IC][LS_CPB][3];
-    __shared__ double mean[LS_CPB][3];
+    __shared__ float prop[LS_IC][CPB][3];
+    __shared__ double mean[CPB][3];
     const int tid = threadIdx.x;
-    const int c = tid % LS_CPB, il = tid / LS_CPB;
-    const int cp = blockIdx.x * LS_CPB + c;
+    const int c = tid % CPB, il = tid / CPB;
+    const int cp = blockIdx.x * CPB + c;
     const bool has_stray = *a.stray != 0u;
 
     // bricks that cover this control point (brick b holds control points b*B .. b*B + B + 2)
@@ -1130,7 +1134,7 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
         }
     }
     // summation thread: (control point sc, axis sa)
-    const int sc = tid % LS_CPB, sa = tid / LS_CPB;
+    const int sc = tid % CPB, sa = tid / CPB;
     double run = 0.0;
     // CENTER: the proposals of up to LS_KEEP passes (groups of up to 512 images) wait in registers for the mean, so that
     // every coefficient is written once; larger groups write the raw proposals and re-read them (the blocks' own L2 lines)
@@ -1203,7 +1207,7 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
     auto accumulate = [&](uint32_t i0, const float4 n4) {
         prop[il][c][0] = n4.x; prop[il][c][1] = n4.y; prop[il][c][2] = n4.z;
         __syncthreads();
-        if (tid < 3 * LS_CPB) {
+        if (tid < 3 * CPB) {
             const uint32_t n = min((uint32_t)LS_IC, a.n_owned - i0);
             for (uint32_t k = 0; k < n; k++) run += (double)prop[k][sc][sa];
         }
@@ -1226,8 +1230,8 @@ __global__ __launch_bounds__(LS_THREADS) void lattice_step_kernel(const LatticeS
     } else {
         for (uint32_t i0 = 0; i0 < a.n_owned; i0 += LS_IC) accumulate(i0, propose(i0, true));
     }
-    if (tid < 3 * LS_CPB) {
-        const int scp = blockIdx.x * LS_CPB + sc;
+    if (tid < 3 * CPB) {
+        const int scp = blockIdx.x * CPB + sc;
         if (scp < g.n_cp) a.gridsum[3 * (size_t)scp + sa] = run;
         mean[sc][sa] = a.n_images ? run / a.n_images : 0.0;
     }
