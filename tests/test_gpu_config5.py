@@ -101,3 +101,23 @@ def test_config5_on_one_gpu():
     assert g.stray_points() == 0
     built, listed, owned = g.cull_stats()
     assert built >= 1 and owned == pairs.n_half_links and 0 < listed < 0.9 * owned
+
+
+def test_config5_group_sharded_eight_ways_on_one_gpu(tmp_path):
+    """configs[4] is quoted for 8 GPUs: its group (4.6e8 half-links) through `bin/frog -ngl 8` -- eight contexts with shards of
+    62-63 images on the one GPU, every collective host-staged -- against the one-context run (scripts/cfg5_sharded_rehearsal.py:
+    levels 0-2, since the files of levels 3-4 of 500 images are tens of GB): energies, matrices and lattices equal, census
+    equal, the eight replicas bit-equal."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "cfg5_sharded.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cfg5_sharded_rehearsal.py"), str(out)], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["contexts"] == 8 and res["replicas_identical"] and res["iterations"] == 12
+    assert res["E_max_rel_dev"] < 1e-5 and res["matrices_max_rel_dev"] < 1e-6 and res["lattices_max_rel_dev"] < 1e-5
+    assert res["half_pairs"][0] == res["half_pairs"][1] > 4e8
