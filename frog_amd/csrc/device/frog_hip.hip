@@ -685,6 +685,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             (const void *)block_fill_kernel, (const void *)block_len_base_kernel, (const void *)block_sort_kernel,
             (const void *)cull_list_cutoff_kernel, (const void *)cull_allow_kernel, (const void *)cull_validate_kernel, (const void *)cull_disp_kernel,
             (const void *)count_reduce_kernel, (const void *)combine_groups_kernel, (const void *)energy_reduce_kernel,
+            (const void *)lattice_step_kernel<true, LS_CPB_SMALL>, (const void *)lattice_step_kernel<false, LS_CPB_SMALL>,
+            (const void *)stats_publish_kernel, (const void *)cull_allow_validate_kernel, (const void *)cull_count_kernel,
+            (const void *)sweep_kernel<SWEEP_LINEAR, true, false, true, false>, (const void *)sweep_kernel<SWEEP_LINEAR, true, false, false, false>,
         };
         for (const void *k : kernels) { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, k); }
         (void)hipGetLastError();
