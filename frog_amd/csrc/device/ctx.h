@@ -331,6 +331,8 @@ struct frog_ctx {
     frog::DevBuf<float> cut_now, cut_list;    // [nI] certified cutoff of the current mixtures / list cutoff at build time
     frog::DevBuf<uint32_t> disp_part;         // per-block maxima of the points' displacement since the build (f32 bits)
     uint32_t disp_n = 0;                      // entries of disp_part the last producer wrote
+    uint32_t disp_own_n = 0;                  // ... of them by the transform of the OWNED points (the rest: frog_comm_unpack_slab)
+    bool disp_others = false;                 // disp_part also covers the other ranks' rows (measured while they were unpacked)
     frog::DevBuf<uint32_t> cull_state;        // [0] 1: list not valid for the current coordinates
     frog::DevBuf<float> disp_allow;           // [0] displacement up to which the list stays good (cull_allow_kernel)
     frog::DevBuf<float4> retired_arena;       // finished lattices are copied here, one after the other (retire_current_grid)

@@ -773,14 +773,14 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
     Span span(ctx, FROG_K_TRANSFORM);
     if (!ctx->deformable) {
         // a context that owns every moving point measures the displacement against the linear stage's list in the same pass
-        const bool with_disp = cull_active_linear(ctx) && ctx->whole_group() && ctx->cull_lin_builds > 0 && !ctx->cull_need_build
-                               && ctx->pos2_snap.p;
+        const bool with_disp = cull_active_linear(ctx) && ctx->cull_lin_builds > 0 && !ctx->cull_need_build && ctx->pos2_snap.p;
         transform_linear_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->mat.p,
                                                                         ctx->own_pt_begin, ctx->own_pt_end, apply,
                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                         ctx->disp_allow.p, ctx->cull_state.p, ctx->energy.p,
                                                                         host_scalars, scalar_seq);
-        if (with_disp) ctx->disp_n = div_up(n, 256);
+        if (with_disp) ctx->disp_n = ctx->disp_own_n = div_up(n, 256);
+        ctx->disp_others = false;
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
         else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
     } else if (ctx->coeff_zero && !after_step) {
@@ -793,7 +793,9 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         { const int rc = join_setup(ctx); if (rc) return rc; }
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
-        const bool with_disp = cull_active(ctx) && ctx->whole_group() && ctx->cull_builds > 0 && !ctx->cull_need_build;
+        // (a context that owns a sub-range measures its own rows; the other ranks' are measured when they arrive:
+        // frog_comm_unpack_slab -- or, when the host gathers some other way, by the check before the sweep)
+        const bool with_disp = cull_active(ctx) && ctx->cull_builds > 0 && !ctx->cull_need_build;
         // The tiled form pays the staging of 343 coefficients per block; measured on cfg 3 (points per brick 1 700 / 210 / 80 at
         // levels 0 / 1 / 2): 0.062 / 0.062 / 0.088 ms against 0.100 / 0.100 / 0.109 ms point by point.  Bricks of 8^3 cells are
         // only chosen below 24 points per brick of 4^3 (make_geometry), where staging 1 331 coefficients per block cannot pay.
@@ -812,7 +814,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                 after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
                 ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
-            if (with_disp) ctx->disp_n = ctx->n_scatter_blocks;
+            if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
             transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
@@ -820,8 +822,9 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
                                                                              ctx->opt.guarantee_diffeomorphism,
                                                                              ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
-            if (with_disp) ctx->disp_n = div_up(n, 256);
+            if (with_disp) ctx->disp_n = ctx->disp_own_n = div_up(n, 256);
         }
+        ctx->disp_others = false;
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
         else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
@@ -1362,12 +1365,14 @@ static int cull_prepare(frog_ctx *ctx)
         ctx->cull_need_build = false;
         if (ctx->deformable) ctx->cull_builds++; else ctx->cull_lin_builds++;
         ctx->disp_n = 0;                    // the points are where the snapshot has them: no displacement to look at
+        ctx->disp_own_n = 0;
         ctx->disp_current = true;
+        ctx->disp_others = true;            // every row, whoever owns it
         ctx->cull_check_due = true;
     }
     // displacement since the build: already in disp_part when the transform that produced the current xyz2 measured it
     // (launch_transform; whole-group contexts whose xyz2 nobody else writes), else one pass over all points
-    const bool measured = ctx->disp_current && ctx->whole_group() && !ctx->xyz2_exported;
+    const bool measured = ctx->disp_current && ((ctx->whole_group() && !ctx->xyz2_exported) || ctx->disp_others);
     if (!measured) {
         uint32_t max_pts = 1;
         for (uint32_t i = 0; i < nI; i++) max_pts = std::max(max_pts, ctx->poff[i + 1] - ctx->poff[i]);
@@ -1378,7 +1383,9 @@ static int cull_prepare(frog_ctx *ctx)
     // The transform that measured the displacement has already compared it with disp_allow and raised cull_state if it
     // had to (k_grid.hip.h); the stand-alone check (which also LOWERS the flag again) runs when the cutoffs or the list
     // have changed since, or when the displacement was measured here.  While the flag is up the host rebuilds anyway.
-    if (ctx->cull_check_due || !measured) {
+    // (a sub-range context: its transform compared only its own rows with the allowance, so the stand-alone check runs
+    // every step there -- one block over a few thousand maxima instead of a pass over every coordinate)
+    if (ctx->cull_check_due || !measured || !ctx->whole_group()) {
         if (ctx->cull_check_due)
             cull_allow_validate_kernel<<<1, 256, 0, s>>>(ctx->cut_now.p, ctx->cut_list.p, ctx->disp_part.p, ctx->disp_n, nI,
                                                          ctx->disp_allow.p, ctx->cull_state.p);
@@ -1994,13 +2001,31 @@ int frog_profile_read(frog_ctx *ctx, frog_kernel_time *out, int reset)
 // rows [row_begin[r], row_begin[r + 1]) of every rank r != self: slab slot r -> the coordinate table
 constexpr int UNPACK_MAX_RANKS = 64;
 struct UnpackArgs { uint64_t row_begin[UNPACK_MAX_RANKS + 1]; uint64_t slot_rows; uint32_t world, self; };
-__global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *pos2, const UnpackArgs a)
+// `snap` (null: no list to check): the block also leaves the largest distance of the rows it copies from the culling list's
+// snapshot in disp_part[blockIdx.y * gridDim.x + blockIdx.x] (k_cull.hip.h: what cull_disp_kernel computes in a pass of its own)
+__global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *pos2, const UnpackArgs a, const P3 *snap, uint32_t *disp_part)
 {
+    __shared__ uint32_t sh[4];
     const uint32_t r = blockIdx.y;
-    if (r == a.self) return;
-    const uint64_t n = a.row_begin[r + 1] - a.row_begin[r];
-    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u)
-        pos2[a.row_begin[r] + k] = slab[(uint64_t)r * a.slot_rows + k];
+    uint32_t m = 0;
+    if (r != a.self) {
+        const uint64_t n = a.row_begin[r + 1] - a.row_begin[r];
+        for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u) {
+            const P3 v = slab[(uint64_t)r * a.slot_rows + k];
+            pos2[a.row_begin[r] + k] = v;
+            if (snap) {
+                const P3 q = snap[a.row_begin[r] + k];
+                const float dx = v.x - q.x, dy = v.y - q.y, dz = v.z - q.z;
+                m = max(m, __float_as_uint(__builtin_sqrtf(dx * dx + dy * dy + dz * dz)) & 0x7FFFFFFFu);
+            }
+        }
+    }
+    if (!snap) return;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) disp_part[blockIdx.y * gridDim.x + blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 }
 
 int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size, const uint64_t *row_begin, uint32_t self)
@@ -2019,9 +2044,17 @@ int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, u
     a.slot_rows = slot_rows; a.world = world_size; a.self = self;
     if (longest == 0) return FROG_OK;
     const dim3 grid((unsigned)std::min<uint64_t>(div_up(longest, 256), 1024), world_size);
-    unpack_slab_kernel<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const P3 *>(slab), ctx->pos2.p, a);
+    // The own rows' displacement against the culling list's snapshot was measured by the transform that produced them
+    // (disp_part[0 .. disp_own_n)); the rows arriving here are measured as they are copied, behind those entries -- the check
+    // before the next sweep then has every row covered without a pass of its own over the whole table.
+    const bool list = ctx->deformable ? (cull_active(ctx) && ctx->cull_builds > 0) : (cull_active_linear(ctx) && ctx->cull_lin_builds > 0);
+    const bool measure = ctx->disp_current && list && !ctx->cull_need_build && ctx->pos2_snap.p && ctx->disp_part.p
+                         && (size_t)ctx->disp_own_n + (size_t)grid.x * grid.y <= ctx->disp_part.n;
+    unpack_slab_kernel<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const P3 *>(slab), ctx->pos2.p, a,
+                                                      measure ? ctx->pos2_snap.p : nullptr, measure ? ctx->disp_part.p + ctx->disp_own_n : nullptr);
     FROG_HIP_CHECK(hipGetLastError());
-    ctx->disp_current = false;          // coordinates from elsewhere: the list's displacement is measured by the next check
+    if (measure) { ctx->disp_n = ctx->disp_own_n + grid.x * grid.y; ctx->disp_others = true; }
+    else { ctx->disp_current = false; ctx->disp_others = false; }      // measured by the check before the next sweep
     return FROG_OK;
 }
 

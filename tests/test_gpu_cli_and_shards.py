@@ -190,14 +190,14 @@ if world > 1:
 '''
 
 
-def _launch(tmp_path, world, tag, images=6):
+def _launch(tmp_path, world, tag, images=6, extra_env=None):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   FROG_TEST_IMAGES=str(images))
+                   FROG_TEST_IMAGES=str(images), **(extra_env or {}))
         procs.append(subprocess.Popen(["python", str(script), ROOT, str(tmp_path / tag)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -240,6 +240,20 @@ def test_three_ranks_with_ragged_shards_match_one_rank(tmp_path):
         for i, grids in res["coeff"].items():
             for k, c in enumerate(grids):
                 assert relerr(c, one["coeff"][i][k]) < 1e-5
+
+
+def test_ragged_ranks_with_a_zero_skin_list(tmp_path):
+    """The same three ranks with culling lists that have NO skin (FROG_CULL_SKIN=1.0,0.0, also for the linear stage): any
+    movement of any point -- this rank's or another's -- invalidates the list, so a rank that failed to notice another rank's
+    points moving (their displacement is measured while their rows are unpacked from the gathered slab) would sweep a stale
+    list and drift away from the one-rank run, whose results do not depend on the skin at all."""
+    zero = {"FROG_CULL_SKIN": "1.0,0.0", "FROG_CULL_SKIN_LINEAR": "1.0,0.0"}
+    one = _launch(tmp_path, 1, "one7d", images=7)[0]
+    three = _launch(tmp_path, 3, "three7z", images=7, extra_env=zero)
+    assert three[0]["E"] == three[1]["E"] == three[2]["E"] and three[0]["grids"] == one["grids"]
+    assert np.max(np.abs(np.array(three[0]["E"]) - np.array(one["E"])) / np.array(one["E"])) < 1e-6
+    assert np.array_equal(np.array(three[0]["xyz2"]), np.array(three[2]["xyz2"]))
+    assert relerr(three[0]["xyz2"], one["xyz2"]) < 1e-6
 
 
 def test_cli_validation_landmarks(tmp_path):
