@@ -95,16 +95,27 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
     uint32_t *st = mt_state + (size_t)img * MT_WORDS;
     for (int k = tid; k < MT_N; k += SELECT_THREADS) x[k] = st[k];
     uint32_t idx = st[MT_N];                       // block-uniform, like everything that steers the loop
+    if (tid == 0) jstar_s = -1;
     __syncthreads();
+    if (idx >= (uint32_t)MT_N) { mt_regenerate(x, tid); idx = 0; }      // (a state saved exactly at its end)
 
+    constexpr int LAG = MT_N - MT_M;
     const float thresh = (float)cap / (float)vs;   // (float) samples.size() / virtualSize
     uint32_t count = 0;                            // kept so far
     uint32_t ordinal = 0;                          // draws consumed this refresh
     bool done = false;
+    // One round = the words [idx, 624) of the current state: tested and ranked -- and, in the same two barrier intervals, the
+    // NEXT state formed in registers from the current one (mt_regenerate's chain), to be written only if the replay goes on
+    // past this state.  Two barriers per 624 draws (four with the regeneration as a step of its own).
     while (!done && ordinal < vs) {
-        if (idx >= (uint32_t)MT_N) { mt_regenerate(x, tid); idx = 0; }
-        // consume the words [idx, idx + n) of the current state: position q = tid + 256 row <-> ordinal + q
         const uint32_t n = min((uint32_t)MT_N - idx, vs - ordinal);
+        uint32_t na = 0, nb = 0, nc = 0;           // the next state's words tid, tid + 227, tid + 454 (mt_regenerate)
+        if (tid < LAG) {
+            na = mt_twist(x[tid], x[tid + 1], x[tid + MT_M]);
+            nb = mt_twist(x[tid + LAG], x[tid + LAG + 1], na);
+            if (tid + 2 * LAG < MT_N - 1) nc = mt_twist(x[tid + 2 * LAG], x[tid + 2 * LAG + 1], nb);
+            else if (tid + 2 * LAG == MT_N - 1) nc = mt_twist(x[MT_N - 1], mt_twist(x[0], x[1], x[MT_M]), nb);
+        }
         // per row: kept? (bit r of keep_bits) and how many lower lanes of this wavefront kept theirs (byte r of below_pk)
         uint32_t keep_bits = 0, below_pk = 0;
         #pragma unroll
@@ -121,8 +132,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
             below_pk |= (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) << (8 * r);
             if (lane == 0) row_cnt[r][wave] = (uint32_t)__popcll(mask);
         }
-        if (tid == 0) jstar_s = -1;
-        __syncthreads();
+        __syncthreads();                           // every read of x and every row_cnt of this round is done
         uint32_t kept = 0;
         #pragma unroll
         for (int r = 0; r < SELECT_ROWS; r++)
@@ -145,8 +155,15 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
             if (((keep_bits >> r) & 1u) && rank < need) ord[count + rank] = ordinal + q;
             if (((keep_bits >> r) & 1u) && fills && rank == need - 1) jstar_s = (int)q;
         }
+        // the replay goes on past this state (block-uniform: `fills`, n, idx, ordinal and vs are): the next state replaces it
+        const bool advance = !fills && idx + n == (uint32_t)MT_N && ordinal + n < vs;
+        if (advance && tid < LAG) {
+            x[tid] = na;
+            x[tid + LAG] = nb;
+            if (tid + 2 * LAG < MT_N) x[tid + 2 * LAG] = nc;
+        }
+        __syncthreads();                           // jstar_s, the new state; row_cnt may be written again
         if (fills) {
-            __syncthreads();
             const uint32_t jstar = (uint32_t)jstar_s;
             idx += jstar + 1;
             ordinal += jstar + 1;
@@ -154,10 +171,9 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(uint32_t *mt_sta
             done = true;
         } else {
             count += kept;
-            idx += n;
             ordinal += n;
+            idx = advance ? 0u : idx + n;
         }
-        __syncthreads();                           // row_cnt / jstar_s are reused, the state may be regenerated
     }
     for (int k = tid; k < MT_N; k += SELECT_THREADS) st[k] = x[k];
     if (tid == 0) { st[MT_N] = idx; sample_count[img] = count; }
