@@ -50,10 +50,11 @@ def schedule(k, levels=3):
     return n_lin, per
 
 
-def cpu_baseline(pairs, n_lin, per_level, stat_interval):
+def cpu_baseline(pairs, n_lin, per_level, stat_interval, repeats=3):
     """Oracle (CPU restatement, OpenMP over images like the reference) on a bounded
-    sample of the same workload: one stats refresh, one linear iteration, one
-    deformable iteration per level; extrapolated to the timed schedule."""
+    sample of the same workload: `repeats` stats refreshes, linear iterations and
+    deformable iterations per level (about ten seconds of CPU work on the box's cores;
+    the mean of each kind), extrapolated to the timed schedule."""
     from frog_amd import _abi
     from oracle.oracle_api import OracleGroup, lib
     cores = lib().frogo_get_max_threads()
@@ -61,8 +62,13 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
     ref.setup_stats()
     ref.linear_init()
     ref.transform_points()
-    t = time.perf_counter(); ref.update_stats(); t_stats = time.perf_counter() - t
-    t = time.perf_counter(); ref.linear_step(); ref.transform_points(); t_lin = time.perf_counter() - t
+
+    def timed(fn):
+        t = time.perf_counter(); fn(); return time.perf_counter() - t
+    t_stats, t_lin = [], []
+    for _ in range(repeats):
+        t_stats.append(timed(ref.update_stats))
+        t_lin.append(timed(lambda: (ref.linear_step(), ref.transform_points())))
     ref.transform_points(True)
     t_def = []
     for level in range(len(per_level)):
@@ -71,14 +77,16 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval):
             continue
         ref.deformable_setup(level, _abi.FrogGridInfo())
         ref.transform_points()
-        t = time.perf_counter(); ref.deformable_step(0.02); ref.transform_points(); t_def.append(time.perf_counter() - t)
+        ts = [timed(lambda: (ref.deformable_step(0.02), ref.transform_points())) for _ in range(repeats)]
+        t_def.append(sum(ts) / len(ts))
         ref.transform_points(True)
+    t_stats, t_lin = sum(t_stats) / len(t_stats), sum(t_lin) / len(t_lin)
     refreshes = -(-n_lin // stat_interval) + sum(-(-n // stat_interval) for n in per_level)
     total = n_lin * t_lin + sum(n * t for n, t in zip(per_level, t_def)) + refreshes * t_stats
     k = n_lin + sum(per_level)
     return {"value": k / total, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": "1 updateStats + 1 linear iteration + 1 deformable iteration per level on the same "
-                      "pairs, timed with the oracle (oracle/frog_oracle.cpp, OpenMP over images) and "
+            "sample": f"{repeats} updateStats + {repeats} linear iterations + {repeats} deformable iterations per level on the "
+                      "same pairs, timed with the oracle (oracle/frog_oracle.cpp, OpenMP over images), the mean of each kind "
                       "extrapolated to the timed schedule",
             "seconds": {"stats_refresh": t_stats, "linear_iteration": t_lin, "deformable_iteration": t_def}}
 
