@@ -221,6 +221,7 @@ struct frog_ctx {
     frog::DevBuf<float4> point_sums;          // [P] (owned rows used)
     // fused deformable sweep (k_links.hip.h FUSED): block -> tile table and whether this context uses it
     frog::DevBuf<uint32_t> tile_order;        // [n_order_blocks] tile of every block, 0xFFFFFFFF = none; block % 8 = the tile's eighth of its image
+    frog::DevBuf<frog::Tile> tiles_bo;        // the tiles in block order (zero tiles where tile_order has none)
     uint32_t n_order_blocks = 0;
     bool fused_sweep = false;
     bool fused_forced = false;                // FROG_SWEEP_FUSED=1 / 2: also without a culling list

@@ -96,7 +96,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.own_pt_begin = ctx->own_pt_begin; a.own_points = ctx->own_pt_end - ctx->own_pt_begin;
     a.act_recs = nullptr; a.act_cnt = nullptr; a.cull_state = nullptr;
     a.cut_list = nullptr; a.build_recs = nullptr; a.build_cnt = nullptr;
-    a.point_sums = ctx->point_sums.p; a.tile_order = ctx->tile_order.p;
+    a.point_sums = ctx->point_sums.p; a.tile_order = ctx->tile_order.p; a.tiles_bo = ctx->tiles_bo.p;
     return a;
 }
 
@@ -536,6 +536,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             for (size_t r = 0; r < lists[x].size(); r++) order[r * N_XCD + x] = lists[x][r];
         c->n_order_blocks = (uint32_t)(rounds * N_XCD);
         CREATE_CHECK(c->tile_order.upload(order, s));
+        {
+            std::vector<Tile> bo(order.size(), Tile{});
+            for (size_t b = 0; b < order.size(); b++) if (order[b] != 0xFFFFFFFFu) bo[b] = lay.tiles[order[b]];
+            CREATE_CHECK(c->tiles_bo.upload(bo, s));
+            CREATE_CHECK(hipStreamSynchronize(s));
+        }
         CREATE_CHECK(hipStreamSynchronize(s));
         // static + dynamic LDS of the fused block must stay under the 64 KB a block gets without asking for more
         uint32_t widest = 0;

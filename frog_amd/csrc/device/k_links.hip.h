@@ -68,6 +68,8 @@ struct SweepArgs {
     float4 *group_sums;         // [N_XCD][own points]  (deformable, one block per (4 tiles, group))
     float4 *point_sums;         // [P]  (deformable, FUSED: one block per tile adds its 8 group sums itself)
     const uint32_t *tile_order; // FUSED: block -> tile (0xFFFFFFFF: no tile), dealt so that block % 8 = the tile's octant of its image
+    const Tile *tiles_bo;       // FUSED: the same tiles in BLOCK order (a zero tile where there is none): fetched side by side with
+                                // tile_order instead of behind it
     uint32_t own_pt_begin, own_points;
     uint32_t sub;               // sub-pass of this launch
     uint32_t n_groups;
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     const bool live = t < a.n_tiles;
 
     uint32_t pt_begin = 0, pt_count = 0, rec_lo = 0, rec_n = 0, image = 0;
-    if (live) {
-        const Tile &tl = a.tiles[t];
+    if (FUSED || live) {
+        const Tile &tl = FUSED ? a.tiles_bo[blockIdx.x] : a.tiles[t];
         pt_begin = tl.pt_begin; pt_count = tl.pt_count; image = tl.image;
         rec_lo = tl.rec_begin + tl.group_off[grp];
         rec_n = tl.group_cnt[grp];
@@ -284,6 +286,21 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
             if (k < OWNER_WORDS) own[k] = 0xFFFFFFFFu;
         }
     }
+    // The first chunks of the record stream are asked for HERE, before the own points and the group's tables are staged: they
+    // come from HBM (the longest latency of the prologue) and need nothing but the range's offset.  A block lives ~25 us and
+    // used to spend its first ~5 in a chain tile -> staging -> barrier -> records -> gathers (measured: 45 % of the sweep's
+    // time does not scale with the links walked; it is per block).
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+    using Rec = std::conditional_t<WIDE, unsigned long long, unsigned int>;
+    using Chunk = std::conditional_t<WIDE, v2u64, v2u32>;          // the lane's records of two steps
+    const Chunk *rec2 = reinterpret_cast<const Chunk *>(listed ? a.act_recs : a.recs);
+    const uint32_t rec2_lo = rec_lo / 2u + lane;
+    auto chunk_at = [&](uint32_t c) { return __builtin_nontemporal_load(rec2 + min(rec2_lo + c * (REC_CHUNK / 2), a.rec2_last)); };
+    Chunk cq_first[CHUNK_AHEAD];
+    #pragma unroll
+    for (int k = 0; k < CHUNK_AHEAD; k++) cq_first[k] = chunk_at(k);
+
     float *px = own_xyz + (FUSED ? 0 : wave * TILE_POINTS);
     constexpr int PLANE = OWN_TILES * TILE_POINTS;
     if constexpr (FUSED) {
@@ -334,14 +351,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     //    compiler, which then also waits with vmcnt(0).  Records read past the end of this
     //    (tile, group) range are padding (null records: point 0) or a neighbour's: real
     //    records, whose partner index is a real point, fetched and then ignored.
-    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
-    typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-    using Rec = std::conditional_t<WIDE, unsigned long long, unsigned int>;
-    using Chunk = std::conditional_t<WIDE, v2u64, v2u32>;          // the lane's records of two steps
-    const Chunk *rec2 = reinterpret_cast<const Chunk *>(listed ? a.act_recs : a.recs);
-    const uint32_t rec2_lo = rec_lo / 2u + lane;
     const uint32_t img_bits = a.img_bits;
-    auto chunk_at = [&](uint32_t c) { return __builtin_nontemporal_load(rec2 + min(rec2_lo + c * (REC_CHUNK / 2), a.rec2_last)); };
     // record fields: own point in the tile, partner image (index into emd_s / img_base_s), partner point
     auto own_of = [&](Rec rq) { return (uint32_t)rq & 0xFFu; };
     auto img_of = [&](Rec rq) {
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     Chunk cq[CHUNK_RING];
     P3 pbq[PT_RING];
     #pragma unroll
-    for (int k = 0; k < CHUNK_RING; k++) cq[k] = (k < CHUNK_AHEAD) ? chunk_at(k) : Chunk{ 0, 0 };
+    for (int k = 0; k < CHUNK_RING; k++) cq[k] = (k < CHUNK_AHEAD) ? cq_first[k < CHUNK_AHEAD ? k : 0] : Chunk{ 0, 0 };
     #pragma unroll
     for (int k = 0; k < PT_RING; k++) pbq[k] = (k < PT_AHEAD) ? gather((k & 1) ? cq[k / 2].y : cq[k / 2].x) : P3{ 0.f, 0.f, 0.f };
 
