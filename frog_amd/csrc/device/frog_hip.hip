@@ -356,6 +356,13 @@ void frog_destroy(frog_ctx *ctx)
     if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+#ifdef FROG_SWEEP_TRACE
+    if (const char *path = getenv("FROG_SWEEP_TRACE_FILE")) {
+        std::vector<unsigned long long> h(8 * 8 * 16384);
+        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_sweep_trace), h.size() * 8);
+        if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+    }
+#endif
 #ifdef FROG_SCATTER_TRACE
     if (const char *path = getenv("FROG_SCATTER_TRACE_FILE")) {
         std::vector<unsigned long long> h(4 * 65536);

@@ -198,6 +198,15 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // BUILD (deformable sweep, narrow records): while walking EVERY record of its range the wavefront also writes the culling
 // list for the coordinates it reads -- what cull_build_kernel does in a pass of its own (0.6 ms for 1e8 records: a record,
 // two coordinates and a distance per half-link, all of which this kernel has in hand anyway).
+#ifdef FROG_SWEEP_TRACE
+// per (block, wavefront) of the last fused steady-state launch: wall_clock64 at kernel entry, tile known, staging barrier passed,
+// first step done, walk done, final barrier passed, end; records walked (scripts/microbench/sweep_trace_an.py)
+__device__ unsigned long long g_sweep_trace[8 * 8 * 16384];
+#define FROG_TR(slot) do { if constexpr (FUSED && !BUILD) { if (lane == 0 && blockIdx.x < 16384) g_sweep_trace[((size_t)blockIdx.x * 8 + wave) * 8 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define FROG_TR(slot) do { } while (0)
+#endif
+
 // FUSED (deformable sweep, one launch per pass): a block is ONE tile and all 8 partner groups, wavefront w = group w.  The
 // eight per-group sums of a point are then in one block's LDS when the walk ends: they are added there, in group order --
 // the same additions in the same order as combine_groups_kernel / the scatter's point phase, i.e. the same bits -- and ONE
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     // the partner group sub*8 + xcd it reads, so during a launch an XCD's L2 only has to hold
     // 1/n_groups of the coordinate table.  Later sub-passes continue the per-XCD partial sums.
     // FUSED: block -> one tile (tile_order), wavefront -> partner group.
+    FROG_TR(0);
     const uint32_t xcd = FUSED ? (uint32_t)wave : blockIdx.x % N_XCD;
     const uint32_t grp = FUSED ? (uint32_t)wave : a.sub * N_XCD + xcd;
     const uint32_t t = FUSED ? a.tile_order[blockIdx.x] : (blockIdx.x / N_XCD) * 4 + wave;
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     const Chunk *rec2 = reinterpret_cast<const Chunk *>(listed ? a.act_recs : a.recs);
     const uint32_t rec2_lo = rec_lo / 2u + lane;
     auto chunk_at = [&](uint32_t c) { return __builtin_nontemporal_load(rec2 + min(rec2_lo + c * (REC_CHUNK / 2), a.rec2_last)); };
+    FROG_TR(1);
     Chunk cq_first[CHUNK_AHEAD];
     #pragma unroll
     for (int k = 0; k < CHUNK_AHEAD; k++) cq_first[k] = chunk_at(k);
@@ -327,6 +338,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
         for (int k = lane; k < TILE_POINTS; k += 64) last_step[k] = 0xFFFFFFFFu;
     }
     __syncthreads();
+    FROG_TR(2);
     const float cutA = BUILD ? a.cut_list[image] : 0.f;
     uint32_t built = 0;                 // BUILD: records listed so far
     bool dup = false;                   //        some step of the list holds one point twice
@@ -474,11 +486,15 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
                     pbq[(j + PT_AHEAD) % PT_RING] = gather(((j + PT_AHEAD) & 1) ? ahead.y : ahead.x);
                 }
                 if (BUILD || r < rec_n) step((j & 1) ? cq[j / 2].y : cq[j / 2].x, pbq[j % PT_RING], elect_c, r < rec_n);
+#ifdef FROG_SWEEP_TRACE
+                if (base == 0 && j == 0) FROG_TR(3);
+#endif
             }
         }
     };
     if (MODE != SWEEP_DEFORMABLE || elect) walk(std::true_type{});
     else walk(std::false_type{});
+    FROG_TR(4);
 
     if constexpr (BUILD) {
         // Null records behind the list's last record, as far as a listed sweep's run-ahead gathers reach (its walk goes in
@@ -510,6 +526,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
             if (lane == 0 && live) a.build_cnt[(size_t)t * a.n_groups + grp] = built | (any_dup ? CULL_DUP_BIT : 0u);
         }
         __syncthreads();
+        FROG_TR(5);
         typedef float v4f __attribute__((ext_vector_type(4)));
         if constexpr (FUSED) {
             // the point's sums = its eight group sums added in group order (combine_groups_kernel's order: same bits)
@@ -522,6 +539,9 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
                 }
                 a.point_sums[pt_begin + k] = v;
             }
+#ifdef FROG_SWEEP_TRACE
+            if constexpr (!BUILD) { if (lane == 0 && blockIdx.x < 16384) { g_sweep_trace[((size_t)blockIdx.x * 8 + wave) * 8 + 6] = wall_clock64(); g_sweep_trace[((size_t)blockIdx.x * 8 + wave) * 8 + 7] = rec_n; } }
+#endif
         } else {
             for (uint32_t k = lane; k < pt_count; k += 64) {                 // written once, read once: non-temporal
                 const float4 v = my[k];
