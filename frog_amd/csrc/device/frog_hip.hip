@@ -534,9 +534,15 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         // Within an XCD's list the tiles go slice by slice, image by image inside a slice (a slice = one of FROG_TILE_SLICES
         // equal parts of the eighth, along the curve): the blocks resident on an XCD at any time then gather from 1/16 of every
         // partner image instead of 1/8 (1.5 MB of coordinates instead of 3 MB beside the record stream in a 4 MB L2).
-        // Measured on cfg 3: 0.2486 -> 0.2446 ms with two slices; 3, 4 and 8 slices the same as two.
+        // Measured on cfg 3: 0.2486 -> 0.2446 ms with two slices; 3, 4 and 8 slices the same as two (0.2451-0.2460).  A context
+        // that owns an eighth of that group (12-13 images, 118 tiles per list: little more than one round of resident blocks)
+        // keeps gaining: 0.0702 / 0.0663 / 0.0651 / 0.0641 ms with 1 / 2 / 4 / 8 slices -- hence eight below 64 owned images.
         std::vector<uint32_t> lists[N_XCD];
-        const int n_slices = [] { const char *e = getenv("FROG_TILE_SLICES"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+        const int n_slices = [&] {
+            const char *e = getenv("FROG_TILE_SLICES");
+            const int v = e ? atoi(e) : (c->ie - c->ib >= 64u ? 2 : 8);
+            return v < 1 ? 1 : v > 64 ? 64 : v;
+        }();
         for (int sl = 0; sl < n_slices; sl++)
             for (uint32_t i = c->ib; i < c->ie; i++) {
                 const uint32_t tb = lay.img_tile_ptr[i], nt = lay.img_tile_ptr[i + 1] - tb;
