@@ -328,6 +328,10 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> act_recs32;        // listed records (narrow form), or ...
     frog::DevBuf<frog::LinkRec> act_recs;     // ... wide form; same offsets as recs32 / recs
     frog::DevBuf<uint32_t> act_cnt;           // [n_tiles][n_groups]
+    bool pos_b_stale = true;                  // pos was written (`apply`) since pos_b was gathered
+    frog::DevBuf<float4> pos_b;               // pos in the order of perm (brick, cell, index): written by every lattice set-up,
+                                              // read (coalesced) by the scatter and the B-spline transforms of that lattice --
+                                              // pos itself does not change while a lattice stands (only `apply` writes it)
     frog::DevBuf<frog::P3> pos2_snap;         // xyz2 of every point when the list was built
     frog::DevBuf<float> cut_now, cut_list;    // [nI] certified cutoff of the current mixtures / list cutoff at build time
     frog::DevBuf<uint32_t> disp_part;         // per-block maxima of the points' displacement since the build (f32 bits)

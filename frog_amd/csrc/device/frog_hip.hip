@@ -263,6 +263,9 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
         std::swap(ctx->perm.p, ctx->perm_tmp.p);
         std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
         std::swap(ctx->perm.n, ctx->perm_tmp.n);
+        gather_positions_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->perm.p, nPts, ctx->pos_b.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        ctx->pos_b_stale = false;
     }
     // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
     // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
@@ -300,6 +303,20 @@ static int join_setup(frog_ctx *ctx)
     if (!ctx->setup_pending) return FROG_OK;
     FROG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->setup_join, 0));
     ctx->setup_pending = false;
+    return FROG_OK;
+}
+
+// join_setup + the positions in perm's order brought up to date (an `apply` that no set-up followed: the C ABI allows it)
+static int join_setup_positions(frog_ctx *ctx)
+{
+    const int rc = join_setup(ctx);
+    if (rc) return rc;
+    const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
+    if (ctx->pos_b_stale && nPts && ctx->pos_b.p && ctx->perm.p) {
+        gather_positions_kernel<<<div_up(nPts, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->perm.p, nPts, ctx->pos_b.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        ctx->pos_b_stale = false;
+    }
     return FROG_OK;
 }
 
@@ -816,7 +833,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         if (out != ctx->pos2.p) ctx->disp_spec = false;
         transform_zero_lattice_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->own_pt_begin, ctx->own_pt_end, apply);
     } else {
-        { const int rc = join_setup(ctx); if (rc) return rc; }
+        { const int rc = join_setup_positions(ctx); if (rc) return rc; }
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
         // of the outlier-culling list: the check before the next sweep then has nothing left to compute
         // (a context that owns a sub-range measures its own rows; the other ranks' are measured when they arrive:
@@ -835,14 +852,14 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
             const GeomDev gd = to_dev(ctx->geom);
             const size_t E = (size_t)gd.brick + 3, lds = E * E * E * sizeof(float4);
             transform_bspline_tile_kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
-                ctx->pos.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
+                ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                 after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
                 ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
-            transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p,
+            transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
@@ -856,6 +873,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
     }
     FROG_HIP_CHECK(hipGetLastError());
+    if (apply) ctx->pos_b_stale = true;         // pos has new values: pos_b (its copy in perm's order) is out of date
     return FROG_OK;
 }
 
@@ -1211,6 +1229,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->scan_sums.alloc(div_up(n_keys, SCAN_BLOCK_ITEMS) + 2, (div_up(n_keys, SCAN_BLOCK_ITEMS) + 2) * reserve));
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     if (ctx->perm_tmp.n != nPts) FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
+    if (ctx->pos_b.n != nPts) FROG_HIP_CHECK(ctx->pos_b.alloc(nPts));
     if (ctx->perm_key.n != nPts) FROG_HIP_CHECK(ctx->perm_key.alloc(nPts));
     if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
     FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
@@ -1450,7 +1469,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
                                            ctx->build_in_sweep);
     }
     FROG_HIP_CHECK(hipGetLastError());
-    { const int rc = join_setup(ctx); if (rc) return rc; }     // the scatter is the first kernel that needs the new lattice's sort
+    { const int rc = join_setup_positions(ctx); if (rc) return rc; }     // the scatter is the first kernel that needs the new lattice's sort
     {
         Span span(ctx, FROG_K_COMBINE);
         // the per-point sums are only materialised when something other than the scatter reads them (landmark
@@ -1488,7 +1507,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             en.stray_next = ctx->stray.p + (ctx->stray_parity ^ 1u);
         }
         scatter_kernel<<<ctx->n_scatter_blocks + (fused_energy ? ENERGY_BLOCKS : 0), 64, tile_bytes, s>>>(
-            ctx->pos.p, ctx->point_sums.p, ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
+            ctx->pos_b.p, ctx->point_sums.p, ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
             ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
             reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p), ctx->brick_slot_ptr.p + (size_t)nO * gd.n_bricks,
             ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p + ctx->stray_parity, gd, en);

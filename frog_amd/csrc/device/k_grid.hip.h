@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 // the host knows whether the diffeomorphism guard accepted it (imageGroup.cxx:434-439); it reads the proposal lattice
 // when the device-side oversize count says "accepted" and the standing coefficients otherwise.  The host then swaps
 // the two buffers instead of copying one onto the other (the commit of :441-468 is a pointer exchange).
-__global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+__global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
                                                                 const P3 *snap, uint32_t *disp_part,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, P3 
     const bool valid = s_raw < n_points;
     const uint32_t s = valid ? s_raw : n_points - 1;
     const uint32_t p = perm[s];
-    const float4 v = pos[p];
+    const float4 v = pos_b[s];                  // = pos[p], as the lattice's set-up gathered it (coalesced here)
     const float4 *cf = coeff + (size_t)(__float_as_int(v.w) - (int)image_begin) * g.n_cp;
     const float in[3] = { v.x, v.y, v.z };
     double F[3][4];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void transform_zero_lattice_kernel(float4 *pos
 // to f32 first: they differ for points within one f32 ulp of a cell face) may need taps outside the tile and reads them
 // from memory.  ScatterBlock is declared further down, with the table's construction.
 struct ScatterBlock;
-__global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+__global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                                                     const uint32_t *perm, const ScatterBlock *blocks,
                                                                     const uint32_t *n_blocks, const GeomDev g, int apply,
                                                                     const P3 *snap, uint32_t *disp_part,
@@ -535,6 +535,13 @@ __global__ __launch_bounds__(256) void cell_order_kernel(const uint32_t *key_ptr
     perm_out[b + rank] = v;
 }
 
+// pos in perm's order (ctx.h pos_b): once per lattice set-up
+__global__ __launch_bounds__(256) void gather_positions_kernel(const float4 *pos, const uint32_t *perm, uint32_t n, float4 *pos_b)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) pos_b[s] = pos[perm[s]];
+}
+
 // ---- the scatter's block table, built on the device (no host round trip inside a lattice set-up) ----------
 // A scatter block = (image, brick, run of <= SCATTER_CHUNK of the brick's points).  Brick k (image-major) holds the
 // points perm[ptr[k * keys_per_brick] .. ptr[(k + 1) * keys_per_brick]); it gets ceil(count / SCATTER_CHUNK) blocks,
@@ -621,7 +628,7 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
+void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                    const uint32_t *perm, const ScatterBlock *blocks,
                                    const uint32_t *n_blocks, const GeomDev g, int apply,
                                    const P3 *snap, uint32_t *disp_part,
@@ -643,11 +650,13 @@ void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     const ScatterBlock blk = blocks[blockIdx.x];
     // the points' indices and positions run one batch ahead of the arithmetic (one wavefront per block: nothing else hides
-    // the two memory round trips perm -> position); loads unconditional, from an index clamped into the block
+    // the memory round trip); loads unconditional, from an index clamped into the block.  The positions come from pos_b, the
+    // copy in perm's order the set-up made: coalesced and independent of the index load (they were 16-byte gathers behind
+    // it: 200 MB fetched per launch for 32 MB of positions)
     const uint32_t s_last = blk.end - 1u;
     uint32_t p_cur = perm[min(blk.begin + lane, s_last)];
     uint32_t p_nxt = perm[min(blk.begin + 64 + lane, s_last)];
-    float4 v_cur = pos[p_cur];
+    float4 v_cur = pos_b[min(blk.begin + lane, s_last)];
     const int E = g.brick + 3, n_tile = E * E * E;
     const uint32_t img = blk.key / g.n_bricks;
     uint32_t bidx = blk.key - img * g.n_bricks;
@@ -669,7 +678,7 @@ void transform_bspline_tile_kernel(float4 *pos, P3 *pos2, const float4 *coeff,
     uint32_t dmax = 0;
     for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
         const uint32_t p_far = perm[min(batch + 128 + lane, s_last)];
-        const float4 v_nxt = pos[p_nxt];
+        const float4 v_nxt = pos_b[min(batch + 64 + lane, s_last)];
         const uint32_t p = p_cur;
         const float4 v = v_cur;
         p_cur = p_nxt; p_nxt = p_far; v_cur = v_nxt;
@@ -837,7 +846,7 @@ struct ScatterScratch {
 };
 static_assert(offsetof(ScatterScratch, sm) % 16 == 0, "ScatterScratch::sm is read with ds_read_b128");
 
-__global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const float4 *point_sums,
+__global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const float4 *point_sums,
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
                                                      const uint32_t *perm, const ScatterBlock *blocks, const uint32_t *n_blocks,
                                                      float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g,
@@ -872,7 +881,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
     // unconditional, from an index clamped into the block (see k_links.hip.h on loads under lane-dependent branches).
     const uint32_t s_last = blk.end - 1u;
     const auto load_index = [&](uint32_t s) -> uint32_t { return perm[min(s, s_last)]; };
-    const auto load_point = [&](uint32_t p, float4 (&part)[N_XCD], float4 &v) __attribute__((always_inline)) {
+    const auto load_point = [&](uint32_t p, uint32_t s, float4 (&part)[N_XCD], float4 &v) __attribute__((always_inline)) {
         if (group_sums) {                        // kernel-uniform
             const uint32_t li = p - own_pt_begin;
             #pragma unroll
@@ -880,14 +889,14 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
         } else {
             part[0] = point_sums[p];
         }
-        v = pos[p];
+        v = pos_b[min(s, s_last)];                // the position, in perm's order (the set-up's copy: coalesced)
     };
     uint32_t p_cur = load_index(blk.begin + lane);
     uint32_t p_nxt = load_index(blk.begin + 64 + lane);
     float4 part_cur[N_XCD], v_cur;
     #pragma unroll
     for (int q = 1; q < N_XCD; q++) part_cur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    load_point(p_cur, part_cur, v_cur);
+    load_point(p_cur, blk.begin + lane, part_cur, v_cur);
 
     for (int k = lane; k < n_tile; k += 64) tile[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -912,7 +921,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos, const fl
         float4 part_nxt[N_XCD], v_nxt;
         #pragma unroll
         for (int q = 1; q < N_XCD; q++) part_nxt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        load_point(p_nxt, part_nxt, v_nxt);
+        load_point(p_nxt, batch + 64 + lane, part_nxt, v_nxt);
 #ifdef FROG_SCATTER_TRACE
         const unsigned long long tb0 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the current batch's loads are the oldest
