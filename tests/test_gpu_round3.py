@@ -249,6 +249,55 @@ def test_fused_sweep_equals_the_per_group_sweep_bit_for_bit(monkeypatch, wide):
         assert np.array_equal(x0, x1)
 
 
+def test_block_order_of_the_fused_sweep_does_not_change_a_bit(monkeypatch):
+    """FROG_TILE_SLICES only decides WHEN a tile is walked (frog_hip.hip: the fused launch's blocks go slice by slice of
+    each image's eighth): image by image, two slices and eight slices give identical energies, sums, lattices, coordinates."""
+    pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+    monkeypatch.setenv("FROG_SWEEP_FUSED", "1")
+    runs = []
+    for slices in ("1", "2", "8"):
+        monkeypatch.setenv("FROG_TILE_SLICES", slices)
+        runs.append(_short_run(pairs))
+    for e, s_, g_, x in runs[1:]:
+        assert np.array_equal(runs[0][0], e) and np.array_equal(runs[0][3], x)
+        for a, b in zip(runs[0][1], s_):
+            assert np.array_equal(a, b)
+        for a, b in zip(runs[0][2], g_):
+            assert np.array_equal(a, b)
+
+
+def test_apply_in_the_middle_of_a_lattice_against_the_oracle(small_pairs):
+    """transformPoints(apply) rewrites the positions a lattice acts on; the C ABI allows going on with the SAME lattice
+    afterwards (the reference's run() never does).  The scatter and the B-spline transforms read the positions from a copy
+    in the lattice's brick order (ctx.h pos_b) that is gathered at set-up: an apply must mark it stale.  Same sequence on
+    both sides, coordinates compared."""
+    g = ImageGroup(small_pairs)
+    ref = OracleGroup(small_pairs.model, _abi.FrogOptions.default())
+    ref.setup_stats()
+    g.setupLinearTransforms(); ref.linear_init()
+    g.transformPoints(); ref.transform_points()
+    for it in range(10):
+        if it % 10 == 0:
+            g.updateStats(); ref.update_stats()
+        g.updateLinearTransforms(); ref.linear_step()
+        g.transformPoints(); ref.transform_points()
+    g.transformPoints(True); ref.transform_points(True)
+    g.setupDeformableTransforms(1); ref.deformable_setup(1, _abi.FrogGridInfo())
+    g.transformPoints(); ref.transform_points()
+    g.updateStats(); ref.update_stats()
+    for phase in range(2):
+        for _ in range(3):
+            assert g.updateDeformableTransforms(0.02) >= 0
+            ref.deformable_step(0.02)
+            g.transformPoints(); ref.transform_points()
+        if phase == 0:
+            g.transformPoints(True); ref.transform_points(True)       # the lattice stands, the positions under it moved
+            g.transformPoints(); ref.transform_points()
+    x, rx = g.points()[1], ref.xyz2()
+    scale = float(np.max(np.abs(rx)))
+    assert float(np.max(np.abs(x.astype(np.float64) - rx))) <= 1e-5 * scale
+
+
 def _linear_run(pairs, n_it, **opt):
     g = ImageGroup(pairs, **opt)
     g.setupLinearTransforms(); g.transformPoints()
