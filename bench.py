@@ -143,9 +143,14 @@ def main():
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--pairs-per-block", type=float, default=None)
     ap.add_argument("--shard-of", type=int, nargs=2, metavar=("R", "N"), default=None,
-                    help="single-GPU proxy of rank R of an N-GPU run: this process owns shard R of N, the other ranks' "
-                         "coordinates stay where the set-up left them, no collective is issued; prints per-phase kernel "
+                    help="single-GPU proxy of rank R of an N-GPU run: this process owns shard R of N, no collective is "
+                         "issued, the other ranks' images stand still (where, see --proxy-partners); prints per-phase kernel "
                          "times of that rank's share (not a metric line)")
+    ap.add_argument("--proxy-partners", choices=("registered", "static"), default="registered",
+                    help="--shard-of: the other ranks' coordinates and mixtures are those a full single-context run of the "
+                         "default schedule ends with (registered: every image in the common frame, as a real rank sees its "
+                         "partners -- partner points lie where the own points are, the sweeps' gathers are local) or stay "
+                         "where the set-up left them (static: unregistered partners, mixtures of other images zero)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
@@ -201,6 +206,19 @@ def main():
     else:
         shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
     opts = _abi.FrogOptions.default()
+    partners = None
+    if args.shard_of and args.proxy_partners == "registered":
+        # what the other ranks would hand over: the whole group registered by one context (default schedule), its final
+        # coordinates and mixtures (both engines number the points alike: the numbering depends on the model only)
+        full = HipEngine(pairs, opts, local_rank, (0, pairs.n_images))
+        gfull = ShardedImageGroup(full, [(0, pairs.n_images)], pairs.point_offset, 0, 1)
+        gfull.deformableLevels = levels
+        gfull.run()
+        torch.cuda.synchronize()
+        partners = (full.points()[1], full.em.clone())
+        torch.cuda.synchronize()
+        del gfull
+        full.close()
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0
@@ -227,6 +245,14 @@ def main():
     # ---- warm-up: linear set-up + W linear iterations --------------------------------
     grp.setupLinearTransforms()
     grp.transformPoints()
+    if partners is not None:
+        own_b, own_e = shards[rank]
+        pb, pe = int(pairs.point_offset[own_b]), int(pairs.point_offset[own_e])
+        mixed = engine.points()[1]              # the model's point order on both sides
+        mixed[:pb] = partners[0][:pb]
+        mixed[pe:] = partners[0][pe:]
+        engine.set_points2(mixed)
+        grp.proxy_em = partners[1]              # stands in for the all-reduce of the mixture table at every refresh
     it = 0
     for _ in range(args.warmup):
         if it % grp.statIntervalUpdate == 0:
@@ -408,7 +434,9 @@ def main():
         }
         if args.shard_of:
             out["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
-                            f"other ranks' coordinates static; `value` is NOT the metric")
+                            + ("other ranks' coordinates and mixtures: those a full run of the default schedule ends with, standing still"
+                               if partners is not None else "other ranks' coordinates static where the set-up left them, their mixtures zero")
+                            + "; `value` is NOT the metric")
             out["proxy_ms_per_iteration"] = {ph: {n: v["ms"] / max(1, (n_lin if ph == "linear" else per_level[int(ph[5:])]))
                                                    for n, v in ks.items()} for ph, ks in phase_k.items()}
         if grp.comm_ms:

@@ -203,6 +203,11 @@ class HipEngine:
                                         xyz2.ctypes.data_as(_abi.c_float_p)), "frog_get_points")
         return xyz, xyz2
 
+    def set_points2(self, xyz2):
+        """xyz2 of every point (the model's order), e.g. another context's replica."""
+        a = np.ascontiguousarray(xyz2, np.float32)
+        check(self._lib.frog_set_points2(self._ctx, a.ctypes.data_as(_abi.c_float_p)), "frog_set_points2")
+
     def cull_stats(self):
         """(lists built, half-links in the last list, half-links owned): frog_cull_stats."""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -374,6 +379,7 @@ class ShardedImageGroup:
         self.shards = list(shards)
         self.po = np.asarray(point_offset, dtype=np.int64)
         self.rank, self.world_size, self.group = rank, world_size, group
+        self.proxy_em = None
         self.linearIterations = 50
         self.deformableLevels = 3
         self.deformableIterations = 200
@@ -475,6 +481,12 @@ class ShardedImageGroup:
 
     def updateStats(self):
         self.engine.update_stats_local()
+        if self.proxy_em is not None and not self.multi:
+            # single-process proxy of one rank (bench.py --shard-of): the other ranks' rows of the mixture table, which the
+            # all-reduce below would bring, from a table handed in
+            b, e = self.engine.image_begin, self.engine.image_end       # (the engine runs on torch's current stream: ordered)
+            self.engine.em[:b] = self.proxy_em[:b]
+            self.engine.em[e:] = self.proxy_em[e:]
         if self.multi and self.native:
             self._collective("all_reduce_em", lambda: self.native.all_reduce(_abi.FROG_BUF_EM))
         elif self.multi:
