@@ -314,6 +314,14 @@ struct frog_ctx {
     float pending_alpha = 0;
     int phase = 0;                            // 0 idle, 1 after phase_a, 2 after phase_b
 
+    // FROG_REFERENCE_ORDER=1 (test hook, k_reforder.hip.h): every solver loop in the reference's own order and arithmetic --
+    // no culling list, no fast weight, no re-associated sum; results are bit-comparable with the tests' CPU restatement of the reference
+    bool ref_order = false;
+    frog::DevBuf<uint32_t> ref_own;           // [L_own] own point (internal numbering) of every half-link, reference order
+    frog::DevBuf<float> ref_w, ref_d;         // [L_own] weight and distance of every half-link (linear step)
+    frog::DevBuf<uint64_t> ref_img_link;      // [nOwned + 1] first half-link of every owned image (relative, reference order)
+    frog::DevBuf<double> ref_pt_energy;       // [ownP][2] energy terms of every owned point (deformable step)
+
     // certified outlier culling of the deformable sweep (k_cull.hip.h)
     bool exact_weights = false;               // FROG_WEIGHT_EXACT=1 (test hook): inlier_probability_exact for every weight
     bool cull_enabled = true;                 // FROG_CULL=0 turns it off (every sweep walks all records)

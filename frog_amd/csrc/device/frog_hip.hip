@@ -10,6 +10,7 @@
 #include "k_grid.hip.h"
 #include "k_cull.hip.h"
 #include "k_ransac.hip.h"
+#include "k_reforder.hip.h"
 #include "similarity.h"
 
 #include <atomic>
@@ -356,6 +357,84 @@ static int produce_selection(frog_ctx *c)
     return FROG_OK;
 }
 
+// ---- FROG_REFERENCE_ORDER=1 (k_reforder.hip.h): launch sequences ---------------------------------------------
+static int ref_alloc(frog_ctx *ctx)
+{
+    if (ctx->ref_img_link.p) return FROG_OK;
+    const uint32_t nO = ctx->n_owned();
+    std::vector<uint64_t> il(nO + 1);
+    for (uint32_t i = 0; i <= nO; i++) il[i] = ctx->img_link_begin[ctx->ib + i];
+    FROG_HIP_CHECK(ctx->ref_img_link.upload(il, ctx->stream));
+    FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    FROG_HIP_CHECK(ctx->ref_own.alloc(std::max<size_t>(1, ctx->L_own)));
+    FROG_HIP_CHECK(ctx->ref_w.alloc(std::max<size_t>(1, ctx->L_own)));
+    FROG_HIP_CHECK(ctx->ref_d.alloc(std::max<size_t>(1, ctx->L_own)));
+    FROG_HIP_CHECK(ctx->ref_pt_energy.alloc(2 * (size_t)std::max(1u, ctx->own_pt_end - ctx->own_pt_begin)));
+    return FROG_OK;
+}
+
+// updateLinearTransforms (imageGroup.cxx:1063-1149) in the reference's order
+static int ref_linear_step(frog_ctx *ctx)
+{
+    { const int rc = ref_alloc(ctx); if (rc) return rc; }
+    hipStream_t s = ctx->stream;
+    const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
+    if (nRows)
+        ref_link_terms_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
+                                                                 ctx->pos2.p, ctx->em.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p);
+    ref_linear_chain_kernel<<<nO, 64, 0, s>>>(ctx->ref_img_link.p, ctx->ref_link.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p, ctx->pos2.p,
+                                              ctx->ib, ctx->mat.p, ctx->opt.linear_alpha, ctx->opt.use_scale, ctx->img_energy.p);
+    ref_energy_total_kernel<<<1, 1, 0, s>>>(ctx->img_energy.p, nO, ctx->energy.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+// per-point sums of the deformable step / the error maps (imageGroup.cxx:252-299, :493-533) in the reference's order
+static int ref_point_sums(frog_ctx *ctx, bool with_energy)
+{
+    { const int rc = ref_alloc(ctx); if (rc) return rc; }
+    hipStream_t s = ctx->stream;
+    const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
+    if (nRows)
+        ref_point_sums_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
+                                                                 ctx->pos2.p, ctx->em.p, ctx->opt.inlier_threshold, ctx->point_sums.p,
+                                                                 with_energy ? ctx->ref_pt_energy.p : nullptr);
+    ctx->point_sums_stale = false;
+    if (with_energy) {
+        ref_image_energy_kernel<<<nO, 64, 0, s>>>(ctx->ref_pt_energy.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, ctx->img_energy.p);
+        ref_energy_total_kernel<<<1, 1, 0, s>>>(ctx->img_energy.p, nO, ctx->energy.p);
+    }
+    if (ctx->n_hard) {                                          // landmark constraints, imageGroup.cxx:280-295, :520-533
+        hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
+                                                                ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2,
+                                                                with_energy ? ctx->hl_partial.p : nullptr);
+        if (with_energy) hard_energy_kernel<<<1, 1, 0, s>>>(ctx->hl_partial.p, ctx->n_hard, ctx->energy.p);
+    }
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+// phase A of updateDeformableTransforms (imageGroup.cxx:239-377 and the proposal sums of :411-415) in the reference's order
+static int ref_deformable_phase_a(frog_ctx *ctx, float alpha)
+{
+    hipStream_t s = ctx->stream;
+    const GeomDev gd = to_dev(ctx->geom);
+    const uint32_t nO = ctx->n_owned();
+    int rc = ref_point_sums(ctx, true);
+    if (rc) return rc;
+    rc = join_setup(ctx);                       // the set-up's stream zeroes and sorts: wait before gradf is touched
+    if (rc) return rc;
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, (size_t)nO * gd.n_cp * sizeof(float4), s));       // Fill(0), :249
+    ref_scatter_kernel<<<nO, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
+                                         ctx->gradf.p);
+    ref_cp_step_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->gradf.p, ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    ctx->centered_in_a = false;                 // phase B subtracts the mean (cp_center_kernel: :417-428 as written)
+    ctx->pending_alpha = alpha;
+    ctx->phase = 1;
+    return FROG_OK;
+}
+
 extern "C" {
 
 int frog_device_count(void)
@@ -671,6 +750,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!(c->cull_enabled && c->opt.inlier_threshold >= 1e-3f) && !c->fused_forced) c->fused_sweep = false;
     // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
     if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
+    // test hook: the solver loops in the reference's own order and arithmetic (k_reforder.hip.h); no list, no fast weight
+    if (const char *e = getenv("FROG_REFERENCE_ORDER")) c->ref_order = atoi(e) != 0;
+    if (c->ref_order) { c->cull_enabled = false; c->exact_weights = true; c->fused_sweep = false; }
     if (const char *e = getenv("FROG_CULL_LINEAR")) c->cull_linear = atoi(e) != 0;
     if (const char *e = getenv("FROG_CULL_SKIN_LINEAR")) {
         float a = 0, b = 0;
@@ -803,7 +885,17 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
     }
     FROG_HIP_CHECK(hipMemcpyAsync(ctx->mat.p, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // A linear stage may follow anything the C ABI allows before it (a deformable level, a speculative transform of the old
+    // matrices): nothing computed for the previous state may be published, and the list -- whatever criterion it was built
+    // for -- is rebuilt under the LINEAR stage's cutoffs before the first linear sweep walks it.
+    { const int rc = join_setup(ctx); if (rc) return rc; }
     ctx->deformable = false;
+    ctx->phase = 0;
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
+    ctx->disp_current = false; ctx->disp_spec = false; ctx->disp_others = false;
+    ctx->cull_need_build = true; ctx->cull_check_due = true;
+    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
+    FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
 
@@ -832,6 +924,13 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         ctx->disp_current = false;
         if (out != ctx->pos2.p) ctx->disp_spec = false;
         transform_zero_lattice_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->own_pt_begin, ctx->own_pt_end, apply);
+    } else if (ctx->ref_order) {
+        { const int rc = join_setup(ctx); if (rc) return rc; }
+        ctx->disp_current = false;
+        if (out != ctx->pos2.p) ctx->disp_spec = false;
+        ref_transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, out, ctx->coeff.p, ctx->own_pt_begin, ctx->own_pt_end,
+                                                                             ctx->ib, to_dev(ctx->geom), apply, after_step ? ctx->grad.p : nullptr,
+                                                                             ctx->energy.p, ctx->opt.guarantee_diffeomorphism, host_scalars, scalar_seq);
     } else {
         { const int rc = join_setup_positions(ctx); if (rc) return rc; }
         // a context that owns every moving point measures, in the same pass, how far the points are from the snapshot
@@ -1090,6 +1189,7 @@ int frog_linear_step_local(frog_ctx *ctx)
 {
     CTX_GUARD(ctx);
     if (ctx->deformable) return fail(FROG_E_STATE, "linear step after deformable set-up");
+    if (ctx->ref_order) { ctx->xyz2_fresh = false; return ref_linear_step(ctx); }
     hipStream_t s = ctx->stream;
     // half-links whose weight is exactly zero are left to a list, as the deformable stage's certain outliers are (k_cull.hip.h)
     bool culled = cull_active_linear(ctx);
@@ -1304,10 +1404,10 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         if (rc) return rc;
     }
 
-    if (!ctx->deformable && ctx->act_cnt.p) {
+    if (!ctx->deformable) {
         // end of the linear stage: its list (if any) is counted for frog_cull_stats_linear, and the deformable stage starts
         // with cutoffs of its own criterion and a list of its own
-        if (ctx->cull_lin_builds) {
+        if (ctx->cull_lin_builds && ctx->act_cnt.p) {
             FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
             cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
         }
@@ -1448,6 +1548,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
     CTX_GUARD(ctx);
     if (!ctx->deformable) return fail(FROG_E_STATE, "deformable step before frog_deformable_setup");
     ctx->xyz2_fresh = false; ctx->res_valid = false;
+    if (ctx->ref_order) return ref_deformable_phase_a(ctx, alpha);
     hipStream_t s = ctx->stream;
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned();
@@ -1826,12 +1927,17 @@ int frog_residual_sums(frog_ctx *ctx)
     if (ctx->phase != 0) return fail(FROG_E_STATE, "residual sums inside a deformable step");
     hipStream_t s = ctx->stream;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
-    for (uint32_t sub = 0; sub < ctx->n_sub; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
-    if (n && !sweep_fused_now(ctx, false)) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
-    ctx->point_sums_stale = false;
-    if (ctx->n_hard)                                            // :520-533
-        hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
-                                                                ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, nullptr);
+    if (ctx->ref_order) {
+        const int rc = ref_point_sums(ctx, false);
+        if (rc) return rc;
+    } else {
+        for (uint32_t sub = 0; sub < ctx->n_sub; sub++) launch_sweep<SWEEP_DEFORMABLE>(ctx, sub, s);
+        if (n && !sweep_fused_now(ctx, false)) combine_groups_kernel<<<div_up(n, 256), 256, 0, s>>>(ctx->group_sums.p, n, ctx->own_pt_begin, ctx->point_sums.p);
+        ctx->point_sums_stale = false;
+        if (ctx->n_hard)                                            // :520-533
+            hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
+                                                                    ctx->hl_partner.p, ctx->n_hard, ctx->hard_weight2, nullptr);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     // host copies of the owned rows (internal numbering): sums and rebased coordinates
     ctx->h_res_sums.resize(n);

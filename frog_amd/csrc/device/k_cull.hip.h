@@ -90,6 +90,9 @@ __device__ inline float cull_cutoff_linear_of(const EmDerived d)
 {
     const double s1 = -(double)d.s1;
     if (!(s1 > 0.0) || !(s1 < 1e30)) return __builtin_inff();          // no usable exponent: every link stays listed
+    // "x1 = +0 makes the weight +0" needs p = x1 / (x1 + x2 + 1e-10) with a positive, finite denominator: a mixture whose
+    // ratio is NaN or outside [0, 1] (kq1 or kq2 negative or not finite) can give 0 * inf = NaN there, and min(NaN, pB) = pB
+    if (!(d.kq1 >= 0.0f) || !(d.kq2 >= 0.0f) || !(d.kq1 < __builtin_inff()) || !(d.kq2 < __builtin_inff())) return __builtin_inff();
     const float c = (float)sqrt(160.0 / s1);
     return fmaxf(c * 1.00001f + 1e-6f, 0.2f);
 }

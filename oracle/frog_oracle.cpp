@@ -278,6 +278,8 @@ struct frogo_group {
     std::vector<Grid> grids;              // allTransforms[1..]
     std::vector<std::vector<float>> gradient;   // per image 4*G (image.gradient)
     std::vector<float> point_sums;        // 4*P, oracle-only: sDisp xyz + sWeight of the last step
+    bool keep_raw = false;                // oracle-only (frogo_keep_raw_gradient): copy the gradient image before the
+    std::vector<std::vector<float>> gradient_raw;   // control-point step overwrites it with the proposals (:346-375)
     // Point::hardLinks (landmark constraints, imageGroup.cxx:1210-1225): CSR over all points, partner = global point
     std::vector<uint64_t> hard_rowp;      // P + 1 (empty: none)
     std::vector<uint64_t> hard_partner;
@@ -615,6 +617,7 @@ void frogo_deformable_phase_a(frogo_group *g, const float alpha, double *gridsum
             }
         }
 
+        if (g->keep_raw) g->gradient_raw[image1].assign(gradient, gradient + 4 * G);
         // control-point step, :346-375 (writes the proposal into gradient[0..2])
         const float *coeffs = grid.coeffs[image1].data();
         for (size_t i = 0; i < G; i++) {
@@ -902,6 +905,21 @@ void frogo_get_point_sums(const frogo_group *g, float *out)
 {
     std::memcpy(out, g->point_sums.data(), g->point_sums.size() * sizeof(float));
 }
+// oracle-only: keep (and read back) the gradient image as the scatter left it, :301-338
+void frogo_keep_raw_gradient(frogo_group *g, int on)
+{
+    g->keep_raw = on != 0;
+    g->gradient_raw.resize(g->keep_raw ? g->nI : 0);
+}
+
+int frogo_get_gradient_raw(const frogo_group *g, uint32_t image, float *out, size_t cap)
+{
+    if (!g->keep_raw || image >= g->gradient_raw.size()) return -1;
+    size_t n = std::min(cap, g->gradient_raw[image].size());
+    std::memcpy(out, g->gradient_raw[image].data(), n * sizeof(float));
+    return (int)g->gradient_raw[image].size();
+}
+
 int frogo_get_gradient(const frogo_group *g, uint32_t image, float *out, size_t cap)
 {
     size_t n = std::min(cap, g->gradient[image].size());

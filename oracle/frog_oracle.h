@@ -105,6 +105,10 @@ void frogo_get_point_sums(const frogo_group *g, float *out4P);
 /* proposed coefficients after the control-point step and mean removal are not
  * kept; the gradient image before the step is: */
 int  frogo_get_gradient(const frogo_group *g, uint32_t image, float *out4G, size_t cap_floats);
+/* oracle-only: keep a copy of the gradient image as the scatter leaves it (imageGroup.cxx:301-338), before the
+ * control-point step overwrites its first three components with the proposals; -1 when not kept */
+void frogo_keep_raw_gradient(frogo_group *g, int on);
+int  frogo_get_gradient_raw(const frogo_group *g, uint32_t image, float *out4G, size_t cap_floats);
 
 /* ---- Stats restated (stats.h / stats.cxx), usable stand-alone ------------- */
 frogo_stats *frogo_stats_new(int max_size, int max_iterations, float epsilon);

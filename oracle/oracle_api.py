@@ -71,6 +71,9 @@ def lib():
         L.frogo_get_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, fp, C.c_size_t]
         L.frogo_get_gradient.restype = C.c_int
         L.frogo_get_gradient.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_size_t]
+        L.frogo_keep_raw_gradient.argtypes = [C.c_void_p, C.c_int]
+        L.frogo_get_gradient_raw.restype = C.c_int
+        L.frogo_get_gradient_raw.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_size_t]
         _bind_stats(L, "frogo_stats_")
         L.frogo_chipdf.restype = C.c_float
         L.frogo_chipdf.argtypes = [C.c_float]
@@ -338,6 +341,15 @@ class OracleGroup:
     def gradient(self, image, n_cp):
         o = np.empty((n_cp, 4), np.float32)
         self.L.frogo_get_gradient(self.h, image, o.ctypes.data_as(fp), 4 * n_cp)
+        return o
+
+    def keep_raw_gradient(self, on=True):
+        self.L.frogo_keep_raw_gradient(self.h, int(on))
+
+    def gradient_raw(self, image, n_cp):
+        """The gradient image as the scatter left it in the last deformable step (keep_raw_gradient() first)."""
+        o = np.empty((n_cp, 4), np.float32)
+        assert self.L.frogo_get_gradient_raw(self.h, image, o.ctypes.data_as(fp), 4 * n_cp) == 4 * n_cp
         return o
 
 
