@@ -87,10 +87,10 @@ def free_run(pairs, li, dl, di, images=None, **opt):
     per_lattice = []
     for k in range(ref.num_grids()):
         w = node_weights(ref, k, po, snapshots[k])
-        worst = {"raw": 0.0, "weighted": 0.0, "field": 0.0, "weak": 0, "nodes": 0, "level": levels[k]}
+        worst = {"raw": 0.0, "weighted": 0.0, "field": 0.0, "dense": 0.0, "weak": 0, "nodes": 0, "level": levels[k]}
         for i in (images if images is not None else range(pairs.n_images)):
             d = lattice_deviation(g, ref, k, i, snapshots[k][po[i]:po[i + 1]], w)
-            for key in ("raw", "weighted", "field"):
+            for key in ("raw", "weighted", "field", "dense"):
                 worst[key] = max(worst[key], d[key])
             worst["weak"], worst["nodes"] = d["weak"], d["nodes"]
         per_lattice.append(worst)
@@ -108,12 +108,13 @@ def test_config3_free_running_schedule_against_the_oracle():
     r = free_run(pairs, 10, 3, 10)
     note("cfg3_free_run", f"E {r['E']:.2e} matrices {r['matrices']:.2e} final_xyz {r['final_xyz']:.2e} grids {r['grids_per_level']}")
     for k, d in enumerate(r["lattices"]):
-        note(f"cfg3_free_run_lattice_{k}", f"level {d['level']} raw {d['raw']:.2e} weighted {d['weighted']:.2e} field {d['field']:.2e} "
+        note(f"cfg3_free_run_lattice_{k}", f"level {d['level']} raw {d['raw']:.2e} weighted {d['weighted']:.2e} field {d['field']:.2e} dense_field {d['dense']:.2e} "
                                              f"weak_nodes {d['weak']}/{d['nodes']}")
     assert r["E"] < REL
     assert r["matrices"] < 1e-6
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL, f"lattice {k}: displacement field off by {d['field']:.2e}"
+        assert d["dense"] <= REL, f"lattice {k}: displacement field on the dense lattice off by {d['dense']:.2e}"
         assert d["weighted"] <= REL, f"lattice {k}: supported coefficients off by {d['weighted']:.2e}"
         assert d["raw"] <= 1e-2, f"lattice {k}: raw coefficients off by {d['raw']:.2e}"
     assert r["final_xyz"] < 1e-6
