@@ -16,12 +16,25 @@ regrid the diffeomorphism guard triggers are inside the timed region.  Warm-up =
 linear set-up + W linear iterations.  Inputs are resident in HBM before the
 timed region starts.
 
+Hosts.  The timed loop is C (`frog_run_schedule`, include/frog_host.h: the loop bodies of ImageGroup::run over the C ABI,
+collectives from C through libfrog_comm.so) -- host "native".  The Python loop over `torch.distributed`
+(frog_amd/distributed.py) is host "torch", kept as the fallback and for the single-GPU proxies (--shard-of).
+
+N > 1.  The process that is started (by hand, or as a rank by torch.distributed.run) never touches the GPU: it runs a
+sequence of ATTEMPTS, each a set of fresh child processes (one per rank it is responsible for) under a timeout:
+  preflight   RCCL known answers (all-reduce, in-place all-gather on the library's own buffers) + latencies
+  native      the timed schedule through the C loop, collectives over RCCL (host-staged shared memory if the preflight failed)
+  torch       the timed schedule through the Python loop over torch.distributed
+The fastest attempt whose ranks end with bit-identical replicas is the line; every attempt's outcome is in it
+(`hosts_tried`).  A hang is a timed-out child with its stderr in the line, not a silent time-out of the whole run.
+
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,6 +50,7 @@ CONFIGS = {
     5: dict(images=500, points=20000, pairs_per_block=16667.0, partners=60, levels=5,
             what="500 images (~60 partner images each), ~2.5e8 pairs, linear + 5 deformable levels, -gd 1"),
 }
+COMM_KINDS = ["all_gather_xyz2", "all_reduce_em", "all_reduce_energy", "all_reduce_gridsum"]
 
 
 def schedule(k, levels=3):
@@ -91,168 +105,436 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval, repeats=3):
             "seconds": {"stats_refresh": t_stats, "linear_iteration": t_lin, "deformable_iteration": t_def}}
 
 
-def free_port():
-    """A TCP port free on 127.0.0.1 right now (the rendezvous port handed to torch.distributed.run)."""
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+# ---- the line -------------------------------------------------------------------------------------------------------------
 
-
-def launch_command(n, argv, port=None):
-    """`python bench.py --gpus N ...` without a launcher around it: the command that starts the N ranks, one process
-    per GPU, as children of this one (the form the driver uses itself for N > 1, README / DESIGN section 6)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
-
-
-def self_launch(n, argv):
-    """Start the ranks as FRESH child processes and pass rank 0's line through.  Called before anything in this process
-    has touched the GPU (before `import torch` and before libfrog_hip is loaded): the parent only waits.  Never
-    os.exec*: the children are ordinary subprocesses and this process exits with their return code."""
-    import subprocess
-    cmd = launch_command(n, argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
-    # torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset; frog_create builds its layout on the host threads
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    if os.environ.get("FROG_BENCH_LAUNCH_DRY_RUN") == "1":
-        print(json.dumps({"launch": cmd, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}), flush=True)
-        return 0
-    # stdout carries ONE line: rank 0's metric line.  Whatever else the children print there (gloo's connection notices in
-    # rehearsals, library banners) goes to stderr.
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-    for line in proc.stdout:
-        out = sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr
-        out.write(line)
-        out.flush()
-    return proc.wait()
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None,
-                    help="timed iterations; default = the reference's schedule for the configuration (650 for config 3: "
-                         "-li 50 -dl 3 -di 200), 130 for config 5")
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
-                    help="BASELINE.json configuration: 3 (default, the one the metric is quoted on), 2 (linear only), 5 (500 images)")
-    ap.add_argument("--levels", type=int, default=None, help="deformable levels (default: the configuration's)")
-    ap.add_argument("--images", type=int, default=None)
-    ap.add_argument("--points", type=int, default=None)
-    ap.add_argument("--pairs-per-block", type=float, default=None)
-    ap.add_argument("--shard-of", type=int, nargs=2, metavar=("R", "N"), default=None,
-                    help="single-GPU proxy of rank R of an N-GPU run: this process owns shard R of N, no collective is "
-                         "issued, the other ranks' images stand still (where, see --proxy-partners); prints per-phase kernel "
-                         "times of that rank's share (not a metric line)")
-    ap.add_argument("--proxy-partners", choices=("registered", "static"), default="registered",
-                    help="--shard-of: the other ranks' coordinates and mixtures are those a full single-context run of the "
-                         "default schedule ends with (registered: every image in the common frame, as a real rank sees its "
-                         "partners -- partner points lie where the own points are, the sweeps' gathers are local) or stay "
-                         "where the set-up left them (static: unregistered partners, mixtures of other images zero)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-times", action="store_true",
-                    help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher (nothing has touched the GPU yet)
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import torch
-    import torch.distributed as dist
+def roofline_and_iteration(prof, cull_def, cull_lin, l_own, p_own, i_own, n_lin, lattices, elapsed, levels):
+    """`roofline` (dominant kernel) and `iteration` objects of the line from the live kernel times and the lists' statistics.
+    prof: {kernel group: [ms, launches]}; cull_*: (lists built, half-links in the last list, half-links owned);
+    lattices: [{"level", "dims", "iterations"}]."""
     from frog_amd import _abi
-    from frog_amd.pairs import Pairs
-    from frog_amd.distributed import HipEngine, NativeComm, ShardedImageGroup, plan_shards
+    dom = "sweep_deformable" if prof["sweep_deformable"][1] else "sweep_linear"
+    ms, launches = prof[dom]
+    # Units one launch processes (DESIGN section 4a): with a culling list the steady-state sweep WALKS the listed
+    # half-links only (the others are decided by a certified distance bound and never touched); the one launch per list
+    # that writes the list ("sweep_build" / "sweep_linear_build") walks every half-link.  `achieved` / `frac` price every
+    # launch at the half-links it walked (20 B each: 8 B link + 12 B gathered xyz2) + 12 B per owned point, over the time
+    # of ALL those launches, list-writing ones included.  The same launches priced at the reference's bytes for all L
+    # half-links (SURVEY 8d: what upstream's loop touches per iteration) are `frac_algorithmic_equiv`: a saving of work,
+    # not a bandwidth.
+    listed = cull_def if dom == "sweep_deformable" else cull_lin
+    build_name = {"sweep_deformable": "sweep_build", "sweep_linear": "sweep_linear_build"}[dom]
+    bms, bl = prof.get(build_name, [0.0, 0])
+    walked = float(listed[1]) if listed[0] else float(l_own)
+    all_ms, all_launches = ms + bms, launches + bl
+    walked_bytes = launches * (20.0 * walked + 12.0 * p_own) + bl * (20.0 * l_own + 12.0 * p_own)
+    alg_bytes = 20.0 * l_own + 12.0 * p_own
+    achieved = walked_bytes / (all_ms * 1e-3) / 1e9 if all_launches else 0.0
+    # `bound`: what the counters say bounds the kernel (profiles/, DESIGN section 6a) -- the fused sweep is held by the
+    # texture path, vector-ALU issue and LDS together (each ~70 % busy), while its HBM traffic is a quarter of the peak;
+    # `frac` stays the fraction of the HBM roofline at the algorithmic bytes of what it walks, as the metric asks.
+    roofline = {"bound": "ta+valu+lds", "bound_note": "on-chip units (texture path, vector ALU, LDS ~70 % busy each); frac is against the "
+                "HBM roofline at the algorithmic bytes of the half-links walked",
+                "frac_rule": "r03: walked half-links, list-writing launches included",
+                "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None,
+                "avg_launch_ms": all_ms / all_launches if all_launches else None, "launches": int(all_launches),
+                "walked_half_links_per_steady_launch": walked, "half_links_owned": l_own, "points_owned": p_own,
+                "bytes_per_steady_launch": 20.0 * walked + 12.0 * p_own,
+                "steady_launches": {"launches": int(launches), "avg_launch_ms": ms / launches if launches else None},
+                "frac_algorithmic_equiv": (alg_bytes * all_launches / (all_ms * 1e-3) / 1e9 / 8000.0) if all_launches else None,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    if bl:
+        roofline["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl, "walks": "every half-link"}
+    if listed[0]:
+        roofline["culling"] = {"lists_built": int(listed[0]), "listed_half_links": int(listed[1]),
+                               "listed_fraction": listed[1] / max(listed[2], 1)}
+    # Whole-iteration fraction = what the metric pays for: the algorithmic bytes of every timed iteration (SURVEY 8d:
+    # B_lin = 20 L + 36 P, B_def = 20 L + 48 P + 104 I G with the I G of the lattices that were really built) over the
+    # timed region's wall time.  `..._walked` prices the half-links at the ones the sweeps walked.
+    b_lin = 20.0 * l_own + 36.0 * p_own
+    def_iters = [(la["dims"][0] * la["dims"][1] * la["dims"][2], la["iterations"]) for la in lattices]
+    b_total = n_lin * b_lin + sum(n * (20.0 * l_own + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
+    walked_lin = float(cull_lin[1]) if cull_lin[0] else float(l_own)
+    walked_def = float(cull_def[1]) if cull_def[0] else float(l_own)
+    b_walked = n_lin * (20.0 * walked_lin + 36.0 * p_own) + sum(n * (20.0 * walked_def + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
+    iteration = {"algorithmic_bytes": b_total, "elapsed_s": elapsed, "iteration_frac": b_total / elapsed / 8e12,
+                 "iteration_frac_walked": b_walked / elapsed / 8e12,
+                 "lattices": [{"level": la["level"], "dims": la["dims"], "iterations": la["iterations"]} for la in lattices],
+                 "formula": "(n_lin (20 L + 36 P) + sum over lattices n (20 L + 48 P + 104 I G)) / elapsed / 8 TB/s, per rank"}
+    # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE collected in their own
+    # rocprofv3 passes by scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
+    # doubled on gfx950).  Counters cannot be read from inside this process, so the committed measurement of
+    # the same workload is reported; null when there is none for this workload / shard size, or when the device
+    # sources have changed since it was taken (profiles/hbm_traffic.json "measured_at").
+    src_hash = _abi.device_source_hash()
+    roofline["device_source_hash"] = src_hash
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            tr = json.load(fh)
+        # keyed on the workload AND on the device sources the counters were collected with: stale after any kernel change
+        if (tr.get("kernel") == dom and tr.get("half_links_owned", tr.get("half_links_per_launch")) == l_own
+                and tr.get("measured_at") == src_hash):
+            roofline["traffic"] = tr["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = tr.get("source")
+            roofline["traffic_measured_at"] = tr.get("measured_at")
+    except (OSError, ValueError, KeyError):
+        pass
+    return roofline, iteration
 
-    if _abi.hip_lib().frog_device_count() < 1:
-        raise SystemExit("no HIP device: bench.py measures the HIP path only")
-    # Rehearsal hook for boxes with a single GPU: FROG_BENCH_BACKEND=gloo puts every rank on
-    # device 0 and moves the collectives through gloo.  The driver's runs use RCCL ("nccl").
-    backend = os.environ.get("FROG_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend=backend)
 
+def workload_of(args):
     cfg = CONFIGS[args.config]
     images = args.images or cfg["images"]
     points = args.points or cfg["points"]
     ppb = args.pairs_per_block or cfg["pairs_per_block"]
     levels = cfg["levels"] if args.levels is None else args.levels
-    if args.steps is None:
-        args.steps = {2: 50, 3: 650, 5: 130}[args.config] if args.levels is None else 50 + 200 * levels
-    if args.config != 3 or args.shard_of:
-        args.no_cpu_baseline = True        # the host baseline is timed on the configuration the metric is quoted on
+    steps = args.steps
+    if steps is None:
+        steps = {2: 50, 3: 650, 5: 130}[args.config] if args.levels is None else 50 + 200 * levels
+    partners = cfg["partners"] if images == cfg["images"] else 0
+    return images, points, ppb, levels, steps, partners
+
+
+def make_line(args, world, k, elapsed, host, collectives, pairs, levels, n_lin, per_level, grids, final_e, roofline, iteration,
+              prof, phase_k, phase_s, setup_seconds):
+    images, points = pairs.n_images, int(pairs.point_offset[1] - pairs.point_offset[0])
+    return {
+        "metric": "registration iterations/sec (linear+deformable)",
+        "value": k / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": k,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / k,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "host": host,
+        "collectives": collectives,
+        "config": {"workload": f"BASELINE.json configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: {images} images x {points} keypoints, "
+                               f"{pairs.n_pairs} pairs ({pairs.n_half_links} half-links), linear + {levels} deformable "
+                               f"levels, -g 100 -gd 1 -si 10",
+                   "schedule": {"linear": n_lin, "deformable_per_level": per_level},
+                   "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
+                   "final_E": final_e},
+        "roofline": roofline,
+        "iteration": iteration,
+        "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items() if v[1]},
+        "kernels_ms_by_phase": phase_k,
+        "phase_iterations_per_s": {
+            "linear": n_lin / phase_s["linear"],
+            **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(levels) if per_level[l]}},
+        "setup_seconds": setup_seconds,
+    }
+
+
+# ---- host "native": the C loop ------------------------------------------------------------------------------------------
+
+class Rendezvous:
+    """What the ranks of one attempt exchange outside the collectives: small files in a directory all of them see
+    (one node).  No torch, no sockets."""
+
+    def __init__(self, directory, attempt, rank, world):
+        self.dir, self.attempt, self.rank, self.world = directory, attempt, rank, world
+
+    def path(self, name):
+        return os.path.join(self.dir, f"a{self.attempt}_{name}")
+
+    def put(self, name, data):
+        tmp = self.path(name) + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as fh:
+            fh.write(data)
+        os.replace(tmp, self.path(name))
+
+    def get(self, name, timeout=120.0):
+        t0 = time.time()
+        while not os.path.exists(self.path(name)):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"rank {self.rank}: {name} never appeared in {self.dir}")
+            time.sleep(0.005)
+        with open(self.path(name), "rb") as fh:
+            return fh.read()
+
+    def gather_json(self, name, obj, timeout=120.0):
+        """Every rank contributes obj; returns the list in rank order (on every rank)."""
+        self.put(f"{name}_{self.rank}", json.dumps(obj).encode())
+        return [json.loads(self.get(f"{name}_{r}", timeout)) for r in range(self.world)]
+
+
+def create_native_comm(rdv, transport, ctx, shards, point_offset, device):
+    """The rank's communicator of include/frog_comm.h, bound to ctx: RCCL (ncclCommInitRank, the id through the
+    rendezvous directory) or the host-staged shared-memory one."""
+    from frog_amd import _abi
+    cl = _abi.comm_lib()
+    h = C.c_void_p()
+    rank, world = rdv.rank, rdv.world
+    if transport == "rccl":
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            _abi.check(cl.frog_comm_unique_id(buf), "frog_comm_unique_id")
+            rdv.put("rccl_id", bytes(buf))
+        ident = (C.c_ubyte * 128).from_buffer_copy(rdv.get("rccl_id"))
+        _abi.check(cl.frog_comm_create_rank(world, rank, ident, device, C.byref(h)), "frog_comm_create_rank")
+    elif transport == "shm":
+        name = f"frogbench_{os.path.basename(rdv.dir)}_{rdv.attempt}".encode()
+        _abi.check(cl.frog_comm_create_shm(world, rank, name, device, C.byref(h)), "frog_comm_create_shm")
+    else:
+        raise SystemExit(f"unknown transport {transport}")
+    ib = (C.c_uint32 * (world + 1))(*([s[0] for s in shards] + [shards[-1][1]]))
+    _abi.check(cl.frog_comm_bind(h, ctx, ib), "frog_comm_bind")
+    rows = (C.c_uint64 * (world + 1))(*([int(point_offset[s[0]]) for s in shards] + [int(point_offset[shards[-1][1]])]))
+    _abi.check(cl.frog_comm_set_rows(h, rows), "frog_comm_set_rows")
+    _abi.check(cl.frog_comm_barrier(h), "frog_comm_barrier")
+    return cl, h
+
+
+def native_plan(args, n_lin, per_level, profile, time_comm, warmup=None):
+    from frog_amd import _abi
+    plan = _abi.FrogSchedulePlan()
+    plan.plan_bytes, plan.result_bytes = C.sizeof(_abi.FrogSchedulePlan), C.sizeof(_abi.FrogScheduleResult)
+    plan.warmup_linear = args.warmup if warmup is None else warmup
+    plan.linear = n_lin
+    plan.n_levels = len(per_level)
+    for l, n in enumerate(per_level):
+        plan.per_level[l] = n
+    plan.stat_interval = 10
+    plan.deformable_alpha = 0.02
+    plan.anchor[0] = plan.anchor[1] = plan.anchor[2] = 0.5
+    plan.profile = profile
+    plan.time_comm = int(time_comm)
+    return plan
+
+
+def run_native(args, rank, world, local_rank, transport, rdv):
+    """One rank of the timed schedule through frog_run_schedule.  Returns the line on rank 0 (None elsewhere)."""
+    from frog_amd import _abi
+    from frog_amd.pairs import Pairs
+    from frog_amd.distributed import plan_shards
+    import numpy as np
+    lib, host = _abi.hip_lib(), _abi.host_lib()
+    if lib.frog_device_count() < 1:
+        raise SystemExit("no HIP device: bench.py measures the HIP path only")
+    images, points, ppb, levels, steps, partners_per_image = workload_of(args)
     t0 = time.perf_counter()
-    pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=cfg["partners"] if images == cfg["images"] else 0)
+    pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=partners_per_image)
     t_gen = time.perf_counter() - t0
+    n_lin, per_level = schedule(steps, levels)
+    opts = _abi.FrogOptions.default()
+    proxy = None
     if args.shard_of:
         if world != 1:
             raise SystemExit("--shard-of is a single-process proxy")
         shards = plan_shards(pairs.row_ptr, pairs.point_offset, args.shard_of[1])
         shards = [shards[args.shard_of[0]]]
+        args.kernel_times = True
+        if args.proxy_partners == "registered":
+            # what the other ranks would hand over: the whole group registered by one context (default schedule), its final
+            # coordinates and mixtures
+            full = C.c_void_p()
+            _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(opts), local_rank, 0, pairs.n_images, C.byref(full)), "frog_create")
+            fl, fp = 50, [200] * levels             # the reference's default schedule, -li 50 -di 200
+            res = _abi.FrogScheduleResult()
+            _abi.check(host.frog_run_schedule(full, None, C.byref(native_plan(args, fl, fp, 0, False, warmup=0)), C.byref(res)), "frog_run_schedule")
+            n_pts = int(pairs.point_offset[-1])
+            xyz2 = np.empty((n_pts, 3), np.float32)
+            _abi.check(lib.frog_get_points(full, None, xyz2.ctypes.data_as(_abi.c_float_p)), "frog_get_points")
+            em = np.zeros((pairs.n_images, 4), np.float32)
+            for i in range(pairs.n_images):
+                _abi.check(lib.frog_get_em(full, i, em[i].ctypes.data_as(_abi.c_float_p)), "frog_get_em")
+            lib.frog_destroy(full)
+            proxy = (xyz2, em)
     else:
         shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
+    t0 = time.perf_counter()
+    ctx = C.c_void_p()
+    b, e = shards[rank]
+    _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(opts), local_rank, b, e, C.byref(ctx)), "frog_create")
+    t_create = time.perf_counter() - t0
+    cl, comm = None, None
+    if world > 1:
+        cl, comm = create_native_comm(rdv, transport, ctx, shards, pairs.point_offset, local_rank)
+    plan = native_plan(args, n_lin, per_level, 1 if args.kernel_times else 2, world > 1)
+    if proxy is not None:
+        plan.proxy_xyz2 = proxy[0].ctypes.data
+        plan.proxy_em = proxy[1].ctypes.data
+    res = _abi.FrogScheduleResult()
+    _abi.check(host.frog_run_schedule(ctx, comm, C.byref(plan), C.byref(res)), "frog_run_schedule")
+
+    def cull(fn):
+        a, bb, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _abi.check(fn(ctx, C.byref(a), C.byref(bb), C.byref(c)), "frog_cull_stats")
+        return a.value, bb.value, c.value
+    cull_def, cull_lin = cull(lib.frog_cull_stats), cull(lib.frog_cull_stats_linear)
+    prof = {n: [res.kernels[i].ms_total, int(res.kernels[i].launches)] for i, n in enumerate(_abi.FROG_K_NAMES)}
+    tags = ["linear"] + [f"level{l}" for l in range(levels)]
+    phase_s = {t: res.phase_s[i] for i, t in enumerate(tags) if i == 0 or per_level[i - 1]}
+    if args.kernel_times:
+        phase_k = {t: {n: {"ms": round(res.kernels_by_phase[i][j].ms_total, 4), "launches": int(res.kernels_by_phase[i][j].launches)}
+                       for j, n in enumerate(_abi.FROG_K_NAMES) if res.kernels_by_phase[i][j].launches}
+                   for i, t in enumerate(tags) if t in phase_s}
+    else:
+        phase_k = {"all": {n: {"ms": round(v[0], 4), "launches": v[1]} for n, v in prof.items() if v[1]}}
+    lattices = [{"level": int(la.level), "dims": [int(d) for d in la.dims], "iterations": int(la.iterations)}
+                for la in res.lattices[:res.n_lattices]]
+    comm_ms = None
+    if world > 1:
+        comm_ms = {}
+        for j, kind in enumerate(COMM_KINDS):
+            if res.comm_calls[j]:
+                avg = res.comm_ms[j] / max(1, res.comm_sampled[j])
+                comm_ms[kind] = {"sampled_ms": res.comm_ms[j], "sampled": int(res.comm_sampled[j]), "calls": int(res.comm_calls[j]),
+                                 "avg_ms": avg, "est_total_ms": avg * res.comm_calls[j]}
+    mine = {"elapsed": res.elapsed_s, "hash": int(res.replica_hash), "kernel_ms": sum(v[0] for v in prof.values()),
+            "sweep_ms": prof["sweep_deformable"][0] + prof["sweep_linear"][0] + prof["sweep_build"][0] + prof["sweep_linear_build"][0],
+            "comm_est_ms": sum(v["est_total_ms"] for v in (comm_ms or {}).values()), "final_E": res.final_E}
+    everyone = rdv.gather_json("result", mine) if world > 1 else [mine]
+    elapsed = max(x["elapsed"] for x in everyone)
+    line = None
+    if rank == 0:
+        po, rp = pairs.point_offset, pairs.row_ptr
+        p_own = int(po[e]) - int(po[b])
+        l_own = int(rp[int(po[e])]) - int(rp[int(po[b])])
+        roofline, iteration = roofline_and_iteration(prof, cull_def, cull_lin, l_own, p_own, e - b, n_lin, lattices, elapsed, levels)
+        k = n_lin + sum(per_level)
+        collectives = "none" if world == 1 else {"rccl": "libfrog_comm (RCCL from C)", "shm": "libfrog_comm (host-staged shared memory)"}[transport]
+        line = make_line(args, world, k, elapsed, "native (frog_run_schedule, C loop)", collectives, pairs, levels, n_lin, per_level,
+                         [int(g) for g in res.grids_per_level[:levels]], res.final_E, roofline, iteration, prof, phase_k, phase_s,
+                         {"generate": t_gen, "create": t_create, "lattice_setups": [la.setup_host_s for la in res.lattices[:res.n_lattices]]})
+        if args.shard_of:
+            line["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
+                             + ("other ranks' coordinates and mixtures: those a full run of the default schedule ends with, standing still"
+                                if proxy is not None else "other ranks' coordinates static where the set-up left them, their mixtures zero")
+                             + "; `value` is NOT the metric")
+            line["proxy_ms_per_iteration"] = {ph: {n: v["ms"] / max(1, (n_lin if ph == "linear" else per_level[int(ph[5:])]))
+                                                   for n, v in ks.items()} for ph, ks in phase_k.items()}
+        if world > 1:
+            line["comm_ms"] = comm_ms
+            line["replicas_identical"] = len({x["hash"] for x in everyone}) == 1
+            line["ranks"] = {"elapsed_s": [x["elapsed"] for x in everyone], "kernel_ms_total": [x["kernel_ms"] for x in everyone],
+                             "sweep_ms_total": [x["sweep_ms"] for x in everyone], "comm_est_ms_total": [x["comm_est_ms"] for x in everyone],
+                             "note": "per rank over the timed region: wall time, sum of the bracketed kernels' device time "
+                                     "(all groups with --kernel-times, else the half-link sweeps), estimated device time of the collectives"}
+        if world == 1 and not args.no_cpu_baseline and args.config == 3 and not args.shard_of:
+            line["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, 10)
+    if comm:
+        if world > 1:
+            rdv.gather_json("done", {"rank": rank})          # nobody tears its communicator down while another still reduces
+        arr = (C.c_void_p * 1)(comm)
+        cl.frog_comm_destroy_all(1, arr)
+    lib.frog_destroy(ctx)
+    return line, (world == 1 or len({x["hash"] for x in everyone}) == 1)
+
+
+# ---- preflight: RCCL known answers and latencies on the library's own buffers ---------------------------------------------
+
+def run_preflight(rank, world, local_rank, transport, rdv):
+    from frog_amd import _abi
+    from frog_amd.pairs import Pairs
+    from frog_amd.distributed import plan_shards
+    import numpy as np
+    lib = _abi.hip_lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    H2D, D2H = 1, 2
+    pairs = Pairs.synthetic(2 * world, 4000, 1500, seed=3)
+    shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
+    ctx = C.c_void_p()
+    _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(_abi.FrogOptions.default()), local_rank, shards[rank][0], shards[rank][1],
+                               C.byref(ctx)), "frog_create")
+    cl, comm = create_native_comm(rdv, transport, ctx, shards, pairs.point_offset, local_rank)
+
+    def buf(which):
+        p, nb, rb, re = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _abi.check(lib.frog_comm_buffer(ctx, which, C.byref(p), C.byref(nb), C.byref(rb), C.byref(re)), "frog_comm_buffer")
+        return p, nb.value, rb.value, re.value
+    ok = True
+    # all-reduce(sum) of (rank + 1, 2^rank, -rank, 0.5) on FROG_BUF_ENERGY
+    p, nb, _, _ = buf(_abi.FROG_BUF_ENERGY)
+    src = np.array([rank + 1.0, 2.0 ** rank, -float(rank), 0.5])
+    _abi.check(lib.frog_synchronize(ctx), "frog_synchronize")
+    hip.hipMemcpy(p, src.ctypes.data_as(C.c_void_p), 32, H2D)
+    _abi.check(cl.frog_comm_all_reduce(comm, _abi.FROG_BUF_ENERGY), "frog_comm_all_reduce")
+    _abi.check(lib.frog_synchronize(ctx), "frog_synchronize")
+    got = np.zeros(4)
+    hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), p, 32, D2H)
+    n = world
+    want = np.array([n * (n + 1) / 2.0, 2.0 ** n - 1.0, -n * (n - 1) / 2.0, 0.5 * n])
+    ok = ok and bool(np.array_equal(got, want))
+    # in-place all-gather: rank r's rows hold r + 1
+    p, nb, rb, re = buf(_abi.FROG_BUF_XYZ2)
+    n_pts = nb // 12
+    mine = np.zeros((n_pts, 3), np.float32)
+    mine[rb:re] = rank + 1.0
+    hip.hipMemcpy(p, mine.ctypes.data_as(C.c_void_p), nb, H2D)
+    _abi.check(cl.frog_comm_all_gather_xyz2(comm), "frog_comm_all_gather_xyz2")
+    _abi.check(lib.frog_synchronize(ctx), "frog_synchronize")
+    got = np.empty((n_pts, 3), np.float32)
+    hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), p, nb, D2H)
+    po = pairs.point_offset
+    for r, (ib, ie) in enumerate(shards):
+        ok = ok and bool((got[int(po[ib]):int(po[ie])] == r + 1.0).all())
+    # latencies: 50 awaited small all-reduces, 20 gathers
+    lat = {}
+    for name, fn, reps in (("all_reduce_32B_us", lambda: cl.frog_comm_all_reduce(comm, _abi.FROG_BUF_ENERGY), 50),
+                           (f"all_gather_{nb // 1024}KB_us", lambda: cl.frog_comm_all_gather_xyz2(comm), 20)):
+        _abi.check(cl.frog_comm_barrier(comm), "frog_comm_barrier")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _abi.check(fn(), name)
+        _abi.check(lib.frog_synchronize(ctx), "frog_synchronize")
+        lat[name] = 1e6 * (time.perf_counter() - t0) / reps
+    everyone = rdv.gather_json("preflight", {"ok": ok, "lat": lat})
+    arr = (C.c_void_p * 1)(comm)
+    rdv.gather_json("done", {"rank": rank})
+    cl.frog_comm_destroy_all(1, arr)
+    lib.frog_destroy(ctx)
+    good = all(x["ok"] for x in everyone)
+    line = {"preflight": transport, "known_answers": good, "latencies_rank0": lat} if rank == 0 else None
+    return line, good
+
+
+# ---- host "torch": the Python loop over torch.distributed (frog_amd/distributed.py) -------------------------------------
+
+def run_torch(args, rank, world, local_rank, backend, rdv):
+    import torch
+    import torch.distributed as dist
+    from frog_amd import _abi
+    from frog_amd.pairs import Pairs
+    from frog_amd.distributed import HipEngine, ShardedImageGroup, plan_shards
+
+    if _abi.hip_lib().frog_device_count() < 1:
+        raise SystemExit("no HIP device: bench.py measures the HIP path only")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        store = f"file://{rdv.path('torch_store')}" if rdv else None
+        kw = dict(init_method=store, rank=rank, world_size=world) if store else {}
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"), **kw)
+        else:
+            dist.init_process_group(backend=backend, **kw)
+    images, points, ppb, levels, steps, partners_per_image = workload_of(args)
+    t0 = time.perf_counter()
+    pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=partners_per_image)
+    t_gen = time.perf_counter() - t0
+    shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
     opts = _abi.FrogOptions.default()
-    partners = None
-    if args.shard_of and args.proxy_partners == "registered":
-        # what the other ranks would hand over: the whole group registered by one context (default schedule), its final
-        # coordinates and mixtures (both engines number the points alike: the numbering depends on the model only)
-        full = HipEngine(pairs, opts, local_rank, (0, pairs.n_images))
-        gfull = ShardedImageGroup(full, [(0, pairs.n_images)], pairs.point_offset, 0, 1)
-        gfull.deformableLevels = levels
-        gfull.run()
-        torch.cuda.synchronize()
-        partners = (full.points()[1], full.em.clone())
-        torch.cuda.synchronize()
-        del gfull
-        full.close()
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0
-    # N > 1 over RCCL: torch.distributed carries the collectives (torch's own RCCL).  FROG_NATIVE_COMM=1 issues them from C
-    # instead (libfrog_comm.so, include/frog_comm.h, on the context's stream: ncclCommInitRank with an id carried by
-    # torch.distributed) -- opt-in until a run with >= 2 GPUs has validated it; it is adopted only if every rank sets it up
-    # AND it passes a known-answer all-reduce and all-gather (NativeComm.create)
-    native = None
-    if world > 1 and backend == "nccl" and os.environ.get("FROG_NATIVE_COMM", "0") == "1":
-        native = NativeComm.create(engine, shards, pairs.point_offset, rank, world, dist, local_rank)
-    grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world, native=native)
-    # per-collective device time in the line ("comm_ms", every eighth call of a kind); FROG_BENCH_TIME_COMM=1 also in rehearsals
-    grp.time_comm = world > 1 and (backend == "nccl" or os.environ.get("FROG_BENCH_TIME_COMM") == "1")
-    if args.shard_of:
-        args.kernel_times = True
-
-    n_lin, per_level = schedule(args.steps, levels)
+    grp = ShardedImageGroup(engine, shards, pairs.point_offset, rank, world)
+    grp.time_comm = world > 1
+    n_lin, per_level = schedule(steps, levels)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up: linear set-up + W linear iterations --------------------------------
     grp.setupLinearTransforms()
     grp.transformPoints()
-    if partners is not None:
-        own_b, own_e = shards[rank]
-        pb, pe = int(pairs.point_offset[own_b]), int(pairs.point_offset[own_e])
-        mixed = engine.points()[1]              # the model's point order on both sides
-        mixed[:pb] = partners[0][:pb]
-        mixed[pe:] = partners[0][pe:]
-        engine.set_points2(mixed)
-        grp.proxy_em = partners[1]              # stands in for the all-reduce of the mixture table at every refresh
     it = 0
     for _ in range(args.warmup):
         if it % grp.statIntervalUpdate == 0:
@@ -260,17 +542,11 @@ def main():
         grp.updateLinearTransforms()
         grp.transformPoints()
         it += 1
-
-    # ---- timed region: exactly K iterations --------------------------------------------
-    # live HIP-event timing of the dominant kernel (the half-link sweeps); every kernel group with --kernel-times
     engine.profile_enable(1 if args.kernel_times else 2)
-    phase_s = {}
-    phase_k = {}
+    phase_s, phase_k = {}, {}
     prof = {n: [0.0, 0] for n in _abi.FROG_K_NAMES}
 
     def take(tag):
-        # HIP-event kernel times of the phase just finished (the events are already complete:
-        # the phase ended with a device synchronisation)
         cur = engine.profile_read(reset=True)
         phase_k[tag] = {n: {"ms": round(v[0], 4), "launches": int(v[1])} for n, v in cur.items() if v[1]}
         for n, v in cur.items():
@@ -278,6 +554,7 @@ def main():
     sync()
     t_start = time.perf_counter()
     tp = t_start
+    e = 0.0
     for _ in range(n_lin):
         if it % grp.statIntervalUpdate == 0:
             grp.updateStats()
@@ -285,10 +562,7 @@ def main():
         grp.transformPoints()
         it += 1
     grp.transformPoints(True)
-    # Phase boundaries: with --kernel-times the device is drained and the per-phase kernel times are read; otherwise nothing
-    # is waited for inside the timed region that the registration itself does not wait for (every step ends with the host
-    # reading its scalars, every level starts with the bounds read-back, so the host clock is at most one transform behind
-    # the device): a drain + read per phase cost 50-90 us of idle GPU each, 2 % of a 20-step run.
+
     def phase_end(tag, t_phase):
         if args.kernel_times:
             torch.cuda.synchronize()
@@ -312,14 +586,13 @@ def main():
         grp.comm_summary()
     if grp.measures:
         e = grp.measures[-1]
-
-    replicas_identical = None
+    replicas_identical = True
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        if backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # after the timed region: every rank holds a replica of all transformed coordinates (the all-gather's product) and
-        # of the mixture table; they must be the same bits on every rank, whatever carried the collectives
         grp.transformPoints(True)
         torch.cuda.synchronize()
         chk = torch.stack([engine.xyz2.double().sum(), engine.xyz2.double().abs().sum(), engine.em.double().sum()])
@@ -329,129 +602,244 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
-
-    k = n_lin + sum(per_level)
-    own_b, own_e = shards[rank]
-    po, rp = pairs.point_offset, pairs.row_ptr
-    p_own = int(po[own_e]) - int(po[own_b])
-    l_own = int(rp[int(po[own_e])]) - int(rp[int(po[own_b])])
-    # dominant kernel: the half-link sweep of the deformable step
-    dom = "sweep_deformable" if prof["sweep_deformable"][1] else "sweep_linear"
     if levels == 0:
         grp.transformPoints(True)
-    ms, launches = prof[dom]
-    # Units one launch processes: with a culling list the steady-state sweep WALKS the listed
-    # half-links only (the others are decided by a certified distance bound and never touched); the one launch per list
-    # that writes the list ("sweep_build" / "sweep_linear_build") walks every half-link.  `achieved` / `frac` price every
-    # launch at the half-links it walked (20 B each: 8 B link + 12 B gathered xyz2) + 12 B per owned point, over the time
-    # of ALL those launches, list-writing ones included.  The same launches priced at the reference's bytes for all L
-    # half-links (what upstream's loop touches per iteration) are `frac_algorithmic_equiv`: a saving of work,
-    # not a bandwidth.
-    listed = engine.cull_stats_kind(dom)                   # (lists built, half-links in the last list, half-links owned)
-    build_name = {"sweep_deformable": "sweep_build", "sweep_linear": "sweep_linear_build"}[dom]
-    bms, bl = prof.get(build_name, [0.0, 0])
-    walked = float(listed[1]) if listed[0] else float(l_own)
-    all_ms, all_launches = ms + bms, launches + bl
-    walked_bytes = launches * (20.0 * walked + 12.0 * p_own) + bl * (20.0 * l_own + 12.0 * p_own)
-    alg_bytes = 20.0 * l_own + 12.0 * p_own
-    achieved = walked_bytes / (all_ms * 1e-3) / 1e9 if all_launches else 0.0
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
-                "avg_launch_ms": all_ms / all_launches if all_launches else None, "launches": int(all_launches),
-                "walked_half_links_per_steady_launch": walked, "half_links_owned": l_own, "points_owned": p_own,
-                "bytes_per_steady_launch": 20.0 * walked + 12.0 * p_own,
-                "steady_launches": {"launches": int(launches), "avg_launch_ms": ms / launches if launches else None},
-                "frac_algorithmic_equiv": (alg_bytes * all_launches / (all_ms * 1e-3) / 1e9 / 8000.0) if all_launches else None,
-                "algorithmic_bytes_per_launch": alg_bytes}
-    if bl:
-        roofline["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl, "walks": "every half-link"}
-    if listed[0]:
-        roofline["culling"] = {"lists_built": int(listed[0]), "listed_half_links": int(listed[1]),
-                               "listed_fraction": listed[1] / max(listed[2], 1)}
-    # Whole-iteration fraction = what the metric pays for: the algorithmic bytes of every timed iteration (SURVEY 8d:
-    # B_lin = 20 L + 36 P, B_def = 20 L + 48 P + 104 I G with the I G of the lattices that were really built) over the
-    # timed region's wall time.  `..._walked` prices the half-links at the ones the sweeps walked.
-    i_own = own_e - own_b
-    b_lin = 20.0 * l_own + 36.0 * p_own
-    def_iters = [(la["control_points"], la["iterations"]) for la in grp.lattices]
-    b_total = n_lin * b_lin + sum(n * (20.0 * l_own + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
-    lin_cull = engine.cull_stats_kind("sweep_linear")
-    walked_lin = float(lin_cull[1]) if lin_cull[0] else float(l_own)
-    walked_def = float(engine.cull_stats_kind("sweep_deformable")[1]) if engine.cull_stats_kind("sweep_deformable")[0] else float(l_own)
-    b_walked = n_lin * (20.0 * walked_lin + 36.0 * p_own) + sum(n * (20.0 * walked_def + 48.0 * p_own + 104.0 * i_own * g) for g, n in def_iters)
-    iteration = {"algorithmic_bytes": b_total, "elapsed_s": elapsed, "iteration_frac": b_total / elapsed / 8e12,
-                 "iteration_frac_walked": b_walked / elapsed / 8e12,
-                 "lattices": [{"level": la["level"], "dims": la["dims"], "iterations": la["iterations"]} for la in grp.lattices],
-                 "formula": "(n_lin (20 L + 36 P) + sum over lattices n (20 L + 48 P + 104 I G)) / elapsed / 8 TB/s, per rank"}
-    # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE collected in their own
-    # rocprofv3 passes by scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE
-    # doubled on gfx950).  Counters cannot be read from inside this process, so the committed measurement of
-    # the same workload is reported; null when there is none for this workload / shard size, or when the device
-    # sources have changed since it was taken (profiles/hbm_traffic.json "measured_at").
-    src_hash = _abi.device_source_hash()
-    roofline["device_source_hash"] = src_hash
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
-            tr = json.load(fh)
-        # keyed on the workload AND on the device sources the counters were collected with: stale after any kernel change
-        if (tr.get("kernel") == dom and tr.get("half_links_per_launch") == l_own
-                and tr.get("measured_at") == src_hash):
-            roofline["traffic"] = tr["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = tr.get("source")
-            roofline["traffic_measured_at"] = tr.get("measured_at")
-    except (OSError, ValueError, KeyError):
-        pass
-
+    line = None
     if rank == 0:
-        out = {
-            "metric": "registration iterations/sec (linear+deformable)",
-            "value": k / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": k,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / k,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "collectives": ("none" if world == 1 else "libfrog_comm (RCCL from C)" if native else f"torch.distributed/{backend}"),
-            "config": {"workload": f"BASELINE.json configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: {images} images x {points} keypoints, "
-                                   f"{pairs.n_pairs} pairs ({pairs.n_half_links} half-links), linear + {levels} deformable "
-                                   f"levels, -g 100 -gd 1 -si 10",
-                       "schedule": {"linear": n_lin, "deformable_per_level": per_level},
-                       "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
-                       "final_E": e},
-            "roofline": roofline,
-            "iteration": iteration,
-            "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items() if v[1]},
-            "kernels_ms_by_phase": phase_k,
-            "phase_iterations_per_s": {
-                "linear": n_lin / phase_s["linear"],
-                **{f"level{l}": per_level[l] / phase_s[f"level{l}"] for l in range(levels) if per_level[l]}},
-            "setup_seconds": {"generate": t_gen, "create": t_create, "lattice_setups": grp.setup_seconds},
-        }
-        if args.shard_of:
-            out["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
-                            + ("other ranks' coordinates and mixtures: those a full run of the default schedule ends with, standing still"
-                               if partners is not None else "other ranks' coordinates static where the set-up left them, their mixtures zero")
-                            + "; `value` is NOT the metric")
-            out["proxy_ms_per_iteration"] = {ph: {n: v["ms"] / max(1, (n_lin if ph == "linear" else per_level[int(ph[5:])]))
-                                                   for n, v in ks.items()} for ph, ks in phase_k.items()}
+        own_b, own_e = shards[rank]
+        po, rp = pairs.point_offset, pairs.row_ptr
+        p_own = int(po[own_e]) - int(po[own_b])
+        l_own = int(rp[int(po[own_e])]) - int(rp[int(po[own_b])])
+        roofline, iteration = roofline_and_iteration(prof, engine.cull_stats_kind("sweep_deformable"), engine.cull_stats_kind("sweep_linear"),
+                                                     l_own, p_own, own_e - own_b, n_lin, grp.lattices, elapsed, levels)
+        line = make_line(args, world, n_lin + sum(per_level), elapsed, "torch (Python loop, frog_amd/distributed.py)",
+                         "none" if world == 1 else f"torch.distributed/{backend}", pairs, levels, n_lin, per_level, grids, e,
+                         roofline, iteration, prof, phase_k, phase_s, {"generate": t_gen, "create": t_create, "lattice_setups": grp.setup_seconds})
         if grp.comm_ms:
-            out["comm_ms"] = grp.comm_ms
-        if replicas_identical is not None:
-            out["replicas_identical"] = replicas_identical
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)
-        print(json.dumps(out), flush=True)
+            line["comm_ms"] = grp.comm_ms
+        if world > 1:
+            line["replicas_identical"] = replicas_identical
+        if world == 1 and not args.no_cpu_baseline and args.config == 3:
+            line["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, grp.statIntervalUpdate)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if replicas_identical is False:
-        # the line above says so; a run whose ranks disagree about the coordinates is not a measurement
-        raise SystemExit("replicas_identical is false: the ranks' replicas of xyz2 / the EM table differ")
+    return line, replicas_identical
+
+
+# ---- the launcher: attempts of fresh children -----------------------------------------------------------------------------
+
+def child_command(argv, host, transport, directory, attempt):
+    return [sys.executable, os.path.abspath(__file__), *argv, "--child", host, "--child-transport", transport,
+            "--child-dir", directory, "--child-attempt", str(attempt)]
+
+
+def attempts_plan(rehearsal):
+    """[(host, transport)] in the order they are tried; FROG_BENCH_HOSTS="native,torch" etc. restricts the measured ones."""
+    want = [h.strip() for h in os.environ.get("FROG_BENCH_HOSTS", "preflight,native,torch").split(",") if h.strip()]
+    t_native, t_torch = ("shm", "gloo") if rehearsal else ("rccl", "nccl")
+    plan = []
+    for h in want:
+        if h == "preflight":
+            plan.append(("preflight", t_native))
+        elif h == "native":
+            plan.append(("native", t_native))
+        elif h == "torch":
+            plan.append(("torch", t_torch))
+        elif h == "native-shm":
+            plan.append(("native", "shm"))
+    return plan
+
+
+def orchestrate(args, argv, n, my_ranks, directory):
+    """Runs the attempts; every participating parent (one under a plain `python bench.py --gpus N`, N under
+    torch.distributed.run) walks the same list and reads the same outcome files, so all take the same decisions.
+    The parent of rank 0 prints the line.  Never touches the GPU itself."""
+    rehearsal = os.environ.get("FROG_BENCH_BACKEND", "nccl") != "nccl"       # one-GPU boxes: every rank on device 0, host-staged collectives
+    os.makedirs(directory, exist_ok=True)
+    env_base = dict(os.environ)
+    env_base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    if "OMP_NUM_THREADS" not in os.environ or os.environ.get("FROG_BENCH_UNDER_TORCHRUN") == "1":
+        # torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset; frog_create builds its layout on the host threads
+        env_base["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or n) // n))
+    timeouts = {"preflight": float(os.environ.get("FROG_BENCH_PREFLIGHT_TIMEOUT", "150")),
+                "native": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "300")),
+                "torch": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "300"))}
+    plan = attempts_plan(rehearsal)
+    tried, lines = [], []
+    rccl_ok = True
+    k = 0
+    queue = list(plan)
+    while queue:
+        host, transport = queue.pop(0)
+        if not rccl_ok and transport in ("rccl", "nccl"):
+            tried.append({"host": host, "transport": transport, "ok": False, "skipped": "the RCCL preflight failed"})
+            continue
+        t0 = time.time()
+        procs = {}
+        for r in my_ranks:
+            env = dict(env_base, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(0 if rehearsal else r))
+            for v in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+                env.pop(v, None)        # the children rendezvous through files in `directory`, not through the launcher's store
+            out = open(os.path.join(directory, f"a{k}_r{r}.out"), "w")
+            err = open(os.path.join(directory, f"a{k}_r{r}.err"), "w")
+            procs[r] = (subprocess.Popen(child_command(argv, host, transport, directory, k), env=env, stdout=out, stderr=err), out, err)
+        for r, (p, out, err) in procs.items():
+            left = max(1.0, timeouts[host] - (time.time() - t0))
+            try:
+                rc = p.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                p.kill()                # this exact child, nothing else
+                p.wait()
+                rc = -9
+            out.close(); err.close()
+            tmp = os.path.join(directory, f"a{k}_rc{r}.tmp")
+            with open(tmp, "w") as fh:
+                fh.write(str(rc))
+            os.replace(tmp, os.path.join(directory, f"a{k}_rc{r}"))
+        # the outcome of the attempt = every rank's return code (other parents write theirs)
+        rcs, t_wait = {}, time.time()
+        while len(rcs) < n and time.time() - t_wait < timeouts[host] + 60.0:
+            for r in range(n):
+                path = os.path.join(directory, f"a{k}_rc{r}")
+                if r not in rcs and os.path.exists(path):
+                    rcs[r] = int(open(path).read().strip() or "1")
+            if len(rcs) < n:
+                time.sleep(0.05)
+        ok = len(rcs) == n and all(v == 0 for v in rcs.values())
+        rec = {"host": host, "transport": transport, "ok": ok, "seconds": round(time.time() - t0, 2),
+               "return_codes": [rcs.get(r) for r in range(n)]}
+        line = None
+        try:
+            for raw in open(os.path.join(directory, f"a{k}_r0.out")):
+                if raw.lstrip().startswith("{"):
+                    line = json.loads(raw)
+        except (OSError, ValueError):
+            pass
+        if host == "preflight":
+            if line:
+                rec.update({kk: line[kk] for kk in ("known_answers", "latencies_rank0") if kk in line})
+            ok = ok and bool(line and line.get("known_answers"))
+            rec["ok"] = ok
+            if not ok:
+                rccl_ok = False
+                if not rehearsal and ("native", "shm") not in queue:
+                    queue.append(("native", "shm"))     # still a multi-GPU run, host-staged: a curve and a diagnosis instead of nothing
+        elif ok and line and line.get("replicas_identical", True):
+            rec.update({"value": line["value"], "replicas_identical": line.get("replicas_identical")})
+            lines.append(line)
+        else:
+            rec["ok"] = False
+            if line:
+                rec["replicas_identical"] = line.get("replicas_identical")
+        if not rec["ok"] and "skipped" not in rec:
+            for r in sorted(set(my_ranks) & {rr for rr, v in rcs.items() if v != 0} or set(my_ranks[:1])):
+                try:
+                    tail = open(os.path.join(directory, f"a{k}_r{r}.err")).read()[-1500:]
+                    rec.setdefault("stderr_tail", {})[str(r)] = tail
+                except OSError:
+                    pass
+        tried.append(rec)
+        k += 1
+    if 0 not in my_ranks:
+        return 0 if lines else 1
+    if not lines:
+        sys.stderr.write(json.dumps({"error": "no attempt produced a valid line", "hosts_tried": tried}, indent=1) + "\n")
+        return 1
+    best = max(lines, key=lambda d: d["value"])
+    best["hosts_tried"] = tried
+    print(json.dumps(best), flush=True)
+    return 0
+
+
+def run_directory(n):
+    """A directory every participating parent derives alike: under torch.distributed.run from its run id and port, otherwise
+    fresh."""
+    import tempfile
+    port, run_id = os.environ.get("MASTER_PORT"), os.environ.get("TORCHELASTIC_RUN_ID")
+    if "WORLD_SIZE" in os.environ and port:
+        return os.path.join(tempfile.gettempdir(), f"frog_bench_{os.getuid()}_{port}_{run_id or 'x'}_{os.getppid()}")
+    return tempfile.mkdtemp(prefix="frog_bench_")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed iterations; default = the reference's schedule for the configuration (650 for config 3: "
+                         "-li 50 -dl 3 -di 200), 130 for config 5")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: 3 (default, the one the metric is quoted on), 2 (linear only), 5 (500 images)")
+    ap.add_argument("--levels", type=int, default=None, help="deformable levels (default: the configuration's)")
+    ap.add_argument("--images", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--pairs-per-block", type=float, default=None)
+    ap.add_argument("--host", choices=("native", "torch"), default="native",
+                    help="N = 1: which loop drives the timed region (native: frog_run_schedule in C, the default; torch: the Python "
+                         "loop).  N > 1 tries both (FROG_BENCH_HOSTS restricts)")
+    ap.add_argument("--shard-of", type=int, nargs=2, metavar=("R", "N"), default=None,
+                    help="single-GPU proxy of rank R of an N-GPU run: this process owns shard R of N, no collective is "
+                         "issued, the other ranks' images stand still (where, see --proxy-partners); prints per-phase kernel "
+                         "times of that rank's share (not a metric line)")
+    ap.add_argument("--proxy-partners", choices=("registered", "static"), default="registered",
+                    help="--shard-of: the other ranks' coordinates and mixtures are those a full single-context run of the "
+                         "default schedule ends with (registered: every image in the common frame, as a real rank sees its "
+                         "partners -- partner points lie where the own points are, the sweeps' gathers are local) or stay "
+                         "where the set-up left them (static: unregistered partners, mixtures of other images zero)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-times", action="store_true",
+                    help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
+    ap.add_argument("--child", choices=("preflight", "native", "torch"), default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-transport", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-attempt", type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    argv = [a for a in sys.argv[1:]]
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if args.child:                                  # a rank of one attempt
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        rdv = Rendezvous(args.child_dir, args.child_attempt, rank, world)
+        if args.child == "preflight":
+            line, good = run_preflight(rank, world, local_rank, args.child_transport, rdv)
+        elif args.child == "native":
+            line, good = run_native(args, rank, world, local_rank, args.child_transport, rdv)
+        else:
+            line, good = run_torch(args, rank, world, local_rank, args.child_transport, rdv)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        raise SystemExit(0 if good else 3)
+
+    if args.gpus > 1:
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            # a rank started by torch.distributed.run: this process stays off the GPU and runs its rank of every attempt as a child
+            if world != args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+            os.environ["FROG_BENCH_UNDER_TORCHRUN"] = "1"
+            raise SystemExit(orchestrate(args, argv, world, [rank], run_directory(world)))
+        if os.environ.get("FROG_BENCH_LAUNCH_DRY_RUN") == "1":
+            d = "<run directory>"
+            print(json.dumps({"attempts": [{"host": h, "transport": t, "command": child_command(argv, h, t, d, i)}
+                                           for i, (h, t) in enumerate(attempts_plan(os.environ.get("FROG_BENCH_BACKEND", "nccl") != "nccl"))],
+                              "ranks": list(range(args.gpus))}), flush=True)
+            raise SystemExit(0)
+        # plain `python bench.py --gpus N`: this process is the launcher of every rank (nothing has touched the GPU yet)
+        raise SystemExit(orchestrate(args, argv, args.gpus, list(range(args.gpus)), run_directory(args.gpus)))
+
+    if world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.host == "torch":
+        if args.shard_of:
+            raise SystemExit("--shard-of runs through the C loop (--host native)")
+        line, _ = run_torch(args, 0, 1, local_rank, "nccl", None)
+    else:
+        line, _ = run_native(args, 0, 1, local_rank, None, None)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -106,6 +106,33 @@ class FrogKernelTime(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64)]
 
 
+SCHEDULE_MAX_LEVELS, SCHEDULE_MAX_LATTICES, FROG_K_COUNT = 16, 512, 10
+
+
+class FrogSchedulePlan(C.Structure):
+    """frog_schedule_plan (include/frog_host.h)."""
+    _fields_ = [("plan_bytes", C.c_uint32), ("result_bytes", C.c_uint32),
+                ("warmup_linear", C.c_int32), ("linear", C.c_int32), ("n_levels", C.c_int32),
+                ("per_level", C.c_int32 * SCHEDULE_MAX_LEVELS), ("stat_interval", C.c_int32),
+                ("deformable_alpha", C.c_float), ("anchor", C.c_float * 3), ("profile", C.c_int32), ("time_comm", C.c_int32),
+                ("proxy_xyz2", C.c_void_p), ("proxy_em", C.c_void_p)]
+
+
+class FrogScheduleLattice(C.Structure):
+    _fields_ = [("level", C.c_int32), ("dims", C.c_int32 * 3), ("iterations", C.c_int32), ("setup_host_s", C.c_double)]
+
+
+class FrogScheduleResult(C.Structure):
+    """frog_schedule_result (include/frog_host.h)."""
+    _fields_ = [("elapsed_s", C.c_double), ("phase_s", C.c_double * (1 + SCHEDULE_MAX_LEVELS)),
+                ("iterations", C.c_int32), ("grids_per_level", C.c_int32 * SCHEDULE_MAX_LEVELS), ("n_lattices", C.c_int32),
+                ("lattices", FrogScheduleLattice * SCHEDULE_MAX_LATTICES), ("final_E", C.c_double),
+                ("kernels", FrogKernelTime * FROG_K_COUNT),
+                ("kernels_by_phase", (FrogKernelTime * FROG_K_COUNT) * (1 + SCHEDULE_MAX_LEVELS)),
+                ("comm_ms", C.c_double * 4), ("comm_calls", C.c_uint64 * 4), ("comm_sampled", C.c_uint64 * 4),
+                ("replica_hash", C.c_uint64)]
+
+
 FROG_K_NAMES = ["sweep_linear", "sweep_deformable", "scatter", "lattice", "transform", "stats", "combine", "cull", "sweep_build", "sweep_linear_build"]
 FROG_OK, FROG_E_INVALID, FROG_E_NODEVICE, FROG_E_HIP, FROG_E_STATE, FROG_E_NOMEM, FROG_E_IO = range(7)
 FROG_BUF_XYZ2, FROG_BUF_EM, FROG_BUF_ENERGY, FROG_BUF_GRIDSUM = range(4)
@@ -169,6 +196,7 @@ HIP_SYMBOLS = {
     "frog_get_linear": (C.c_int, [C.c_void_p, C.c_uint32, c_double_p]),
     "frog_get_em": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
     "frog_set_em": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
+    "frog_set_em_rows": (C.c_int, [C.c_void_p, c_float_p, C.c_uint32, C.c_uint32]),
     "frog_get_samples": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, c_u32_p, C.c_int, C.POINTER(C.c_int)]),
     "frog_get_histogram": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, C.c_int, C.POINTER(C.c_int)]),
     "frog_num_grids": (C.c_int, [C.c_void_p]),
@@ -254,6 +282,25 @@ HOST_SYMBOLS = {
     "frog_transform_links": (C.POINTER(FrogChainLink), [C.c_void_p]),
     "frog_volume_geometry": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p]),
     "frog_nifti_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), c_double_p, c_double_p, C.c_uint32, c_float_p]),
+    "frog_run_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FrogSchedulePlan), C.POINTER(FrogScheduleResult)]),
+}
+
+# include/frog_comm.h (libfrog_comm.so: RCCL; loaded only by hosts that shard over GPUs from C)
+COMM_SYMBOLS = {
+    "frog_comm_create_rccl": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "frog_comm_create_loopback": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "frog_comm_create_rank": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_comm_set_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "frog_comm_destroy_all": (None, [C.c_int, C.POINTER(C.c_void_p)]),
+    "frog_comm_bind": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p]),
+    "frog_comm_all_gather_xyz2": (C.c_int, [C.c_void_p]),
+    "frog_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_comm_all_reduce_bounds": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "frog_comm_barrier": (C.c_int, [C.c_void_p]),
+    "frog_comm_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_comm_timing_read": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 
@@ -273,6 +320,16 @@ def _load(name, symbols):
 
 _hip = None
 _host = None
+_comm = None
+
+
+def comm_lib():
+    """libfrog_comm.so (maps RCCL): only for hosts that shard over GPUs through include/frog_comm.h."""
+    global _comm
+    if _comm is None:
+        hip_lib()
+        _comm = _load("libfrog_comm.so", COMM_SYMBOLS)
+    return _comm
 
 
 def hip_lib():

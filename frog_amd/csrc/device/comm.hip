@@ -9,8 +9,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -48,6 +56,18 @@ struct Shared {
     std::vector<std::vector<unsigned char>> stage;      // one buffer per rank
     std::vector<float> xyz2_all;
     double box[64][6];
+    // host-staged collectives ACROSS PROCESSES (frog_comm_create_shm): a control block and a data area in POSIX shared memory
+    struct ShmCtl {
+        std::atomic<uint32_t> arrived, generation;
+        double box[64][6];
+    };
+    bool shm = false;
+    std::string shm_name;
+    ShmCtl *ctl = nullptr;
+    unsigned char *area = nullptr;      // current data area (n slots of area_slot bytes), re-created larger on demand
+    size_t area_bytes = 0;
+    unsigned area_seq = 0;
+    double barrier_timeout_s = 120.0;
 };
 
 int comm_fail(int code, const std::string &msg)
@@ -78,7 +98,88 @@ struct frog_comm {
     hipStream_t stream = nullptr;
     double *d_box = nullptr;        // [6] max xyz, -min xyz
     double *h_box = nullptr;        // pinned
+    // device time of the collectives (frog_comm_timing): every TIMING_SAMPLE-th call of a kind is bracketed by an event pair
+    bool timing = false;
+    struct Timed { hipEvent_t a, b; int kind; };
+    std::vector<Timed> timed;
+    uint64_t calls[4] = {}, sampled[4] = {};
+    double ms[4] = {};
 };
+
+namespace {
+constexpr int TIMING_SAMPLE = 8;
+// kinds: 0 all_gather_xyz2, 1 all_reduce EM, 2 all_reduce ENERGY, 3 all_reduce GRIDSUM
+struct TimeSpan {
+    frog_comm *c; hipEvent_t a = nullptr, b = nullptr; int kind;
+    TimeSpan(frog_comm *comm, int k) : c(comm), kind(k)
+    {
+        if (!c->timing || !c->stream) { c = nullptr; return; }
+        if (c->calls[k]++ % TIMING_SAMPLE) { c = nullptr; return; }
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { c = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~TimeSpan() { if (c) { (void)hipEventRecord(b, c->stream); c->timed.push_back({ a, b, kind }); } }
+};
+
+// barrier between the ranks' PROCESSES: sense reversal on two counters in shared memory; bounded (a rank that died must not
+// leave the others spinning for ever)
+int shm_barrier(Shared &sh)
+{
+    Shared::ShmCtl *ctl = sh.ctl;
+    const uint32_t g = ctl->generation.load(std::memory_order_acquire);
+    if (ctl->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)sh.n) {
+        ctl->arrived.store(0, std::memory_order_relaxed);
+        ctl->generation.fetch_add(1, std::memory_order_release);
+        return FROG_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (ctl->generation.load(std::memory_order_acquire) == g) {
+        if ((++spins & 63u) == 0u) sched_yield();
+        if ((spins & 0xFFFFu) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sh.barrier_timeout_s)
+            return comm_fail(FROG_E_STATE, "shared-memory barrier timed out: a rank is missing");
+    }
+    return FROG_OK;
+}
+
+void *shm_map(const std::string &name, size_t bytes, bool create, std::string &err)
+{
+    int fd = shm_open(name.c_str(), create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { err = "shm_open " + name + ": " + strerror(errno); return nullptr; }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { err = "ftruncate " + name + ": " + strerror(errno); close(fd); return nullptr; }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { err = "mmap " + name + ": " + strerror(errno); return nullptr; }
+    return p;
+}
+
+// a data area of at least `bytes`, the same on every rank (all ranks make the same calls in the same order): rank 0 creates
+// the larger segment, the others attach to it
+int shm_area(Shared &sh, int rank, size_t bytes)
+{
+    if (sh.area_bytes >= bytes) return FROG_OK;
+    int rc = shm_barrier(sh);           // nobody still reads the old area
+    if (rc) return rc;
+    const size_t want = std::max(bytes, (size_t)1 << 20) * 2;
+    const std::string old_name = sh.shm_name + "_d" + std::to_string(sh.area_seq);
+    if (sh.area) { munmap(sh.area, sh.area_bytes); sh.area = nullptr; if (rank == 0) shm_unlink(old_name.c_str()); }
+    sh.area_seq++;
+    const std::string name = sh.shm_name + "_d" + std::to_string(sh.area_seq);
+    std::string err;
+    if (rank == 0) {
+        sh.area = (unsigned char *)shm_map(name, want, true, err);
+        if (!sh.area) return comm_fail(FROG_E_HIP, err);
+    }
+    rc = shm_barrier(sh);
+    if (rc) return rc;
+    if (rank != 0) {
+        sh.area = (unsigned char *)shm_map(name, want, false, err);
+        if (!sh.area) return comm_fail(FROG_E_HIP, err);
+    }
+    sh.area_bytes = want;
+    return shm_barrier(sh);
+}
+} // namespace
 
 extern "C" {
 
@@ -150,6 +251,71 @@ int frog_comm_create_rank(int n, int rank, const unsigned char id_in[128], int d
     return FROG_OK;
 }
 
+int frog_comm_create_shm(int n, int rank, const char *name, int device, frog_comm **out)
+{
+    if (n < 1 || n > 64 || rank < 0 || rank >= n || !name || !name[0] || !out) return comm_fail(FROG_E_INVALID, "bad communicator arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return comm_fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return comm_fail(FROG_E_INVALID, "device index out of range");
+    auto sh = std::make_shared<Shared>();
+    sh->n = n; sh->rccl = false; sh->shm = true; sh->one_rank_per_process = true; sh->barrier.n = 1;
+    sh->row_begin.assign(n, 0); sh->row_end.assign(n, 0);
+    sh->shm_name = std::string(name[0] == '/' ? "" : "/") + name;
+    std::string err;
+    // rank 0 creates the control block (zero-filled by ftruncate); the others wait for it to appear
+    const std::string ctl_name = sh->shm_name + "_ctl";
+    if (rank == 0) {
+        shm_unlink(ctl_name.c_str());
+        sh->ctl = (Shared::ShmCtl *)shm_map(ctl_name, sizeof(Shared::ShmCtl), true, err);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!sh->ctl) {
+            struct stat st;
+            int fd = shm_open(ctl_name.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                const bool ready = fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(Shared::ShmCtl);
+                close(fd);
+                if (ready) { sh->ctl = (Shared::ShmCtl *)shm_map(ctl_name, sizeof(Shared::ShmCtl), false, err); break; }
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sh->barrier_timeout_s) { err = "rank 0 never created " + ctl_name; break; }
+            usleep(2000);
+        }
+    }
+    if (!sh->ctl) return comm_fail(FROG_E_HIP, err);
+    frog_comm *c = new frog_comm;
+    c->sh = sh; c->rank = rank; c->device = device;
+    *out = c;
+    const int rc = shm_barrier(*sh);            // everybody is attached
+    if (rc) { delete c; *out = nullptr; return rc; }
+    if (rank == 0) shm_unlink(ctl_name.c_str());        // the mappings keep it alive; nothing is left behind in /dev/shm
+    return FROG_OK;
+}
+
+int frog_comm_timing(frog_comm *c, int on)
+{
+    if (!c) return comm_fail(FROG_E_INVALID, "null communicator");
+    c->timing = on != 0;
+    return FROG_OK;
+}
+
+int frog_comm_timing_read(frog_comm *c, double ms_out[4], uint64_t calls_out[4], uint64_t sampled_out[4])
+{
+    if (!c) return comm_fail(FROG_E_INVALID, "null communicator");
+    if (c->stream || c->ctx) { COMM_HIP(hipSetDevice(c->device)); COMM_HIP(hipStreamSynchronize(c->stream)); }
+    for (auto &t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { c->ms[t.kind] += (double)ms; c->sampled[t.kind]++; }
+        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    }
+    c->timed.clear();
+    for (int k = 0; k < 4; k++) {
+        if (ms_out) ms_out[k] = c->ms[k];
+        if (calls_out) calls_out[k] = c->calls[k];
+        if (sampled_out) sampled_out[k] = c->sampled[k];
+    }
+    return FROG_OK;
+}
+
 int frog_comm_set_rows(frog_comm *c, const uint64_t *row_begin)
 {
     if (!c || !row_begin) return comm_fail(FROG_E_INVALID, "null argument");
@@ -170,6 +336,12 @@ void frog_comm_destroy_all(int n, frog_comm **comms)
         if (c->d_box) (void)hipFree(c->d_box);
         if (c->h_box) (void)hipHostFree(c->h_box);
         if (c->nccl) (void)ncclCommDestroy(c->nccl);
+        for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        if (c->sh && c->sh->shm) {
+            Shared &sh = *c->sh;
+            if (sh.area) { munmap(sh.area, sh.area_bytes); if (c->rank == 0) shm_unlink((sh.shm_name + "_d" + std::to_string(sh.area_seq)).c_str()); sh.area = nullptr; }
+            if (sh.ctl) { munmap(sh.ctl, sizeof(Shared::ShmCtl)); sh.ctl = nullptr; }
+        }
         delete c;
         comms[r] = nullptr;
     }
@@ -204,6 +376,10 @@ int frog_comm_bind(frog_comm *c, frog_ctx *ctx, const uint32_t *image_begin)
 int frog_comm_barrier(frog_comm *c)
 {
     if (!c) return comm_fail(FROG_E_INVALID, "null communicator");
+    if (c->sh->shm) {
+        if (c->ctx) { COMM_HIP(hipSetDevice(c->device)); COMM_HIP(hipStreamSynchronize(c->stream)); }
+        return shm_barrier(*c->sh);
+    }
     if (c->sh->one_rank_per_process) {
         // across processes: a one-element all-reduce, awaited
         if (!c->d_box || !c->ctx) return comm_fail(FROG_E_STATE, "communicator not bound");      // (the stream may be the null stream)
@@ -227,6 +403,23 @@ int frog_comm_all_gather_xyz2(frog_comm *c)
     if (rc) return rc;
     float *base = (float *)p;
     Shared &sh = *c->sh;
+    TimeSpan span(c, 0);
+    if (sh.shm) {
+        // across processes, host-staged: own rows -> the shared table, barrier, the other ranks' rows <- the shared table
+        rc = shm_area(sh, c->rank, bytes);
+        if (rc) return rc;
+        const size_t b = sh.row_begin[c->rank], e = sh.row_end[c->rank];
+        if (e > b) COMM_HIP(hipMemcpyAsync(sh.area + 3 * b * sizeof(float), base + 3 * b, (e - b) * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        rc = shm_barrier(sh);
+        if (rc) return rc;
+        // the rows before and after the own ones are contiguous in the table: two copies
+        if (b > 0) COMM_HIP(hipMemcpyAsync(base, sh.area, 3 * b * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        const size_t P = bytes / (3 * sizeof(float));
+        if (e < P) COMM_HIP(hipMemcpyAsync(base + 3 * e, sh.area + 3 * e * sizeof(float), 3 * (P - e) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        return shm_barrier(sh);         // nobody overwrites its rows before everybody has read them
+    }
     if (sh.rccl) {
         // ragged shards: rank q broadcasts its rows, in place (send = receive = the rows' place in the replica);
         // the n broadcasts are one grouped operation
@@ -270,6 +463,27 @@ int frog_comm_all_reduce(frog_comm *c, int which)
     const bool f32 = which == FROG_BUF_EM;
     const size_t count = bytes / (f32 ? sizeof(float) : sizeof(double));
     Shared &sh = *c->sh;
+    TimeSpan span(c, which == FROG_BUF_EM ? 1 : which == FROG_BUF_ENERGY ? 2 : 3);
+    if (sh.shm) {
+        // across processes, host-staged: every rank's buffer into its slot, barrier, every rank adds the slots in rank order
+        rc = shm_area(sh, c->rank, bytes * (size_t)sh.n);
+        if (rc) return rc;
+        COMM_HIP(hipMemcpyAsync(sh.area + bytes * (size_t)c->rank, p, bytes, hipMemcpyDeviceToHost, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        rc = shm_barrier(sh);
+        if (rc) return rc;
+        std::vector<unsigned char> out(bytes);
+        if (f32) {
+            float *o = (float *)out.data();
+            for (size_t k = 0; k < count; k++) { float s = 0; for (int q = 0; q < sh.n; q++) s += ((const float *)(sh.area + bytes * (size_t)q))[k]; o[k] = s; }
+        } else {
+            double *o = (double *)out.data();
+            for (size_t k = 0; k < count; k++) { double s = 0; for (int q = 0; q < sh.n; q++) s += ((const double *)(sh.area + bytes * (size_t)q))[k]; o[k] = s; }
+        }
+        COMM_HIP(hipMemcpyAsync(p, out.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        return shm_barrier(sh);         // nobody refills its slot before everybody has read it
+    }
     if (sh.rccl) {
         COMM_NCCL(ncclAllReduce(p, p, count, f32 ? ncclFloat : ncclDouble, ncclSum, c->nccl, c->stream));
         return FROG_OK;
@@ -296,6 +510,17 @@ int frog_comm_all_reduce_bounds(frog_comm *c, double mins[3], double maxs[3])
     if (!c || !c->ctx || !mins || !maxs) return comm_fail(FROG_E_INVALID, "communicator not bound");
     if (c->sh->n == 1) return FROG_OK;
     Shared &sh = *c->sh;
+    if (sh.shm) {
+        for (int k = 0; k < 3; k++) { sh.ctl->box[c->rank][k] = mins[k]; sh.ctl->box[c->rank][3 + k] = maxs[k]; }
+        int rc = shm_barrier(sh);
+        if (rc) return rc;
+        for (int q = 0; q < sh.n; q++)
+            for (int k = 0; k < 3; k++) {
+                if (sh.ctl->box[q][k] < mins[k]) mins[k] = sh.ctl->box[q][k];
+                if (sh.ctl->box[q][3 + k] > maxs[k]) maxs[k] = sh.ctl->box[q][3 + k];
+            }
+        return shm_barrier(sh);
+    }
     if (sh.rccl) {
         COMM_HIP(hipSetDevice(c->device));
         for (int k = 0; k < 3; k++) { c->h_box[k] = maxs[k]; c->h_box[3 + k] = -mins[k]; }

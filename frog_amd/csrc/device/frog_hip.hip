@@ -1826,6 +1826,16 @@ int frog_set_em(frog_ctx *ctx, uint32_t image, const float in[3])
     return frog_stats_publish(ctx);
 }
 
+int frog_set_em_rows(frog_ctx *ctx, const float *table4, uint32_t image_begin, uint32_t image_end)
+{
+    CTX_GUARD(ctx);
+    if (!table4 || image_begin > image_end || image_end > ctx->nI) return fail(FROG_E_INVALID, "bad rows");
+    if (image_end > image_begin)
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->em.p + image_begin, table4 + 4 * (size_t)image_begin, (size_t)(image_end - image_begin) * sizeof(float4),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    return FROG_OK;
+}
+
 int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *ordinals, int cap, int *n)
 {
     CTX_GUARD(ctx);

@@ -24,42 +24,35 @@
 
 #include "../../../include/frog_comm.h"
 
-// libfrog_comm.so (RCCL) is loaded on demand, for -ng / -ngl only: a process that brings its own communicator (the Python
-// drivers over torch.distributed) uses this library without ever mapping a second RCCL.
-namespace {
-struct CommApi {
-    decltype(&frog_comm_create_rccl) create_rccl = nullptr;
-    decltype(&frog_comm_create_loopback) create_loopback = nullptr;
-    decltype(&frog_comm_destroy_all) destroy_all = nullptr;
-    decltype(&frog_comm_bind) bind = nullptr;
-    decltype(&frog_comm_all_gather_xyz2) all_gather_xyz2 = nullptr;
-    decltype(&frog_comm_all_reduce) all_reduce = nullptr;
-    decltype(&frog_comm_all_reduce_bounds) all_reduce_bounds = nullptr;
-    decltype(&frog_comm_barrier) barrier = nullptr;
-    bool load(std::string &err)
-    {
-        if (create_rccl) return true;
-        Dl_info info;
-        std::string dir;
-        if (dladdr((void *)&frog_pairs_read, &info) && info.dli_fname) {
-            dir = info.dli_fname;
-            const size_t slash = dir.rfind('/');
-            dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
-        }
-        void *h = dlopen((dir + "libfrog_comm.so").c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("libfrog_comm.so", RTLD_NOW | RTLD_LOCAL);
-        if (!h) { err = dlerror(); return false; }
-#define LOAD(field, name) field = (decltype(field))dlsym(h, name); if (!field) { err = std::string("missing symbol ") + name; return false; }
-        LOAD(create_rccl, "frog_comm_create_rccl"); LOAD(create_loopback, "frog_comm_create_loopback");
-        LOAD(destroy_all, "frog_comm_destroy_all"); LOAD(bind, "frog_comm_bind");
-        LOAD(all_gather_xyz2, "frog_comm_all_gather_xyz2"); LOAD(all_reduce, "frog_comm_all_reduce");
-        LOAD(all_reduce_bounds, "frog_comm_all_reduce_bounds"); LOAD(barrier, "frog_comm_barrier");
-#undef LOAD
-        return true;
+#include "comm_api.h"
+
+// libfrog_comm.so (RCCL) is loaded on demand, for -ng / -ngl and frog_run_schedule only: a process that brings its own
+// communicator (the Python drivers over torch.distributed) uses this library without ever mapping a second RCCL.
+bool CommApi::load(std::string &err)
+{
+    if (create_rccl) return true;
+    Dl_info info;
+    std::string dir;
+    if (dladdr((void *)&frog_pairs_read, &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
     }
-};
-CommApi g_comm;
+    void *h = dlopen((dir + "libfrog_comm.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libfrog_comm.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { err = dlerror(); return false; }
+#define LOAD(field, name) field = (decltype(field))dlsym(h, name); if (!field) { err = std::string("missing symbol ") + name; return false; }
+    LOAD(create_loopback, "frog_comm_create_loopback");
+    LOAD(destroy_all, "frog_comm_destroy_all"); LOAD(bind, "frog_comm_bind");
+    LOAD(all_gather_xyz2, "frog_comm_all_gather_xyz2"); LOAD(all_reduce, "frog_comm_all_reduce");
+    LOAD(all_reduce_bounds, "frog_comm_all_reduce_bounds"); LOAD(barrier, "frog_comm_barrier");
+    LOAD(timing, "frog_comm_timing"); LOAD(timing_read, "frog_comm_timing_read");
+    LOAD(create_rccl, "frog_comm_create_rccl");
+#undef LOAD
+    return true;
 }
+CommApi &host_comm_api() { static CommApi api; return api; }
+#define g_comm (host_comm_api())
 
 using std::cout;
 using std::endl;

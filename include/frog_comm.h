@@ -47,6 +47,12 @@ int frog_comm_create_loopback(int n_ranks, frog_comm **out);
  * range of every rank, which one process reads from its contexts, has to be told: frog_comm_set_rows. */
 int frog_comm_unique_id(unsigned char id_out[128]);
 int frog_comm_create_rank(int n_ranks, int rank, const unsigned char id[128], int device, frog_comm **out);
+/* The same one-process-per-rank interface WITHOUT RCCL: the collectives are staged through POSIX shared memory on the host
+ * (named `name`, which every rank of the run passes; rank 0 creates it, nothing is left in /dev/shm afterwards) and a
+ * barrier between the ranks' processes that gives up after two minutes.  Ranks may share a device.  What it is for: rehearsing the
+ * one-process-per-GPU host on a box with a single GPU, and the fallback that still yields a (host-staged) multi-GPU run
+ * when RCCL itself does not come up.  frog_comm_bind / frog_comm_set_rows / the collectives work as for frog_comm_create_rank. */
+int frog_comm_create_shm(int n_ranks, int rank, const char *name, int device, frog_comm **out);
 /* row_begin[r] .. row_begin[r + 1] = the xyz2 rows (points) of rank r; n_ranks + 1 entries.  Call after frog_comm_bind. */
 int frog_comm_set_rows(frog_comm *comm, const uint64_t *row_begin);
 /* Destroys all n communicators of one create call (pass the array it filled; n = 1 for frog_comm_create_rank). */
@@ -65,6 +71,11 @@ int frog_comm_all_reduce(frog_comm *comm, int which);
 int frog_comm_all_reduce_bounds(frog_comm *comm, double mins[3], double maxs[3]);
 /* host-side barrier between the ranks' threads (both kinds) */
 int frog_comm_barrier(frog_comm *comm);
+/* Device time of the collectives: with on != 0 every eighth call of a kind is bracketed by a pair of HIP events on the
+ * context's stream.  frog_comm_timing_read waits for the stream and returns, per kind (0 all_gather_xyz2, 1 all_reduce of
+ * FROG_BUF_EM, 2 of FROG_BUF_ENERGY, 3 of FROG_BUF_GRIDSUM): the milliseconds of the sampled calls, all calls, sampled calls. */
+int frog_comm_timing(frog_comm *comm, int on);
+int frog_comm_timing_read(frog_comm *comm, double ms[4], uint64_t calls[4], uint64_t sampled[4]);
 
 #ifdef __cplusplus
 }

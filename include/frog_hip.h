@@ -119,6 +119,10 @@ int frog_get_points2_subset(frog_ctx *ctx, const uint64_t *points, size_t n, flo
 int frog_get_linear(frog_ctx *ctx, uint32_t image, double matrix16[16]);
 int frog_get_em(frog_ctx *ctx, uint32_t image, float c1_c2_ratio[3]);
 int frog_set_em(frog_ctx *ctx, uint32_t image, const float c1_c2_ratio[3]);
+/* Rows [image_begin, image_end) of the mixture table from a host table of n_images x 4 floats (c1, c2, ratio, 0), queued on the
+ * context's stream; NOT followed by frog_stats_publish.  For a host that stands in for the all-reduce of FROG_BUF_EM
+ * (a single-process proxy of one rank of a sharded run: the other ranks' rows come from a table handed in). */
+int frog_set_em_rows(frog_ctx *ctx, const float *table4, uint32_t image_begin, uint32_t image_end);
 /* Retained samples of the last refresh, and the ordinal (position in the
  * image's half-link traversal) each one was drawn from. */
 int frog_get_samples(frog_ctx *ctx, uint32_t image, float *samples, uint32_t *ordinals,

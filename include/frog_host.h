@@ -20,6 +20,7 @@
 #define FROG_HOST_H
 
 #include "frog_types.h"
+#include "frog_hip.h"
 #include "frog_match.h"
 #include "frog_chain.h"
 
@@ -88,6 +89,63 @@ int frog_pairs_append_points(frog_pairs *p, uint32_t image, const float *xyz, ui
  * images, whose keypoints are moved to their registered position before the solve
  * (readAndApplyFixedImagesTransforms, imageGroup.cxx:1419-1456: `xyz := T(xyz)`). */
 int frog_pairs_set_points(frog_pairs *p, uint32_t image, const float *xyz);
+
+/* ---- one rank's share of a timed schedule --------------------------------------------------------------------------
+ * The loops of ImageGroup::run (imageGroup.cxx:54-66, :78-128) for ONE context, timed: what `bench.py` measures, without
+ * an interpreter between two iterations.  `comm` = NULL: the context owns the whole group (or is a stand-alone proxy of one
+ * rank: see proxy_*), no collective is issued; otherwise the context's communicator of include/frog_comm.h (one process per
+ * GPU: frog_comm_create_rank over RCCL, or frog_comm_create_shm), bound to `ctx`, and the places where the reference's loops
+ * read another image's state are its collectives, exactly as in `bin/frog -ng N` (image_group.cpp runSharded).
+ *
+ * Sequence: setupLinearTransforms, transformPoints, warmup_linear untimed linear iterations; then, between two barriers
+ * (frog_comm_barrier + frog_synchronize), `linear` linear iterations, transformPoints(apply), and for every level with
+ * per_level[l] > 0 a lattice set-up and per_level[l] ACCEPTED deformable iterations with the reference's regrid /
+ * alpha-halving state machine and re-basing; updateStats whenever the iteration counter of its loop is a multiple of
+ * stat_interval (the linear counter runs on from the warm-up, as in run()). */
+#define FROG_SCHEDULE_MAX_LEVELS 16
+#define FROG_SCHEDULE_MAX_LATTICES 512
+typedef struct frog_schedule_plan {
+    uint32_t plan_bytes, result_bytes;      /* sizeof(frog_schedule_plan), sizeof(frog_schedule_result) as the CALLER sees them:
+                                             * a binding whose layout differs is refused instead of being misread     */
+    int32_t warmup_linear;
+    int32_t linear;
+    int32_t n_levels;
+    int32_t per_level[FROG_SCHEDULE_MAX_LEVELS];
+    int32_t stat_interval;          /* statIntervalUpdate, 10                                         */
+    float   deformable_alpha;       /* 0.02                                                           */
+    float   anchor[3];              /* linearInitializationAnchor                                     */
+    int32_t profile;                /* frog_profile_enable mode for the timed region: 0, 1 (every kernel group, read per
+                                     * phase behind a device drain) or 2 (the half-link sweeps only)   */
+    int32_t time_comm;              /* frog_comm_timing for the timed region                          */
+    /* stand-alone proxy of one rank (comm = NULL, context owns a sub-range): what the other ranks would send -- their
+     * xyz2 (model order, 3 floats per point of the whole group; own rows ignored) installed once after the first
+     * transformPoints, and their rows of the mixture table (n_images x 4 floats) after every statistics refresh */
+    const float *proxy_xyz2;
+    const float *proxy_em;
+} frog_schedule_plan;
+
+typedef struct frog_schedule_lattice {
+    int32_t level, dims[3], iterations;     /* accepted iterations taken on this lattice */
+    double  setup_host_s;                   /* host time of its set-up call               */
+} frog_schedule_lattice;
+
+typedef struct frog_schedule_result {
+    double   elapsed_s;                                 /* the timed region on this rank's clock, barrier to barrier */
+    double   phase_s[1 + FROG_SCHEDULE_MAX_LEVELS];     /* linear, level 0, level 1, ...                             */
+    int32_t  iterations;                                /* timed iterations done                                     */
+    int32_t  grids_per_level[FROG_SCHEDULE_MAX_LEVELS];
+    int32_t  n_lattices;
+    frog_schedule_lattice lattices[FROG_SCHEDULE_MAX_LATTICES];
+    double   final_E;                                   /* as run() records it: rounded to float                     */
+    frog_kernel_time kernels[FROG_K_COUNT_];            /* frog_profile_read over the timed region                   */
+    frog_kernel_time kernels_by_phase[1 + FROG_SCHEDULE_MAX_LEVELS][FROG_K_COUNT_];     /* profile == 1 only         */
+    double   comm_ms[4];                                /* frog_comm_timing_read                                     */
+    uint64_t comm_calls[4], comm_sampled[4];
+    uint64_t replica_hash;      /* FNV-1a over the bits of this rank's replica of every xyz2 and of the mixture table after a
+                                 * final transformPoints(apply): equal on every rank, whatever carried the collectives       */
+} frog_schedule_result;
+
+int frog_run_schedule(frog_ctx *ctx, struct frog_comm *comm, const frog_schedule_plan *plan, frog_schedule_result *out);
 
 /* ---- NIfTI-1 writer for lattice images ------------------------------------------
  * Replaces vtkNIFTIImageWriter at tools/transformIO.h:196-208 (B-spline coefficient

@@ -40,6 +40,7 @@ def test_comm_library_exports_every_declared_symbol():
     import sys
     names = declared("frog_comm.h")
     assert len(names) >= 8
+    assert sorted(_abi.COMM_SYMBOLS) == names       # the ctypes table of the hosts that shard from C is complete
     code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); "
             "missing = [n for n in sys.argv[2:] if not hasattr(L, n)]; print(missing); sys.exit(1 if missing else 0)")
     r = subprocess.run([sys.executable, "-c", code, os.path.join(_abi.LIB_DIR, "libfrog_comm.so")] + names,
@@ -55,6 +56,18 @@ def test_struct_layouts_match_the_headers():
     assert C.sizeof(_abi.FrogModel) == 8 + 5 * 8
     assert C.sizeof(_abi.FrogKeypoints) == 8 + 5 * 8
     assert C.sizeof(_abi.FrogMatchOptions) == 4 * 4 + 4 * 4
+    # frog_schedule_plan / frog_schedule_result (frog_host.h): the library itself refuses a caller whose sizes differ
+    # (plan_bytes / result_bytes); the sizes a C compiler gives the header, checked where a compiler is at hand
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("g++"):
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "s.cpp")
+            open(src, "w").write('#include "frog_host.h"\n#include <cstdio>\nint main(){printf("%zu %zu", sizeof(frog_schedule_plan), sizeof(frog_schedule_result));}')
+            subprocess.run(["g++", "-I", INC, src, "-o", os.path.join(d, "s")], check=True)
+            a, b = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True).stdout.split()
+        assert (int(a), int(b)) == (C.sizeof(_abi.FrogSchedulePlan), C.sizeof(_abi.FrogScheduleResult))
 
 
 def test_no_cpu_fallback(tiny_pairs):

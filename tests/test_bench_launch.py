@@ -1,7 +1,7 @@
-"""bench.py --gpus N without a launcher around it: the command it would start (dry run: nothing touches a GPU)."""
+"""bench.py --gpus N: the attempts it would run as fresh child processes (dry run: nothing touches a GPU), and the
+launcher's bookkeeping with children that are not GPU programs at all."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -17,36 +17,92 @@ def _dry(args, extra_env=None):
     return r
 
 
-def test_gpus_n_becomes_a_torch_distributed_run_of_n_children():
+def test_gpus_n_becomes_attempts_of_n_fresh_children():
     r = _dry(["--gpus", "4", "--steps", "20", "--warmup", "5"])
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    cmd = out["launch"]
-    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
-    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    port = int(cmd[cmd.index("--master-port") + 1])
-    assert 1024 <= port < 65536
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:        # the port was free when it was chosen
-        sk.bind(("127.0.0.1", port))
-    k = cmd.index(os.path.join(ROOT, "bench.py"))
-    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]      # the caller's arguments, unchanged
-    assert out["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert int(out["env"]["OMP_NUM_THREADS"]) >= 1
+    assert out["ranks"] == [0, 1, 2, 3]
+    hosts = [(a["host"], a["transport"]) for a in out["attempts"]]
+    assert hosts == [("preflight", "rccl"), ("native", "rccl"), ("torch", "nccl")]
+    for i, a in enumerate(out["attempts"]):
+        cmd = a["command"]
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py")
+        assert cmd[2:8] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]          # the caller's arguments, unchanged
+        assert cmd[cmd.index("--child") + 1] == a["host"] and cmd[cmd.index("--child-attempt") + 1] == str(i)
 
 
-def test_a_rank_of_a_launched_run_does_not_launch_again():
-    # WORLD_SIZE set (what torch.distributed.run gives its children) and --gpus disagreeing: an error, not a second launch
+def test_rehearsal_backend_and_host_selection():
+    r = _dry(["--gpus", "2"], {"FROG_BENCH_BACKEND": "gloo", "FROG_BENCH_HOSTS": "native"})
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [(a["host"], a["transport"]) for a in out["attempts"]] == [("native", "shm")]
+
+
+def test_a_rank_of_a_launched_run_checks_its_world_size():
+    # WORLD_SIZE set (what torch.distributed.run gives its children) and --gpus disagreeing: an error, not a launch
     r = _dry(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
-    assert "launch" not in r.stdout
 
 
-def test_launch_command_is_importable_without_torch_or_the_device_library():
+def test_the_launcher_is_importable_without_torch_or_the_device_library():
     code = ("import sys, json; sys.path.insert(0, %r); import bench; "
             "assert 'torch' not in sys.modules and 'frog_amd' not in sys.modules; "
-            "print(json.dumps(bench.launch_command(2, ['--gpus', '2'], port=29555)))" % ROOT)
+            "print(json.dumps(bench.child_command(['--gpus', '2'], 'native', 'rccl', '/tmp/x', 1)))" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     cmd = json.loads(r.stdout)
-    assert cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-8:] == ["--child", "native", "--child-transport", "rccl", "--child-dir", "/tmp/x", "--child-attempt", "1"]
+
+
+def test_orchestrator_with_failing_and_hanging_children(tmp_path, monkeypatch):
+    """The launcher's bookkeeping on children that never touch a GPU: a preflight that fails puts the host-staged attempt
+    in the queue and skips the RCCL ones; a child that hangs is killed at its time-out and reported with its stderr; the
+    line that comes out carries every attempt."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "fake_child.py"
+    fake.write_text(
+        "import json, os, sys, time\n"
+        "a = sys.argv; host = a[a.index('--child') + 1]; tr = a[a.index('--child-transport') + 1]\n"
+        "rank = int(os.environ['RANK'])\n"
+        "if host == 'preflight':\n"
+        "    sys.stderr.write('rccl says no\\n'); sys.exit(5)\n"
+        "if host == 'native' and tr == 'shm':\n"
+        "    if rank == 0: print(json.dumps({'metric': 'm', 'value': 42.0, 'replicas_identical': True}))\n"
+        "    sys.exit(0)\n"
+        "time.sleep(60)\n")
+    monkeypatch.setattr(bench, "child_command", lambda argv, host, tr, d, k: [sys.executable, str(fake), "--child", host, "--child-transport", tr])
+    monkeypatch.setenv("FROG_BENCH_PREFLIGHT_TIMEOUT", "20")
+    monkeypatch.setenv("FROG_BENCH_ATTEMPT_TIMEOUT", "3")
+    monkeypatch.delenv("FROG_BENCH_BACKEND", raising=False)
+    monkeypatch.delenv("FROG_BENCH_HOSTS", raising=False)
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.orchestrate(None, [], 2, [0, 1], str(tmp_path / "run"))
+    assert rc == 0
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert line["value"] == 42.0
+    tried = line["hosts_tried"]
+    assert [(t["host"], t["transport"]) for t in tried] == [("preflight", "rccl"), ("native", "rccl"), ("torch", "nccl"), ("native", "shm")]
+    assert tried[0]["ok"] is False and "rccl says no" in tried[0]["stderr_tail"]["0"]
+    assert tried[1].get("skipped") and tried[2].get("skipped") and tried[3]["ok"] is True
+
+    # a hang: the RCCL preflight passes, the native attempt never returns
+    fake.write_text(
+        "import json, os, sys, time\n"
+        "a = sys.argv; host = a[a.index('--child') + 1]\n"
+        "rank = int(os.environ['RANK'])\n"
+        "if host == 'preflight':\n"
+        "    if rank == 0: print(json.dumps({'preflight': 'rccl', 'known_answers': True, 'latencies_rank0': {}}))\n"
+        "    sys.exit(0)\n"
+        "if host == 'native':\n"
+        "    sys.stderr.write('stuck in a collective\\n'); sys.stderr.flush(); time.sleep(60)\n"
+        "if rank == 0: print(json.dumps({'metric': 'm', 'value': 7.0, 'replicas_identical': True}))\n")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.orchestrate(None, [], 2, [0, 1], str(tmp_path / "run2"))
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    tried = line["hosts_tried"]
+    assert rc == 0 and line["value"] == 7.0
+    assert tried[1]["host"] == "native" and tried[1]["ok"] is False and tried[1]["return_codes"] == [-9, -9]
+    assert "stuck in a collective" in tried[1]["stderr_tail"]["0"] and tried[1]["seconds"] < 10
