@@ -536,3 +536,27 @@ print("native comm ok")
 """
     r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "native comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_native_host_three_ranks_over_shared_memory_matches_one_rank(tmp_path):
+    """bench.py's launcher and the C loop (frog_run_schedule) with three ranks on the one GPU, collectives through the
+    cross-process shared-memory communicator of libfrog_comm (what a box with one GPU can rehearse of `--gpus N`): the
+    preflight's known answers hold, the ranks' replicas are bit-identical and the schedule ends on the energy of the
+    one-rank run."""
+    import sys
+    args = ["--images", "14", "--points", "4000", "--pairs-per-block", "1500", "--steps", "26", "--warmup", "3", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    env.update(FROG_BENCH_BACKEND="gloo", FROG_BENCH_HOSTS="preflight,native")
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", *args], capture_output=True, text=True, timeout=900, env=env)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    three = json.loads(r3.stdout.strip().splitlines()[-1])
+    assert [(t["host"], t["transport"], t["ok"]) for t in three["hosts_tried"]] == [("preflight", "shm", True), ("native", "shm", True)]
+    assert three["hosts_tried"][0]["known_answers"] is True
+    assert three["n_gpus"] == 3 and three["replicas_identical"] is True
+    assert three["config"]["grids_per_level"] == one["config"]["grids_per_level"]
+    assert abs(three["config"]["final_E"] - one["config"]["final_E"]) <= 1e-6 * one["config"]["final_E"]
+    assert set(three["comm_ms"]) == {"all_gather_xyz2", "all_reduce_em", "all_reduce_energy", "all_reduce_gridsum"}
+    assert len(three["ranks"]["elapsed_s"]) == 3
