@@ -237,7 +237,13 @@ struct frog_ctx {
     // the context is created, every refresh consumes one and queues the production of one more.  (Two buffers, i.e. one
     // refresh ahead, put the 2.4 ms replay of the generator on the critical path of a context whose ten iterations take
     // less than that: one rank of eight.)
-    static constexpr int SEL_RING_MAX = 16;
+    // Round 4: the ring holds, as a rule, the selections of a WHOLE run (80 buffers: the reference's default schedule has 65
+    // refreshes, a few more with the guard's regrids; 12 bytes per kept half-link and buffer, up to 1 GB), all replayed at
+    // frog_create, and a refresh queues a new replay only when fewer than SEL_LOW_WATER selections are left -- the 1.5 ms
+    // replay otherwise overlapped the sweeps of every refresh's iteration and cost each a resident block per CU (0.278
+    // instead of 0.250 ms).
+    static constexpr int SEL_RING_MAX = 96;
+    static constexpr int SEL_LOW_WATER = 3;
     int sel_ring = 2;
     frog::DevBuf<uint32_t> sample_ord[SEL_RING_MAX];     // [nOwned][cap]
     frog::DevBuf<uint32_t> sample_count[SEL_RING_MAX];   // [nOwned]

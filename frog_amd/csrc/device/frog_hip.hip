@@ -690,7 +690,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(hipMemsetAsync(c->em_guess.p, 0, c->em_guess.bytes(), s));
     // ring of pre-computed selections (ctx.h): FROG_SELECT_RING buffers (default 6: five refreshes ahead), fewer when they
     // would take more than 1 GB
-    c->sel_ring = 6;
+    c->sel_ring = 80;
     if (const char *e = getenv("FROG_SELECT_RING")) c->sel_ring = atoi(e);
     c->sel_ring = std::max(2, std::min(c->sel_ring, (int)frog_ctx::SEL_RING_MAX));
     while (c->sel_ring > 2 && (size_t)c->sel_ring * c->n_owned() * cap * 12 > ((size_t)1 << 30)) c->sel_ring--;
@@ -819,9 +819,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     }
     scratch_warm_kernel<<<1, 64, 0, s>>>(c->stray.p, 0);
     (void)hipGetLastError();
-    // selections of the first sel_ring - 1 refreshes, ahead of time
+    // selections of the first sel_ring - 1 refreshes, ahead of time -- and awaited: a context leaves frog_create with an idle
+    // side stream (80 replays are 0.12 s of one-block-per-image work that would otherwise run beside the first iterations)
     for (int k = 0; k + 1 < c->sel_ring; k++)
         if (int rc_ = produce_selection(c)) { frog_destroy(c); return rc_; }
+    if (hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
 #undef CREATE_CHECK
     *out = c;
     return FROG_OK;
@@ -1027,8 +1029,15 @@ int frog_update_stats_local(frog_ctx *ctx)
     FROG_HIP_CHECK(hipEventRecord(ctx->ord_read[cur], s));
     ctx->sel_used = cur;
     ctx->sel_consumed++;
-    // one more selection for the ring: into the buffer the PREVIOUS refresh consumed (this one's stays readable: getters)
-    { const int rc = produce_selection(ctx); if (rc) return rc; }
+    // More selections for the ring once it runs low (ctx.h SEL_LOW_WATER), never into the buffer this refresh consumed (it
+    // stays readable: getters): a short ring (FROG_SELECT_RING, or a group whose buffers would not fit) produces one per
+    // refresh as before, a long one never during the schedules it was sized for.
+    if (ctx->sel_produced - ctx->sel_consumed < (uint64_t)std::min((int)frog_ctx::SEL_LOW_WATER, ctx->sel_ring - 1))
+        while (ctx->sel_produced - ctx->sel_consumed < (uint64_t)(ctx->sel_ring - 1)) {
+            const int rc = produce_selection(ctx);
+            if (rc) return rc;
+            if (ctx->sel_ring > 8) break;           // a long ring refills one replay per refresh, spread over the iterations
+        }
     // rows of other ranks' images: zero, so that an all-reduce(sum) completes the table
     if (ctx->ib > 0) FROG_HIP_CHECK(hipMemsetAsync(ctx->em.p, 0, (size_t)ctx->ib * sizeof(float4), s));
     if (ctx->ie < ctx->nI)
