@@ -37,13 +37,44 @@ using namespace frog;
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
-// RAII bracket: records a HIP event pair around the launches issued in its scope.
+// FROG_ROCTX=1: a roctx range around every kernel group (the names of FROG_K_*), for `rocprofv3 --marker-trace`.  The
+// library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so: both export roctxRangePushA / roctxRangePop),
+// so that nothing links against a profiler.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("FROG_ROCTX");
+        if (!e || !atoi(e)) return;
+        for (const char *name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" }) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static Roctx r; return r; }
+const char *const K_GROUP_NAMES[FROG_K_COUNT_] = { "frog:sweep_linear", "frog:sweep_deformable", "frog:scatter", "frog:lattice_step", "frog:transform_points",
+                                                    "frog:update_stats", "frog:combine_energy", "frog:cull_check", "frog:sweep_deformable_build_list",
+                                                    "frog:sweep_linear_build_list" };
+}
+
+// RAII bracket: records a HIP event pair around the launches issued in its scope (frog_profile_enable) and, with FROG_ROCTX=1,
+// a roctx range around their enqueueing.
 struct Span {
     frog_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
     bool attached;          // the events ride on ONE kernel's own dispatch packet (hipExtLaunchKernelGGL) instead of being
                             // recorded around it: no marker packets, so no bubbles before and after the kernel
+    bool range = false;
     Span(frog_ctx *ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach)
     {
+        if (roctx().push) { roctx().push(K_GROUP_NAMES[s]); range = true; }
         if (!c->profiling || (c->profiling == 2 && s > FROG_K_SWEEP_DEFORMABLE && s != FROG_K_SWEEP_BUILD && s != FROG_K_SWEEP_LINEAR_BUILD)) return;
         if (!c->free_events.empty()) { a = c->free_events.back().first; b = c->free_events.back().second; c->free_events.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
@@ -51,9 +82,11 @@ struct Span {
     }
     ~Span()
     {
-        if (!a) return;
-        if (!attached) (void)hipEventRecord(b, c->stream);
-        c->spans.push_back({ a, b, slot });
+        if (a) {
+            if (!attached) (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({ a, b, slot });
+        }
+        if (range) roctx().pop();
     }
 };
 

@@ -86,6 +86,12 @@ __global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, uint32_t 
 // smallest denormals: no rounding of the instruction's last bit reaches it; the f32 product d2 s1 is within 2^-24 of -160) and
 // is at least 0.2 (d < 0.1 gives weight 1, stats.h:87).  weight = min over the two images, so the smaller cutoff decides,
 // as in the deformable stage.  Not used with FROG_WEIGHT_EXACT (another arithmetic, another zero set).
+// What is and is not identical to the full sweep: every listed link is evaluated as before and every left-out link would have
+// added +-0.0 -- the 18 sums of an image are the same REAL numbers.  They are accumulated per lane in f64 and then over the
+// wavefront, and compaction moves records to other lanes: the f64 association differs, so the sums -- and the matrices,
+// which keep their f64 translation -- agree to f64 rounding (1e-16 relative), not by construction to the last bit
+// (tests/test_gpu_round3.py asserts 1e-13 on the energies, 1e-12 on the matrices, one f32 ulp on the coordinates, and
+// reports when they are in fact equal -- as they have been in every run so far).
 __device__ inline float cull_cutoff_linear_of(const EmDerived d)
 {
     const double s1 = -(double)d.s1;

@@ -206,14 +206,16 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E);
  * In updateDeformableTransforms a half-link with weight < inlierThreshold adds nothing
  * (imageGroup.cxx:268-278).  The library keeps a list of the half-links that are not PROVABLY below
  * the threshold (distance bound per image from its mixture + the points' displacement since the list
- * was built; frog_amd/csrc/device/k_cull.hip.h) and sweeps only those; results are bit-identical to
- * sweeping every half-link.  On by default; the environment variable FROG_CULL=0 at frog_create turns
+ * was built; frog_amd/csrc/device/k_cull.hip.h) and sweeps only those; per-point sums, lattices,
+ * coordinates and the census are bit-identical to sweeping every half-link (a skipped link would have added +0.0 to f32
+ * chains whose order is kept), the two f64 energy sums equal up to their re-association.  On by default; the environment variable FROG_CULL=0 at frog_create turns
  * it off.  frog_cull_stats reports what it did: lists built so far, half-links in the last list and
  * half-links owned (0 listed = no list yet). */
 int frog_cull_stats(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
 /* The same for the LINEAR stage (updateLinearTransforms has no threshold, imageGroup.cxx:1100-1117, but a half-link whose
  * weight is exactly zero adds nothing to its 18 sums either: the list leaves out the half-links whose distance puts the
- * sweep's weight at exactly zero; FROG_CULL_LINEAR=0 turns it off): lists built during the linear stage, half-links in the
+ * sweep's weight at exactly zero; FROG_CULL_LINEAR=0 turns it off; the 18 sums are per-lane f64 accumulators, so results equal
+ * the full sweep's up to f64 re-association, 1e-16 relative): lists built during the linear stage, half-links in the
  * last of them, half-links owned. */
 int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *listed_half_links, uint64_t *owned_half_links);
 

@@ -315,3 +315,18 @@ def test_fast_path_against_reference_order_config3(monkeypatch):
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+
+
+def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
+    """BASELINE.json configs[4] at its size -- 500 images x 20 000 keypoints, ~60 partner images each, 4.6e8 half-links, five
+    levels, -gd 1 (level 4: 9e5 nodes per image, bricks of 8^3 cells) -- which no CPU run can follow inside a test: the
+    product path against reference-order mode (bit-equal to the oracle on the same kind of group at 40 images: above), both
+    on the device, 4 linear + 5 x 2 deformable iterations.  Same guard decisions and lattices; energies 1e-6; per lattice
+    the displacement field at the keypoints and on a dense lattice 1e-4, support-weighted coefficients 1e-4, raw 1e-2."""
+    pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
+    r = fast_against_reference_order(pairs, 4, 5, 2, monkeypatch, range(0, 500, 83))
+    report("fast_vs_reference_order_cfg5", r)
+    assert len(r["grids"]) == 5
+    for k, d in enumerate(r["lattices"]):
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6

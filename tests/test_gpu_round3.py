@@ -313,13 +313,15 @@ def _linear_run(pairs, n_it, **opt):
 
 
 @pytest.mark.parametrize("skin", ["1.25,10", "1.0,0"])
-def test_linear_stage_with_the_zero_weight_list_is_bit_identical(monkeypatch, skin):
+def test_linear_stage_with_the_zero_weight_list_equals_the_full_sweep(monkeypatch, skin):
     """updateLinearTransforms has no threshold (imageGroup.cxx:1100-1117), but a half-link whose weight is exactly zero
     adds nothing to the 18 sums: the linear sweep walks a list that leaves out the half-links whose distance puts the
     sweep's weight at exactly +0 (k_cull.hip.h cull_cutoff_linear_of).  40 linear iterations with the list (default skin,
     and a zero skin that invalidates the list at every step so that every sweep walks all records and rewrites it) against
-    FROG_CULL_LINEAR=0: energies, matrices and coordinates identical bits; and the list really leaves links out once the
-    images have come together."""
+    FROG_CULL_LINEAR=0.  Every left-out link would have added +-0.0, so the sums are the same real numbers; they are per-lane f64
+    accumulators and compaction moves records between lanes, so equality holds up to f64 re-association, not by construction
+    to the last bit: energies 1e-13, matrices 1e-12, coordinates one f32 ulp (whether they were in fact equal is reported);
+    and the list really leaves links out once the images have come together."""
     pairs = Pairs.synthetic(8, 3000, 1200, seed=5)
     monkeypatch.setenv("FROG_CULL_LINEAR", "0")
     e0, m0, x0, st0 = _linear_run(pairs, 40)
@@ -327,9 +329,12 @@ def test_linear_stage_with_the_zero_weight_list_is_bit_identical(monkeypatch, sk
     monkeypatch.setenv("FROG_CULL_LINEAR", "1")
     monkeypatch.setenv("FROG_CULL_SKIN_LINEAR", skin)
     e1, m1, x1, st1 = _linear_run(pairs, 40)
-    assert np.array_equal(e0, e1) and np.array_equal(m0, m1) and np.array_equal(x0, x1)
+    assert np.max(np.abs(e0 - e1) / e0) <= 1e-13
+    assert np.max(np.abs(m0 - m1)) <= 1e-12 * np.max(np.abs(m0))
+    assert np.max(np.abs(x0.astype(np.float64) - x1)) <= 1.2e-7 * np.max(np.abs(x0))
     lists, listed, owned = st1
-    note(f"linear_list_skin_{skin}", f"lists {lists} listed {listed} of {owned} half-links")
+    same = bool(np.array_equal(e0, e1) and np.array_equal(m0, m1) and np.array_equal(x0, x1))
+    note(f"linear_list_skin_{skin}", f"lists {lists} listed {listed} of {owned} half-links; identical bits: {same}")
     assert lists >= 4 and 0 < listed < owned
 
 
