@@ -32,5 +32,21 @@ cp $O/bench.json gpurun_out/${TAG}_bench_n1.json
 cp $O/bench_kernel_times.json gpurun_out/${TAG}_bench_n1_kernel_times.json
 cp $O/bench_steps20.json gpurun_out/${TAG}_bench_n1_steps20.json
 cp $O/under_rocprof.json gpurun_out/${TAG}_bench_n1_under_rocprof.json
+# roctx ranges of the kernel groups (FROG_ROCTX=1): a marker trace next to the kernel trace
+FROG_ROCTX=1 timeout -k 10 200 rocprofv3 --kernel-trace --marker-trace -d $O/roctx -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/roctx.log || true
+python3 - <<PY > gpurun_out/${TAG}_roctx_ranges.txt || true
+import csv, glob, collections
+files = glob.glob("$O/roctx/**/p_marker_api_trace.csv", recursive=True)
+tot = collections.Counter(); cnt = collections.Counter()
+for f in files:
+    for r in csv.DictReader(open(f)):
+        name = r.get("Function") or r.get("Name") or ""
+        if name.startswith("frog:"):
+            tot[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[name] += 1
+print("# FROG_ROCTX=1 bench.py --steps 20 --warmup 5 under rocprofv3 --marker-trace: roctx ranges (host-side enqueue time, us)")
+for n, v in tot.most_common(): print(f"{n:40s} {v:10.1f} us  x{cnt[n]}")
+print("files", files)
+PY
+python3 scripts/trace_gaps.py $(dirname $(find $O/roctx -name p_kernel_trace.csv | head -1)) > gpurun_out/${TAG}_timeline_steps20.txt || true
 head -12 gpurun_out/${TAG}_bench_n1.txt
 python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_n1.json')); print(d['value'], d['roofline'], d['cpu_baseline']['value'])"

@@ -58,7 +58,8 @@ def main():
         from frog_amd._abi import device_source_hash
         json.dump({"kernel": "sweep_deformable", "measured_at": device_source_hash(), "fetch_size_kb": fetch, "write_size_kb": write,
                    "traffic_bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0,
-                   "half_links_per_launch": int(sys.argv[-1]) if sys.argv[-1].isdigit() else None,
+                   "half_links_owned": int(sys.argv[-1]) if sys.argv[-1].isdigit() else None,      # = roofline.half_links_owned of the bench line
+                   "half_links_per_launch": int(sys.argv[-1]) if sys.argv[-1].isdigit() else None,  # the key's name until round 3
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"},
                   open(out.replace("_bench_n1.txt", "_hbm_traffic.json"), "w"), indent=1)
     open(out, "w").write("\n".join(lines) + "\n")
