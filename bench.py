@@ -321,7 +321,7 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=partners_per_image)
     t_gen = time.perf_counter() - t0
     n_lin, per_level = schedule(steps, levels)
-    opts = _abi.FrogOptions.default()
+    opts = _abi.FrogOptions.default(max_levels_hint=levels)      # what a host knows before it starts: -dl
     proxy = None
     if args.shard_of:
         if world != 1:
@@ -520,7 +520,7 @@ def run_torch(args, rank, world, local_rank, backend, rdv):
     pairs = Pairs.synthetic(images, points, ppb, seed=1, partners_per_image=partners_per_image)
     t_gen = time.perf_counter() - t0
     shards = plan_shards(pairs.row_ptr, pairs.point_offset, world)
-    opts = _abi.FrogOptions.default()
+    opts = _abi.FrogOptions.default(max_levels_hint=levels)
     t0 = time.perf_counter()
     engine = HipEngine(pairs, opts, local_rank, shards[rank])
     t_create = time.perf_counter() - t0

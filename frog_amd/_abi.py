@@ -55,7 +55,8 @@ class FrogOptions(C.Structure):
                 ("stats_max_iterations", C.c_int32),
                 ("stats_epsilon", C.c_float),
                 ("n_fixed_images", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("max_levels_hint", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
     @classmethod
     def default(cls, **kw):

@@ -534,7 +534,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         frog_ctx *moving = nullptr, *fixed = nullptr;
         int rc = frog_create(m, &o2, device, nf, m->n_images, &moving);
         if (rc) return rc;
-        rc = frog_create(m, &o2, device, 0, nf, &fixed);
+        frog_options o3 = o2;
+        o3.max_levels_hint = 0;                                     // a statistics-only context never holds a lattice
+        rc = frog_create(m, &o3, device, 0, nf, &fixed);
         if (rc) { frog_destroy(moving); return rc; }
         fixed->cull_enabled = false;                                // a statistics-only context never sweeps a lattice step
         fixed->act_recs32.release(); fixed->act_recs.release(); fixed->act_cnt.release(); fixed->pos2_snap.release();
@@ -823,7 +825,37 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             // for a size it has not served yet, however much it holds): one block for them, about what three levels with their
             // regrids take (1 + 2 x 8 + 3 x 64 lattices of level 0), best effort.
             const size_t lattice0 = (size_t)c->n_owned() * (size_t)g0.n_cp;
-            const size_t arena = std::min<size_t>(((size_t)2 << 30) / sizeof(float4), 224 * lattice0);
+            size_t arena = std::min<size_t>(((size_t)2 << 30) / sizeof(float4), 224 * lattice0);
+            // The caller said how many levels it will run (frog_options::max_levels_hint): the buffers of the FINEST of them now,
+            // and an arena for three finished lattices per level.  A group of 500 images reaches 7.7 GB per lattice buffer at its
+            // fifth level; hipMalloc of such blocks took between 5 and 1 500 ms on the test boxes, inside the timed loops (the
+            // 130-step figure of BASELINE configs[4] moved between 45 and 166 it/s with it).  Best effort, and only while it leaves
+            // half of the free memory alone.
+            if (o->max_levels_hint > 1) {
+                const int finest = std::min(o->max_levels_hint, 12) - 1;
+                GridGeom gh{};
+                frog_grid_info ih{};
+                size_t free_b = 0, total_b = 0;
+                if (make_geometry(c, finest, mn, mx, gh, ih) == FROG_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    gh.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)gh.n_cp * 5 / 4);
+                    const size_t nO = c->n_owned(), nPts = c->own_pt_end - c->own_pt_begin;
+                    const size_t blocks = scatter_max_blocks((uint32_t)std::min<size_t>(0xFFFFFFFFu, nO * (size_t)gh.n_bricks), (uint32_t)nPts);
+                    const size_t E = (size_t)gh.brick + 3;
+                    size_t arena_h = 0;
+                    for (int l = 0; l <= finest; l++) {
+                        GridGeom gl{};
+                        frog_grid_info il{};
+                        if (make_geometry(c, l, mn, mx, gl, il) == FROG_OK) arena_h += 3 * ((nO * (size_t)gl.n_cp * 5 / 4 + 63) / 64 * 64);
+                    }
+                    const size_t need = (3 * nO * (size_t)gh.n_cp + blocks * E * E * E + arena_h) * sizeof(float4)
+                                        + 3 * nO * (size_t)gh.n_bricks * (size_t)(gh.brick * gh.brick * gh.brick) * sizeof(uint32_t);
+                    if (need < free_b / 2) {
+                        if (int rc_ = lattice_alloc(c, gh)) { (void)rc_; (void)hipGetLastError(); }
+                        arena = std::max(arena, arena_h);
+                    }
+                }
+                (void)hipGetLastError();
+            }
             if (c->retired_arena.alloc(arena) != hipSuccess) (void)hipGetLastError();
             c->retired_used = 0;
         }

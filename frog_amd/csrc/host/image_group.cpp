@@ -143,7 +143,7 @@ void ImageGroup::createShardedContexts()
     o.linear_alpha = linearAlpha; o.use_scale = useScale; o.initial_grid_size = initialGridSize;
     o.bounding_box_margin = boundingBoxMargin; o.inlier_threshold = inlierThreshold;
     o.guarantee_diffeomorphism = guaranteeDiffeomorphism; o.max_displacement_ratio = maxDisplacementRatio;
-    o.stats_max_size = statsMaxSize; o.stats_max_iterations = statsMaxIterations; o.stats_epsilon = statsEpsilon;
+    o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize; o.stats_max_iterations = statsMaxIterations; o.stats_epsilon = statsEpsilon;
     frog_model m;
     frog_pairs_model(pairs, &m);
     std::vector<int> devices(nGpus);
@@ -382,7 +382,7 @@ void ImageGroup::createContext()
     o.inlier_threshold = inlierThreshold;
     o.guarantee_diffeomorphism = guaranteeDiffeomorphism;
     o.max_displacement_ratio = maxDisplacementRatio;
-    o.stats_max_size = statsMaxSize;
+    o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize;
     o.stats_max_iterations = statsMaxIterations;
     o.stats_epsilon = statsEpsilon;
     o.n_fixed_images = numberOfFixedImages;

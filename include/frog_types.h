@@ -52,7 +52,11 @@ typedef struct frog_options {
     float   stats_epsilon;              /* -se   1e-6   stats.cxx:12    */
     int32_t n_fixed_images;             /* -fi   0      imageGroup.h:69: the first n images are already
                                          * registered (their xyz is final) and never move            */
-    int32_t reserved[5];                /* must be 0                      */
+    int32_t max_levels_hint;            /* -dl          0 = unknown.  A HINT, not a limit: how many deformable levels the caller
+                                         * is going to run (imageGroup.h:62 deformableLevels).  frog_create then sizes the
+                                         * lattice buffers for the finest of them at once, so that no multi-gigabyte device
+                                         * allocation happens between two iterations                                  */
+    int32_t reserved[4];                /* must be 0                      */
 } frog_options;
 
 /* Geometry of one B-spline control-point lattice
@@ -100,6 +104,7 @@ static inline void frog_options_default(frog_options *o)
     o->stats_max_iterations = 10000;
     o->stats_epsilon = 1e-6f;
     o->n_fixed_images = 0;
+    o->max_levels_hint = 0;
     for (i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++) o->reserved[i] = 0;
 }
 
