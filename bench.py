@@ -328,7 +328,7 @@ def run_native(args, rank, world, local_rank, transport, rdv):
             raise SystemExit("--shard-of is a single-process proxy")
         shards = plan_shards(pairs.row_ptr, pairs.point_offset, args.shard_of[1])
         shards = [shards[args.shard_of[0]]]
-        args.kernel_times = True
+        args.kernel_times = os.environ.get("FROG_PROXY_SWEEPS_ONLY") != "1"      # (the proxy's point is the per-kernel table)
         if args.proxy_partners == "registered":
             # what the other ranks would hand over: the whole group registered by one context (default schedule), its final
             # coordinates and mixtures
@@ -370,6 +370,8 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     prof = {n: [res.kernels[i].ms_total, int(res.kernels[i].launches)] for i, n in enumerate(_abi.FROG_K_NAMES)}
     tags = ["linear"] + [f"level{l}" for l in range(levels)]
     phase_s = {t: res.phase_s[i] for i, t in enumerate(tags) if i == 0 or per_level[i - 1]}
+    if args.shard_of and not args.kernel_times:
+        args.shard_of = None            # no per-kernel table to print: the plain line
     if args.kernel_times:
         phase_k = {t: {n: {"ms": round(res.kernels_by_phase[i][j].ms_total, 4), "launches": int(res.kernels_by_phase[i][j].launches)}
                        for j, n in enumerate(_abi.FROG_K_NAMES) if res.kernels_by_phase[i][j].launches}

@@ -42,6 +42,7 @@ class Side:
     def __init__(self, pairs, oracle=False, **opt):
         self.oracle = oracle
         self.pairs = pairs
+        self.first = int(opt.get("n_fixed_images", 0))       # -fi: the first images are fixed, the context owns the others
         if oracle:
             self.g = OracleGroup(pairs.model, _abi.FrogOptions.default(**opt))
             self.g.setup_stats()
@@ -74,7 +75,7 @@ class Side:
         return self.g.xyz2() if self.oracle else self.g.points()[1]
 
     def matrices(self):
-        return np.stack([self.g.matrix(i) for i in range(self.pairs.n_images)])
+        return np.stack([self.g.matrix(i) for i in range(self.first, self.pairs.n_images)])
 
     def ems(self):
         return np.stack([self.g.em(i) for i in range(self.pairs.n_images)])
@@ -148,7 +149,7 @@ def equality_checker(images, counters):
             assert abs(e[0] - e[1]) <= 1e-12 * abs(e[1]), (tag, e)
         if kind == "step":
             assert np.array_equal(a.point_sums(), b.point_sums()), f"{tag}: per-point sums differ"
-            info = a.grid(0, a.num_grids() - 1)[0]
+            info = a.grid(images[0], a.num_grids() - 1)[0]
             n_cp = info.dims[0] * info.dims[1] * info.dims[2]
             for i in images:
                 assert np.array_equal(a.gradient_raw(i, n_cp), b.gradient_raw(i, n_cp)), f"{tag}: gradient image {i} differs"
@@ -171,12 +172,12 @@ def run_equal(pairs, li, dl, di, monkeypatch, images=None, **opt):
     dev = Side(pairs, **opt)
     monkeypatch.delenv("FROG_REFERENCE_ORDER")
     ref = Side(pairs, oracle=True, **opt)
-    images = list(images if images is not None else range(pairs.n_images))
+    images = list(images if images is not None else range(dev.first, pairs.n_images))
     counters = {"steps": 0}
     grids = lockstep([dev, ref], li, dl, di, equality_checker(images, counters))
     assert dev.num_grids() == ref.num_grids() == sum(grids)
     for k in range(ref.num_grids()):                       # every lattice of the chain, finished ones included
-        for i in range(pairs.n_images):
+        for i in range(dev.first, pairs.n_images):
             assert np.array_equal(dev.grid(i, k)[1], ref.grid(i, k)[1]), f"lattice {k} of image {i} differs"
     assert np.array_equal(dev.xyz(), ref.xyz()) and np.array_equal(dev.matrices(), ref.matrices())
     return grids, counters
@@ -330,3 +331,57 @@ def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+
+
+# ---- reference-order mode on the inputs the reference's loops have special cases for ------------------------------------
+
+def test_reference_order_mode_equals_the_oracle_ragged_group_with_duplicate_links(monkeypatch):
+    """Images of 25 .. 1 500 points, points without links, 400 duplicate links of ONE point into one partner image, an image
+    pair whose block appears twice in the file (tests/test_gpu_parity.py ragged_pairs), a reservoir smaller than the link
+    count: 12 linear + 2 x 8 deformable iterations, every quantity equal to the oracle's after every step."""
+    from test_gpu_parity import ragged_pairs
+    pairs = ragged_pairs()
+    grids, counters = run_equal(pairs, 12, 2, 8, monkeypatch, stats_max_size=500)
+    assert counters["linear"] == 12 and counters["deformable"] == 16
+
+
+def test_reference_order_mode_equals_the_oracle_with_landmark_constraints_and_error_maps(monkeypatch):
+    """-lc: hard links between landmarks (link-less extra points) enter a point's f32 sums after its regular links
+    (imageGroup.cxx:280-295) and the error maps (:520-533): per-point sums, lattices and error maps equal to the oracle's."""
+    pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+    po0 = np.asarray(pairs.point_offset).copy()
+    rng = np.random.default_rng(8)
+    for i in range(6):
+        pts = np.asarray(pairs.xyz)[po0[i]:po0[i + 1]]
+        pairs.append_points(i, pts[rng.choice(3000, 3, replace=False)])
+    po = np.asarray(pairs.point_offset)
+    point, partner = [], []
+    for k in range(3):
+        ids = [po[i] + 3000 + k for i in range(6)]
+        for a in ids:
+            for b in ids:
+                if a != b:
+                    point.append(a); partner.append(b)
+    w2 = np.float32(6 * 50.0) ** 2
+    monkeypatch.setenv("FROG_REFERENCE_ORDER", "1")
+    dev = Side(pairs)
+    monkeypatch.delenv("FROG_REFERENCE_ORDER")
+    ref = Side(pairs, oracle=True)
+    dev.g.set_hard_links(point, partner, w2); ref.g.set_hard_links(point, partner, w2)
+    counters = {"steps": 0}
+    lockstep([dev, ref], 12, 2, 6, equality_checker(range(6), counters))
+    assert counters["deformable"] == 12
+    dev.g.residualSums()
+    info = dev.grid(0, dev.num_grids() - 1)[0]
+    n_cp = info.dims[0] * info.dims[1] * info.dims[2]
+    for i in range(6):
+        assert np.array_equal(dev.g.errorMap(i)[1], ref.g.error_map(i, n_cp)), f"error map of image {i}"
+
+
+@pytest.mark.parametrize("n_fixed", [1, 4])
+def test_reference_order_mode_equals_the_oracle_with_fixed_images(monkeypatch, n_fixed):
+    """-fi n: the first n images keep their position, every loop but updateStats starts at image n, the group mean is not
+    removed (imageGroup.cxx:398): a 15 + 2 x 12 schedule, equal to the oracle's after every step."""
+    pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
+    grids, counters = run_equal(pairs, 15, 2, 12, monkeypatch, n_fixed_images=n_fixed)
+    assert counters["deformable"] == 24
