@@ -560,3 +560,25 @@ def test_bench_native_host_three_ranks_over_shared_memory_matches_one_rank(tmp_p
     assert abs(three["config"]["final_E"] - one["config"]["final_E"]) <= 1e-6 * one["config"]["final_E"]
     assert set(three["comm_ms"]) == {"all_gather_xyz2", "all_reduce_em", "all_reduce_energy", "all_reduce_gridsum"}
     assert len(three["ranks"]["elapsed_s"]) == 3
+
+
+def test_bench_as_ranks_of_torch_distributed_run(tmp_path):
+    """The way the round-end driver starts N > 1: `python -m torch.distributed.run ... bench.py --gpus N`.  Every rank process
+    stays off the GPU and runs its rank of each attempt as a fresh child; the ranks' parents agree through the run directory.
+    Two ranks on the one GPU over the shared-memory communicator: one line, from rank 0, the one-rank run's energy."""
+    import sys
+    args = ["--images", "12", "--points", "3000", "--pairs-per-block", "1200", "--steps", "26", "--warmup", "3", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    env.update(FROG_BENCH_BACKEND="gloo", FROG_BENCH_HOSTS="native")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *args],
+                        capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = [l for l in r2.stdout.splitlines() if l.lstrip().startswith('{"metric"')]
+    assert len(lines) == 1, r2.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["replicas_identical"] is True and two["hosts_tried"][0]["ok"] is True
+    assert abs(two["config"]["final_E"] - one["config"]["final_E"]) <= 1e-6 * one["config"]["final_E"]
