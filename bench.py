@@ -831,7 +831,14 @@ def main():
                               "ranks": list(range(args.gpus))}), flush=True)
             raise SystemExit(0)
         # plain `python bench.py --gpus N`: this process is the launcher of every rank (nothing has touched the GPU yet)
-        raise SystemExit(orchestrate(args, argv, args.gpus, list(range(args.gpus)), run_directory(args.gpus)))
+        directory = run_directory(args.gpus)
+        try:
+            rc = orchestrate(args, argv, args.gpus, list(range(args.gpus)), directory)
+        finally:
+            if os.environ.get("FROG_BENCH_KEEP_DIR") != "1":        # (under a launcher the other ranks' parents may still be reading it)
+                import shutil
+                shutil.rmtree(directory, ignore_errors=True)
+        raise SystemExit(rc)
 
     if world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
