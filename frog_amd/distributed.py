@@ -240,10 +240,12 @@ class NativeComm:
     handful of ctypes calls instead of three ``torch.distributed`` collectives (tens of microseconds of host time each --
     more than a rank's kernels take at 8 GPUs).  ``create`` returns None when any rank could not set it up or when the
     new communicator fails a known-answer all-reduce / all-gather: the caller then keeps the ``torch.distributed``
-    collectives.  Opt-in (``FROG_NATIVE_COMM=1``) until a run with two or more GPUs has validated it: libfrog_comm.so
-    names librccl.so.1, the SONAME of the RCCL torch ships and has already mapped, so inside a torch process the calls
-    land in torch's RCCL build (one instance) with the image's rccl.h (the entry points used -- unique id, init rank,
-    all-reduce, broadcast, group start/end, destroy -- have had one ABI since NCCL 2.4)."""
+    collectives.  Since round 4 ``bench.py`` no longer mixes the two (its native host runs the whole loop in C,
+    ``frog_run_schedule``, and its torch host uses ``torch.distributed`` throughout); this class remains for hosts that
+    want the Python loop with the C collectives, and for ``tests/test_gpu_cli_and_shards.py``.  Inside a torch process
+    libfrog_comm.so's ``librccl.so.1`` resolves to the RCCL build torch ships (same SONAME, already mapped: one instance,
+    the image's rccl.h; the entry points used -- unique id, init rank, all-reduce, broadcast, group start/end, destroy --
+    have had one ABI since NCCL 2.4)."""
 
     def __init__(self, lib, handle):
         self._lib, self._h = lib, handle
