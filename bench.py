@@ -253,9 +253,30 @@ class Rendezvous:
         while not os.path.exists(self.path(name)):
             if time.time() - t0 > timeout:
                 raise TimeoutError(f"rank {self.rank}: {name} never appeared in {self.dir}")
+            self.check_peers()
             time.sleep(0.005)
         with open(self.path(name), "rb") as fh:
             return fh.read()
+
+    def fail(self, why):
+        """Tell the other ranks of this attempt that this one is gone (they stop waiting for it at once)."""
+        try:
+            self.put(f"failed_{self.rank}", str(why).encode()[:2000])
+        except OSError:
+            pass
+
+    def check_peers(self):
+        for r in range(self.world):
+            if r != self.rank and os.path.exists(self.path(f"failed_{r}")):
+                raise RuntimeError(f"rank {r} of this attempt failed: " + open(self.path(f"failed_{r}"), "rb").read().decode(errors="replace")[:500])
+
+    def all_ready(self, what, timeout=120.0):
+        """Every rank has reached `what` (or one has failed): called in front of a call that blocks in a collective --
+        ncclCommInitRank waits for every rank, for ever -- so that a rank that could not even create its context costs the
+        others a second, not the attempt's whole time-out."""
+        self.put(f"{what}_{self.rank}", b"1")
+        for r in range(self.world):
+            self.get(f"{what}_{r}", timeout)
 
     def gather_json(self, name, obj, timeout=120.0):
         """Every rank contributes obj; returns the list in rank order (on every rank)."""
@@ -270,6 +291,7 @@ def create_native_comm(rdv, transport, ctx, shards, point_offset, device):
     cl = _abi.comm_lib()
     h = C.c_void_p()
     rank, world = rdv.rank, rdv.world
+    rdv.all_ready("context")            # every rank has its context (on its own device): now the communicator
     if transport == "rccl":
         if rank == 0:
             buf = (C.c_ubyte * 128)()
@@ -807,12 +829,16 @@ def main():
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
         rdv = Rendezvous(args.child_dir, args.child_attempt, rank, world)
-        if args.child == "preflight":
-            line, good = run_preflight(rank, world, local_rank, args.child_transport, rdv)
-        elif args.child == "native":
-            line, good = run_native(args, rank, world, local_rank, args.child_transport, rdv)
-        else:
-            line, good = run_torch(args, rank, world, local_rank, args.child_transport, rdv)
+        try:
+            if args.child == "preflight":
+                line, good = run_preflight(rank, world, local_rank, args.child_transport, rdv)
+            elif args.child == "native":
+                line, good = run_native(args, rank, world, local_rank, args.child_transport, rdv)
+            else:
+                line, good = run_torch(args, rank, world, local_rank, args.child_transport, rdv)
+        except BaseException as exc:                # noqa: BLE001 -- whatever it was, the other ranks must not wait for this one
+            rdv.fail(f"{type(exc).__name__}: {exc}")
+            raise
         if line is not None:
             print(json.dumps(line), flush=True)
         raise SystemExit(0 if good else 3)

@@ -106,3 +106,25 @@ def test_orchestrator_with_failing_and_hanging_children(tmp_path, monkeypatch):
     assert rc == 0 and line["value"] == 7.0
     assert tried[1]["host"] == "native" and tried[1]["ok"] is False and tried[1]["return_codes"] == [-9, -9]
     assert "stuck in a collective" in tried[1]["stderr_tail"]["0"] and tried[1]["seconds"] < 10
+
+
+def test_a_failed_rank_stops_the_others_waiting(tmp_path):
+    """Rendezvous: a rank that dies before a collective tells the others, who stop waiting at once with its reason."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    a, b = bench.Rendezvous(str(tmp_path), 0, 0, 2), bench.Rendezvous(str(tmp_path), 0, 1, 2)
+    b.fail("FrogError: frog_create: device index out of range")
+    t0 = time.time()
+    try:
+        a.all_ready("context", timeout=30.0)
+        raise AssertionError("rank 0 went on without rank 1")
+    except RuntimeError as exc:
+        assert "rank 1 of this attempt failed" in str(exc) and "device index out of range" in str(exc)
+    assert time.time() - t0 < 5.0
+    # and the ordinary case: both arrive, both go on; values travel
+    c, d = bench.Rendezvous(str(tmp_path), 1, 0, 2), bench.Rendezvous(str(tmp_path), 1, 1, 2)
+    d.put("context_1", b"1")
+    c.all_ready("context", timeout=5.0)
+    d.put("result_1", json.dumps({"x": 2}).encode())
+    assert c.gather_json("result", {"x": 1}, timeout=5.0) == [{"x": 1}, {"x": 2}]
