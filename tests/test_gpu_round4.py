@@ -56,3 +56,61 @@ def test_a_second_linear_stage_after_a_deformable_level(monkeypatch):
     assert np.max(np.abs(a[3] - b[3]) / a[3]) <= 1e-13
     assert np.max(np.abs(a[4] - b[4])) <= 1e-12 * np.max(np.abs(a[4]))
     assert np.max(np.abs(a[5].astype(np.float64) - b[5])) <= 1.2e-7 * np.max(np.abs(a[5]))
+
+
+def test_the_c_loop_and_the_python_loop_end_on_the_same_bits():
+    """frog_run_schedule (the C loop bench.py times) against the ImageGroup mirror driving the same C ABI from Python: the
+    same schedule -- warm-up, linear iterations, three levels with their refreshes and any regrid -- ends on the same
+    energy, the same lattices per level and the same coordinates, bit for bit (both are hosts of the same device path)."""
+    import ctypes as C
+    from frog_amd import _abi
+    pairs = Pairs.synthetic(10, 3000, 1300, seed=4)
+    lib, host = _abi.hip_lib(), _abi.host_lib()
+    opts = _abi.FrogOptions.default(max_levels_hint=3)
+    ctx = C.c_void_p()
+    _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(opts), 0, 0, pairs.n_images, C.byref(ctx)), "frog_create")
+    plan = _abi.FrogSchedulePlan()
+    plan.plan_bytes, plan.result_bytes = C.sizeof(_abi.FrogSchedulePlan), C.sizeof(_abi.FrogScheduleResult)
+    plan.warmup_linear, plan.linear, plan.n_levels = 4, 11, 3
+    for l, n in enumerate((14, 13, 12)):
+        plan.per_level[l] = n
+    plan.stat_interval, plan.deformable_alpha = 10, 0.02
+    plan.anchor[0] = plan.anchor[1] = plan.anchor[2] = 0.5
+    res = _abi.FrogScheduleResult()
+    _abi.check(host.frog_run_schedule(ctx, None, C.byref(plan), C.byref(res)), "frog_run_schedule")
+    assert res.iterations == 11 + 14 + 13 + 12 and res.n_lattices >= 3 and res.elapsed_s > 0
+    n = int(pairs.point_offset[-1])
+    xyz_c = np.empty((n, 3), np.float32)
+    _abi.check(lib.frog_get_points(ctx, xyz_c.ctypes.data_as(_abi.c_float_p), None), "frog_get_points")
+    lib.frog_destroy(ctx)
+
+    g = ImageGroup(pairs, max_levels_hint=3)
+    g.setupLinearTransforms(); g.transformPoints()
+    it, e = 0, 0.0
+    for _ in range(4 + 11):
+        if it % 10 == 0:
+            g.updateStats()
+        e = g.updateLinearTransforms(); g.transformPoints()
+        it += 1
+    g.transformPoints(True)
+    grids = []
+    for level, n_it in enumerate((14, 13, 12)):
+        g.setupDeformableTransforms(level); g.transformPoints()
+        alpha, nd, k, ng = np.float32(0.02), 0, 0, 1
+        while k < n_it:
+            if k % 10 == 0:
+                g.updateStats()
+            ee = g.updateDeformableTransforms(float(alpha))
+            if ee < 0:
+                if nd == 0:
+                    alpha = np.float32(alpha / np.float32(2))
+                ng += 1
+                g.transformPoints(True); g.setupDeformableTransforms(level); g.transformPoints()
+                nd = 0
+                continue
+            nd += 1; g.transformPoints(); e = ee; k += 1
+        grids.append(ng)
+        g.transformPoints(True)
+    assert list(res.grids_per_level[:3]) == grids
+    assert float(np.float32(e)) == res.final_E
+    assert np.array_equal(g.points()[0], xyz_c)
