@@ -261,6 +261,29 @@ def fast_against_reference_order(pairs, li, dl, di, monkeypatch, images, **opt):
             d["weak"], d["nodes"] = r["weak"], r["nodes"]
         d["dense_field"], d["max_disp"] = dense_field_deviation(fast.g, ref.g, k, images, snaps[k])
         out.append(d)
+    # the WHOLE chain of an image (matrix, then every lattice in creation order: what transforms/<i>.json holds and
+    # tools/VolumeTransform.cxx / PointsTransform.cxx evaluate) on a dense lattice of points over the image's own keypoint
+    # box, through the device's chain evaluation (include/frog_chain.h): deviation of the displacement T(x) - x
+    from frog_amd.chain import Chain, Link
+    chain = {"rel": 0.0, "mm": 0.0, "max_disp_mm": 0.0}
+    x0 = np.asarray(pairs.xyz, np.float64).reshape(-1, 3)
+    for i in images:
+        pts_i = x0[po[i]:po[i + 1]]
+        lo, hi = pts_i.min(axis=0), pts_i.max(axis=0)
+        grid = np.stack(np.meshgrid(*[np.linspace(lo[d], hi[d], 20) for d in range(3)], indexing="ij"), axis=-1).reshape(-1, 3)
+        disp = []
+        for side in (fast, ref):
+            links = [Link.linear(side.g.matrix(i))]
+            for k in range(side.num_grids()):
+                info, c = side.g.grid(i, k)
+                links.append(Link.bspline(list(info.dims), list(info.origin), list(info.spacing), c))
+            ch = Chain(links)
+            disp.append(ch.apply(grid) - grid)
+            ch.close()
+        dev = float(np.max(np.abs(disp[0] - disp[1])))
+        scale = float(np.max(np.abs(disp[1])))
+        chain["mm"] = max(chain["mm"], dev); chain["max_disp_mm"] = max(chain["max_disp_mm"], scale)
+        chain["rel"] = max(chain["rel"], dev / max(scale, 1e-30))
     mf, mr = fast.matrices(), ref.matrices()
     diag = lambda a: np.stack([a[:, 0, 0], a[:, 1, 1], a[:, 2, 2]])
     m = max(float(np.max(np.abs(diag(mf) - diag(mr))) / np.max(np.abs(diag(mr)))),
@@ -268,11 +291,12 @@ def fast_against_reference_order(pairs, li, dl, di, monkeypatch, images, **opt):
     x = float(np.max(np.abs(fast.xyz().astype(np.float64) - ref.xyz())) / np.max(np.abs(ref.xyz())))
     ca, cb = fast.g.countInliers(), ref.g.countInliers()
     census = sum(abs(ca[i].inliers - cb[i].inliers) for i in range(pairs.n_images))
-    return {"lattices": out, "grids": grids, "E": worst["E"], "matrices": m, "xyz": x, "census": census}
+    return {"lattices": out, "grids": grids, "E": worst["E"], "matrices": m, "xyz": x, "census": census, "chain": chain}
 
 
 def report(name, r):
-    note(name, f"E {r['E']:.2e} matrices {r['matrices']:.2e} xyz {r['xyz']:.2e} grids {r['grids']} census_differs_by {r['census']}")
+    note(name, f"E {r['E']:.2e} matrices {r['matrices']:.2e} xyz {r['xyz']:.2e} grids {r['grids']} census_differs_by {r['census']} "
+               f"whole_chain_dense rel {r['chain']['rel']:.2e} abs {r['chain']['mm']:.2e} mm of {r['chain']['max_disp_mm']:.1f} mm")
     for k, d in enumerate(r["lattices"]):
         note(f"{name}_lattice_{k}", " ".join(f"{a} {b:.2e}" if isinstance(b, float) else f"{a} {b}" for a, b in d.items()))
 
@@ -287,7 +311,7 @@ def test_fast_path_against_reference_order_small_group(monkeypatch):
     report("fast_vs_reference_order_small", r)
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= REL
 
 
 def test_fast_path_against_reference_order_small_group_whole_schedule(monkeypatch):
@@ -315,7 +339,7 @@ def test_fast_path_against_reference_order_config3(monkeypatch):
     report("fast_vs_reference_order_cfg3", r)
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= REL
 
 
 def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
