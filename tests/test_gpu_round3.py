@@ -95,7 +95,25 @@ def free_run(pairs, li, dl, di, images=None, **opt):
             worst["weak"], worst["nodes"] = d["weak"], d["nodes"]
         per_lattice.append(worst)
     final = relerr(g.points()[0], ref.xyz())
-    return {"E": worst_e, "matrices": worst_m, "lattices": per_lattice, "grids_per_level": grids, "final_xyz": final}
+    # the whole chain of an image (matrix + every lattice) on a dense lattice over its keypoint box, through the device's
+    # chain evaluation (include/frog_chain.h; what tools/PointsTransform.cxx / VolumeTransform.cxx do with transforms/<i>.json)
+    from frog_amd.chain import Chain, Link
+    x0 = np.asarray(pairs.xyz, np.float64).reshape(-1, 3)
+    chain_rel = chain_mm = 0.0
+    for i in list(images if images is not None else range(pairs.n_images))[:12]:
+        lo, hi = x0[po[i]:po[i + 1]].min(axis=0), x0[po[i]:po[i + 1]].max(axis=0)
+        pts = np.stack(np.meshgrid(*[np.linspace(lo[d], hi[d], 16) for d in range(3)], indexing="ij"), axis=-1).reshape(-1, 3)
+        disp = []
+        for m, grid_of in ((g.matrix(i), lambda k: g.grid(i, k)), (ref.matrix(i), lambda k: ref.grid(i, k, _abi.FrogGridInfo()))):
+            links = [Link.linear(m)]
+            for k in range(ref.num_grids()):
+                info, c = grid_of(k)
+                links.append(Link.bspline(list(info.dims), list(info.origin), list(info.spacing), c))
+            ch = Chain(links); disp.append(ch.apply(pts) - pts); ch.close()
+        dev = float(np.max(np.abs(disp[0] - disp[1])))
+        chain_mm = max(chain_mm, dev); chain_rel = max(chain_rel, dev / max(float(np.max(np.abs(disp[1]))), 1e-30))
+    return {"E": worst_e, "matrices": worst_m, "lattices": per_lattice, "grids_per_level": grids, "final_xyz": final,
+            "chain_rel": chain_rel, "chain_mm": chain_mm}
 
 
 def test_config3_free_running_schedule_against_the_oracle():
@@ -106,7 +124,9 @@ def test_config3_free_running_schedule_against_the_oracle():
     coefficient deviation per lattice is printed, not hidden behind the weighted bar."""
     pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
     r = free_run(pairs, 10, 3, 10)
-    note("cfg3_free_run", f"E {r['E']:.2e} matrices {r['matrices']:.2e} final_xyz {r['final_xyz']:.2e} grids {r['grids_per_level']}")
+    note("cfg3_free_run", f"E {r['E']:.2e} matrices {r['matrices']:.2e} final_xyz {r['final_xyz']:.2e} grids {r['grids_per_level']} "
+                          f"whole_chain_dense rel {r['chain_rel']:.2e} abs {r['chain_mm']:.2e} mm")
+    assert r["chain_rel"] <= REL
     for k, d in enumerate(r["lattices"]):
         note(f"cfg3_free_run_lattice_{k}", f"level {d['level']} raw {d['raw']:.2e} weighted {d['weighted']:.2e} field {d['field']:.2e} dense_field {d['dense']:.2e} "
                                              f"weak_nodes {d['weak']}/{d['nodes']}")
