@@ -830,6 +830,13 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
         rdv = Rendezvous(args.child_dir, args.child_attempt, rank, world)
         try:
+            # the device of this rank: LOCAL_RANK, unless the launcher gave every process a view of its own GPU only
+            # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank: one visible device, index 0)
+            from frog_amd import _abi
+            n_dev = _abi.hip_lib().frog_device_count()
+            if n_dev >= 1 and local_rank >= n_dev:
+                sys.stderr.write(f"[bench] rank {rank}: LOCAL_RANK {local_rank} but {n_dev} visible device(s): using device {local_rank % n_dev}\n")
+                local_rank %= n_dev
             if args.child == "preflight":
                 line, good = run_preflight(rank, world, local_rank, args.child_transport, rdv)
             elif args.child == "native":
