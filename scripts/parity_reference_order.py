@@ -16,14 +16,21 @@ class Env:                       # the two calls of monkeypatch the test helper 
     def delenv(self, k): os.environ.pop(k, None)
 
 
-li, dl, di = ([int(x) for x in sys.argv[1:4]] + [50, 3, 200][len(sys.argv) - 1:])[:3]
-pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
+argv = [a for a in sys.argv[1:] if a != "--config5"]
+cfg5 = "--config5" in sys.argv[1:]          # BASELINE.json configs[4]: 500 images, ~60 partners each, five levels
+li, dl, di = ([int(x) for x in argv[:3]] + ([20, 5, 40] if cfg5 else [50, 3, 200])[len(argv):])[:3]
+if cfg5:
+    pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
+    images = range(0, 500, 71)
+else:
+    pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
+    images = range(0, 100, 9)
 t0 = time.time()
-r = T.fast_against_reference_order(pairs, li, dl, di, Env(), range(0, 100, 9))
+r = T.fast_against_reference_order(pairs, li, dl, di, Env(), images)
 r["seconds"] = time.time() - t0
 r["schedule"] = {"li": li, "dl": dl, "di": di}
-r["workload"] = "100 images x 20 000 keypoints, %d half-links" % pairs.n_half_links
-out = os.path.join(ROOT, "gpurun_out", "parity_reference_order.json")
+r["workload"] = "%d images x 20 000 keypoints, %d half-links" % (pairs.n_images, pairs.n_half_links)
+out = os.path.join(ROOT, "gpurun_out", "parity_reference_order_cfg5.json" if cfg5 else "parity_reference_order.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as fh:
     json.dump(r, fh, indent=1)

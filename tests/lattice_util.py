@@ -112,3 +112,43 @@ def compare_lattice(g, ref, k, i, pts, weights):
     d = lattice_deviation(g, ref, k, i, pts, weights)
     assert d["raw"] <= RIM_REL, f"lattice {k} image {i}: coefficients off by {d['raw']:.2e}"
     return d["weighted"], d["field"], d["weak"], d["nodes"]
+
+
+# ---- control points reached across a cell face -------------------------------------------------------------------------
+# The scatter places a point in the cell floor((float) lattice coordinate) (imageGroup.cxx:303-310) and the proposal
+# divides by whatever weight a control point received (:346-375: gw > 0).  A point within one f32 ulp of a cell face is
+# therefore a discontinuity of the reference's own update: on one side of the face the far plane of its 4^3 stencil gets the
+# weight t^3 / 6 = 1e-17 -- enough for gw > 0, so a control point nothing else supports moves by the FULL step alpha g / gw,
+# every iteration the lattice lives (its coefficient does not move the point back: weight 1e-17) -- and on the other side, or
+# at t == 0 exactly, the same control point is not reached and keeps its value.  Two runs whose coordinates differ in the
+# last bit decide such a point differently about once per 1e6 points and lattice (measured: one of 8e5 points at level 4 of
+# a cfg-5-shaped group of 40 images, profiles/r04_level4_face_crossing.txt): up to 64 + 16 control points of that image end
+# a step per iteration apart (0.035 mm x 10 iterations against max|c| 2.4 mm), and the same nodes of every other image
+# 1 / nImages of it through the group mean.  That is the reference's conditioning, not a property of either run, and
+# FROG_REFERENCE_ORDER=1 is the mode that reproduces the reference's side of every face bit for bit.  The comparison of the
+# product path therefore reports the control points of such stencils separately: `face_crossing_nodes` finds them from the
+# two runs' input coordinates of the lattice.
+
+def scatter_cells(xyz, info):
+    """Cell and fraction as the scatter computes them: the lattice coordinate rounded to f32, then floor."""
+    q = ((np.asarray(xyz, np.float64) - np.array(list(info.origin))) / np.array(list(info.spacing))).astype(np.float32)
+    c = np.floor(q)
+    return c.astype(np.int64), q - c
+
+
+def face_crossing_nodes(xyz_a, xyz_b, info):
+    """Points two runs place in different cells (or on a face, fraction exactly 0, in one run only), and the mask of the
+    control points of either run's 4^3 stencil of those points.  xyz_a, xyz_b: the same points' input coordinates of the
+    lattice in the two runs.  Returns (point indices, mask[n_cp])."""
+    dims = [int(d) for d in info.dims]
+    mask = np.zeros(dims[0] * dims[1] * dims[2], bool)
+    ca, fa = scatter_cells(xyz_a, info)
+    cb, fb = scatter_cells(xyz_b, info)
+    pts = np.nonzero(np.any(ca != cb, axis=1) | np.any((fa == 0) != (fb == 0), axis=1))[0]
+    o = np.arange(-1, 3)
+    for c in (ca[pts], cb[pts]):
+        for cx, cy, cz in c:
+            gx, gy, gz = cx + o, cy + o, cz + o
+            gx, gy, gz = gx[(gx >= 0) & (gx < dims[0])], gy[(gy >= 0) & (gy < dims[1])], gz[(gz >= 0) & (gz < dims[2])]
+            mask[(gx[None, None, :] + dims[0] * (gy[None, :, None] + dims[1] * gz[:, None, None])).ravel()] = True
+    return pts, mask

@@ -23,7 +23,7 @@ from frog_amd import _abi
 from frog_amd.image_group import ImageGroup
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup
-from lattice_util import lattice_deviation, node_weights, lattice_taps
+from lattice_util import lattice_deviation, node_weights, lattice_taps, face_crossing_nodes
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -205,9 +205,10 @@ def test_reference_order_mode_equals_the_oracle_config5_shaped(monkeypatch):
 
 # ---- the product path against reference-order mode, both on the device --------------------------------------------------
 
-def dense_field_deviation(a, b, k, images, xyz, n_per_axis=24):
+def dense_field_deviation(a, b, k, images, xyz, n_per_axis=24, skip=None):
     """Displacement of lattice k on both sides on a dense lattice of points over the bounding box of the coordinates the
-    lattice acts on (what a resampler evaluates: tools/VolumeTransform.cxx:119-136), relative to the largest displacement."""
+    lattice acts on (what a resampler evaluates: tools/VolumeTransform.cxx:119-136), relative to the largest displacement.
+    skip: mask of control points whose difference is left out (tests/lattice_util.py face_crossing_nodes)."""
     lo, hi = xyz.min(axis=0).astype(np.float64), xyz.max(axis=0).astype(np.float64)
     axes = [np.linspace(lo[d], hi[d], n_per_axis) for d in range(3)]
     pts = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3)
@@ -216,9 +217,11 @@ def dense_field_deviation(a, b, k, images, xyz, n_per_axis=24):
         info, ca = a.grid(i, k)
         _, cb = b.grid(i, k)
         idx, wt = lattice_taps(pts, info)
-        da = np.einsum("nt,ntk->nk", wt, ca.astype(np.float64)[idx])
+        diff = ca.astype(np.float64) - cb
+        if skip is not None:
+            diff[skip] = 0.0
         db = np.einsum("nt,ntk->nk", wt, cb.astype(np.float64)[idx])
-        worst = max(worst, float(np.max(np.abs(da - db))))
+        worst = max(worst, float(np.max(np.abs(np.einsum("nt,ntk->nk", wt, diff[idx])))))
         scale = max(scale, float(np.max(np.abs(db))))
     return worst / max(scale, 1e-30), scale
 
@@ -240,12 +243,13 @@ def fast_against_reference_order(pairs, li, dl, di, monkeypatch, images, **opt):
     monkeypatch.delenv("FROG_REFERENCE_ORDER")
     fast = Side(pairs, **opt)
     po = np.asarray(pairs.point_offset)
-    snaps, worst = [], {"E": 0.0}
+    snaps, snaps_fast, worst = [], [], {"E": 0.0}
 
     def check(tag, sides, e=None, infos=None):
         if infos is not None:
             assert list(infos[0].dims) == list(infos[1].dims), tag
             snaps.append(sides[1].xyz().copy())
+            snaps_fast.append(sides[0].xyz().copy())
         if e is not None and e[0] >= 0 and tag[0] != "step":
             worst["E"] = max(worst["E"], abs(e[0] - e[1]) / abs(e[1]))
     grids = lockstep([fast, ref], li, dl, di, check)
@@ -260,6 +264,20 @@ def fast_against_reference_order(pairs, li, dl, di, monkeypatch, images, **opt):
                 d[key] = max(d[key], r[key])
             d["weak"], d["nodes"] = r["weak"], r["nodes"]
         d["dense_field"], d["max_disp"] = dense_field_deviation(fast.g, ref.g, k, images, snaps[k])
+        # control points one of the two runs reaches across a cell face (tests/lattice_util.py): counted, and the same two
+        # numbers without them
+        info = ref.g.grid(0 + ref.first, k)[0]
+        crossing, skip = face_crossing_nodes(snaps_fast[k], snaps[k], info)
+        d["face_crossings"], d["crossing_nodes"] = int(len(crossing)), int(skip.sum())
+        d["raw_elsewhere"], d["dense_field_elsewhere"] = d["raw"], d["dense_field"]
+        if len(crossing):
+            d["raw_elsewhere"], scale = 0.0, 0.0
+            for i in images:
+                ca, cb = fast.g.grid(i, k)[1], ref.g.grid(i, k)[1]
+                d["raw_elsewhere"] = max(d["raw_elsewhere"], float(np.abs(ca.astype(np.float64) - cb)[~skip].max()))
+                scale = max(scale, float(np.abs(cb).max()))
+            d["raw_elsewhere"] /= max(scale, 1e-30)
+            d["dense_field_elsewhere"] = dense_field_deviation(fast.g, ref.g, k, images, snaps[k], skip=skip)[0]
         out.append(d)
     # the WHOLE chain of an image (matrix, then every lattice in creation order: what transforms/<i>.json holds and
     # tools/VolumeTransform.cxx / PointsTransform.cxx evaluate) on a dense lattice of points over the image's own keypoint
@@ -355,6 +373,25 @@ def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
     for k, d in enumerate(r["lattices"]):
         assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+
+
+def test_fast_path_against_reference_order_config5_shaped_long_level4(monkeypatch):
+    """cfg-5-shaped group of 40 images (20 000 keypoints, 20 partner images, five levels: level 4 has 8.5e5 control points per
+    image, about one keypoint per cell) over 20 + 5 x 12 iterations -- long enough for the level-4 guard to reject a step and
+    for a lattice to live ten iterations.  That is where the reference's update is discontinuous in a way the coarser levels
+    hide (tests/lattice_util.py, face_crossing_nodes): a control point whose only support is a point within an ulp of a cell
+    face moves a full step per iteration in the run that sees the point on one side, and not at all in the other.  Reported
+    per lattice: how many points the two runs place across a face, the deviations with and without the control points of
+    those points' stencils.  Asserted: same guard decisions; energies; the field at the keypoints (what the energy sees);
+    coefficients and dense field away from the crossings."""
+    pairs = Pairs.synthetic(40, 20000, 16667, seed=2, partners_per_image=20)
+    r = fast_against_reference_order(pairs, 20, 5, 12, monkeypatch, range(40))
+    report("fast_vs_reference_order_cfg5_shaped_long", r)
+    assert len(r["grids"]) == 5 and sum(r["grids"]) > 5           # the guard rejected at least once
+    for k, d in enumerate(r["lattices"]):
+        assert d["face_crossings"] <= 8, (k, d)
+        assert d["field"] <= 1e-3 and d["raw_elsewhere"] <= 1e-2 and d["dense_field_elsewhere"] <= 1e-3, (k, d)
+    assert r["E"] < 1e-5
 
 
 # ---- reference-order mode on the inputs the reference's loops have special cases for ------------------------------------
