@@ -162,7 +162,7 @@ class FrogChainLink(C.Structure):
 
 class FrogMatchOptions(C.Structure):
     _fields_ = [("threshold", C.c_float), ("dist2second", C.c_float), ("anat", C.c_float), ("sym", C.c_int),
-                ("reserved", C.c_int * 4)]
+                ("all", C.c_int), ("reserved", C.c_int * 3)]
 
     @classmethod
     def default(cls, **kw):

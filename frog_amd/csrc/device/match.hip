@@ -57,6 +57,7 @@ struct DevImage {
     float norm_max = 0.f;
     bool finite = true;                 // every descriptor value is finite
     uint32_t *orig = nullptr;           // sorted position -> index in the caller's order
+    uint32_t *pos = nullptr;            // index in the caller's order -> sorted position (matchAll walks the caller's order)
     std::vector<uint32_t> h_orig;
 };
 
@@ -566,6 +567,102 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
         }                                                                                    \
     } while (0)
 
+// ---- matchAll (`-all`, match.cpp:297-302) -----------------------------------------------------------------------------
+// With matchAll every candidate that passes the filters and lies within the threshold (sqrt(dist) < threshold) emits a pair
+// at once -- and what upstream pushes is not that candidate but its `match` variable: the nearest so far among the candidates
+// that were NOT within the threshold (only those reach the d1 / d2 / match update of :303-313), or, before the first such
+// candidate, whatever an earlier query of the same call left there (`int match = 0;` lives outside the query loop, :259).
+// The emitted values therefore depend on the order the candidates are met in: the caller's.  One lane = one query, every
+// lane of the wavefront meets the same candidate at the same time, candidates staged in the CALLER's order (rows gathered
+// through `c_pos`: original index -> position in the device's sorted copy); no candidate range is skipped and none is split
+// over blocks -- the state is sequential.  Two passes: COUNT leaves the number of emissions and the final `match` of
+// every query (-1: no update), the host turns the counts into offsets, EMIT runs the same loop again and writes the values
+// (-1 where the value is the one carried in from earlier queries: the host, which walks the queries in order, knows it).
+// Rarely used and quadratic by definition (no filter can bound "every candidate within the threshold" away): built to be
+// upstream's list bit for bit, not to be fast -- 20 000 x 20 000 keypoints take two passes of ~6 ms.
+constexpr int ALL_BLOCK = 64;
+
+struct AllArgs {
+    const float *q_desc, *q_sign, *q_scale, *q_xyz;
+    const float *c_desc, *c_sign, *c_lo, *c_hi, *c_xyz;
+    const uint32_t *c_pos;              // candidate, caller's index -> sorted position
+    uint32_t nq, nc;
+    float anat, threshold;
+    int *count, *last;                  // [nq] (sorted query order)
+    const unsigned long long *offset;   // EMIT: where a query's values start
+    int *values;
+};
+
+template <int D, bool EMIT>
+__global__ __launch_bounds__(ALL_BLOCK) void match_all_kernel(const AllArgs a)
+{
+    __shared__ float4 tile[CAND_TILE][D / 4];
+    __shared__ float cs[CAND_TILE], clo[CAND_TILE], chi[CAND_TILE], cx[CAND_TILE], cy[CAND_TILE], cz[CAND_TILE];
+    const uint32_t qi = blockIdx.x * ALL_BLOCK + threadIdx.x;
+    const bool valid = qi < a.nq;
+    float q[D];
+    float qsign = 0.f, qscale = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) {
+        const float4 *row = reinterpret_cast<const float4 *>(a.q_desc + (size_t)qi * D);
+        #pragma unroll
+        for (int k = 0; k < D / 4; k++) { const float4 v = row[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+        qsign = a.q_sign[qi]; qscale = a.q_scale[qi];
+        qx = a.q_xyz[3 * (size_t)qi]; qy = a.q_xyz[3 * (size_t)qi + 1]; qz = a.q_xyz[3 * (size_t)qi + 2];
+    } else {
+        #pragma unroll
+        for (int k = 0; k < D; k++) q[k] = 0.f;
+    }
+    float d1 = FLT_MAX, d2 = FLT_MAX;
+    int match = -1, emitted = 0;
+    const bool use_anat = a.anat != 0.f;
+    int *dst = EMIT && valid ? a.values + a.offset[qi] : nullptr;
+
+    for (uint32_t base = 0; base < a.nc; base += CAND_TILE) {
+        const uint32_t cnt = min((uint32_t)CAND_TILE, a.nc - base);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt * (D / 4); k += ALL_BLOCK) {
+            const uint32_t c = k / (D / 4), w = k - c * (D / 4);
+            tile[c][w] = reinterpret_cast<const float4 *>(a.c_desc + (size_t)a.c_pos[base + c] * D)[w];
+        }
+        if (threadIdx.x < cnt) {
+            const uint32_t c = a.c_pos[base + threadIdx.x];
+            cs[threadIdx.x] = a.c_sign[c]; clo[threadIdx.x] = a.c_lo[c]; chi[threadIdx.x] = a.c_hi[c];
+            cx[threadIdx.x] = a.c_xyz[3 * (size_t)c]; cy[threadIdx.x] = a.c_xyz[3 * (size_t)c + 1]; cz[threadIdx.x] = a.c_xyz[3 * (size_t)c + 2];
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < cnt; c++) {
+            float dist = 0.f;                                               // norm, match.cpp:242-251
+            #pragma unroll
+            for (int k = 0; k < D / 4; k++) {
+                const float4 v = tile[c][k];
+                float t;
+                t = q[4 * k] - v.x;     dist += t * t;
+                t = q[4 * k + 1] - v.y; dist += t * t;
+                t = q[4 * k + 2] - v.z; dist += t * t;
+                t = q[4 * k + 3] - v.w; dist += t * t;
+            }
+            bool pass = valid && qsign == cs[c] && qscale > clo[c] && qscale < chi[c];      // :270-275
+            if (use_anat) {                                                                 // :278-291
+                const float ex = qx - cx[c], ey = qy - cy[c], ez = qz - cz[c];
+                const float eucl = sqrtf(ex * ex + ey * ey + ez * ez);
+                pass = pass && !(eucl > a.anat);
+            }
+            const bool near = pass && sqrtf(dist) < a.threshold;                            // :297
+            if (near) {
+                if (EMIT) dst[emitted] = match;
+                emitted++;
+            }
+            const bool far = pass && !near;                                                 // :303-313
+            const bool better = far && dist < d1;
+            const bool second = far && !better && dist < d2;
+            d2 = better ? d1 : (second ? dist : d2);
+            d1 = better ? dist : d1;
+            match = better ? (int)(base + c) : match;
+        }
+    }
+    if (!EMIT && valid) { a.count[qi] = emitted; a.last[qi] = match; }
+}
+
 int fail(int code, const std::string &msg) { frog::set_last_error(msg); return code; }
 
 // smallest positive float s with (double)(s / sc) > 1.3  (reject when s >= hi), +inf if none
@@ -604,6 +701,102 @@ struct frog_matcher {
     double last_ms = 0, last_dist = 0, last_computed = 0, last_fallback = 0;
 };
 
+// frog_matcher_run with o->all (see match_all_kernel).  Passes run one after the other: the second launch of a pass needs the
+// first one's counts.
+static int run_all(frog_matcher *m, const uint16_t *first, const uint16_t *second, size_t n_jobs, const frog_match_options *o,
+                   std::vector<std::vector<uint32_t>> &ja, std::vector<std::vector<uint32_t>> &jb)
+{
+    uint32_t max_n = 1;
+    for (size_t k = 0; k < n_jobs; k++) max_n = std::max(max_n, std::max(m->img[first[k]].n, m->img[second[k]].n));
+    int *d_count = nullptr, *d_last = nullptr, *d_values = nullptr;
+    unsigned long long *d_offset = nullptr;
+    size_t values_cap = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    auto cleanup = [&]() {
+        if (d_count) (void)hipFree(d_count);
+        if (d_last) (void)hipFree(d_last);
+        if (d_values) (void)hipFree(d_values);
+        if (d_offset) (void)hipFree(d_offset);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+    };
+#define ACHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return FROG_E_HIP; } } while (0)
+    ACHECK(hipMalloc((void **)&d_count, (size_t)max_n * sizeof(int)));
+    ACHECK(hipMalloc((void **)&d_last, (size_t)max_n * sizeof(int)));
+    ACHECK(hipMalloc((void **)&d_offset, (size_t)max_n * sizeof(unsigned long long)));
+    ACHECK(hipEventCreate(&t0));
+    ACHECK(hipEventCreate(&t1));
+    ACHECK(hipEventRecord(t0, m->stream));
+    std::vector<int> count(max_n), last(max_n), values;
+    std::vector<unsigned long long> offset(max_n);
+    double distances = 0;
+    for (size_t k = 0; k < n_jobs; k++)
+        for (int dir = 0; dir < (o->sym ? 2 : 1); dir++) {
+            const DevImage &C = m->img[dir ? second[k] : first[k]], &Q = m->img[dir ? first[k] : second[k]];
+            const uint32_t nq = Q.n;
+            if (!nq) continue;
+            AllArgs a;
+            a.q_desc = Q.desc; a.q_sign = Q.sign; a.q_scale = Q.scale; a.q_xyz = Q.xyz;
+            a.c_desc = C.desc; a.c_sign = C.sign; a.c_lo = C.lo; a.c_hi = C.hi; a.c_xyz = C.xyz; a.c_pos = C.pos;
+            a.nq = nq; a.nc = C.n; a.anat = o->anat; a.threshold = o->threshold;
+            a.count = d_count; a.last = d_last; a.offset = d_offset; a.values = nullptr;
+            const uint32_t blocks = (nq + ALL_BLOCK - 1) / ALL_BLOCK;
+#define ALL_LAUNCH(EMIT)                                                                                       \
+            switch (m->dp) {                                                                                   \
+            case 48: match_all_kernel<48, EMIT><<<blocks, ALL_BLOCK, 0, m->stream>>>(a); break;                \
+            case 64: match_all_kernel<64, EMIT><<<blocks, ALL_BLOCK, 0, m->stream>>>(a); break;                \
+            case 96: match_all_kernel<96, EMIT><<<blocks, ALL_BLOCK, 0, m->stream>>>(a); break;                \
+            default: match_all_kernel<128, EMIT><<<blocks, ALL_BLOCK, 0, m->stream>>>(a); break;               \
+            }
+            ALL_LAUNCH(false)
+            ACHECK(hipGetLastError());
+            ACHECK(hipMemcpyAsync(count.data(), d_count, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            ACHECK(hipMemcpyAsync(last.data(), d_last, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            ACHECK(hipStreamSynchronize(m->stream));
+            distances += (double)nq * (double)C.n;
+            unsigned long long total = 0;
+            for (uint32_t s = 0; s < nq; s++) { offset[s] = total; total += (unsigned long long)count[s]; }
+            if (total) {
+                if (total > values_cap) {
+                    if (d_values) { (void)hipFree(d_values); d_values = nullptr; }
+                    values_cap = (size_t)total + (size_t)total / 2;
+                    ACHECK(hipMalloc((void **)&d_values, values_cap * sizeof(int)));
+                }
+                ACHECK(hipMemcpyAsync(d_offset, offset.data(), (size_t)nq * sizeof(unsigned long long), hipMemcpyHostToDevice, m->stream));
+                a.values = d_values;
+                ALL_LAUNCH(true)
+                ACHECK(hipGetLastError());
+                values.resize(total);
+                ACHECK(hipMemcpyAsync(values.data(), d_values, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+                ACHECK(hipStreamSynchronize(m->stream));
+                distances += (double)nq * (double)C.n;
+            }
+#undef ALL_LAUNCH
+            // the queries in the caller's order; `stale` is upstream's `match` between two queries (match.cpp:259)
+            std::vector<uint32_t> pos(nq);
+            for (uint32_t s = 0; s < nq; s++) pos[Q.h_orig[s]] = s;
+            int stale = 0;
+            for (uint32_t q = 0; q < nq; q++) {
+                const uint32_t s = pos[q];
+                for (int e = 0; e < count[s]; e++) {
+                    int v = values[offset[s] + (unsigned long long)e];
+                    if (v < 0) v = stale;
+                    if (dir) { ja[k].push_back(q); jb[k].push_back((uint32_t)v); }        // make_pair(i, match)
+                    else { ja[k].push_back((uint32_t)v); jb[k].push_back(q); }            // make_pair(match, i)
+                }
+                if (last[s] >= 0) stale = last[s];
+            }
+        }
+    ACHECK(hipEventRecord(t1, m->stream));
+    ACHECK(hipStreamSynchronize(m->stream));
+    float ms = 0;
+    ACHECK(hipEventElapsedTime(&ms, t0, t1));
+#undef ACHECK
+    m->last_ms = ms; m->last_dist = distances; m->last_computed = distances; m->last_fallback = 0;
+    cleanup();
+    return FROG_OK;
+}
+
 extern "C" {
 
 void frog_match_options_default(frog_match_options *o)
@@ -626,6 +819,7 @@ void frog_matcher_destroy(frog_matcher *m)
         if (d.hi) (void)hipFree(d.hi);
         if (d.xyz) (void)hipFree(d.xyz);
         if (d.orig) (void)hipFree(d.orig);
+        if (d.pos) (void)hipFree(d.pos);
         if (d.norm) (void)hipFree(d.norm);
         if (d.mf) (void)hipFree(d.mf);
     }
@@ -726,6 +920,10 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
             CCHECK(hipMemcpy(d.hi, hi.data(), k.n * sizeof(float), hipMemcpyHostToDevice));
             CCHECK(hipMemcpy(d.xyz, xyz.data(), (size_t)k.n * 3 * sizeof(float), hipMemcpyHostToDevice));
             CCHECK(hipMemcpy(d.orig, d.h_orig.data(), k.n * sizeof(uint32_t), hipMemcpyHostToDevice));
+            std::vector<uint32_t> inv(k.n);
+            for (uint32_t p = 0; p < k.n; p++) inv[d.h_orig[p]] = p;
+            CCHECK(hipMalloc((void **)&d.pos, n * sizeof(uint32_t)));
+            CCHECK(hipMemcpy(d.pos, inv.data(), k.n * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
 #undef CCHECK
@@ -777,6 +975,23 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     hipEvent_t done[RING] = {}, t0 = nullptr, t1 = nullptr;
     std::vector<std::vector<uint32_t>> ja(n_jobs), jb(n_jobs);
     int rc = FROG_OK;
+    auto hand_over = [&]() -> int {
+        offset[0] = 0;
+        for (size_t k = 0; k < n_jobs; k++) offset[k + 1] = offset[k] + ja[k].size();
+        *p_first = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
+        *p_second = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
+        if (!*p_first || !*p_second) { std::free(*p_first); std::free(*p_second); *p_first = *p_second = nullptr; return fail(FROG_E_NOMEM, "out of host memory"); }
+        for (size_t k = 0; k < n_jobs; k++) {
+            if (ja[k].empty()) continue;
+            std::memcpy(*p_first + offset[k], ja[k].data(), ja[k].size() * sizeof(uint32_t));
+            std::memcpy(*p_second + offset[k], jb[k].data(), jb[k].size() * sizeof(uint32_t));
+        }
+        return FROG_OK;
+    };
+    if (o->all) {                                   // matchAll: its own sequential kernels
+        rc = run_all(m, first, second, n_jobs, o, ja, jb);
+        return rc ? rc : hand_over();
+    }
     auto cleanup = [&]() {
         if (partial) (void)hipFree(partial);
         if (qrange) (void)hipFree(qrange);
@@ -921,16 +1136,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
 #undef RCHECK
     cleanup();
 
-    offset[0] = 0;
-    for (size_t k = 0; k < n_jobs; k++) offset[k + 1] = offset[k] + ja[k].size();
-    *p_first = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
-    *p_second = (uint32_t *)std::malloc(std::max<size_t>(1, offset[n_jobs]) * sizeof(uint32_t));
-    if (!*p_first || !*p_second) { std::free(*p_first); std::free(*p_second); *p_first = *p_second = nullptr; return fail(FROG_E_NOMEM, "out of host memory"); }
-    for (size_t k = 0; k < n_jobs; k++) {
-        if (ja[k].empty()) continue;
-        std::memcpy(*p_first + offset[k], ja[k].data(), ja[k].size() * sizeof(uint32_t));
-        std::memcpy(*p_second + offset[k], jb[k].data(), jb[k].size() * sizeof(uint32_t));
-    }
+    rc = hand_over();
     return rc;
 }
 

@@ -3,7 +3,7 @@
 //   match pointFiles.txt|directory [options]
 //
 // Same flags (-n -sp -np -nt -d -d2 -zmin -zmax -o -p -anat -sym -targ), same input files, same
-// pairs.bin, plus -transformPrefix (positions for the -anat test).  Not built: -all (exits 1).
+// pairs.bin, plus -transformPrefix (positions for the -anat test).  -all is upstream's matchAll, quirk included (include/frog_match.h).
 // A directory is read in sorted name order (upstream: the file system's order).
 #include "frog_host.h"
 #include "frog_match.h"
@@ -38,7 +38,7 @@ int main(int argc, char *argv[])
     }
     const fs::path full_path = fs::absolute(fs::path(argv[1]));
     float dist = 0.22f, dist2second = 1, zmin = -1e20f, zmax = 1e20f, anatVal = 0.0f;
-    bool writePoints = false, symFlag = false;
+    bool writePoints = false, symFlag = false, matchAll = false;
     char *outputFileName = 0;
     int target = -1, device = 0;
     char *transformPrefix = 0;
@@ -56,7 +56,7 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-zmax") == 0) zmax = atof(value);
         if (strcmp(key, "-o") == 0) outputFileName = value;
         if (strcmp(key, "-dev") == 0) device = atoi(value);
-        if (strcmp(key, "-all") == 0) { cout << "Error : -all is not supported by this build" << endl; return 1; }
+        if (strcmp(key, "-all") == 0) matchAll = true;                 // as -p: the next word is skipped too (:406-408, :433)
         if (strcmp(key, "-p") == 0) writePoints = true;
         if (strcmp(key, "-anat") == 0) anatVal = atof(value);
         if (strcmp(key, "-sym") == 0) { symFlag = true; argumentsIndex -= 1; }
@@ -208,7 +208,7 @@ int main(int argc, char *argv[])
     if (frog_matcher_create(matchViews.data(), (uint32_t)nb, device, &m)) { cout << "Error : " << frog_last_error() << endl; return 1; }
     frog_match_options o;
     frog_match_options_default(&o);
-    o.threshold = dist; o.dist2second = dist2second; o.anat = anatVal; o.sym = symFlag ? 1 : 0;
+    o.threshold = dist; o.dist2second = dist2second; o.anat = anatVal; o.sym = symFlag ? 1 : 0; o.all = matchAll ? 1 : 0;
     std::vector<uint64_t> offset(first.size() + 1, 0);
     uint32_t *pa = nullptr, *pb = nullptr;
     if (frog_matcher_run(m, first.data(), second.data(), first.size(), &o, offset.data(), &pa, &pb)) {

@@ -20,7 +20,10 @@
  *
  * The anatomical test (`-anat`) compares frog_keypoints.xyz: pass the positions it is meant for
  * (bin/match -transformPrefix hands over the transformed ones, match.cpp:517-558).
- * Not built: matchAll (`-all`; upstream's branch emits the running best index, not the candidate).
+ * matchAll (`-all`, match.cpp:297-302): every candidate within the threshold emits a pair at once -- and, as upstream, the
+ * index pushed is the `match` variable (the nearest candidate so far that was NOT within the threshold, carried over from
+ * earlier queries when there is none yet), not the candidate itself; the second-nearest test does not apply.  Reproduced as
+ * it is, in the caller's candidate order, by a sequential pair of kernels (device/match.hip match_all_kernel).
  */
 #ifndef FROG_MATCH_H
 #define FROG_MATCH_H
@@ -51,7 +54,8 @@ typedef struct frog_match_options {
     float dist2second;          /* -d2  (1)                                    */
     float anat;                 /* -anat (0 = off)                             */
     int sym;                    /* -sym: also match first against second       */
-    int reserved[4];
+    int all;                    /* -all: matchAll (match.cpp:297-302)          */
+    int reserved[3];
 } frog_match_options;
 
 void frog_match_options_default(frog_match_options *o);

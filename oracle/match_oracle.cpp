@@ -27,9 +27,9 @@ inline float norm_sq(const float *p1, const float *p2, int size)
     return result;
 }
 
-// match.cpp:255-336, matchAll == false.  points2 = candidates, points1 = queries.
+// match.cpp:255-336.  points2 = candidates, points1 = queries.
 void compute_matches(const frog_keypoints &points2, const frog_keypoints &points1, float threshold, float dist2second,
-                     float anatVal, bool sym, std::vector<uint32_t> &out_a, std::vector<uint32_t> &out_b)
+                     bool matchAll, float anatVal, bool sym, std::vector<uint32_t> &out_a, std::vector<uint32_t> &out_b)
 {
     float d1, d2;
     int match = 0;                                  // declared outside the query loop upstream: it carries over
@@ -48,9 +48,15 @@ void compute_matches(const frog_keypoints &points2, const frog_keypoints &points
                 if (euclNorm > anatVal) continue;
             }
             float dist = norm_sq(points1.desc + (size_t)i * points1.dim, points2.desc + (size_t)j * points2.dim, (int)points1.dim);
-            if (dist < d1) { d2 = d1; d1 = dist; match = j; }                                   // :303-313
-            else if (dist < d2) { d2 = dist; }
+            if (matchAll && std::sqrt(dist) < threshold) {                                      // :297-302: pushes `match`, not j
+                if (sym) { out_a.push_back((uint32_t)i); out_b.push_back((uint32_t)match); }
+                else { out_a.push_back((uint32_t)match); out_b.push_back((uint32_t)i); }
+            } else {
+                if (dist < d1) { d2 = d1; d1 = dist; match = j; }                               // :303-313
+                else if (dist < d2) { d2 = dist; }
+            }
         }
+        if (matchAll) continue;                                                                 // :318
         if ((std::sqrt(d1 / d2) < dist2second || (d2 == FLT_MAX)) && (std::sqrt(d1) < threshold)) {   // :320-321
             if (sym) { out_a.push_back((uint32_t)i); out_b.push_back((uint32_t)match); }        // make_pair(i, match)
             else { out_a.push_back((uint32_t)match); out_b.push_back((uint32_t)i); }            // make_pair(match, i)
@@ -74,8 +80,8 @@ int frogo_match_run(const frog_keypoints *images, uint32_t n_images, const uint1
     #pragma omp parallel for schedule(dynamic)
     for (long k = 0; k < (long)n_jobs; k++) {
         const frog_keypoints &A = images[first[k]], &B = images[second[k]];
-        compute_matches(A, B, o->threshold, o->dist2second, o->anat, false, a[k], b[k]);
-        if (o->sym) compute_matches(B, A, o->threshold, o->dist2second, o->anat, true, a[k], b[k]);
+        compute_matches(A, B, o->threshold, o->dist2second, o->all != 0, o->anat, false, a[k], b[k]);
+        if (o->sym) compute_matches(B, A, o->threshold, o->dist2second, o->all != 0, o->anat, true, a[k], b[k]);
     }
     offset[0] = 0;
     for (size_t k = 0; k < n_jobs; k++) offset[k + 1] = offset[k] + a[k].size();

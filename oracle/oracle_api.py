@@ -354,7 +354,7 @@ class OracleGroup:
 
 
 # ---- pairing stage of the reference's `match` tool (oracle/match_oracle.cpp) ---------------
-def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, threads=None):
+def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, all=0, threads=None):
     """ComputeMatches (match/match.cpp:255-336) per (first, second) job on the CPU.
     `images`: frog_amd.match.Keypoints.  Returns per job (indices in first, indices in second)."""
     from frog_amd import _abi
@@ -369,7 +369,7 @@ def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, th
         L.frogo_match_set_threads(int(threads))
     views = (_abi.FrogKeypoints * len(images))(*[k.view() for k in images])
     o = _abi.FrogMatchOptions()
-    o.threshold, o.dist2second, o.anat, o.sym = threshold, dist2second, anat, sym
+    o.threshold, o.dist2second, o.anat, o.sym, o.all = threshold, dist2second, anat, sym, all
     n = len(jobs)
     f = (C.c_uint16 * max(n, 1))(*[j[0] for j in jobs])
     s = (C.c_uint16 * max(n, 1))(*[j[1] for j in jobs])

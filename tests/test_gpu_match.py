@@ -32,6 +32,34 @@ def test_pairs_identical_to_oracle(opts):
     assert sum(len(a) for a, _ in got) > 0 or opts["threshold"] < 0.3
 
 
+@pytest.mark.parametrize("opts", [dict(threshold=0.9), dict(threshold=0.9, sym=1), dict(threshold=1.2, anat=40.0),
+                                  dict(threshold=0.3), dict(threshold=1e10), dict(threshold=0.0)])
+def test_match_all_identical_to_oracle(opts):
+    """matchAll (match.cpp:297-302): one pair per candidate within the threshold, carrying upstream's `match` variable --
+    the nearest candidate so far BEYOND the threshold, in the caller's candidate order, carried over from query to query."""
+    imgs = synthetic_keypoints(4, 1500, seed=13)
+    imgs[2] = Keypoints.from_rows(imgs[2].rows()[:777])
+    imgs[3] = Keypoints.from_rows(imgs[3].rows()[:33])
+    jobs = all_pairs(4) + [(3, 0)]
+    m = Matcher(imgs)
+    got = m.run(jobs, all=1, **opts)
+    want = match_run(imgs, jobs, all=1, **opts)
+    same(got, want)
+    n = sum(len(a) for a, _ in want)
+    assert n == 0 if opts["threshold"] == 0.0 else (n > 100 or opts["threshold"] < 0.9)
+    if opts["threshold"] == 1e10:           # every candidate that passes the filters is "within": the carried value is 0
+        assert all((b == 0).all() if opts.get("sym") else (a == 0).all() for a, b in got)
+
+
+@pytest.mark.parametrize("dim", [8, 100])
+def test_match_all_descriptor_lengths_and_empty_images(dim):
+    imgs = synthetic_keypoints(3, 300, dim=dim, seed=dim)
+    e = imgs[2]
+    imgs[2] = Keypoints(e.xyz[:0], e.scale[:0], e.laplacian[:0], e.response[:0], e.desc[:0])
+    jobs = [(0, 1), (1, 0), (0, 2), (2, 1)]
+    same(Matcher(imgs).run(jobs, all=1, threshold=1.0, sym=1), match_run(imgs, jobs, all=1, threshold=1.0, sym=1))
+
+
 @pytest.mark.parametrize("dim", [8, 48, 50, 64, 100, 128])
 def test_descriptor_lengths(dim):
     imgs = synthetic_keypoints(2, 600, dim=dim, seed=dim)
@@ -208,7 +236,15 @@ def test_match_cli_end_to_end(tmp_path):
     r = subprocess.run([os.path.join(root, "bin", "frog"), "pairs.bin", "-li", "3", "-dl", "0", "-q", "1"], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "pairs read" in r.stdout, r.stdout[-1500:]
-    assert subprocess.run([exe, "list.txt", "-all", "1"], cwd=tmp_path, capture_output=True).returncode == 1
+    # -all (match.cpp:406: a flag that, like -p, swallows the next word)
+    r = subprocess.run([exe, "list.txt", "-all", "x", "-o", "all.bin", "-d", "0.9", "-sym"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    _, blocks = _read_pairs_bin(tmp_path / "all.bin")
+    want = match_run(imgs, all_pairs(4), threshold=0.9, sym=1, all=1)
+    assert [(b[0], b[1]) for b in blocks] == all_pairs(4)
+    for (i, j, pr), (wa, wb) in zip(blocks, want):
+        assert np.array_equal(pr[:, 0], wa) and np.array_equal(pr[:, 1], wb)
+    assert sum(len(b[2]) for b in blocks) > 100
     # -anat with -transformPrefix (match.cpp:517-558, :278-290): the anatomical-distance test is taken on positions
     # moved by <prefix><image>.json.  Image 1 is written 150 mm off; its transform brings it back.
     import json

@@ -90,3 +90,30 @@ def test_stale_match_variable_quirk():
 
 def test_job_order_and_all_pairs():
     assert all_pairs(3) == [(0, 1), (0, 2), (1, 2)]
+
+
+def test_match_all_pushes_the_running_match_variable():
+    """matchAll (match.cpp:297-302), worked by hand.  Candidates in 1-D at 0, 10, 3, 0.25, 9; threshold 1 (on sqrt(dist)).
+    query 0 at 0:   cand 0: |0| < 1 -> push `match` (= 0, the initial value, :259); cand 1: 10 far -> d1 = 100, match = 1;
+                    cand 2: 3 far, 9 < 100 -> match = 2; cand 3: 0.25 < 1 -> push 2; cand 4: 9 far, 81 > 9 -> match stays 2.
+    query 1 at 9.5: cand 0: far, d1 = 90.25, match = 0; cand 1: 0.5 < 1 -> push 0; cand 2: far, 42.25 -> match = 2;
+                    cand 3: far, 85.56 no; cand 4: 0.5 < 1 -> push 2.
+    query 2 at 0.5: sign -1, sees nothing: no push, `match` stays 2.
+    query 3 at 3.5: cand 0: far 12.25 -> match 0; cand 1: far 42.25; cand 2: 0.5 < 1 -> push 0; cand 3: far 10.56 -> match 3;
+                    cand 4: far.
+    The second-nearest test does not apply (:318)."""
+    cand = kp([[0.0], [10.0], [3.0], [0.25], [9.0]])
+    qry = kp([[0.0], [9.5], [0.5], [3.5]], sign=np.array([1, 1, -1, 1], np.float32))
+    (a, b), = match_run([cand, qry], [(0, 1)], threshold=1.0, dist2second=0.0, all=1)
+    assert a.tolist() == [0, 2, 0, 2, 0] and b.tolist() == [0, 0, 1, 1, 3]
+    # carried over from query to query: a query whose first candidate is within the threshold pushes the previous query's match
+    qry2 = kp([[9.5], [0.1]])
+    (a, b), = match_run([cand, qry2], [(0, 1)], threshold=1.0, all=1)
+    assert a.tolist() == [0, 2, 2, 2] and b.tolist() == [0, 0, 1, 1]      # query 1: cand 0 within -> 2 (query 0's last), cand 3 within -> still 2 (cand 1, 2 far: 98.01, 8.41 -> match 2)
+    # -sym: the reverse direction appended with the pair turned round (make_pair(i, match), :299)
+    (a, b), = match_run([cand, qry2], [(0, 1)], threshold=1.0, all=1, sym=1)
+    assert a.tolist()[:4] == [0, 2, 2, 2] and b.tolist()[:4] == [0, 0, 1, 1]
+    # reverse: queries = cand (5), candidates = qry2 (9.5, 0.1): q0 at 0: c0 far (match 0), c1 0.1 within -> push 0; q1 at 10: c0 0.5
+    # within -> push 0; c1 far -> match 1; q2 at 3: both far, match -> c1 (8.41 < 42.25) = 1; q3 at 0.25: c0 far -> match 0, c1 0.15
+    # within -> push 0; q4 at 9: c0 0.5 within -> push 0 (carried), c1 far -> match 1
+    assert a.tolist()[4:] == [0, 1, 3, 4] and b.tolist()[4:] == [0, 0, 0, 0]
