@@ -315,7 +315,8 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
     const uint32_t *n_blocks_dev = ctx->brick_slot_ptr.p + n_bricks_total;
     block_fill_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->brick_slot_ptr.p, n_bricks_total, keys_per_brick,
                                                                  blk_tmp, len_hist);
-    block_len_base_kernel<<<1, 512, 0, s>>>(len_hist, len_cursor);
+    static_assert(SCATTER_CHUNK + 1 <= 1024, "block_len_base_kernel: one thread per block length");
+    block_len_base_kernel<<<1, (SCATTER_CHUNK + 1 + 63) / 64 * 64, 0, s>>>(len_hist, len_cursor);
     if (max_blocks)
         block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
     FROG_HIP_CHECK(hipGetLastError());
