@@ -382,7 +382,16 @@ def run_native(args, rank, world, local_rank, transport, rdv):
         plan.proxy_xyz2 = proxy[0].ctypes.data
         plan.proxy_em = proxy[1].ctypes.data
     res = _abi.FrogScheduleResult()
+    if os.environ.get("FROG_BENCH_PREWARM"):         # experiment: N census passes (state untouched) right before the schedule
+        counts = (_abi.FrogCounts * pairs.n_images)()
+        _abi.check(lib.frog_linear_init(ctx, (C.c_float * 3)(0.5, 0.5, 0.5)), "frog_linear_init")
+        _abi.check(lib.frog_transform_points(ctx, 0), "frog_transform_points")
+        for _ in range(int(os.environ["FROG_BENCH_PREWARM"])):
+            _abi.check(lib.frog_count_inliers(ctx, counts), "frog_count_inliers")
+    t_call = time.perf_counter()
     _abi.check(host.frog_run_schedule(ctx, comm, C.byref(plan), C.byref(res)), "frog_run_schedule")
+    if os.environ.get("FROG_BENCH_TRACE_HOST"):
+        print(f"[bench] create done -> schedule call {t_call - t0 - t_create:.4f} s; schedule call {time.perf_counter() - t_call:.4f} s of which timed {res.elapsed_s:.4f} s", file=sys.stderr)
 
     def cull(fn):
         a, bb, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -140,8 +140,12 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
     r.whole = !comm && r.ib == 0 && r.ie == r.nI;
 
     // ---- untimed: linear set-up, first transform, (proxy: the other ranks' coordinates), warm-up iterations
+    const bool trace = getenv("FROG_SCHEDULE_TRACE") != nullptr;
+    const auto t_in = clk::now();
     r.ok(frog_linear_init(ctx, plan->anchor));
+    if (trace) std::fprintf(stderr, "[schedule] linear_init returned at %.4f s\n", since(t_in));
     r.transformPoints(0);
+    if (trace) { frog_synchronize(ctx); std::fprintf(stderr, "[schedule] first transform done at %.4f s\n", since(t_in)); }
     if (!r.rc && plan->proxy_xyz2 && !comm && !r.whole) {
         size_t pb = 0, pe = 0;
         const uint64_t P = frog_num_points(ctx);
@@ -162,6 +166,7 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
         r.transformPoints(0);
     }
 
+    if (trace) { frog_synchronize(ctx); std::fprintf(stderr, "[schedule] warm-up done at %.4f s\n", since(t_in)); }
     // ---- timed region
     r.ok(frog_profile_enable(ctx, plan->profile));
     if (comm && plan->time_comm) r.ok(r.api->timing(comm, 1));
@@ -210,6 +215,7 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
     }
     r.barrier();
     out->elapsed_s = since(t_start);
+    if (trace) std::fprintf(stderr, "[schedule] timed region %.4f s, ends at %.4f s\n", out->elapsed_s, since(t_in));
     out->final_E = (double)(float)E;
     if (r.rc) return r.rc;
 
