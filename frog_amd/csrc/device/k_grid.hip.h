@@ -627,7 +627,10 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
     else if (live) sorted[atomicAdd(&len_cursor[b.end - b.begin], 1u)] = b;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+#ifndef FROG_TRANSFORM_WAVES
+#define FROG_TRANSFORM_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROG_TRANSFORM_WAVES)))
 void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                    const uint32_t *perm, const ScatterBlock *blocks,
                                    const uint32_t *n_blocks, const GeomDev g, int apply,
