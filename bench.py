@@ -695,18 +695,20 @@ def orchestrate(args, argv, n, my_ranks, directory):
     if "OMP_NUM_THREADS" not in os.environ or os.environ.get("FROG_BENCH_UNDER_TORCHRUN") == "1":
         # torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset; frog_create builds its layout on the host threads
         env_base["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or n) // n))
-    timeouts = {"preflight": float(os.environ.get("FROG_BENCH_PREFLIGHT_TIMEOUT", "150")),
-                "native": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "300")),
-                "torch": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "300"))}
+    # a healthy attempt takes 5-20 s (the torch host up to two minutes more on a fresh box: its first `import torch`); the
+    # worst case of a whole run -- preflight passes, the native RCCL attempt hangs, fallback -- stays near five minutes
+    timeouts = {"preflight": float(os.environ.get("FROG_BENCH_PREFLIGHT_TIMEOUT", "90")),
+                "native": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "150")),
+                "torch": float(os.environ.get("FROG_BENCH_ATTEMPT_TIMEOUT", "240"))}
     plan = attempts_plan(rehearsal)
     tried, lines = [], []
-    rccl_ok = True
+    rccl_ok, rccl_why = True, "the RCCL preflight failed"
     k = 0
     queue = list(plan)
     while queue:
         host, transport = queue.pop(0)
         if not rccl_ok and transport in ("rccl", "nccl"):
-            tried.append({"host": host, "transport": transport, "ok": False, "skipped": "the RCCL preflight failed"})
+            tried.append({"host": host, "transport": transport, "ok": False, "skipped": rccl_why})
             continue
         t0 = time.time()
         procs = {}
@@ -765,6 +767,13 @@ def orchestrate(args, argv, n, my_ranks, directory):
             rec["ok"] = False
             if line:
                 rec["replicas_identical"] = line.get("replicas_identical")
+            if transport in ("rccl", "nccl") and (any(v == -9 for v in rcs.values()) or len(rcs) < n):
+                # a rank had to be killed at the time-out: RCCL hangs on this box, and the other RCCL host would sit out its
+                # own time-out the same way -- go to the host-staged transport at once
+                rec["timed_out"] = True
+                rccl_ok, rccl_why = False, "the previous RCCL attempt hung until its time-out"
+                if not rehearsal and ("native", "shm") not in queue and not lines:
+                    queue.append(("native", "shm"))
         if not rec["ok"] and "skipped" not in rec:
             for r in sorted(set(my_ranks) & {rr for rr, v in rcs.items() if v != 0} or set(my_ranks[:1])):
                 try:

@@ -90,22 +90,26 @@ def test_orchestrator_with_failing_and_hanging_children(tmp_path, monkeypatch):
     # a hang: the RCCL preflight passes, the native attempt never returns
     fake.write_text(
         "import json, os, sys, time\n"
-        "a = sys.argv; host = a[a.index('--child') + 1]\n"
+        "a = sys.argv; host = a[a.index('--child') + 1]; tr = a[a.index('--child-transport') + 1]\n"
         "rank = int(os.environ['RANK'])\n"
         "if host == 'preflight':\n"
         "    if rank == 0: print(json.dumps({'preflight': 'rccl', 'known_answers': True, 'latencies_rank0': {}}))\n"
         "    sys.exit(0)\n"
-        "if host == 'native':\n"
+        "if host == 'native' and tr == 'rccl':\n"
         "    sys.stderr.write('stuck in a collective\\n'); sys.stderr.flush(); time.sleep(60)\n"
-        "if rank == 0: print(json.dumps({'metric': 'm', 'value': 7.0, 'replicas_identical': True}))\n")
+        "if rank == 0: print(json.dumps({'metric': 'm', 'value': 7.0 if tr == 'shm' else 9.0, 'replicas_identical': True}))\n")
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rc = bench.orchestrate(None, [], 2, [0, 1], str(tmp_path / "run2"))
     line = json.loads(buf.getvalue().strip().splitlines()[-1])
     tried = line["hosts_tried"]
+    # the native RCCL attempt hung: the other RCCL host is not given the chance to sit out its own time-out, the host-staged
+    # transport runs at once
     assert rc == 0 and line["value"] == 7.0
-    assert tried[1]["host"] == "native" and tried[1]["ok"] is False and tried[1]["return_codes"] == [-9, -9]
+    assert [(t["host"], t["transport"]) for t in tried] == [("preflight", "rccl"), ("native", "rccl"), ("torch", "nccl"), ("native", "shm")]
+    assert tried[1]["ok"] is False and tried[1]["return_codes"] == [-9, -9] and tried[1]["timed_out"] is True
     assert "stuck in a collective" in tried[1]["stderr_tail"]["0"] and tried[1]["seconds"] < 10
+    assert "hung" in tried[2]["skipped"] and tried[3]["ok"] is True
 
 
 def test_a_failed_rank_stops_the_others_waiting(tmp_path):
