@@ -783,6 +783,8 @@ def orchestrate(args, argv, n, my_ranks, directory):
                     pass
         tried.append(rec)
         k += 1
+        if not queue and not lines and not rehearsal and not any(t["transport"] == "shm" for t in tried):
+            queue.append(("native", "shm"))             # every RCCL attempt failed, however the preflight went: the last resort
     if 0 not in my_ranks:
         return 0 if lines else 1
     if not lines:

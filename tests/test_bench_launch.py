@@ -112,6 +112,34 @@ def test_orchestrator_with_failing_and_hanging_children(tmp_path, monkeypatch):
     assert "hung" in tried[2]["skipped"] and tried[3]["ok"] is True
 
 
+def test_orchestrator_falls_back_when_every_rccl_attempt_fails_after_a_good_preflight(tmp_path, monkeypatch):
+    """Preflight passes, both RCCL hosts fail fast: the host-staged attempt still produces the line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "fake_child.py"
+    fake.write_text(
+        "import json, os, sys\n"
+        "a = sys.argv; host = a[a.index('--child') + 1]; tr = a[a.index('--child-transport') + 1]\n"
+        "rank = int(os.environ['RANK'])\n"
+        "if host == 'preflight':\n"
+        "    if rank == 0: print(json.dumps({'preflight': 'rccl', 'known_answers': True, 'latencies_rank0': {}}))\n"
+        "    sys.exit(0)\n"
+        "if tr != 'shm': sys.stderr.write('boom\\n'); sys.exit(3)\n"
+        "if rank == 0: print(json.dumps({'metric': 'm', 'value': 5.0, 'replicas_identical': True}))\n")
+    monkeypatch.setattr(bench, "child_command", lambda argv, host, tr, d, k: [sys.executable, str(fake), "--child", host, "--child-transport", tr])
+    monkeypatch.delenv("FROG_BENCH_BACKEND", raising=False)
+    monkeypatch.delenv("FROG_BENCH_HOSTS", raising=False)
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.orchestrate(None, [], 2, [0, 1], str(tmp_path / "run"))
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert rc == 0 and line["value"] == 5.0
+    assert [(t["host"], t["transport"], t["ok"]) for t in line["hosts_tried"]] == [
+        ("preflight", "rccl", True), ("native", "rccl", False), ("torch", "nccl", False), ("native", "shm", True)]
+    assert "boom" in line["hosts_tried"][1]["stderr_tail"]["0"]
+
+
 def test_a_failed_rank_stops_the_others_waiting(tmp_path):
     """Rendezvous: a rank that dies before a collective tells the others, who stop waiting at once with its reason."""
     import time
