@@ -323,6 +323,7 @@ struct frog_ctx {
     // FROG_REFERENCE_ORDER=1 (test hook, k_reforder.hip.h): every solver loop in the reference's own order and arithmetic --
     // no culling list, no fast weight, no re-associated sum; results are bit-comparable with the tests' CPU restatement of the reference
     bool ref_order = false;
+    bool k11_f64 = false;           // FROG_K11_F64=1: the B-spline transform's weights and sums in f64 (rounds 1-4), for comparison
     frog::DevBuf<uint32_t> ref_own;           // [L_own] own point (internal numbering) of every half-link, reference order
     frog::DevBuf<float> ref_w, ref_d;         // [L_own] weight and distance of every half-link (linear step)
     frog::DevBuf<uint64_t> ref_img_link;      // [nOwned + 1] first half-link of every owned image (relative, reference order)

@@ -787,7 +787,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
     if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
     // test hook: the solver loops in the reference's own order and arithmetic (k_reforder.hip.h); no list, no fast weight
-    if (const char *e = getenv("FROG_REFERENCE_ORDER")) c->ref_order = atoi(e) != 0;
+    c->ref_order = o->reference_order != 0;                    // frog_options::reference_order (bin/frog -exact 1)
+    if (const char *e = getenv("FROG_REFERENCE_ORDER")) c->ref_order = atoi(e) != 0;        // the tests' switch, overrides
+    if (const char *e = getenv("FROG_K11_F64")) c->k11_f64 = atoi(e) != 0;
     if (c->ref_order) { c->cull_enabled = false; c->exact_weights = true; c->fused_sweep = false; }
     if (const char *e = getenv("FROG_CULL_LINEAR")) c->cull_linear = atoi(e) != 0;
     if (const char *e = getenv("FROG_CULL_SKIN_LINEAR")) {
@@ -869,7 +871,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, false>, (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, true, false>,
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, true>, (const void *)sweep_kernel<SWEEP_COUNT, true, false, false, false>,
             (const void *)scatter_kernel, (const void *)lattice_step_kernel<true>, (const void *)lattice_step_kernel<false>,
-            (const void *)transform_bspline_tile_kernel, (const void *)transform_bspline_kernel, (const void *)transform_zero_lattice_kernel,
+            (const void *)transform_bspline_tile_kernel<float>, (const void *)transform_bspline_kernel<float>, (const void *)transform_zero_lattice_kernel,
             (const void *)cp_center_kernel, (const void *)bounds_kernel, (const void *)bounds_final_kernel, (const void *)zero_buffers_kernel,
             (const void *)brick_count_kernel, (const void *)brick_place_kernel, (const void *)cell_order_kernel, (const void *)brick_chunks_kernel,
             (const void *)scan_block_sums_kernel, (const void *)scan_of_sums_kernel, (const void *)scan_apply_kernel,
@@ -1018,7 +1020,8 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
             // one wavefront per scatter block, the brick's coefficients in LDS (k_grid.hip.h)
             const GeomDev gd = to_dev(ctx->geom);
             const size_t E = (size_t)gd.brick + 3, lds = E * E * E * sizeof(float4);
-            transform_bspline_tile_kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
+            auto kernel = ctx->k11_f64 ? transform_bspline_tile_kernel<double> : transform_bspline_tile_kernel<float>;
+            kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
                 ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
@@ -1026,7 +1029,8 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
-            transform_bspline_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
+            auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : transform_bspline_kernel<float>;
+            kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
@@ -2161,6 +2165,32 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d2
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
     FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FROG_OK;
+}
+
+__global__ void test_weights_kernel(const double *f, size_t n, double *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double F[4];
+    bspline_weights<double>(F, f[i]);
+    for (int k = 0; k < 4; k++) out[4 * i + k] = F[k];
+}
+
+int frog_test_bspline_weights(int device, const double *f, size_t n, double *out4n)
+{
+    if (n && (!f || !out4n)) return fail(FROG_E_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
+    FROG_HIP_CHECK(hipSetDevice(device));
+    if (!n) return FROG_OK;
+    DevBuf<double> df, dw;
+    FROG_HIP_CHECK(df.alloc(n)); FROG_HIP_CHECK(dw.alloc(4 * n));
+    FROG_HIP_CHECK(hipMemcpy(df.p, f, n * sizeof(double), hipMemcpyHostToDevice));
+    test_weights_kernel<<<div_up(n, 256), 256>>>(df.p, n, dw.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpy(out4n, dw.p, 4 * n * sizeof(double), hipMemcpyDeviceToHost));
     return FROG_OK;
 }
 

@@ -19,6 +19,7 @@ struct GeomDev {
     int n_cp;
     double origin[3];
     double spacing[3];
+    double inv_spacing[3];      // 1 / spacing: the f32 form of K11 multiplies (a B-spline is continuous across a cell face)
     int brick;
     int nbricks[3];
     int n_bricks;
@@ -27,22 +28,50 @@ struct GeomDev {
 inline GeomDev to_dev(const GridGeom &g)
 {
     GeomDev d;
-    for (int k = 0; k < 3; k++) { d.dims[k] = g.dims[k]; d.origin[k] = g.origin[k]; d.spacing[k] = g.spacing[k]; d.nbricks[k] = g.nbricks[k]; }
+    for (int k = 0; k < 3; k++) { d.dims[k] = g.dims[k]; d.origin[k] = g.origin[k]; d.spacing[k] = g.spacing[k]; d.inv_spacing[k] = 1.0 / g.spacing[k]; d.nbricks[k] = g.nbricks[k]; }
     d.n_cp = g.n_cp; d.brick = g.brick; d.n_bricks = g.n_bricks;
     return d;
 }
 
 // imageGroup.cxx:221-232
-__device__ __forceinline__ void bspline_weights(double F[4], double f)
+template <typename T>
+__device__ __forceinline__ void bspline_weights(T F[4], T f)
 {
-    const double sixth = 1.0 / 6.0;
-    const double half = 0.5;
-    const double f2 = f * f;
+    const T sixth = (T)(1.0 / 6.0);
+    const T half = (T)0.5;
+    const T f2 = f * f;
     F[3] = f2 * f * sixth;
     F[0] = (f2 - f) * half - F[3] + sixth;
     F[2] = f + F[0] - F[3] * 2;
     F[1] = 1 - F[0] - F[2] - F[3];
 }
+
+// K11's cell and weights of one axis.  T = double: vtkBSplineTransform's arithmetic as VTK defines it (f64 quotient,
+// floor, f64 weights).  T = float (the product path since round 5): the lattice coordinate still in f64 -- a point at 300 mm
+// is 1e7 f32 ulps from the origin and the fraction must not lose them -- but through the reciprocal of the spacing, and
+// the fraction and the four weights in f32: their 6e-8 moves a displacement of a few mm by 1e-7 mm, against an ulp of the
+// result of 3e-5 mm at 300 mm.  Which side of a cell face the quotient's last bit puts a point on does not matter to a C2
+// function (it does matter to the scatter, which therefore keeps the reference's f32-rounded f64 quotient: scatter_cell).
+template <typename T>
+__device__ __forceinline__ int bspline_axis(T F[4], float x, double origin, double spacing, double inv_spacing)
+{
+    double q;
+    if constexpr (sizeof(T) == 8) q = ((double)x - origin) / spacing;
+    else q = ((double)x - origin) * inv_spacing;
+    const double fl = floor(q);
+    bspline_weights<T>(F, (T)(q - fl));
+    return (int)fl - 1;
+}
+
+// Four f32 lanes at a time: a stored control point is a float4 (x, y, z, pad).  Read and multiplied as a whole it is one
+// ds_read_b128 (4 LDS cycles per wavefront; the three components alone are a ds_read_b96: 8 cycles) and two v_pk_fma_f32
+// instead of three v_fma_f32.  The f32 form of K11 therefore carries the pad along: its sum is +0.0 when the staged pad is
+// (transform_bspline_tile_kernel stages it as 0), and it is ADDED to every component at the end -- x + (+0.0f) = x for every x
+// the sums can produce but -0.0 -- which keeps the compiler from narrowing the reads; the thread-per-point form adds the same
+// +0.0f, so both forms have the same bits.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 fma4(f32x4 c, float f, f32x4 acc) { return __builtin_elementwise_fma(c, (f32x4)(f), acc); }
+__device__ __forceinline__ f32x4 as_f32x4(const float4 v) { return f32x4{ v.x, v.y, v.z, v.w }; }
 
 // The four scalars a deformable step hands to the host (energy sums, oversize count, list flag), written straight into
 // pinned host memory by the first thread of the transform that is queued behind the step -- the kernel that starts once
@@ -107,6 +136,9 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 // the host knows whether the diffeomorphism guard accepted it (imageGroup.cxx:434-439); it reads the proposal lattice
 // when the device-side oversize count says "accepted" and the standing coefficients otherwise.  The host then swaps
 // the two buffers instead of copying one onto the other (the commit of :441-468 is a pointer exchange).
+// T: the type the weights and the 64-tap sums are formed in (bspline_axis): float on the product path, double behind
+// FROG_K11_F64=1 (the form of rounds 1-4, kept to measure the difference; the reference's bits live in k_reforder.hip.h).
+template <typename T>
 __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
@@ -126,24 +158,41 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, con
     const float4 v = pos_b[s];                  // = pos[p], as the lattice's set-up gathered it (coalesced here)
     const float4 *cf = coeff + (size_t)(__float_as_int(v.w) - (int)image_begin) * g.n_cp;
     const float in[3] = { v.x, v.y, v.z };
-    double F[3][4];
+    T F[3][4];
     int i0[3];
     #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double q = ((double)in[k] - g.origin[k]) / g.spacing[k];
-        double fl = floor(q);
-        i0[k] = (int)fl - 1;
-        bspline_weights(F[k], q - fl);
-    }
-    double disp[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; k++) i0[k] = bspline_axis<T>(F[k], in[k], g.origin[k], g.spacing[k], g.inv_spacing[k]);
+    T disp[3] = { 0, 0, 0 };
     const int dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
-    // explicit f64 fma below: fusing only removes one rounding at 1e-16 before the result is rounded
-    // to f32 (VTK itself is unpinned)
+    // explicit fma below: fusing only removes one rounding before the result is rounded to f32 (VTK itself is unpinned)
     if (i0[0] >= 0 && i0[1] >= 0 && i0[2] >= 0 && i0[0] + 3 < dx && i0[1] + 3 < dy && i0[2] + 3 < dz) {
         // all 64 taps exist -- always the case for the group's own points (the lattice covers 1.2x
         // their bounding box): no per-tap test, so the 16 loads of a z-slab are issued together
         // instead of one row at a time behind a branch (the kernel waits on memory 79 % of the time)
         const float4 *base = cf + (size_t)i0[0] + (size_t)dx * ((size_t)i0[1] + (size_t)dy * i0[2]);
+        if constexpr (sizeof(T) == 4) {
+            f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float4 c[4][4];
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4 *row = base + (size_t)dx * ((size_t)j + (size_t)dy * k);
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) c[j][i] = row[i];
+                }
+                f32x4 vz = { 0.f, 0.f, 0.f, 0.f };
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    f32x4 vy = { 0.f, 0.f, 0.f, 0.f };
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) vy = fma4(as_f32x4(c[j][i]), F[0][i], vy);
+                    vz = fma4(vy, F[1][j], vz);
+                }
+                acc = fma4(vz, F[2][k], acc);
+            }
+            disp[0] = acc.x + 0.0f; disp[1] = acc.y + 0.0f; disp[2] = acc.z + 0.0f;       // the tiled form's pad (fma4 above)
+        } else
         #pragma unroll
         for (int k = 0; k < 4; k++) {
             float4 c[4][4];
@@ -153,49 +202,50 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, con
                 #pragma unroll
                 for (int i = 0; i < 4; i++) c[j][i] = row[i];
             }
-            double vz[3] = { 0, 0, 0 };
+            T vz[3] = { 0, 0, 0 };
             #pragma unroll
             for (int j = 0; j < 4; j++) {
-                double vy[3] = { 0, 0, 0 };
+                T vy[3] = { 0, 0, 0 };
                 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const double f = F[0][i];
-                    vy[0] = fma((double)c[j][i].x, f, vy[0]); vy[1] = fma((double)c[j][i].y, f, vy[1]); vy[2] = fma((double)c[j][i].z, f, vy[2]);
+                    const T f = F[0][i];
+                    vy[0] = fma((T)c[j][i].x, f, vy[0]); vy[1] = fma((T)c[j][i].y, f, vy[1]); vy[2] = fma((T)c[j][i].z, f, vy[2]);
                 }
-                const double f = F[1][j];
+                const T f = F[1][j];
                 vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
             }
-            const double f = F[2][k];
+            const T f = F[2][k];
             disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
         }
     } else {
         for (int k = 0; k < 4; k++) {                   // BorderModeZero: taps outside the lattice contribute nothing
             const int z = i0[2] + k;
             if (z < 0 || z >= dz) continue;
-            double vz[3] = { 0, 0, 0 };
+            T vz[3] = { 0, 0, 0 };
             for (int j = 0; j < 4; j++) {
                 const int y = i0[1] + j;
                 if (y < 0 || y >= dy) continue;
-                double vy[3] = { 0, 0, 0 };
+                T vy[3] = { 0, 0, 0 };
                 const float4 *row = cf + (size_t)dx * ((size_t)y + (size_t)dy * z);
                 for (int i = 0; i < 4; i++) {
                     const int x = i0[0] + i;
                     if (x < 0 || x >= dx) continue;
                     const float4 c = row[x];
-                    const double f = F[0][i];
-                    vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
+                    const T f = F[0][i];
+                    vy[0] = fma((T)c.x, f, vy[0]); vy[1] = fma((T)c.y, f, vy[1]); vy[2] = fma((T)c.z, f, vy[2]);
                 }
-                const double f = F[1][j];
+                const T f = F[1][j];
                 vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
             }
-            const double f = F[2][k];
+            const T f = F[2][k];
             disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
         }
+        if constexpr (sizeof(T) == 4) { disp[0] += 0.0f; disp[1] += 0.0f; disp[2] += 0.0f; }      // as the branch above
     }
     float4 o;
-    o.x = (float)((double)in[0] + disp[0] * 1.0);
-    o.y = (float)((double)in[1] + disp[1] * 1.0);
-    o.z = (float)((double)in[2] + disp[2] * 1.0);
+    o.x = (float)((double)in[0] + (double)disp[0] * 1.0);
+    o.y = (float)((double)in[1] + (double)disp[1] * 1.0);
+    o.z = (float)((double)in[2] + (double)disp[2] * 1.0);
     o.w = v.w;
     if (valid) {
         pos2[p] = P3{ o.x, o.y, o.z };
@@ -245,6 +295,7 @@ __global__ __launch_bounds__(256) void transform_zero_lattice_kernel(float4 *pos
 // to f32 first: they differ for points within one f32 ulp of a cell face) may need taps outside the tile and reads them
 // from memory.  ScatterBlock is declared further down, with the table's construction.
 struct ScatterBlock;
+template <typename T>
 __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                                                     const uint32_t *perm, const ScatterBlock *blocks,
                                                                     const uint32_t *n_blocks, const GeomDev g, int apply,
@@ -630,6 +681,10 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
 #ifndef FROG_TRANSFORM_WAVES
 #define FROG_TRANSFORM_WAVES 4
 #endif
+#ifndef FROG_K11_F32_UNROLL
+#define FROG_K11_F32_UNROLL 1          // z-planes of the f32 form unrolled together
+#endif
+template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROG_TRANSFORM_WAVES)))
 void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                    const uint32_t *perm, const ScatterBlock *blocks,
@@ -673,6 +728,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
         const int x = cp0[0] + k % E, y = cp0[1] + (k / E) % E, z = cp0[2] + k / (E * E);
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
         if (x < dx && y < dy && z < dz) c = cf[(size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z)];
+        c.w = 0.f;                                      // the pad the f32 form sums along with x, y, z (fma4)
         tile4[k] = c;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -687,68 +743,82 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
         p_cur = p_nxt; p_nxt = p_far; v_cur = v_nxt;
         if (batch + lane >= blk.end) continue;
         const float in[3] = { v.x, v.y, v.z };
-        double F[3][4];
+        T F[3][4];
         int i0[3];
         #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double q = ((double)in[k] - g.origin[k]) / g.spacing[k];
-            double fl = floor(q);
-            i0[k] = (int)fl - 1;
-            bspline_weights(F[k], q - fl);
-        }
+        for (int k = 0; k < 3; k++) i0[k] = bspline_axis<T>(F[k], in[k], g.origin[k], g.spacing[k], g.inv_spacing[k]);
         const int l0 = i0[0] - cp0[0], l1 = i0[1] - cp0[1], l2 = i0[2] - cp0[2];
-        double disp[3] = { 0, 0, 0 };
+        T disp[3] = { 0, 0, 0 };
         if (l0 >= 0 && l1 >= 0 && l2 >= 0 && l0 + 3 < E && l1 + 3 < E && l2 + 3 < E) {
             const int base = l0 + E * (l1 + E * l2);
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 *tile = reinterpret_cast<const f32x4 *>(tile4);
+                f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+                #pragma unroll FROG_K11_F32_UNROLL
+                for (int k = 0; k < 4; k++) {
+                    f32x4 vz = { 0.f, 0.f, 0.f, 0.f };
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        f32x4 vy = { 0.f, 0.f, 0.f, 0.f };
+                        const int row = base + E * (j + E * k);
+                        #pragma unroll
+                        for (int i = 0; i < 4; i++) vy = fma4(tile[row + i], F[0][i], vy);
+                        vz = fma4(vy, F[1][j], vz);
+                    }
+                    acc = fma4(vz, F[2][k], acc);
+                }
+                disp[0] = acc.x + acc.w; disp[1] = acc.y + acc.w; disp[2] = acc.z + acc.w;       // acc.w = +0.0: see fma4
+            } else
             // one z-plane of 16 taps at a time: unrolled over all 64 the compiler keeps every tap in registers (232 of them:
             // two wavefronts per SIMD, and the LDS latency shows)
             #pragma unroll 1
             for (int k = 0; k < 4; k++) {
-                double vz[3] = { 0, 0, 0 };
+                T vz[3] = { 0, 0, 0 };
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    double vy[3] = { 0, 0, 0 };
+                    T vy[3] = { 0, 0, 0 };
                     const int row = base + E * (j + E * k);
                     #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const double f = F[0][i];
+                        const T f = F[0][i];
                         const float4 c = tile4[row + i];
-                        vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
+                        vy[0] = fma((T)c.x, f, vy[0]); vy[1] = fma((T)c.y, f, vy[1]); vy[2] = fma((T)c.z, f, vy[2]);
                     }
-                    const double f = F[1][j];
+                    const T f = F[1][j];
                     vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
                 }
-                const double f = F[2][k];
+                const T f = F[2][k];
                 disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
             }
         } else {
             for (int k = 0; k < 4; k++) {               // stencil not inside the tile: from memory, border = zero
                 const int z = i0[2] + k;
                 if (z < 0 || z >= dz) continue;
-                double vz[3] = { 0, 0, 0 };
+                T vz[3] = { 0, 0, 0 };
                 for (int j = 0; j < 4; j++) {
                     const int y = i0[1] + j;
                     if (y < 0 || y >= dy) continue;
-                    double vy[3] = { 0, 0, 0 };
+                    T vy[3] = { 0, 0, 0 };
                     const float4 *row = cf + (size_t)dx * ((size_t)y + (size_t)dy * z);
                     for (int i = 0; i < 4; i++) {
                         const int x = i0[0] + i;
                         if (x < 0 || x >= dx) continue;
                         const float4 c = row[x];
-                        const double f = F[0][i];
-                        vy[0] = fma((double)c.x, f, vy[0]); vy[1] = fma((double)c.y, f, vy[1]); vy[2] = fma((double)c.z, f, vy[2]);
+                        const T f = F[0][i];
+                        vy[0] = fma((T)c.x, f, vy[0]); vy[1] = fma((T)c.y, f, vy[1]); vy[2] = fma((T)c.z, f, vy[2]);
                     }
-                    const double f = F[1][j];
+                    const T f = F[1][j];
                     vz[0] = fma(vy[0], f, vz[0]); vz[1] = fma(vy[1], f, vz[1]); vz[2] = fma(vy[2], f, vz[2]);
                 }
-                const double f = F[2][k];
+                const T f = F[2][k];
                 disp[0] = fma(vz[0], f, disp[0]); disp[1] = fma(vz[1], f, disp[1]); disp[2] = fma(vz[2], f, disp[2]);
             }
+            if constexpr (sizeof(T) == 4) { disp[0] += 0.0f; disp[1] += 0.0f; disp[2] += 0.0f; }      // as the branch above
         }
         float4 o;
-        o.x = (float)((double)in[0] + disp[0] * 1.0);
-        o.y = (float)((double)in[1] + disp[1] * 1.0);
-        o.z = (float)((double)in[2] + disp[2] * 1.0);
+        o.x = (float)((double)in[0] + (double)disp[0] * 1.0);
+        o.y = (float)((double)in[1] + (double)disp[1] * 1.0);
+        o.z = (float)((double)in[2] + (double)disp[2] * 1.0);
         o.w = v.w;
         pos2[p] = P3{ o.x, o.y, o.z };
         if (apply) pos[p] = o;

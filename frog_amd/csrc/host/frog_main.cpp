@@ -93,6 +93,8 @@ int main(int argc, char *argv[])
         cout << "-ng number    : shard the images over this many GPUs (devices dev .. dev+n-1), RCCL collectives. Default : " << group.nGpus << endl;
         cout << "-ngl number   : the same with n contexts on ONE device and host-staged collectives (rehearsal)" << endl;
         cout << "-q 0/1        : do not print one line per iteration. Default : " << group.quiet << endl;
+        cout << "-exact 0/1    : every solver loop in the reference's own order and arithmetic (bit-equal to the CPU path's" << endl
+             << "                coefficients; about 100 times slower). Default : " << group.exact << endl;
         return 1;
     }
 
@@ -144,6 +146,7 @@ int main(int argc, char *argv[])
         if (strcmp(key, "-ng") == 0) { group.nGpus = atoi(value); group.loopback = false; }
         if (strcmp(key, "-ngl") == 0) { group.nGpus = atoi(value); group.loopback = true; }
         if (strcmp(key, "-q") == 0) group.quiet = atoi(value);
+        if (strcmp(key, "-exact") == 0) group.exact = atoi(value);
         if (strcmp(key, "-j") == 0) {
             group.writeSingleFileTransforms = true;
             increment = 1;

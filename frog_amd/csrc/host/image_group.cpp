@@ -144,6 +144,7 @@ void ImageGroup::createShardedContexts()
     o.bounding_box_margin = boundingBoxMargin; o.inlier_threshold = inlierThreshold;
     o.guarantee_diffeomorphism = guaranteeDiffeomorphism; o.max_displacement_ratio = maxDisplacementRatio;
     o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize; o.stats_max_iterations = statsMaxIterations; o.stats_epsilon = statsEpsilon;
+    o.reference_order = exact;
     frog_model m;
     frog_pairs_model(pairs, &m);
     std::vector<int> devices(nGpus);
@@ -383,6 +384,7 @@ void ImageGroup::createContext()
     o.guarantee_diffeomorphism = guaranteeDiffeomorphism;
     o.max_displacement_ratio = maxDisplacementRatio;
     o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize;
+    o.reference_order = exact;
     o.stats_max_iterations = statsMaxIterations;
     o.stats_epsilon = statsEpsilon;
     o.n_fixed_images = numberOfFixedImages;

@@ -57,6 +57,8 @@ public:
     bool loopback = false;       // new: -ngl N, the same control flow with N contexts on ONE device and host-staged
                                  // collectives (rehearsal / tests on a single-GPU box)
     bool quiet = false;          // suppress per-iteration lines (new: -q)
+    bool exact = false;          // new: -exact 1 = frog_options::reference_order: every solver loop in the reference's own order
+                                 // and arithmetic (the CPU restatement's bits, raw coefficients included), ~100 x slower
 
     // results of run()
     struct Measure { float E, landmarkAv, landmarkMax, landmarkSTD; };

@@ -228,6 +228,11 @@ int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *liste
 int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d2, size_t n,
                                  float *fast, float *exact);
 
+/* Test hook: vtkBSplineTransformWeights (imageGroup.cxx:221-232) as the device's scatter and reference-order kernels
+ * evaluate it: the four f64 weights of every fraction f[i] into out4n[4 i .. 4 i + 3].  tests/test_gpu_round5.py compares
+ * them bit for bit with the reference's own function (oracle/_ref/libfrog_refweights.so). */
+int frog_test_bspline_weights(int device, const double *f, size_t n, double *out4n);
+
 /* Test hook: how many points the B-spline scatter has found outside the brick they were sorted into since the context
  * was created (they are handled, through global atomics: slowly and in no fixed order).  Inside the lattice's box --
  * always, for the group's own points -- this must stay 0; a non-zero count means the (image, brick, cell) sort is broken. */

@@ -56,7 +56,15 @@ typedef struct frog_options {
                                          * is going to run (imageGroup.h:62 deformableLevels).  frog_create then sizes the
                                          * lattice buffers for the finest of them at once, so that no multi-gigabyte device
                                          * allocation happens between two iterations                                  */
-    int32_t reserved[4];                /* must be 0                      */
+    int32_t reference_order;            /* -exact 0     0 = the product kernels (sums re-associated: per-point sums per partner
+                                         * group, tree-reduced f64 sums, tiled scatter, fast f32 weight, f32 B-spline
+                                         * evaluation; results within the bars of DESIGN.md 2a of the mode below).
+                                         * 1 = every solver loop in the reference's own order and arithmetic (one f32
+                                         * chain per point in readPairs order, getInlierProbability with its f64 exp, the
+                                         * scatter image by image and point by point, f64 B-spline evaluation): the mode
+                                         * that meets "transform parameters within 1e-4 relative" on RAW coefficients -- it
+                                         * has the CPU restatement's bits -- at about 1/100 of the speed               */
+    int32_t reserved[3];                /* must be 0                      */
 } frog_options;
 
 /* Geometry of one B-spline control-point lattice
@@ -105,6 +113,7 @@ static inline void frog_options_default(frog_options *o)
     o->stats_epsilon = 1e-6f;
     o->n_fixed_images = 0;
     o->max_levels_hint = 0;
+    o->reference_order = 0;
     for (i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++) o->reserved[i] = 0;
 }
 

@@ -957,5 +957,6 @@ int frogo_stats_histogram(frogo_stats *s, float bin, float *out, int cap)
     return (int)s->s.histogram.size();
 }
 float frogo_chipdf(float x) { return chi_pdf(x); }
+void frogo_bspline_weights_n(const double *f, int n, double *out4n) { for (int i = 0; i < n; i++) bspline_weights(out4n + 4 * (long)i, f[i]); }
 
 } // extern "C"

@@ -124,6 +124,7 @@ int   frogo_stats_size(const frogo_stats *s);
 int   frogo_stats_get_samples(const frogo_stats *s, float *out, int cap);
 int   frogo_stats_histogram(frogo_stats *s, float bin, float *out, int cap); /* stats.cxx:121 */
 float frogo_chipdf(float x);                                      /* stats.h:10 */
+void  frogo_bspline_weights_n(const double *f, int n, double *out4n); /* imageGroup.cxx:221-232, pinned by _ref/libfrog_refweights.so */
 
 #ifdef __cplusplus
 }

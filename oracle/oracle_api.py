@@ -77,6 +77,8 @@ def lib():
         _bind_stats(L, "frogo_stats_")
         L.frogo_chipdf.restype = C.c_float
         L.frogo_chipdf.argtypes = [C.c_float]
+        L.frogo_bspline_weights_n.restype = None
+        L.frogo_bspline_weights_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -95,6 +97,35 @@ def ref_lib():
         L.refstats_chipdf.argtypes = [C.c_float]
         _ref = L
     return _ref
+
+
+_ref_weights = None
+
+
+def ref_weights_lib():
+    """The reference's own vtkBSplineTransformWeights (imageGroup.cxx:221-232), cut out of the file and compiled by
+    oracle/Makefile into oracle/_ref/libfrog_refweights.so; None when it was not built."""
+    global _ref_weights
+    if _ref_weights is None:
+        path = os.path.join(_HERE, "_ref", "libfrog_refweights.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.refweights_n.restype = None
+        L.refweights_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _ref_weights = L
+    return _ref_weights
+
+
+def bspline_weights(f, which="oracle"):
+    """The four cubic B-spline weights of every fraction in f (f64): which = "oracle" (the restatement) or "reference"."""
+    f = np.ascontiguousarray(f, np.float64)
+    out = np.empty((len(f), 4), np.float64)
+    L = lib() if which == "oracle" else ref_weights_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libfrog_refweights.so not built")
+    (L.frogo_bspline_weights_n if which == "oracle" else L.refweights_n)(f.ctypes.data, len(f), out.ctypes.data)
+    return out
 
 
 def _bind_stats(L, pre):

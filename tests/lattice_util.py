@@ -2,7 +2,7 @@
 
 `compare_lattice` applies the criterion of tests/test_gpu_round2.py::test_parity_sweep to one lattice of one image:
 coefficients of well supported control points within 1e-4 of the lattice's largest coefficient, weakly supported ones
-within 1e-2, and the displacement field at every point of the image within 1e-4 of its maximum."""
+within 1e-3, and the displacement field at every point of the image within 1e-4 of its maximum."""
 import numpy as np
 
 from frog_amd import _abi
@@ -23,7 +23,11 @@ REL = 1e-4
 # control point by how well the group's data determine its node:
 #   * w = min(1, smallest non-zero support of the node over the images)  (1 = the plain bar; no support anywhere: 1)
 #     |c - c_ref| * w <= 1e-4 max|c_ref|;
-#   * every control point, unweighted: 1e-2 of max|c_ref| -- they still have to be the same numbers;
+#   * every control point, unweighted: 1e-3 of max|c_ref| (RIM_REL; 1e-2 until round 4) -- they still have to be the same
+#     numbers.  The bar is what is measured with head-room for the rim's amplification, so that a ten-fold regression fails:
+#     product path vs reference-order mode at cfg 3's size 2.7e-4 (level 2, 20 + 3 x 20 iterations; 5.6e-4 after the whole
+#     default schedule, scripts/parity_reference_order.py), cfg 5 at full size 4.8e-5, the ten-case sweep against the oracle
+#     <= 4e-4; levels 0-3 of the 40-image cfg-5-shaped long run 8.0e-4 (its own bar, 2e-3, in test_gpu_reference_order.py);
 #   * and the quantity the coefficients exist for, the displacement field at EVERY point of the image: 1e-4 of its maximum.
 # Even at the keypoint density of the benchmark configuration (20 000 per image) 40 % of the finest lattice's nodes are
 # weakly supported (7 100 of 18 216 at level 2 of cfg 3: the rim of the 1.2 x box), and the raw coefficients of cfg 3 deviate
@@ -32,7 +36,7 @@ REL = 1e-4
 # own order and arithmetic (FROG_REFERENCE_ORDER=1) has the oracle's BITS, raw coefficients included, so whatever separates
 # the product path from it is re-association -- and `dense` below measures the field where a resampler evaluates it (a
 # regular lattice of points over the whole bounding box, tools/VolumeTransform.cxx:119-136), not only at the keypoints.
-RIM_REL = 1e-2
+RIM_REL = 1e-3
 DENSE_PER_AXIS = 16
 
 
@@ -107,7 +111,7 @@ def lattice_deviation(g, ref, k, i, pts, weights):
 
 
 def compare_lattice(g, ref, k, i, pts, weights):
-    """lattice_deviation with the unweighted 1e-2 bar asserted; returns (weighted coefficient deviation, field deviation,
+    """lattice_deviation with the unweighted RIM_REL bar asserted; returns (weighted coefficient deviation, field deviation,
     nodes with a weight below 1, nodes)."""
     d = lattice_deviation(g, ref, k, i, pts, weights)
     assert d["raw"] <= RIM_REL, f"lattice {k} image {i}: coefficients off by {d['raw']:.2e}"

@@ -5,7 +5,7 @@ The volumes -> surf3d half of the configuration cannot exist here (SURVEY.md sec
 lattice, the surf3d submodule is absent); the chain starts at what surf3d would have written: pointsK.csv.gz.
 
 Two runs of bin/frog on the pairs.bin bin/match wrote:
-  * FROG_REFERENCE_ORDER=1 (frog_amd/csrc/device/k_reforder.hip.h): every number in the files equals the oracle's --
+  * `bin/frog -exact 1` (frog_options::reference_order; frog_amd/csrc/device/k_reforder.hip.h): every number in the files equals the oracle's --
     matrices, every coefficient of every lattice (compact .nii.gz sidecars, the default output form), energies as printed,
     histograms, census;
   * the product path: same lattices and guard decisions; deviations reported.  Four images of 900 keypoints are 1e4
@@ -73,11 +73,10 @@ def read_transforms(d, n_images):
     return out
 
 
-def run_frog(d, env_extra=None):
+def run_frog(d, flags=()):
     env = dict(os.environ)
     env.pop("FROG_REFERENCE_ORDER", None)
-    env.update(env_extra or {})
-    r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin"], cwd=d, capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([os.path.join(ROOT, "bin", "frog"), "pairs.bin", *flags], cwd=d, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -104,11 +103,12 @@ def test_config0_keypoint_files_through_match_and_frog_at_the_default_schedule(t
     counts = ref.count_inliers((_abi.FrogCounts * n_images)())
 
     runs = {}
-    for tag, env in (("reference_order", {"FROG_REFERENCE_ORDER": "1"}), ("product", None)):
+    # `-exact 1` = frog_options::reference_order: the mode a user asks bin/frog for, not a test hook
+    for tag, flags in (("reference_order", ("-exact", "1")), ("product", ())):
         d = tmp_path / tag
         d.mkdir()
         os.link(tmp_path / "pairs.bin", d / "pairs.bin")
-        out = run_frog(d, env)
+        out = run_frog(d, flags)
         assert "Linear registration" in out and "Total time" in out
         runs[tag] = d
 
@@ -155,4 +155,6 @@ def test_config0_keypoint_files_through_match_and_frog_at_the_default_schedule(t
             worst["field"] = max(worst["field"], float(np.max(np.abs(da - db))) / max(float(np.max(np.abs(db))), 1e-30))
             worst["raw"] = max(worst["raw"], relerr(vox, c))
     note("config0_product_vs_oracle", " ".join(f"{a} {b:.2e}" for a, b in worst.items()) + f" grids {grids_per_level} half_links {pairs.n_half_links}")
-    assert worst["E"] < 1e-3 and worst["matrices"] < 1e-5 and worst["field"] < 1e-3 and worst["raw"] < 1e-2
+    # measured: E 4.4e-6 (print precision), matrices 6.8e-7, dense field 1.7e-5, raw 1.1e-4; the E / field bars leave room for
+    # one threshold flip on 1e4 half-links (header)
+    assert worst["E"] < 1e-3 and worst["matrices"] < 1e-5 and worst["field"] < 1e-3 and worst["raw"] < 2e-3

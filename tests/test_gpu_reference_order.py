@@ -23,7 +23,7 @@ from frog_amd import _abi
 from frog_amd.image_group import ImageGroup
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup
-from lattice_util import lattice_deviation, node_weights, lattice_taps, face_crossing_nodes
+from lattice_util import RIM_REL, lattice_deviation, node_weights, lattice_taps, face_crossing_nodes
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -323,13 +323,13 @@ def test_fast_path_against_reference_order_small_group(monkeypatch):
     """The product path against the mode the tests above hold equal to the CPU oracle, on the same group and schedule
     (6 images, 50 + 3 x 40 iterations): same guard decisions; energies 1e-6; per lattice the displacement field at the
     keypoints AND on a dense lattice over the bounding box within 1e-4 of the largest displacement, support-weighted
-    coefficients 1e-4, raw coefficients 1e-2 (reported)."""
+    coefficients 1e-4, raw coefficients 1e-3 (measured 4.4e-5), the whole chain on a dense lattice 1e-5 (measured 5.5e-7)."""
     pairs = Pairs.synthetic(6, 3000, 1500, seed=7)
     r = fast_against_reference_order(pairs, 50, 3, 40, monkeypatch, range(6))
     report("fast_vs_reference_order_small", r)
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= REL
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5
 
 
 def test_fast_path_against_reference_order_small_group_whole_schedule(monkeypatch):
@@ -343,8 +343,8 @@ def test_fast_path_against_reference_order_small_group_whole_schedule(monkeypatc
     r = fast_against_reference_order(pairs, 50, 3, 200, monkeypatch, range(6))
     report("fast_vs_reference_order_small_whole_schedule", r)
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= 1e-3 and d["dense_field"] <= 1e-3 and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-3
+        assert d["field"] <= 1e-3 and d["dense_field"] <= 1e-3 and d["raw"] <= 2e-3, (k, d)          # measured 3.8e-4 / 1.6e-4 / 2.6e-4
+    assert r["E"] < 1e-3 and r["chain"]["rel"] <= 1e-4                                                   # measured 6.4e-5 / 6.2e-6
 
 
 def test_fast_path_against_reference_order_config3(monkeypatch):
@@ -356,8 +356,9 @@ def test_fast_path_against_reference_order_config3(monkeypatch):
     r = fast_against_reference_order(pairs, 20, 3, 20, monkeypatch, range(0, 100, 9))
     report("fast_vs_reference_order_cfg3", r)
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= REL
+        # measured: field 5.3e-6, dense 5.4e-6, weighted 3.7e-6, raw 2.7e-4 (level 2: 7 100 of 18 216 nodes on the rim)
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5      # measured 6.2e-8, 2.0e-7, 1.3e-7
 
 
 def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
@@ -365,14 +366,15 @@ def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
     levels, -gd 1 (level 4: 9e5 nodes per image, bricks of 8^3 cells) -- which no CPU run can follow inside a test: the
     product path against reference-order mode (bit-equal to the oracle on the same kind of group at 40 images: above), both
     on the device, 4 linear + 5 x 2 deformable iterations.  Same guard decisions and lattices; energies 1e-6; per lattice
-    the displacement field at the keypoints and on a dense lattice 1e-4, support-weighted coefficients 1e-4, raw 1e-2."""
+    the displacement field at the keypoints and on a dense lattice 1e-4, support-weighted coefficients 1e-4, raw 1e-3 (measured
+    4.8e-5 on level 4), the whole chain on a dense lattice 1e-5 (measured 3.3e-8)."""
     pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
     r = fast_against_reference_order(pairs, 4, 5, 2, monkeypatch, range(0, 500, 83))
     report("fast_vs_reference_order_cfg5", r)
     assert len(r["grids"]) == 5
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
-    assert r["E"] < 1e-6 and r["xyz"] < 1e-6
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+    assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5
 
 
 def test_fast_path_against_reference_order_config5_shaped_long_level4(monkeypatch):
@@ -388,10 +390,16 @@ def test_fast_path_against_reference_order_config5_shaped_long_level4(monkeypatc
     r = fast_against_reference_order(pairs, 20, 5, 12, monkeypatch, range(40))
     report("fast_vs_reference_order_cfg5_shaped_long", r)
     assert len(r["grids"]) == 5 and sum(r["grids"]) > 5           # the guard rejected at least once
+    n_coarse = sum(r["grids"][:4])             # lattices of levels 0-3
     for k, d in enumerate(r["lattices"]):
         assert d["face_crossings"] <= 8, (k, d)
-        assert d["field"] <= 1e-3 and d["raw_elsewhere"] <= 1e-2 and d["dense_field_elsewhere"] <= 1e-3, (k, d)
-    assert r["E"] < 1e-5
+        # levels 0-3: measured raw <= 8.0e-4 (away from crossings 2.8e-4 .. 8.0e-4), dense field <= 3.5e-5; level 4: raw away
+        # from the crossings 2.6e-3, dense field 2.3e-4 away from them (7.7e-4 with them), field at the keypoints 5.7e-4
+        if k < n_coarse:
+            assert d["raw_elsewhere"] <= 2e-3 and d["field"] <= REL and d["dense_field_elsewhere"] <= REL, (k, d)
+        else:
+            assert d["field"] <= 1e-3 and d["raw_elsewhere"] <= 1e-2 and d["dense_field_elsewhere"] <= 1e-3, (k, d)
+    assert r["E"] < 1e-6 and r["chain"]["rel"] <= 1e-5          # measured 3.5e-8, 2.0e-6
 
 
 # ---- reference-order mode on the inputs the reference's loops have special cases for ------------------------------------

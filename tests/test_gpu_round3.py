@@ -15,7 +15,7 @@ from frog_amd import _abi
 from frog_amd.image_group import ImageGroup
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup
-from lattice_util import lattice_deviation, node_weights
+from lattice_util import RIM_REL, lattice_deviation, node_weights
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -136,7 +136,7 @@ def test_config3_free_running_schedule_against_the_oracle():
         assert d["field"] <= REL, f"lattice {k}: displacement field off by {d['field']:.2e}"
         assert d["dense"] <= REL, f"lattice {k}: displacement field on the dense lattice off by {d['dense']:.2e}"
         assert d["weighted"] <= REL, f"lattice {k}: supported coefficients off by {d['weighted']:.2e}"
-        assert d["raw"] <= 1e-2, f"lattice {k}: raw coefficients off by {d['raw']:.2e}"
+        assert d["raw"] <= RIM_REL, f"lattice {k}: raw coefficients off by {d['raw']:.2e}"       # measured 1.05e-4
     assert r["final_xyz"] < 1e-6
 
 
@@ -172,7 +172,7 @@ def test_rim_deviations_do_not_come_from_the_fast_weight(monkeypatch):
          f"{max(d['field'] for d in fast['lattices']):.2e} exact {max(d['field'] for d in exact['lattices']):.2e}")
     for r in (fast, exact):
         for d in r["lattices"]:
-            assert d["weighted"] <= REL and d["field"] <= REL and d["raw"] <= 1e-2
+            assert d["weighted"] <= REL and d["field"] <= REL and d["raw"] <= RIM_REL       # measured 3.4e-4 / 3.8e-4
     if raw_f > REL:
         assert raw_x > 0.2 * raw_f, f"raw deviation {raw_f:.2e} with the fast weight, {raw_x:.2e} with the exact one"
 
@@ -375,4 +375,4 @@ def test_config5_shaped_group_five_levels_against_the_oracle():
     assert len(r["grids_per_level"]) == 5 and r["E"] < REL and r["matrices"] < 1e-6
     assert max(d["nodes"] for d in r["lattices"]) > 500000            # the fine lattice really is fine
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["weighted"] <= REL and d["raw"] <= 1e-2, (k, d)
+        assert d["field"] <= REL and d["weighted"] <= REL and d["raw"] <= (RIM_REL if d["level"] < 4 else 2e-3), (k, d)       # measured 3.3e-5 / 4.8e-4 (level 4)

@@ -1,0 +1,107 @@
+"""Round 5: D2 pinned on the device; the f32 form of the product path's B-spline transform against the f64 form."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from frog_amd import _abi
+from frog_amd.image_group import ImageGroup
+from frog_amd.pairs import Pairs
+from oracle import oracle_api
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def device_weights(f):
+    f = np.ascontiguousarray(f, np.float64)
+    out = np.empty((len(f), 4), np.float64)
+    rc = _abi.hip_lib().frog_test_bspline_weights(0, f.ctypes.data, len(f), out.ctypes.data)
+    assert rc == 0, _abi.hip_lib().frog_last_error()
+    return out
+
+
+def test_device_bspline_weights_equal_the_reference_build_bit_for_bit():
+    """vtkBSplineTransformWeights (imageGroup.cxx:221-232) as the scatter and the reference-order kernels evaluate it on
+    the device, against the reference's own function (oracle/_ref/libfrog_refweights.so, built by `make -C oracle ref`
+    from the file where it lies; it travels to the GPU box) and against the committed fixture generated from it."""
+    from test_oracle_weights import fractions
+    fx = json.load(open(os.path.join(HERE, "golden", "weights_golden.json")))
+    f = np.array([int(h, 16) for h in fx["f_bits"]], np.uint64).view(np.float64)
+    want = np.array([[int(h, 16) for h in row] for row in fx["weights_bits"]], np.uint64)
+    assert np.array_equal(device_weights(f).view(np.uint64), want)
+    if oracle_api.ref_weights_lib() is None:
+        pytest.skip("oracle/_ref/libfrog_refweights.so absent: compared with the fixture only")
+    f = fractions()
+    assert np.array_equal(device_weights(f).view(np.uint64), oracle_api.bspline_weights(f, "reference").view(np.uint64))
+
+
+def run_schedule(pairs, monkeypatch, f64, li=6, dl=3, di=8, forms=(None,)):
+    """A free-running li + dl x di schedule; returns final coordinates, energies, lattices of image 0."""
+    monkeypatch.setenv("FROG_K11_F64", "1" if f64 else "0")
+    g = ImageGroup(pairs, device=0)
+    g.setupLinearTransforms(); g.transformPoints()
+    E = []
+    for it in range(li):
+        if it % 10 == 0:
+            g.updateStats()
+        E.append(g.updateLinearTransforms()); g.transformPoints()
+    g.transformPoints(True)
+    for level in range(dl):
+        g.setupDeformableTransforms(level); g.transformPoints()
+        alpha, it, first = 0.02, 0, True
+        while it < di:
+            if it % 10 == 0:
+                g.updateStats()
+            e = g.updateDeformableTransforms(alpha)
+            if e < 0:
+                if first:
+                    alpha /= 2
+                g.transformPoints(True); g.setupDeformableTransforms(level); g.transformPoints()
+                first = True
+                continue
+            first = False
+            E.append(e); g.transformPoints(); it += 1
+        g.transformPoints(True)
+    return g.points()[1].copy(), np.array(E), [g.grid(0, k)[1].copy() for k in range(g.num_grids())]
+
+
+def test_f32_transform_against_the_f64_form(monkeypatch):
+    """The product path's B-spline transform forms its weights and its 64-tap sums in f32 since round 5 (k_grid.hip.h
+    bspline_axis; the lattice coordinate itself stays f64).  Against the f64 form of rounds 1-4 (FROG_K11_F64=1) over a
+    free-running 6 + 3 x 8 schedule: ONE transform differs by at most one f32 ulp of a coordinate (asserted on the first
+    deformable transform, where both runs still have identical inputs); the whole schedule's energies agree to 1e-6 and the
+    final coordinates to 1e-6 of their size.  Both forms of the kernel (one wavefront per brick / thread per point) give
+    identical bits in f32 too."""
+    pairs = Pairs.synthetic(8, 6000, 3000, seed=3)
+    x64, e64, c64 = run_schedule(pairs, monkeypatch, True)
+    x32, e32, c32 = run_schedule(pairs, monkeypatch, False)
+    assert len(e64) == len(e32) and len(c64) == len(c32)
+    assert np.max(np.abs(e32 - e64) / e64) < 1e-6
+    scale = float(np.max(np.abs(x64)))
+    assert float(np.max(np.abs(x32.astype(np.float64) - x64))) / scale < 1e-6
+    # one transform, identical inputs: re-run the f64 run's first lattice through both forms
+    for form in ("FROG_K11_POINTWISE", "FROG_K11_TILED"):
+        outs = []
+        for f64 in (True, False):
+            monkeypatch.setenv("FROG_K11_F64", "1" if f64 else "0")
+            monkeypatch.setenv(form, "1")
+            g = ImageGroup(pairs, device=0)
+            g.setupLinearTransforms(); g.transformPoints(); g.updateStats()
+            for _ in range(3):
+                g.updateLinearTransforms(); g.transformPoints()
+            g.transformPoints(True)
+            g.setupDeformableTransforms(1); g.transformPoints(); g.updateStats()
+            assert g.updateDeformableTransforms(0.02) >= 0
+            g.transformPoints()
+            outs.append(g.points()[1].copy())
+            monkeypatch.delenv(form)
+        a, b = outs[0], outs[1]
+        ulp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+        assert np.all(np.abs(a - b) <= ulp), form
+        if form == "FROG_K11_POINTWISE":
+            pointwise32 = b
+        else:
+            assert np.array_equal(b, pointwise32), "f32: tiled form differs from thread-per-point form"
