@@ -444,6 +444,9 @@ def run_native(args, rank, world, local_rank, transport, rdv):
                                                    for n, v in ks.items()} for ph, ks in phase_k.items()}
         if world > 1:
             line["comm_ms"] = comm_ms
+            # every collective issued inside the timed region over its iterations: 2 per deformable iteration + 1 per linear one
+            # + 1 per statistics refresh and a few per lattice set-up since round 5 (include/frog_hip.h frog_comm_mode; 3 + 2 before)
+            line["collectives_per_iteration"] = round(sum(v["calls"] for v in comm_ms.values()) / max(1, k), 3)
             line["replicas_identical"] = len({x["hash"] for x in everyone}) == 1
             line["ranks"] = {"elapsed_s": [x["elapsed"] for x in everyone], "kernel_ms_total": [x["kernel_ms"] for x in everyone],
                              "sweep_ms_total": [x["sweep_ms"] for x in everyone], "comm_est_ms_total": [x["comm_est_ms"] for x in everyone],

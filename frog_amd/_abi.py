@@ -239,6 +239,10 @@ HIP_SYMBOLS = {
     "frog_deformable_phase_c": (C.c_int, [C.c_void_p, c_double_p]),
     "frog_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "frog_comm_unpack_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32]),
+    "frog_comm_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "frog_transform_points_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "frog_comm_unpack_slab_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]),
+    "frog_step_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_cull_stats_linear": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_stray_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -299,6 +303,9 @@ COMM_SYMBOLS = {
     "frog_comm_destroy_all": (None, [C.c_int, C.POINTER(C.c_void_p)]),
     "frog_comm_bind": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p]),
     "frog_comm_all_gather_xyz2": (C.c_int, [C.c_void_p]),
+    "frog_comm_slab": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "frog_comm_all_gather_slab": (C.c_int, [C.c_void_p]),
+    "frog_comm_gather_points": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
     "frog_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_comm_all_reduce_bounds": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "frog_comm_barrier": (C.c_int, [C.c_void_p]),

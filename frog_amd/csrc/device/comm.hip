@@ -4,11 +4,12 @@
 // Only the public ABI of libfrog_hip.so is used (frog_comm_buffer for the device pointers, frog_get_stream for the
 // stream the operation is enqueued on), so this is also the template for a host that drives the library with its own
 // communicator.  RCCL usage is the single-process / multi-thread form: ncclCommInitAll once, then every rank's thread
-// calls the same collective on its own communicator and stream; ragged all-gathers are n grouped broadcasts.
+// calls the same collective on its own communicator and stream; ragged all-gathers are one equal-size all-gather of padded slots.
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -55,6 +56,7 @@ struct Shared {
     // loopback staging
     std::vector<std::vector<unsigned char>> stage;      // one buffer per rank
     std::vector<float> xyz2_all;
+    std::vector<unsigned char> slab_host;               // loopback: the slab's host image
     double box[64][6];
     // host-staged collectives ACROSS PROCESSES (frog_comm_create_shm): a control block and a data area in POSIX shared memory
     struct ShmCtl {
@@ -99,6 +101,10 @@ struct frog_comm {
     hipStream_t stream = nullptr;
     double *d_box = nullptr;        // [6] max xyz, -min xyz
     double *h_box = nullptr;        // pinned
+    // the coordinate gather's slab (include/frog_hip.h: world slots of FROG_SLAB_SLOT_BYTES(slot_rows) bytes), on this rank's device
+    unsigned char *slab = nullptr;
+    uint64_t slot_rows = 0;
+    std::vector<uint64_t> rows;     // row_begin of every rank + the end: what frog_comm_unpack_slab_step wants
     // device time of the collectives (frog_comm_timing): every TIMING_SAMPLE-th call of a kind is bracketed by an event pair
     bool timing = false;
     struct Timed { hipEvent_t a, b; int kind; };
@@ -332,6 +338,7 @@ int frog_comm_set_rows(frog_comm *c, const uint64_t *row_begin)
         if (row_begin[r + 1] < row_begin[r]) return comm_fail(FROG_E_INVALID, "rows must be ascending");
         c->sh->row_begin[r] = (size_t)row_begin[r]; c->sh->row_end[r] = (size_t)row_begin[r + 1];
     }
+    c->slot_rows = 0;               // the slab follows the rows: re-made on demand
     return FROG_OK;
 }
 
@@ -343,6 +350,7 @@ void frog_comm_destroy_all(int n, frog_comm **comms)
         if (!c) continue;
         if (c->d_box || c->h_box || c->nccl) (void)hipSetDevice(c->device);
         if (c->d_box) (void)hipFree(c->d_box);
+        if (c->slab) { (void)hipSetDevice(c->device); (void)hipFree(c->slab); }
         if (c->h_box) (void)hipHostFree(c->h_box);
         if (c->nccl) (void)ncclCommDestroy(c->nccl);
         for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -406,6 +414,8 @@ int frog_comm_barrier(frog_comm *c)
     return FROG_OK;
 }
 
+static int ensure_slab(frog_comm *c);
+
 int frog_comm_all_gather_xyz2(frog_comm *c)
 {
     if (!c || !c->ctx) return comm_fail(FROG_E_INVALID, "communicator not bound");
@@ -435,17 +445,16 @@ int frog_comm_all_gather_xyz2(frog_comm *c)
         return shm_barrier(sh);         // nobody overwrites its rows before everybody has read them
     }
     if (sh.rccl) {
-        // ragged shards: rank q broadcasts its rows, in place (send = receive = the rows' place in the replica);
-        // the n broadcasts are one grouped operation
-        COMM_NCCL(ncclGroupStart());
-        for (int q = 0; q < sh.n; q++) {
-            const size_t cnt = (sh.row_end[q] - sh.row_begin[q]) * 3;
-            if (!cnt) continue;
-            float *rows = base + sh.row_begin[q] * 3;
-            COMM_NCCL(ncclBroadcast(rows, rows, cnt, ncclFloat, q, c->nccl, c->stream));
-        }
-        COMM_NCCL(ncclGroupEnd());
-        return FROG_OK;
+        // ragged shards, ONE collective: the own rows into the rank's slot of the slab, an equal-size all-gather of the slots,
+        // every slot's rows into the replica in one launch (frog_comm_unpack_slab_step; the own rows come back unchanged).
+        // Until round 5: n grouped in-place broadcasts -- n collective launches per iteration.
+        rc = ensure_slab(c);
+        if (rc) return rc;
+        const size_t slot = FROG_SLAB_SLOT_BYTES(c->slot_rows);
+        const size_t b = sh.row_begin[c->rank], e = sh.row_end[c->rank];
+        if (e > b) COMM_HIP(hipMemcpyAsync(c->slab + slot * (size_t)c->rank, base + 3 * b, (e - b) * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        COMM_NCCL(ncclAllGather(c->slab + slot * (size_t)c->rank, c->slab, slot, ncclChar, c->nccl, c->stream));
+        return frog_comm_unpack_slab_step(c->ctx, c->slab, c->slot_rows, (uint32_t)sh.n, c->rows.data(), (uint32_t)c->rank, 0u);
     }
     // loopback: own rows -> host, barrier, the other ranks' rows <- host
     const size_t P = bytes / (3 * sizeof(float));
@@ -462,6 +471,92 @@ int frog_comm_all_gather_xyz2(frog_comm *c)
     }
     sh.barrier.wait();
     return FROG_OK;
+}
+
+// the slab of the padded gather: slot_rows = the longest shard, every rank's rows known (frog_comm_bind / frog_comm_set_rows)
+static int ensure_slab(frog_comm *c)
+{
+    Shared &sh = *c->sh;
+    uint64_t longest = 0;
+    for (int r = 0; r < sh.n; r++) longest = std::max<uint64_t>(longest, sh.row_end[r] - sh.row_begin[r]);
+    if (c->slab && c->slot_rows == longest && (int)c->rows.size() == sh.n + 1) return FROG_OK;
+    COMM_HIP(hipSetDevice(c->device));
+    if (c->slab) { COMM_HIP(hipStreamSynchronize(c->stream)); COMM_HIP(hipFree(c->slab)); c->slab = nullptr; }
+    const size_t bytes = FROG_SLAB_SLOT_BYTES(longest) * (size_t)sh.n;
+    COMM_HIP(hipMalloc((void **)&c->slab, bytes));
+    COMM_HIP(hipMemsetAsync(c->slab, 0, bytes, c->stream));
+    c->slot_rows = longest;
+    c->rows.resize(sh.n + 1);
+    for (int r = 0; r < sh.n; r++) c->rows[r] = sh.row_begin[r];
+    c->rows[sh.n] = sh.row_end[sh.n - 1];
+    return FROG_OK;
+}
+
+int frog_comm_slab(frog_comm *c, void **slab, uint64_t *slot_rows)
+{
+    if (!c || !c->ctx) return comm_fail(FROG_E_INVALID, "communicator not bound");
+    const int rc = ensure_slab(c);
+    if (rc) return rc;
+    if (slab) *slab = c->slab;
+    if (slot_rows) *slot_rows = c->slot_rows;
+    return FROG_OK;
+}
+
+int frog_comm_all_gather_slab(frog_comm *c)
+{
+    if (!c || !c->ctx) return comm_fail(FROG_E_INVALID, "communicator not bound");
+    int rc = ensure_slab(c);
+    if (rc) return rc;
+    Shared &sh = *c->sh;
+    if (sh.n == 1) return FROG_OK;
+    COMM_HIP(hipSetDevice(c->device));
+    const size_t slot = FROG_SLAB_SLOT_BYTES(c->slot_rows), all = slot * (size_t)sh.n;
+    unsigned char *mine = c->slab + slot * (size_t)c->rank;
+    TimeSpan span(c, 0);
+    if (sh.rccl) {
+        // ONE equal-size all-gather, in place (send = the rank's slot inside the receive buffer): ragged shards cost padding,
+        // not a broadcast per rank -- each collective launch costs tens of microseconds over xGMI, a rank's whole share of an
+        // iteration at eight GPUs
+        COMM_NCCL(ncclAllGather(mine, c->slab, slot, ncclChar, c->nccl, c->stream));
+        return FROG_OK;
+    }
+    if (sh.shm) {
+        rc = shm_area(sh, c->rank, all);
+        if (rc) return rc;
+        COMM_HIP(hipMemcpyAsync(sh.area + slot * (size_t)c->rank, mine, slot, hipMemcpyDeviceToHost, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        rc = shm_barrier(sh);
+        if (rc) return rc;
+        // the slots before and after the own one: two copies
+        if (c->rank > 0) COMM_HIP(hipMemcpyAsync(c->slab, sh.area, slot * (size_t)c->rank, hipMemcpyHostToDevice, c->stream));
+        if (c->rank + 1 < sh.n)
+            COMM_HIP(hipMemcpyAsync(mine + slot, sh.area + slot * (size_t)(c->rank + 1), slot * (size_t)(sh.n - 1 - c->rank), hipMemcpyHostToDevice, c->stream));
+        COMM_HIP(hipStreamSynchronize(c->stream));
+        return shm_barrier(sh);         // nobody refills its slot before everybody has read it
+    }
+    // loopback (threads of one process): the same through a host image of the slab
+    COMM_HIP(hipStreamSynchronize(c->stream));
+    if (c->rank == 0 && sh.slab_host.size() != all) sh.slab_host.assign(all, 0);
+    sh.barrier.wait();
+    COMM_HIP(hipMemcpy(sh.slab_host.data() + slot * (size_t)c->rank, mine, slot, hipMemcpyDeviceToHost));
+    sh.barrier.wait();
+    if (c->rank > 0) COMM_HIP(hipMemcpy(c->slab, sh.slab_host.data(), slot * (size_t)c->rank, hipMemcpyHostToDevice));
+    if (c->rank + 1 < sh.n)
+        COMM_HIP(hipMemcpy(mine + slot, sh.slab_host.data() + slot * (size_t)(c->rank + 1), slot * (size_t)(sh.n - 1 - c->rank), hipMemcpyHostToDevice));
+    sh.barrier.wait();
+    return FROG_OK;
+}
+
+int frog_comm_gather_points(frog_comm *c, int apply, int after_step, uint32_t sum_mask)
+{
+    if (!c || !c->ctx) return comm_fail(FROG_E_INVALID, "communicator not bound");
+    int rc = ensure_slab(c);
+    if (rc) return rc;
+    rc = frog_transform_points_slab(c->ctx, apply, after_step, c->slab, c->slot_rows, (uint32_t)c->rank);
+    if (rc) return rc;
+    rc = frog_comm_all_gather_slab(c);
+    if (rc) return rc;
+    return frog_comm_unpack_slab_step(c->ctx, c->slab, c->slot_rows, (uint32_t)c->sh->n, c->rows.data(), (uint32_t)c->rank, sum_mask);
 }
 
 int frog_comm_all_reduce(frog_comm *c, int which)

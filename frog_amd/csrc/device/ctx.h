@@ -323,6 +323,8 @@ struct frog_ctx {
     // FROG_REFERENCE_ORDER=1 (test hook, k_reforder.hip.h): every solver loop in the reference's own order and arithmetic --
     // no culling list, no fast weight, no re-associated sum; results are bit-comparable with the tests' CPU restatement of the reference
     bool ref_order = false;
+    bool two_collectives = false;   // frog_comm_mode: the energy sums ride on the all-reduce of the proposal sums, the oversize count on the coordinate gather
+    double pending_seq = 0.0;       // sequence number of the scalars frog_comm_unpack_slab_step published and frog_step_finish has not read yet
     bool k11_f64 = false;           // FROG_K11_F64=1: the B-spline transform's weights and sums in f64 (rounds 1-4), for comparison
     frog::DevBuf<uint32_t> ref_own;           // [L_own] own point (internal numbering) of every half-link, reference order
     frog::DevBuf<float> ref_w, ref_d;         // [L_own] weight and distance of every half-link (linear step)

@@ -449,6 +449,8 @@ static int ref_point_sums(frog_ctx *ctx, bool with_energy)
 }
 
 // phase A of updateDeformableTransforms (imageGroup.cxx:239-377 and the proposal sums of :411-415) in the reference's order
+__global__ void energy_fold_kernel(const double *energy, double *tail) { tail[0] = energy[0]; tail[1] = energy[1]; tail[2] = 0.0; tail[3] = energy[3]; }
+
 static int ref_deformable_phase_a(frog_ctx *ctx, float alpha)
 {
     hipStream_t s = ctx->stream;
@@ -462,6 +464,7 @@ static int ref_deformable_phase_a(frog_ctx *ctx, float alpha)
     ref_scatter_kernel<<<nO, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
                                          ctx->gradf.p);
     ref_cp_step_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->gradf.p, ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    if (ctx->two_collectives) energy_fold_kernel<<<1, 1, 0, s>>>(ctx->energy.p, ctx->gridsum.p + 3 * (size_t)gd.n_cp);      // as lattice_step_kernel
     FROG_HIP_CHECK(hipGetLastError());
     ctx->centered_in_a = false;                 // phase B subtracts the mean (cp_center_kernel: :417-428 as written)
     ctx->pending_alpha = alpha;
@@ -970,7 +973,11 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
 }
 
 // ---- transformPoints (imageGroup.cxx:910-916, image.cxx:3-13) -----------------------
-static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step = false, double scalar_seq = 0.0)
+__global__ void slab_trailer_kernel(const double *energy, double *trailer) { write_slab_trailer(energy, trailer); }
+
+// `trailer` (null in every call but frog_transform_points_slab's): where the kernel's first thread leaves the step's four
+// scalars as they stand on this rank (k_grid.hip.h write_slab_trailer)
+static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step = false, double scalar_seq = 0.0, double *trailer = nullptr)
 {
     double *host_scalars = scalar_seq != 0.0 ? ctx->h_energy_dev : nullptr;
     const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
@@ -983,7 +990,8 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                                                                         ctx->own_pt_begin, ctx->own_pt_end, apply,
                                                                         with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                         ctx->disp_allow.p, ctx->cull_state.p, ctx->energy.p,
-                                                                        host_scalars, scalar_seq);
+                                                                        host_scalars, scalar_seq, trailer);
+        trailer = nullptr;
         if (with_disp) ctx->disp_n = ctx->disp_own_n = div_up(n, 256);
         ctx->disp_others = false;
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
@@ -1026,7 +1034,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                 after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
-                ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
+                ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
             auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : transform_bspline_kernel<float>;
@@ -1035,14 +1043,17 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
                                                                              ctx->opt.guarantee_diffeomorphism,
-                                                                             ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq);
+                                                                             ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = div_up(n, 256);
         }
+        trailer = nullptr;
         ctx->disp_others = false;
         // the per-block maxima now describe `out`: the current xyz2, or the speculative copy until it is published
         if (out == ctx->pos2.p) ctx->disp_current = with_disp;
         else { ctx->disp_spec = with_disp; ctx->disp_current = false; }
     }
+    // the forms that do not write the trailer themselves (fresh lattice, reference-order mode)
+    if (trailer) slab_trailer_kernel<<<1, 1, 0, ctx->stream>>>(ctx->energy.p, trailer);
     FROG_HIP_CHECK(hipGetLastError());
     if (apply) ctx->pos_b_stale = true;         // pos has new values: pos_b (its copy in perm's order) is out of date
     return FROG_OK;
@@ -1400,7 +1411,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
-    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G, 3 * G * reserve));
+    FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G + 4, (3 * G + 4) * reserve));      // + 4: the energy sums' seat on the all-reduce (frog_comm_mode)
     FROG_HIP_CHECK(ctx->key_counts.alloc(n_keys, n_keys * reserve));
     FROG_HIP_CHECK(ctx->brick_ptr_scratch.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
     FROG_HIP_CHECK(ctx->key_ptr.alloc(n_keys + 1, (n_keys + 1) * reserve));
@@ -1701,6 +1712,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p;
         la.gradf = ctx->gradf.p; la.stray = ctx->stray.p + ctx->stray_parity;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
+        la.energy_tail = ctx->two_collectives && !ctx->whole_group() ? ctx->gridsum.p + 3 * (size_t)gd.n_cp : nullptr;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
         la.energy = ctx->energy.p;
@@ -1735,7 +1747,8 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     // :398: the group mean is removed only when no image is fixed
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
-                                                        (double)maxD * g.spacing[2], ctx->energy.p);
+                                                        (double)maxD * g.spacing[2], ctx->energy.p,
+                                                        ctx->two_collectives ? ctx->gridsum.p + 3 * (size_t)g.n_cp : nullptr);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->phase = 2;
     return FROG_OK;
@@ -2266,18 +2279,45 @@ int frog_profile_read(frog_ctx *ctx, frog_kernel_time *out, int reset)
 
 // rows [row_begin[r], row_begin[r + 1]) of every rank r != self: slab slot r -> the coordinate table
 constexpr int UNPACK_MAX_RANKS = 64;
-struct UnpackArgs { uint64_t row_begin[UNPACK_MAX_RANKS + 1]; uint64_t slot_rows; uint32_t world, self; };
+struct UnpackArgs {
+    uint64_t row_begin[UNPACK_MAX_RANKS + 1];
+    uint64_t slot_bytes;            // distance between two ranks' slots
+    uint32_t world, self;           // self == world: the own rows are copied too (frog_comm_unpack_slab_step)
+    // frog_comm_unpack_slab_step: the slots' trailers (4 doubles at slot + trailer_off) are added up over the ranks for the scalars in
+    // sum_mask and the step's four scalars handed to the host (k_grid.hip.h publish_step_scalars)
+    uint64_t trailer_off;
+    uint32_t sum_mask;
+    double *energy, *host_scalars;
+    double seq;
+};
 // `snap` (null: no list to check): the block also leaves the largest distance of the rows it copies from the culling list's
 // snapshot in disp_part[blockIdx.y * gridDim.x + blockIdx.x] (k_cull.hip.h: what cull_disp_kernel computes in a pass of its own)
 __global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *pos2, const UnpackArgs a, const P3 *snap, uint32_t *disp_part)
 {
     __shared__ uint32_t sh[4];
     const uint32_t r = blockIdx.y;
+    if (a.host_scalars && blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
+        // the ranks' trailers in rank order: integers (oversize counts, flags) add exactly; the energy sums of a linear step
+        // in the same order on every rank, so every rank prints the same E
+        for (int k = 0; k < 4; k++) {
+            if (!(a.sum_mask >> k & 1u)) continue;
+            double sum = 0.0;
+            for (uint32_t q = 0; q < a.world; q++)
+                sum += reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(slab) + q * a.slot_bytes + a.trailer_off)[k];
+            a.energy[k] = sum;
+        }
+        __threadfence();
+        #pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&a.host_scalars[k], a.energy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&a.host_scalars[7], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     uint32_t m = 0;
     if (r != a.self) {
         const uint64_t n = a.row_begin[r + 1] - a.row_begin[r];
+        const P3 *slot = reinterpret_cast<const P3 *>(reinterpret_cast<const unsigned char *>(slab) + r * a.slot_bytes);
         for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256u) {
-            const P3 v = slab[(uint64_t)r * a.slot_rows + k];
+            const P3 v = slot[k];
             pos2[a.row_begin[r] + k] = v;
             if (snap) {
                 const P3 q = snap[a.row_begin[r] + k];
@@ -2307,7 +2347,7 @@ int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, u
         longest = std::max(longest, row_begin[r + 1] - row_begin[r]);
     }
     if (longest > slot_rows) return fail(FROG_E_INVALID, "slot shorter than the longest shard");
-    a.slot_rows = slot_rows; a.world = world_size; a.self = self;
+    a.slot_bytes = slot_rows * sizeof(P3); a.world = world_size; a.self = self;
     if (longest == 0) return FROG_OK;
     const dim3 grid((unsigned)std::min<uint64_t>(div_up(longest, 256), 1024), world_size);
     // The own rows' displacement against the culling list's snapshot was measured by the transform that produced them
@@ -2324,6 +2364,102 @@ int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, u
     return FROG_OK;
 }
 
+// ---- sharded contexts: two collectives per deformable iteration, one per linear iteration (include/frog_hip.h) -----------------
+int frog_comm_mode(frog_ctx *ctx, int two_collectives)
+{
+    CTX_GUARD(ctx);
+    if (ctx->phase != 0) return fail(FROG_E_STATE, "frog_comm_mode inside a deformable step");
+    ctx->two_collectives = two_collectives != 0;
+    return FROG_OK;
+}
+
+int frog_transform_points_slab(frog_ctx *ctx, int apply, int after_step, void *slab, uint64_t slot_rows, uint32_t self)
+{
+    CTX_GUARD(ctx);
+    if (!slab) return fail(FROG_E_INVALID, "null slab");
+    const uint32_t n = ctx->own_pt_end - ctx->own_pt_begin;
+    if (n > slot_rows) return fail(FROG_E_INVALID, "slot shorter than this context's shard");
+    if (after_step && ctx->phase != 2) return fail(FROG_E_STATE, "frog_transform_points_slab(after_step) without phase_b");
+    if (after_step && apply) return fail(FROG_E_INVALID, "the transform behind a step does not re-base");
+    unsigned char *slot = static_cast<unsigned char *>(slab) + (size_t)self * FROG_SLAB_SLOT_BYTES(slot_rows);
+    double *trailer = reinterpret_cast<double *>(slot + FROG_SLAB_SLOT_BYTES(slot_rows) - FROG_SLAB_TRAILER_BYTES);
+    ctx->xyz2_fresh = false; ctx->res_valid = false;
+    if (!n) {           // a context whose images are all empty still owes its trailer
+        slab_trailer_kernel<<<1, 1, 0, ctx->stream>>>(ctx->energy.p, trailer);
+        FROG_HIP_CHECK(hipGetLastError());
+        return FROG_OK;
+    }
+    // the kernels address their output by point index: row own_pt_begin is the slot's first
+    P3 *out = reinterpret_cast<P3 *>(slot) - ctx->own_pt_begin;
+    return launch_transform(ctx, out, apply, after_step != 0, 0.0, trailer);
+}
+
+int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size, const uint64_t *row_begin,
+                               uint32_t self, uint32_t sum_mask)
+{
+    CTX_GUARD(ctx);
+    if (!slab || !row_begin || world_size < 1 || world_size > (uint32_t)UNPACK_MAX_RANKS || self >= world_size || sum_mask > 15u)
+        return fail(FROG_E_INVALID, "bad slab arguments");
+    if (sum_mask && !ctx->h_energy_dev) return fail(FROG_E_STATE, "no host-visible scalar block");
+    UnpackArgs a{};
+    uint64_t longest = 0;
+    for (uint32_t r = 0; r <= world_size; r++) a.row_begin[r] = row_begin[r];
+    for (uint32_t r = 0; r < world_size; r++) {
+        if (row_begin[r + 1] < row_begin[r] || row_begin[r + 1] > ctx->P) return fail(FROG_E_INVALID, "rows must be ascending and inside the table");
+        longest = std::max(longest, row_begin[r + 1] - row_begin[r]);
+    }
+    if (longest > slot_rows) return fail(FROG_E_INVALID, "slot shorter than the longest shard");
+    if (row_begin[self] != ctx->own_pt_begin || row_begin[self + 1] != ctx->own_pt_end) return fail(FROG_E_INVALID, "row_begin[self] is not this context's shard");
+    a.slot_bytes = FROG_SLAB_SLOT_BYTES(slot_rows); a.world = world_size; a.self = world_size;      // every slot, the own one included
+    a.trailer_off = a.slot_bytes - FROG_SLAB_TRAILER_BYTES;
+    a.sum_mask = sum_mask;
+    if (sum_mask) {
+        a.energy = ctx->energy.p; a.host_scalars = ctx->h_energy_dev;
+        a.seq = (double)(++ctx->scalar_seq);
+        ctx->pending_seq = a.seq;
+    }
+    const dim3 grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(div_up(longest, 256), 1), 1024), world_size);
+    // the own rows' displacement against the culling list's snapshot: measured by the transform that wrote them into the slab
+    // (disp_part[0 .. disp_own_n), recorded as "speculative" because its output was not the table); the other ranks' as they are copied
+    ctx->disp_current = ctx->disp_spec; ctx->disp_spec = false;
+    const bool list = ctx->deformable ? (cull_active(ctx) && ctx->cull_builds > 0) : (cull_active_linear(ctx) && ctx->cull_lin_builds > 0);
+    const bool measure = ctx->disp_current && list && !ctx->cull_need_build && ctx->pos2_snap.p && ctx->disp_part.p
+                         && (size_t)ctx->disp_own_n + (size_t)grid.x * grid.y <= ctx->disp_part.n;
+    unpack_slab_kernel<<<grid, 256, 0, ctx->stream>>>(reinterpret_cast<const P3 *>(slab), ctx->pos2.p, a,
+                                                      measure ? ctx->pos2_snap.p : nullptr, measure ? ctx->disp_part.p + ctx->disp_own_n : nullptr);
+    FROG_HIP_CHECK(hipGetLastError());
+    // (the own slot's rows are measured twice when `measure`: once by the transform, once here -- a maximum does not mind)
+    if (measure) { ctx->disp_n = ctx->disp_own_n + grid.x * grid.y; ctx->disp_others = true; }
+    else { ctx->disp_current = false; ctx->disp_others = false; }      // measured by the check before the next sweep
+    return FROG_OK;
+}
+
+int frog_step_finish(frog_ctx *ctx, double *E)
+{
+    CTX_GUARD(ctx);
+    if (ctx->pending_seq == 0.0) return fail(FROG_E_STATE, "frog_step_finish without frog_comm_unpack_slab_step(sum_mask != 0)");
+    const int rc = wait_step_scalars(ctx, ctx->pending_seq);
+    ctx->pending_seq = 0.0;
+    if (rc) return rc;
+    if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // a rank's sweep found its culling list out of date
+    const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
+    if (ctx->phase == 2) {
+        // updateDeformableTransforms' decision (imageGroup.cxx:434-439) and commit (:441-468), as frog_deformable_phase_c
+        const bool rejected = ctx->opt.guarantee_diffeomorphism && nbig > 0;
+        if (!rejected) {
+            std::swap(ctx->coeff.p, ctx->grad.p);
+            std::swap(ctx->coeff.cap, ctx->grad.cap);
+            std::swap(ctx->coeff.n, ctx->grad.n);
+            ctx->coeff_zero = false;
+        }
+        ctx->phase = 0;
+        if (E) *E = rejected ? -1.0 : e;
+        return FROG_OK;
+    }
+    if (E) *E = e;
+    return FROG_OK;
+}
+
 int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t *row_begin, size_t *row_end)
 {
     CTX_GUARD(ctx);
@@ -2335,7 +2471,8 @@ int frog_comm_buffer(frog_ctx *ctx, int which, void **ptr, size_t *bytes, size_t
     case FROG_BUF_ENERGY: p = ctx->energy.p; b = ctx->energy.bytes(); rb = 0; re = 4; break;
     case FROG_BUF_GRIDSUM:
         if (!ctx->deformable) return fail(FROG_E_STATE, "no lattice");
-        p = ctx->gridsum.p; b = ctx->gridsum.bytes(); rb = 0; re = ctx->gridsum.n; break;
+        // 3 G proposal sums; with two collectives per iteration (frog_comm_mode) the step's energy sums and list flag behind them
+        p = ctx->gridsum.p; re = 3 * (size_t)ctx->geom.n_cp + (ctx->two_collectives ? 4 : 0); b = re * sizeof(double); rb = 0; break;
     default: return fail(FROG_E_INVALID, "unknown buffer");
     }
     if (ptr) *ptr = p;

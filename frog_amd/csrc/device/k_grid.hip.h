@@ -87,6 +87,19 @@ __device__ __forceinline__ void publish_step_scalars(const double *energy, doubl
     }
 }
 
+// Sharded contexts, two collectives per iteration (include/frog_hip.h frog_transform_points_slab): the transform writes the rank's rows
+// straight into its slot of the slab the coordinate all-gather moves, and its first thread appends the step's four scalars as
+// they stand on this rank -- energy sums, the rank's OWN oversize count, list flag -- as the slot's trailer: what used to be an
+// all-reduce of its own between the step and the transform travels with the coordinates (frog_comm_unpack_slab_step adds the
+// ranks' trailers up on the other side).
+__device__ __forceinline__ void write_slab_trailer(const double *energy, double *trailer)
+{
+    if (trailer && blockIdx.x == 0 && threadIdx.x == 0) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) trailer[k] = energy[k];
+    }
+}
+
 // ---- K5: linear transform (vtkLinearTransformPoint, f64 row products -> f32) ----
 // `snap` (null: no list): the kernel also measures how far its block's points are from the culling list's snapshot and
 // compares with the list's allowance, as the B-spline transforms do (k_cull.hip.h); `host_scalars`: the launch queued behind a
@@ -94,9 +107,11 @@ __device__ __forceinline__ void publish_step_scalars(const double *energy, doubl
 __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *pos2, const double *mat,
                                                                uint32_t pt_begin, uint32_t pt_end, int apply,
                                                                const P3 *snap, uint32_t *disp_part, const float *disp_allow,
-                                                               uint32_t *cull_state, const double *energy, double *host_scalars, double seq)
+                                                               uint32_t *cull_state, const double *energy, double *host_scalars, double seq,
+                                                               double *trailer)
 {
     publish_step_scalars(energy, host_scalars, seq);
+    write_slab_trailer(energy, trailer);
     __shared__ uint32_t dmax_s[4];
     const uint32_t p = pt_begin + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t dmax = 0;
@@ -145,9 +160,10 @@ __global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, con
                                                                 const P3 *snap, uint32_t *disp_part,
                                                                 const float4 *proposal, const double *energy, int guarantee,
                                                                 const float *disp_allow, uint32_t *cull_state,
-                                                                double *host_scalars, double seq)
+                                                                double *host_scalars, double seq, double *trailer)
 {
     publish_step_scalars(energy, host_scalars, seq);
+    write_slab_trailer(energy, trailer);
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
     // reduction at the end is wave-wide
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                                                                     const P3 *snap, uint32_t *disp_part,
                                                                     const float4 *proposal, const double *energy, int guarantee,
                                                                     const float *disp_allow, uint32_t *cull_state,
-                                                                    double *host_scalars, double seq);
+                                                                    double *host_scalars, double seq, double *trailer);
 
 // Zeroes up to ZERO_MAX device buffers in ONE launch (a lattice set-up clears six: every hipMemsetAsync is a launch
 // of its own with a few microseconds of idle stream in front of it).  A block clears ZERO_BLOCK_BYTES of one buffer with
@@ -692,9 +708,10 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
                                    const P3 *snap, uint32_t *disp_part,
                                    const float4 *proposal, const double *energy, int guarantee,
                                    const float *disp_allow, uint32_t *cull_state,
-                                   double *host_scalars, double seq)
+                                   double *host_scalars, double seq, double *trailer)
 {
     publish_step_scalars(energy, host_scalars, seq);
+    write_slab_trailer(energy, trailer);
     // the brick's (B+3)^3 coefficients as they are in memory (f32 x, y, z, pad): one ds_read_b128 per tap.  The first
     // version kept them as three f64 arrays ("converted once"): 192 ds_read_b64 per point, and the kernel ran at the LDS's
     // bandwidth (1.5 KB per point; 81 us).  Converting each tap again costs three v_cvt per tap on a vector unit that had
@@ -1186,6 +1203,7 @@ struct LatticeStepArgs {
     const float4 *coeff;
     float4 *grad;
     double *gridsum;
+    double *energy_tail;            // null, or gridsum + 3 G: the step's energy sums and list flag ride on the all-reduce of the proposal sums
     uint32_t n_owned, n_images;     // n_images = 0: fixed images present, no mean removal
     float alpha;
     double lim[3];
@@ -1317,7 +1335,14 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
         if (scp < g.n_cp) a.gridsum[3 * (size_t)scp + sa] = run;
         mean[sc][sa] = a.n_images ? run / a.n_images : 0.0;
     }
-    if (!CENTER) return;
+    if (!CENTER) {
+        // sharded contexts with two collectives per iteration: energy[0], [1] (this rank's sums, final since the scatter's launch)
+        // and [3] (list flag) behind the proposal sums, so that ONE all-reduce adds both up; cp_center_kernel puts them back
+        if (a.energy_tail && blockIdx.x == 0 && tid == 0) {
+            a.energy_tail[0] = a.energy[0]; a.energy_tail[1] = a.energy[1]; a.energy_tail[2] = 0.0; a.energy_tail[3] = a.energy[3];
+        }
+        return;
+    }
     __syncthreads();
     unsigned int cnt = 0;
     if (cp < g.n_cp) {
@@ -1354,9 +1379,12 @@ constexpr int CP_BATCH = 10;
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
-                                                        double *energy)
+                                                        double *energy, const double *energy_tail)
 {
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
+    // two collectives per iteration: the all-reduced energy sums and list flag come back from behind the proposal sums
+    // (lattice_step_kernel put them there); energy[2], which the other threads count into, is not touched
+    if (energy_tail && cp == 0) { energy[0] = energy_tail[0]; energy[1] = energy_tail[1]; energy[3] = energy_tail[3]; }
     unsigned int cnt = 0;
     if (cp < n_cp) {
         // n_images == 0: fixed images present, `sum` stays 0 (imageGroup.cxx:398,409-419)

@@ -12,6 +12,7 @@ struct CommApi {
     decltype(&frog_comm_destroy_all) destroy_all = nullptr;
     decltype(&frog_comm_bind) bind = nullptr;
     decltype(&frog_comm_all_gather_xyz2) all_gather_xyz2 = nullptr;
+    decltype(&frog_comm_gather_points) gather_points = nullptr;
     decltype(&frog_comm_all_reduce) all_reduce = nullptr;
     decltype(&frog_comm_all_reduce_bounds) all_reduce_bounds = nullptr;
     decltype(&frog_comm_barrier) barrier = nullptr;

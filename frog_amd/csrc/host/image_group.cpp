@@ -45,6 +45,7 @@ bool CommApi::load(std::string &err)
     LOAD(create_loopback, "frog_comm_create_loopback");
     LOAD(destroy_all, "frog_comm_destroy_all"); LOAD(bind, "frog_comm_bind");
     LOAD(all_gather_xyz2, "frog_comm_all_gather_xyz2"); LOAD(all_reduce, "frog_comm_all_reduce");
+    LOAD(gather_points, "frog_comm_gather_points");
     LOAD(all_reduce_bounds, "frog_comm_all_reduce_bounds"); LOAD(barrier, "frog_comm_barrier");
     LOAD(timing, "frog_comm_timing"); LOAD(timing_read, "frog_comm_timing_read");
     LOAD(create_rccl, "frog_comm_create_rccl");
@@ -190,7 +191,18 @@ void ImageGroup::runSharded()
         auto ck = [&](int rc, const char *what) { if (rc) { 
             #pragma omp critical
             { cout << "Error : " << what << " failed on rank " << r << " (" << rc << "): " << frog_last_error() << endl; exit(1); } } };
+        // two collectives per deformable iteration, one per linear iteration (include/frog_hip.h frog_comm_mode; rank_schedule.cpp
+        // has the same flow); FROG_THREE_COLLECTIVES=1: the flow of rounds 2-4
+        const bool two = !getenv("FROG_THREE_COLLECTIVES");
+        bool gathered = false;
+        ck(frog_comm_mode(c, two ? 1 : 0), "frog_comm_mode");
         auto transformPoints = [&](int apply) {
+            if (two) {
+                const bool done = gathered && !apply;
+                gathered = false;
+                if (!done) ck(g_comm.gather_points(cm, apply, 0, 0u), "frog_comm_gather_points");
+                return;
+            }
             ck(frog_transform_points_local(c, apply), "frog_transform_points_local");
             ck(g_comm.all_gather_xyz2(cm), "frog_comm_all_gather_xyz2");
         };
@@ -239,9 +251,15 @@ void ImageGroup::runSharded()
             if (root && !quiet) cout << "Linear registration, iteration " << iteration + 1 << "/" << linearIterations << endl;
             if (!(iteration % statIntervalUpdate)) updateStats();
             ck(frog_linear_step_local(c), "frog_linear_step_local");
-            ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");
             double E = 0;
-            ck(frog_energy_read(c, &E, nullptr), "frog_energy_read");
+            if (two) {
+                ck(g_comm.gather_points(cm, 0, 0, 0xBu), "frog_comm_gather_points");        // the two sums ride on the gather
+                ck(frog_step_finish(c, &E), "frog_step_finish");
+                gathered = true;
+            } else {
+                ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");
+                ck(frog_energy_read(c, &E, nullptr), "frog_energy_read");
+            }
             transformPoints(0);
             if (root) computeLandmarkDistances((float)E);
         }
@@ -274,9 +292,16 @@ void ImageGroup::runSharded()
                     ck(frog_deformable_phase_a(c, alpha), "frog_deformable_phase_a");
                     ck(g_comm.all_reduce(cm, FROG_BUF_GRIDSUM), "frog_comm_all_reduce");        // the shared common-space grid, :400-432
                     ck(frog_deformable_phase_b(c), "frog_deformable_phase_b");
-                    ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");         // energy sums + oversize count
                     double E = 0;
-                    ck(frog_deformable_phase_c(c, &E), "frog_deformable_phase_c");
+                    if (two) {
+                        // the oversize count rides on the coordinate gather, the transform queued speculatively (frog_hip.h)
+                        ck(g_comm.gather_points(cm, 0, 1, 0x4u), "frog_comm_gather_points");
+                        ck(frog_step_finish(c, &E), "frog_step_finish");
+                        gathered = (float)E >= 0;
+                    } else {
+                        ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");         // energy sums + oversize count
+                        ck(frog_deformable_phase_c(c, &E), "frog_deformable_phase_c");
+                    }
                     const float e = (float)E;
                     if (e < 0) {                                                  // :97-115, the same on every rank
                         if (root) cout << endl << "Diffeomorphism is not guaranteed : Iteration canceled" << endl;

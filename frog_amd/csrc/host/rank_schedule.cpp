@@ -23,6 +23,11 @@ struct Runner {
     const frog_schedule_plan *plan;
     frog_schedule_result *out;
     bool whole = false;             // the context owns every image and there is no communicator: the plain entry points
+    // Two collectives per deformable iteration, one per linear iteration (include/frog_hip.h frog_comm_mode): the energy sums ride
+    // on the all-reduce of the proposal sums, the oversize count on the coordinate gather, whose transform is queued speculatively.
+    // FROG_THREE_COLLECTIVES=1 keeps the flow of rounds 2-4 (three / two), for comparison.
+    bool two = false;
+    bool gathered = false;          // the step just finished has already transformed and gathered: the transformPoints() that follows it is done
     uint32_t ib = 0, ie = 0, nI = 0;
     int rc = 0;
 
@@ -32,6 +37,12 @@ struct Runner {
     {
         if (rc) return;
         if (whole) { ok(frog_transform_points(c, apply)); return; }
+        if (two) {
+            const bool done = gathered && !apply;
+            gathered = false;
+            if (!done) ok(api->gather_points(cm, apply, 0, 0u));
+            return;
+        }
         if (!ok(frog_transform_points_local(c, apply))) return;
         if (cm) ok(api->all_gather_xyz2(cm));
     }
@@ -52,6 +63,14 @@ struct Runner {
         if (rc) return E;
         if (whole) { ok(frog_linear_step(c, &E)); return E; }
         if (!ok(frog_linear_step_local(c))) return E;
+        if (two) {
+            // the step's two sums and its list flag travel in the trailers of the coordinate gather (imageGroup.cxx:1147 needs
+            // them for the printed E only; the matrices are image-local): ONE collective per linear iteration
+            if (!ok(api->gather_points(cm, 0, 0, 0xBu))) return E;
+            ok(frog_step_finish(c, &E));
+            gathered = true;
+            return E;
+        }
         if (cm && !ok(api->all_reduce(cm, FROG_BUF_ENERGY))) return E;
         ok(frog_energy_read(c, &E, nullptr));
         return E;
@@ -81,8 +100,17 @@ struct Runner {
         if (rc) return E;
         if (whole) { ok(frog_deformable_step(c, alpha, &E)); return E; }
         if (!ok(frog_deformable_phase_a(c, alpha))) return E;
-        if (cm && !ok(api->all_reduce(cm, FROG_BUF_GRIDSUM))) return E;        // the shared common-space grid, :400-432
+        if (cm && !ok(api->all_reduce(cm, FROG_BUF_GRIDSUM))) return E;        // the shared common-space grid, :400-432 (+ the energy sums when `two`)
         if (!ok(frog_deformable_phase_b(c))) return E;
+        if (two) {
+            // the transform that follows the step, queued before the group's oversize count exists (each rank goes by its own),
+            // the counts in the gather's trailers; decision and commit once they are added up.  A rejected step has left
+            // speculative coordinates in the replicas: run()'s reject path re-bases and gathers before anything reads them.
+            if (!ok(api->gather_points(cm, 0, 1, 0x4u))) return E;
+            ok(frog_step_finish(c, &E));
+            gathered = (float)E >= 0;
+            return E;
+        }
         if (cm && !ok(api->all_reduce(cm, FROG_BUF_ENERGY))) return E;         // energy sums + oversize count
         ok(frog_deformable_phase_c(c, &E));
         return E;
@@ -138,6 +166,8 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
         r.ib = (uint32_t)b; r.ie = (uint32_t)e;
     }
     r.whole = !comm && r.ib == 0 && r.ie == r.nI;
+    r.two = comm && !getenv("FROG_THREE_COLLECTIVES");
+    if (comm) { const int rc = frog_comm_mode(ctx, r.two ? 1 : 0); if (rc) return rc; }
 
     // ---- untimed: linear set-up, first transform, (proxy: the other ranks' coordinates), warm-up iterations
     const bool trace = getenv("FROG_SCHEDULE_TRACE") != nullptr;

@@ -62,9 +62,21 @@ void frog_comm_destroy_all(int n_ranks, frog_comm **comms);
  * images of rank r (n_ranks + 1 entries, the same on every rank). */
 int frog_comm_bind(frog_comm *comm, frog_ctx *ctx, const uint32_t *image_begin);
 
-/* all-gather of the owned rows of FROG_BUF_XYZ2, in place in every rank's replica (one grouped RCCL
- * operation of n broadcasts: shards are ragged) */
+/* all-gather of the owned rows of FROG_BUF_XYZ2 into every rank's replica (RCCL: the rows go through the slab below --
+ * one equal-size all-gather of padded slots + one unpack launch; until round 5 n grouped broadcasts) */
 int frog_comm_all_gather_xyz2(frog_comm *comm);
+/* ---- the padded coordinate gather (include/frog_hip.h, "Two collectives per deformable iteration") -----------------
+ * The communicator owns the slab (on its rank's device; slot_rows = the longest shard).
+ *   frog_comm_slab             its address and slot length (allocated on the first call, once every rank's rows are known)
+ *   frog_comm_all_gather_slab  ONE equal-size all-gather of the ranks' slots, in place (ncclAllGather; host-staged on the
+ *                              shared-memory and loopback transports)
+ *   frog_comm_gather_points    transformPoints of the rank's images + the gather + every slot into FROG_BUF_XYZ2:
+ *                              frog_transform_points_slab, frog_comm_all_gather_slab, frog_comm_unpack_slab_step(sum_mask).
+ *                              With sum_mask != 0 the step's scalars ride along: call frog_step_finish(ctx, &E) next. */
+int frog_comm_slab(frog_comm *comm, void **slab, uint64_t *slot_rows);
+int frog_comm_all_gather_slab(frog_comm *comm);
+int frog_comm_gather_points(frog_comm *comm, int apply, int after_step, uint32_t sum_mask);
+
 /* all-reduce(sum) of FROG_BUF_EM (float), FROG_BUF_ENERGY or FROG_BUF_GRIDSUM (double), in place */
 int frog_comm_all_reduce(frog_comm *comm, int which);
 /* group-wide box from the ranks' own boxes (frog_bounds_local): mins / maxs are replaced */

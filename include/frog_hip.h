@@ -165,7 +165,7 @@ enum {
                             * inside each image); owned rows written by transform          */
     FROG_BUF_EM      = 1,  /* float4[n_images]  c1,c2,ratio,0; owned rows written by stats  */
     FROG_BUF_ENERGY  = 2,  /* double[4]   sum w2 d2, sum w2, #oversize coefficients, 0      */
-    FROG_BUF_GRIDSUM = 3   /* double[3*G] sum over owned images of the proposed coefficients */
+    FROG_BUF_GRIDSUM = 3   /* double[3*G] sum over owned images of the proposed coefficients (+ 4 doubles with frog_comm_mode(ctx, 1)) */
 };
 /* Device pointer + size of a collective buffer; `row_begin`/`row_end` (in
  * elements of the buffer's row type) delimit what this context owns (NULL ok). */
@@ -178,6 +178,40 @@ int frog_comm_buffer(frog_ctx *ctx, int which, void **device_ptr, size_t *bytes,
  * stream (a host that unpacks with one copy per rank pays world_size - 1 launches per iteration). */
 int frog_comm_unpack_slab(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size,
                           const uint64_t *row_begin, uint32_t self);
+
+/* ---- Two collectives per deformable iteration, one per linear iteration (round 5) ------------------------------------------
+ * The split phases below cost a deformable iteration three collectives: all-reduce of the proposal sums, all-reduce of
+ * (energy sums, oversize count, list flag), all-gather of the coordinates -- each latency-bound, against ~0.15 ms of kernels
+ * per rank at eight ranks.  With frog_comm_mode(ctx, 1) the middle one disappears:
+ *   - the energy sums and the list flag ride on the all-reduce of the proposal sums: FROG_BUF_GRIDSUM grows by four doubles,
+ *     phase A leaves the rank's sums there, phase B takes the group's back;
+ *   - the oversize count (known only after phase B) rides on the NEXT coordinate gather: the transform that follows the step
+ *     is queued at once, from the proposal lattice unless the rank's OWN count forbids it, straight into the rank's slot of
+ *     the slab the gather moves (frog_transform_points_slab, after_step = 1), with the rank's four scalars as the slot's
+ *     trailer; frog_comm_unpack_slab_step copies every slot's rows into FROG_BUF_XYZ2, adds the trailers up and hands the
+ *     step's scalars to the host; frog_step_finish waits for them, decides (imageGroup.cxx:434-439) and commits.  A rejected
+ *     step leaves speculative coordinates in the table, which is harmless: run()'s reject path re-bases from the standing
+ *     coefficients and gathers again before anything reads them (imageGroup.cxx:97-115).
+ * A linear iteration's two sums travel the same way (sum_mask 0b1011): one collective instead of two.
+ *
+ * Slab layout: world_size slots of FROG_SLAB_SLOT_BYTES(slot_rows) bytes, slot r = rank r's rows (12 bytes each, slot_rows >=
+ * the longest shard) padded to a multiple of 64 bytes, then a trailer of FROG_SLAB_TRAILER_BYTES whose first four doubles are
+ * the rank's (sum w2 d2, sum w2, oversize count, list flag).  ONE equal-size all-gather of slot bytes moves it
+ * (ncclAllGather in place: include/frog_comm.h frog_comm_all_gather_slab). */
+#define FROG_SLAB_TRAILER_BYTES 64
+#define FROG_SLAB_SLOT_BYTES(slot_rows) (((size_t)(slot_rows) * 12 + 63) / 64 * 64 + FROG_SLAB_TRAILER_BYTES)
+int frog_comm_mode(frog_ctx *ctx, int two_collectives);
+/* transformPoints of the owned images into slot `self` of `slab` (not into FROG_BUF_XYZ2: frog_comm_unpack_slab_step puts every
+ * slot there after the gather).  after_step = 1: the transform that follows frog_deformable_phase_b, see above. */
+int frog_transform_points_slab(frog_ctx *ctx, int apply, int after_step, void *slab, uint64_t slot_rows, uint32_t self);
+/* Every slot's rows -> FROG_BUF_XYZ2 (one launch).  sum_mask: bit k set = scalar k of FROG_BUF_ENERGY becomes the sum of the
+ * ranks' trailers (0b0100 after a deformable step: the oversize count; 0b1011 after a linear step: energy sums and list flag);
+ * sum_mask != 0 also hands the four scalars to the host: call frog_step_finish next.  0: coordinates only. */
+int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_rows, uint32_t world_size,
+                               const uint64_t *row_begin, uint32_t self, uint32_t sum_mask);
+/* Waits for the scalars.  After a deformable step: *E as frog_deformable_phase_c (-1 = rejected, nothing committed),
+ * the proposal committed otherwise; after a linear step: *E. */
+int frog_step_finish(frog_ctx *ctx, double *E);
 
 /* updateStats, owned images only; afterwards all-reduce(sum) FROG_BUF_EM
  * (non-owned rows are zero) and call frog_stats_publish. */

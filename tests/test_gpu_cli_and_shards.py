@@ -558,7 +558,10 @@ def test_bench_native_host_three_ranks_over_shared_memory_matches_one_rank(tmp_p
     assert three["n_gpus"] == 3 and three["replicas_identical"] is True
     assert three["config"]["grids_per_level"] == one["config"]["grids_per_level"]
     assert abs(three["config"]["final_E"] - one["config"]["final_E"]) <= 1e-6 * one["config"]["final_E"]
-    assert set(three["comm_ms"]) == {"all_gather_xyz2", "all_reduce_em", "all_reduce_energy", "all_reduce_gridsum"}
+    # two collectives per deformable iteration, one per linear one (round 5): the all-reduce of the energy sums and the oversize
+    # count is gone from the loop -- they ride on the proposal sums' all-reduce and on the coordinate gather
+    assert set(three["comm_ms"]) == {"all_gather_xyz2", "all_reduce_em", "all_reduce_gridsum"}
+    assert three["collectives_per_iteration"] < 2.6        # 26 steps: 2 + 3 x 8, three refreshes, four set-ups
     assert len(three["ranks"]["elapsed_s"]) == 3
 
 

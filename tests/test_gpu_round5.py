@@ -105,3 +105,61 @@ def test_f32_transform_against_the_f64_form(monkeypatch):
             pointwise32 = b
         else:
             assert np.array_equal(b, pointwise32), "f32: tiled form differs from thread-per-point form"
+
+
+# ---- two collectives per deformable iteration (include/frog_hip.h frog_comm_mode) ------------------------------------------
+
+def _frog(cwd, *flags, env_extra=None):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("FROG_THREE_COLLECTIVES", None)
+    env.update(env_extra or {})
+    r = subprocess.run([os.path.join(os.path.dirname(HERE), "bin", "frog"), "pairs.bin", "-li", "12", "-dl", "2", "-di", "10", "-j", "-q", "1", *flags],
+                       cwd=cwd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _same_files(a, b, n_images):
+    """measures.csv and every transforms/<i>.json: the same text."""
+    assert open(a / "measures.csv").read() == open(b / "measures.csv").read()
+    for i in range(n_images):
+        assert open(a / "transforms" / f"{i}.json").read() == open(b / "transforms" / f"{i}.json").read(), i
+
+
+@pytest.mark.parametrize("ranks", [3, 8])
+def test_two_collectives_give_the_files_of_three(tmp_path, ranks):
+    """bin/frog -ngl N (the C++ multi-GPU host, ranks sharing the one GPU, host-staged transport): the flow of round 5 -- energy
+    sums on the proposal sums' all-reduce, oversize count in the trailers of the coordinate gather, the transform behind a
+    step queued speculatively -- against the flow of rounds 2-4 (FROG_THREE_COLLECTIVES=1).  The arithmetic is the same and
+    the ranks' scalars are added in rank order either way: identical files."""
+    pairs = Pairs.synthetic(20, 2000, 700, seed=21)
+    two, three = tmp_path / "two", tmp_path / "three"
+    for d in (two, three):
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+    _frog(two, "-ngl", str(ranks))
+    _frog(three, "-ngl", str(ranks), env_extra={"FROG_THREE_COLLECTIVES": "1"})
+    _same_files(two, three, pairs.n_images)
+
+
+def test_two_collectives_with_rejected_steps(tmp_path):
+    """The guard's rejection under the speculative flow: with -gm 0.004 (a coefficient may reach 0.4 mm on the coarsest lattice)
+    steps ARE rejected -- by then every rank has transformed from the proposal and the replicas hold coordinates of a step that
+    did not happen; run()'s reject path (imageGroup.cxx:97-115) re-bases from the standing coefficients, makes a new lattice
+    and gathers again.  Three ranks: same files as the three-collective flow, same lattices / energies / coefficients as ONE
+    context (sums over ranks associate differently: 1e-6)."""
+    from test_gpu_cli_and_shards import _compare_runs
+    pairs = Pairs.synthetic(9, 3000, 1200, seed=4)
+    one, two, three = tmp_path / "one", tmp_path / "two", tmp_path / "three"
+    for d in (one, two, three):
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+    flags = ("-gm", "0.004")
+    out1 = _frog(one, *flags)
+    out2 = _frog(two, "-ngl", "3", *flags)
+    _frog(three, "-ngl", "3", *flags, env_extra={"FROG_THREE_COLLECTIVES": "1"})
+    n_rejected = out2.count("Iteration canceled")
+    assert n_rejected >= 2 and n_rejected == out1.count("Iteration canceled"), (n_rejected, out1.count("Iteration canceled"))
+    _same_files(two, three, pairs.n_images)
+    _compare_runs(one, two, pairs.n_images)
