@@ -23,10 +23,11 @@ from frog_amd import _abi
 from frog_amd.image_group import ImageGroup
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup
-from lattice_util import RIM_REL, lattice_deviation, node_weights, lattice_taps, face_crossing_nodes
+from lattice_util import lattice_deviation, node_weights, lattice_taps, face_crossing_nodes
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
+RAW_REL = 1e-3      # raw coefficients, product path vs reference-order mode, levels 0-3 at benchmark sizes: measured <= 2.7e-4 (a ten-fold regression fails)
 
 
 def note(name, value):
@@ -328,7 +329,7 @@ def test_fast_path_against_reference_order_small_group(monkeypatch):
     r = fast_against_reference_order(pairs, 50, 3, 40, monkeypatch, range(6))
     report("fast_vs_reference_order_small", r)
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RAW_REL, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5
 
 
@@ -357,7 +358,7 @@ def test_fast_path_against_reference_order_config3(monkeypatch):
     report("fast_vs_reference_order_cfg3", r)
     for k, d in enumerate(r["lattices"]):
         # measured: field 5.3e-6, dense 5.4e-6, weighted 3.7e-6, raw 2.7e-4 (level 2: 7 100 of 18 216 nodes on the rim)
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RAW_REL, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5      # measured 6.2e-8, 2.0e-7, 1.3e-7
 
 
@@ -373,7 +374,7 @@ def test_fast_path_against_reference_order_config5_full_size(monkeypatch):
     report("fast_vs_reference_order_cfg5", r)
     assert len(r["grids"]) == 5
     for k, d in enumerate(r["lattices"]):
-        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RIM_REL, (k, d)
+        assert d["field"] <= REL and d["dense_field"] <= REL and d["weighted"] <= REL and d["raw"] <= RAW_REL, (k, d)
     assert r["E"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= 1e-5
 
 

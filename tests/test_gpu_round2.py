@@ -181,7 +181,7 @@ def test_parity_sweep(case):
         (tests/lattice_util.py): |c - c_ref| w <= 1e-4 max|c_ref|, w = min(1, smallest non-zero support over the images);
       * the displacement field of every lattice evaluated at EVERY point of its image: <= 1e-4 of the largest displacement;
       * the final coordinates.
-    and every coefficient, unweighted, within 1e-3 (lattice_util.RIM_REL)."""
+    and every coefficient, unweighted, within 3e-3 (lattice_util.RIM_REL)."""
     cfg, opt = SWEEP[case]
     pairs = Pairs.synthetic(cfg["n"], cfg["pts"], cfg["ppb"], seed=cfg["seed"])
     g = ImageGroup(pairs, **opt)

@@ -71,7 +71,7 @@ def run_schedule(pairs, monkeypatch, f64, li=6, dl=3, di=8, forms=(None,)):
 def test_f32_transform_against_the_f64_form(monkeypatch):
     """The product path's B-spline transform forms its weights and its 64-tap sums in f32 since round 5 (k_grid.hip.h
     bspline_axis; the lattice coordinate itself stays f64).  Against the f64 form of rounds 1-4 (FROG_K11_F64=1) over a
-    free-running 6 + 3 x 8 schedule: ONE transform differs by at most one f32 ulp of a coordinate (asserted on the first
+    free-running 6 + 3 x 8 schedule: ONE transform differs by at most one f32 ulp of a coordinate (4e-7 of the largest displacement for coordinates near 0; asserted on the first
     deformable transform, where both runs still have identical inputs); the whole schedule's energies agree to 1e-6 and the
     final coordinates to 1e-6 of their size.  Both forms of the kernel (one wavefront per brick / thread per point) give
     identical bits in f32 too."""
@@ -97,10 +97,14 @@ def test_f32_transform_against_the_f64_form(monkeypatch):
             assert g.updateDeformableTransforms(0.02) >= 0
             g.transformPoints()
             outs.append(g.points()[1].copy())
+            disp_max = float(np.max(np.abs(g.points()[1].astype(np.float64) - g.points()[0])))
             monkeypatch.delenv(form)
         a, b = outs[0], outs[1]
-        ulp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
-        assert np.all(np.abs(a - b) <= ulp), form
+        # one f32 ulp of the coordinate, or -- for the few coordinates near 0, whose ulp is smaller than any displacement's
+        # rounding -- the f32 sum's own error: 64 products of weights good to 6e-8, i.e. < 4e-7 of the largest displacement
+        tol = np.maximum(np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)), np.float32(4e-7 * disp_max))
+        worst = np.unravel_index(np.argmax(np.abs(a - b) / tol), a.shape)
+        assert np.all(np.abs(a - b) <= tol), (form, worst, float(a[worst]), float(b[worst]), float(np.max(np.abs(a - b) / tol)), disp_max)
         if form == "FROG_K11_POINTWISE":
             pointwise32 = b
         else:
