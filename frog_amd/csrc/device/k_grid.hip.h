@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256) void gather_positions_kernel(const float4 *pos
 #endif
 constexpr int SCATTER_CHUNK = FROG_SCATTER_CHUNK;
 
+
 struct ScatterBlock {
     uint32_t key;           // image_local * n_bricks + brick
     uint32_t begin, end;    // range in perm
@@ -647,8 +648,9 @@ __global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr,
     if (k < n_bricks_total) {
         const uint32_t b = ptr[(size_t)k * keys_per_brick], e = ptr[(size_t)(k + 1) * keys_per_brick];
         uint32_t slot = slot_ptr[k];
-        for (uint32_t b0 = b; b0 < e; b0 += SCATTER_CHUNK, slot++) {
-            const uint32_t e0 = min(b0 + (uint32_t)SCATTER_CHUNK, e);
+        const uint32_t step = SCATTER_CHUNK;
+        for (uint32_t b0 = b; b0 < e; b0 += step, slot++) {
+            const uint32_t e0 = min(b0 + step, e);
             blocks[slot] = ScatterBlock{ k, b0, e0, slot };
             if (e0 - b0 == (uint32_t)SCATTER_CHUNK) full++; else atomicAdd(&len_hist[e0 - b0], 1u);
         }
@@ -873,6 +875,10 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
 __device__ unsigned long long g_scatter_trace[4 * 65536];
 #endif
 constexpr int BRICK_CP_MAX = 11;            // brick 8 -> 11^3 control points
+#ifndef FROG_SCATTER_FMA
+#define FROG_SCATTER_FMA 1         // round 5: 0.0698 -> 0.0670 ms per launch (cfg 3), one rounding per tap as in the reference
+#endif
+
 
 // The energy reduction that rides on the scatter's launch (see scatter_kernel).
 struct ScatterEnergy {
@@ -926,15 +932,53 @@ __device__ __forceinline__ void scatter_energy_block(const ScatterEnergy &en, co
 // instruction serves 64 points; in phase 2 an instruction serves ONE point, and that loop is where a block spends its time
 // (per-block trace, -DFROG_SCATTER_TRACE + scripts/microbench/scatter_trace_an.py: 63 % of a block's 52 us before this
 // layout, with the three weights read separately and multiplied per point).
+#ifndef FROG_SCATTER_QUADS
+#define FROG_SCATTER_QUADS 1       // phase 2 reads the weights of FOUR points per LDS instruction (see there); 0: point by point (rounds 2-4)
+#endif
 constexpr int SC_AHEAD = 3, SC_RING = 4;        // phase 2 fetches a point's values SC_AHEAD points before it uses them
+#if FROG_SCATTER_QUADS
+constexpr int SC_PTS = 64 + 4;                  // ... a group of four ahead, unconditionally: one group past the batch is read (unused)
+#else
 constexpr int SC_PTS = 64 + SC_AHEAD;           // ... unconditionally, so up to SC_AHEAD entries past the batch are read (unused)
+#endif
+#ifndef FROG_SCATTER_WXY
+#define FROG_SCATTER_WXY 0         // 1: the 16 products wx wy formed in phase 1 and handed over (rounds 2-4); 0: the 12 weights, multiplied in phase 2
+#endif
 struct ScatterScratch {
+#if FROG_SCATTER_WXY
     float wxy[16][SC_PTS];      // wx[i] * wy[j] at [4 j + i]: f32 products of the f32-rounded weights (imageGroup.cxx:322, left to right)
+#else
+    // Round 5: the twelve weights as they are -- 68 instead of 100 bytes per point, 4.6 instead of 6.7 KB per block, which with the
+    // 5.5 KB tile is what decides how many one-wavefront blocks a CU holds: 16 (the register file's limit) instead of 12.  The
+    // per-block trace (scripts/microbench/scatter_trace_an.py) shows the launch as rounds of resident blocks -- 5 527 blocks of
+    // 23 us in 1.8 rounds of 3 072 on level 0 -- and phase 2 is not bound by its instruction count (a branch-free form for runs of
+    // one cell issued half the instructions per point and was no faster), so one more read and one more multiplication per
+    // point (wx wy, the same f32 product phase 1 used to form) cost less than the fourth block per SIMD gains.
+    float wx[4][SC_PTS], wy[4][SC_PTS];
+#endif
     float wz[4][SC_PTS];
     float4 sm[SC_PTS];          // sDisp xyz, sWeight
     int base[SC_PTS];           // tile offset of tap (0,0,0)
 };
 static_assert(offsetof(ScatterScratch, sm) % 16 == 0, "ScatterScratch::sm is read with ds_read_b128");
+
+// run += w * (the four values `s` holds in lane (t & ~3) + P): four v_fmac_f32 with quad_perm [P, P, P, P] on their first source -- the
+// broadcast inside the quad is a modifier of the multiply-add, not an instruction.  Written out because the compiler, given a builtin
+// DPP move and four multiply-adds, forms two v_pk_fma_f32 (which cannot take the modifier) behind four v_mov_b32_dpp: six
+// instructions for four.  ONE asm statement per point, led by s_nop 1: a DPP source written by a vector instruction needs two wait
+// states before it is read, the compiler's hazard recogniser cannot see inside an asm statement, and nothing can be scheduled
+// into the middle of one.
+#define FROG_FMAC_DPP(D, S, Q) "v_fmac_f32_dpp %" #D ", %" #S ", %8 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf\n\t"
+#define FROG_FMAC4_DPP(Q) asm("s_nop 1\n\t" FROG_FMAC_DPP(0, 4, Q) FROG_FMAC_DPP(1, 5, Q) FROG_FMAC_DPP(2, 6, Q) FROG_FMAC_DPP(3, 7, Q)      \
+                              : "+v"(run.x), "+v"(run.y), "+v"(run.z), "+v"(run.w) : "v"(s.x), "v"(s.y), "v"(s.z), "v"(s.w), "v"(w))
+template <int P> __device__ __forceinline__ void fmac4_quad_bcast(float4 &run, const float4 s, float w)
+{
+    static_assert(P >= 0 && P < 4, "quad lane");
+    if constexpr (P == 0) FROG_FMAC4_DPP(0);
+    if constexpr (P == 1) FROG_FMAC4_DPP(1);
+    if constexpr (P == 2) FROG_FMAC4_DPP(2);
+    if constexpr (P == 3) FROG_FMAC4_DPP(3);
+}
 
 __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const float4 *point_sums,
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
@@ -1019,7 +1063,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
 #endif
         // ---- phase 1: lane = point.  Cell, the 12 cubic weights in f64 as the reference computes them
         // (imageGroup.cxx:303-310), rounded once to f32, the 16 products wx wy, the tile offset of the first tap.
-        float wxy[16], wz[4];
+        float wxy[16], wz[4], wx4[4], wy4[4];
         float4 sm = part_cur[0];
         int base = -1;
         if (batch + lane < blk.end) {
@@ -1046,7 +1090,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
                     #pragma unroll
                     for (int i = 0; i < 4; i++) wxy[4 * j + i] = w12[i] * w12[4 + j];
                 #pragma unroll
-                for (int k = 0; k < 4; k++) wz[k] = w12[8 + k];
+                for (int k = 0; k < 4; k++) { wz[k] = w12[8 + k]; wx4[k] = w12[k]; wy4[k] = w12[4 + k]; }
                 const int lx = ic[0] - 1 - cp0[0], ly = ic[1] - 1 - cp0[1], lz = ic[2] - 1 - cp0[2];
                 if (lx >= 0 && ly >= 0 && lz >= 0 && lx + 3 < E && ly + 3 < E && lz + 3 < E) {
                     base = lx + E * (ly + E * lz);
@@ -1071,8 +1115,13 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
         const int n_live = __popcll(live);
         if (base >= 0) {
             const int slot = __popcll(live & ((1ull << lane) - 1ull));
+#if FROG_SCATTER_WXY
             #pragma unroll
             for (int k = 0; k < 16; k++) sc.wxy[k][slot] = wxy[k];
+#else
+            #pragma unroll
+            for (int k = 0; k < 4; k++) { sc.wx[k][slot] = wx4[k]; sc.wy[k][slot] = wy4[k]; }
+#endif
             #pragma unroll
             for (int k = 0; k < 4; k++) sc.wz[k][slot] = wz[k];
             sc.sm[slot] = sm;
@@ -1095,14 +1144,66 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
             const int before = lane == 0 ? run_base : (lane < n_live ? sc.base[lane - 1] : -1);
             chg = __ballot(lane < n_live && mine != before);
         }
+#if FROG_SCATTER_QUADS && !FROG_SCATTER_WXY
+        // Round 5.  The launch is bound by the LDS: point by point a tap's three weights are three ds_read_b32 (2 LDS cycles
+        // each for the wavefront, however many lanes share an address) and the sums a broadcast ds_read_b128 (4): 10 cycles per
+        // point and CU, 7 800 points per CU -> 33 us of a 64 us launch (level 0; on level 2 the tile's read-add-write at nearly
+        // every point adds 17 more).  A ds_read_b128 costs 4 cycles and brings the weights of FOUR consecutive points
+        // (the scratch is point-minor), and the four points' sums arrive with ONE more: lane t reads the sums of point q0 + (t & 3)
+        // and the quad hands them round by DPP, a modifier of the multiply-add (fmac4_quad_bcast), not an instruction: 16 cycles per four points.
+        // Same operations on the same values in the same order as point by point: identical bits.
+        {
+            const f32x4 *gwx = reinterpret_cast<const f32x4 *>(sc.wx[lane & 3]), *gwy = reinterpret_cast<const f32x4 *>(sc.wy[(lane >> 2) & 3]),
+                        *gwz = reinterpret_cast<const f32x4 *>(sc.wz[lane >> 4]);
+            const float4 *gsm = sc.sm + (lane & 3);
+            f32x4 cwx = gwx[0], cwy = gwy[0], cwz = gwz[0];
+            float4 csm4 = gsm[0];
+            auto spill_and_restart = [&](int q) __attribute__((always_inline)) {
+                if (run_base >= 0) {
+                    float4 t = tile[run_base + tap_off];
+                    t.x += run.x; t.y += run.y; t.z += run.z; t.w += run.w;
+                    tile[run_base + tap_off] = t;
+                }
+                run = make_float4(0.f, 0.f, 0.f, 0.f);
+                run_base = __builtin_amdgcn_readfirstlane(sc.base[q]);
+            };
+            for (int q0 = 0; q0 < n_live; q0 += 4) {
+                const int g1 = (q0 >> 2) + 1;
+                const f32x4 nwx = gwx[g1], nwy = gwy[g1], nwz = gwz[g1];       // the next group's, one trip ahead (unconditional)
+                const float4 nsm = gsm[4 * g1];
+                const f32x4 w4 = (cwx * cwy) * cwz;                              // (wx wy) wz, imageGroup.cxx:322 left to right
+                const unsigned m = (unsigned)(chg >> q0) & 15u;
+                const int left = n_live - q0;                                    // >= 1
+#define FROG_SCATTER_ADD(P)                                                                                            \
+                if (P < left) {                                                                                         \
+                    if (m >> P & 1u) spill_and_restart(q0 + P);                                                         \
+                    fmac4_quad_bcast<P>(run, csm4, w4[P]);                                                              \
+                }
+                FROG_SCATTER_ADD(0) FROG_SCATTER_ADD(1) FROG_SCATTER_ADD(2) FROG_SCATTER_ADD(3)
+#undef FROG_SCATTER_ADD
+                cwx = nwx; cwy = nwy; cwz = nwz; csm4 = nsm;
+            }
+        }
+#else
         float rwxy[SC_RING], rwz[SC_RING];
         float4 rsm[SC_RING];
+#if FROG_SCATTER_WXY
         const float *lane_wxy = sc.wxy[lane & 15], *lane_wz = sc.wz[lane >> 4];
         auto fetch = [&](int q, int slot) __attribute__((always_inline)) {
             rwxy[slot] = lane_wxy[q];
             rwz[slot] = lane_wz[q];
             rsm[slot] = sc.sm[q];
         };
+#else
+        float rwy[SC_RING];
+        const float *lane_wx = sc.wx[lane & 3], *lane_wy = sc.wy[(lane >> 2) & 3], *lane_wz = sc.wz[lane >> 4];
+        auto fetch = [&](int q, int slot) __attribute__((always_inline)) {
+            rwxy[slot] = lane_wx[q];
+            rwy[slot] = lane_wy[q];
+            rwz[slot] = lane_wz[q];
+            rsm[slot] = sc.sm[q];
+        };
+#endif
         auto add_point = [&](int q, int slot) __attribute__((always_inline)) {
             if ((chg >> q) & 1ull) {                               // wave-uniform: cell changed -> spill the run
                 if (run_base >= 0) {
@@ -1113,9 +1214,19 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
                 run = make_float4(0.f, 0.f, 0.f, 0.f);
                 run_base = __builtin_amdgcn_readfirstlane(sc.base[q]);
             }
+#if FROG_SCATTER_WXY
             const float w = rwxy[slot] * rwz[slot];
+#else
+            const float w = (rwxy[slot] * rwy[slot]) * rwz[slot];          // (wx wy) wz, imageGroup.cxx:322 left to right
+#endif
             const float4 csm = rsm[slot];
+#if FROG_SCATTER_FMA
+            // g += w s with ONE rounding: what imageGroup.cxx:330-337 computes ((float)((double) g + w * s): the product of two
+            // f32 values is exact in f64), and two v_pk_fma_f32 instead of two v_pk_mul_f32 + two v_pk_add_f32
+            run.x = fmaf(w, csm.x, run.x); run.y = fmaf(w, csm.y, run.y); run.z = fmaf(w, csm.z, run.z); run.w = fmaf(w, csm.w, run.w);
+#else
             run.x += w * csm.x; run.y += w * csm.y; run.z += w * csm.z; run.w += w * csm.w;
+#endif
         };
         #pragma unroll
         for (int j = 0; j < SC_AHEAD; j++) fetch(j, j);
@@ -1130,6 +1241,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
         #pragma unroll
         for (int j = 0; j < SC_RING - 1; j++)                       // the last n_live % 4 points: fetched by the last full trip
             if (n_full + j < n_live) add_point(n_full + j, j);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #ifdef FROG_SCATTER_TRACE
