@@ -374,6 +374,12 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     b, e = shards[rank]
     _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(opts), local_rank, b, e, C.byref(ctx)), "frog_create")
     t_create = time.perf_counter() - t0
+    cs, nsel = (C.c_double * 3)(), C.c_int()
+    _abi.check(lib.frog_create_seconds(ctx, cs, C.byref(nsel)), "frog_create_seconds")
+    create_breakdown = {"layout_build_host": round(cs[0], 4), "allocate_upload": round(cs[1], 4), "selection_replay": round(cs[2], 4),
+                        "selections_replayed": int(nsel.value),
+                        "note": "frog_create: host-side layout build (all cores) / device allocations + uploads / reservoir selections "
+                                "of the whole run replayed ahead on the side stream (one block per image: latency-bound, off the timed region)"}
     cl, comm = None, None
     if world > 1:
         cl, comm = create_native_comm(rdv, transport, ctx, shards, pairs.point_offset, local_rank)
@@ -434,7 +440,8 @@ def run_native(args, rank, world, local_rank, transport, rdv):
         collectives = "none" if world == 1 else {"rccl": "libfrog_comm (RCCL from C)", "shm": "libfrog_comm (host-staged shared memory)"}[transport]
         line = make_line(args, world, k, elapsed, "native (frog_run_schedule, C loop)", collectives, pairs, levels, n_lin, per_level,
                          [int(g) for g in res.grids_per_level[:levels]], res.final_E, roofline, iteration, prof, phase_k, phase_s,
-                         {"generate": t_gen, "create": t_create, "lattice_setups": [la.setup_host_s for la in res.lattices[:res.n_lattices]]})
+                         {"generate": t_gen, "create": t_create, "create_breakdown": create_breakdown,
+                          "lattice_setups": [la.setup_host_s for la in res.lattices[:res.n_lattices]]})
         if args.shard_of:
             line["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
                              + ("other ranks' coordinates and mixtures: those a full run of the default schedule ends with, standing still"
@@ -454,13 +461,55 @@ def run_native(args, rank, world, local_rank, transport, rdv):
                                      "(all groups with --kernel-times, else the half-link sweeps), estimated device time of the collectives"}
         if world == 1 and not args.no_cpu_baseline and args.config == 3 and not args.shard_of:
             line["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, 10)
+    # (with the CPU baseline, i.e. on the full default line: the A/B scripts pass --no-cpu-baseline and get neither)
+    end_to_end_pending = (world == 1 and rank == 0 and line is not None and not args.shard_of and not args.no_end_to_end
+                          and (args.end_to_end or (not args.no_cpu_baseline and args.config == 3)))
     if comm:
         if world > 1:
             rdv.gather_json("done", {"rank": rank})          # nobody tears its communicator down while another still reduces
         arr = (C.c_void_p * 1)(comm)
         cl.frog_comm_destroy_all(1, arr)
     lib.frog_destroy(ctx)
+    if end_to_end_pending:
+        line["end_to_end"] = end_to_end(pairs, levels)
     return line, (world == 1 or len({x["hash"] for x in everyone}) == 1)
+
+
+def end_to_end(pairs, levels):
+    """`bin/frog pairs.bin` as a user runs it, wall clock of the whole process: read pairs.bin, frog_create, the reference's default
+    schedule (-li 50 -di 200; -dl as the configuration), write transforms/ + the csv / json reports.  After the timed region, in a
+    child process, with the context above already destroyed.  pairs.bin goes to a temporary directory (memory-backed when
+    /dev/shm exists: the file's 0.4 GB are then read at memory speed -- a disk would add its own time)."""
+    import re, shutil, subprocess, tempfile
+    exe = os.path.join(ROOT, "bin", "frog")
+    if not os.path.exists(exe):
+        return {"error": "bin/frog not built"}
+    d = tempfile.mkdtemp(prefix="frog_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.perf_counter()
+        pairs.write(os.path.join(d, "pairs.bin"))
+        t_write = time.perf_counter() - t0
+        size = os.path.getsize(os.path.join(d, "pairs.bin"))
+        cmd = [exe, "pairs.bin", "-q", "1", "-dl", str(levels)]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": f"bin/frog exited {r.returncode}", "stderr": r.stderr[-500:]}
+        out = {"command": "bin/frog pairs.bin -q 1 -dl %d" % levels, "wall_s": round(wall, 3), "pairs_bin_bytes": size,
+               "pairs_bin_written_in_s": round(t_write, 3)}
+        m = re.search(r"Iteration loops : (\d+) iterations in ([0-9.eE+-]+)s", r.stdout)
+        if m:
+            out["iterations"] = int(m.group(1)); out["loops_s"] = float(m.group(2))
+            out["iterations_per_s_of_the_whole_process"] = round(int(m.group(1)) / wall, 1)
+        m = re.search(r"Total time : ([0-9.eE+-]+)s", r.stdout)
+        if m:
+            out["total_time_printed_s"] = float(m.group(1))
+        out["note"] = ("whole process, default schedule: reading pairs.bin, frog_create (layout build, upload, selection replay), the "
+                       "iteration loops, error maps, transforms/ and reports; `value` above is the loops alone (SURVEY 8d)")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 # ---- preflight: RCCL known answers and latencies on the library's own buffers ---------------------------------------------
@@ -835,6 +884,8 @@ def main():
                          "partners -- partner points lie where the own points are, the sweeps' gathers are local) or stay "
                          "where the set-up left them (static: unregistered partners, mixtures of other images zero)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the bin/frog whole-process run after the timed region (N = 1)")
+    ap.add_argument("--end-to-end", action="store_true", help="run it even with --no-cpu-baseline / another --config")
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
     ap.add_argument("--child", choices=("preflight", "native", "torch"), default=None, help=argparse.SUPPRESS)

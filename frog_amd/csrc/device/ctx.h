@@ -323,6 +323,8 @@ struct frog_ctx {
     // FROG_REFERENCE_ORDER=1 (test hook, k_reforder.hip.h): every solver loop in the reference's own order and arithmetic --
     // no culling list, no fast weight, no re-associated sum; results are bit-comparable with the tests' CPU restatement of the reference
     bool ref_order = false;
+    double create_s[3] = { 0, 0, 0 };   // frog_create: host layout build, allocations + uploads + first kernels, reservoir selections replayed ahead
+    int create_selections = 0;
     bool two_collectives = false;   // frog_comm_mode: the energy sums ride on the all-reduce of the proposal sums, the oversize count on the coordinate gather
     double pending_seq = 0.0;       // sequence number of the scalars frog_comm_unpack_slab_step published and frog_step_finish has not read yet
     bool k11_f64 = false;           // FROG_K11_F64=1: the B-spline transform's weights and sums in f64 (rounds 1-4), for comparison

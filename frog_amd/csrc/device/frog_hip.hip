@@ -577,8 +577,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     c->n_sub = 1;
     if (const char *e = getenv("FROG_SUBPASSES")) c->n_sub = (uint32_t)std::min(MAX_SUBPASS, std::max(1, atoi(e)));
     c->n_groups = N_XCD * c->n_sub;
+    const auto t_create0 = std::chrono::steady_clock::now();
     int rc = build_layout(*m, c->ib, c->ie, wide_env && wide_env[0] == '1', (int)c->n_groups, lay, err);
     if (rc) { delete c; return fail(rc, err); }
+    const auto t_layout = std::chrono::steady_clock::now();
+    c->create_s[0] = std::chrono::duration<double>(t_layout - t_create0).count();
     c->L_own = lay.ref_link.size();
     c->rec_format = lay.format;
     for (uint32_t g = 0; lay.format.narrow && g < c->n_groups; g++)
@@ -890,13 +893,27 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     }
     scratch_warm_kernel<<<1, 64, 0, s>>>(c->stray.p, 0);
     (void)hipGetLastError();
+    (void)hipStreamSynchronize(s);
+    const auto t_resident = std::chrono::steady_clock::now();
+    c->create_s[1] = std::chrono::duration<double>(t_resident - t_layout).count();
     // selections of the first sel_ring - 1 refreshes, ahead of time -- and awaited: a context leaves frog_create with an idle
     // side stream (80 replays are 0.12 s of one-block-per-image work that would otherwise run beside the first iterations)
     for (int k = 0; k + 1 < c->sel_ring; k++)
         if (int rc_ = produce_selection(c)) { frog_destroy(c); return rc_; }
     if (hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
+    c->create_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_resident).count();
+    c->create_selections = c->sel_ring > 0 ? c->sel_ring - 1 : 0;
 #undef CREATE_CHECK
     *out = c;
+    return FROG_OK;
+}
+
+int frog_create_seconds(frog_ctx *ctx, double seconds3[3], int *selections_replayed)
+{
+    CTX_GUARD(ctx);
+    if (!seconds3) return fail(FROG_E_INVALID, "null output");
+    for (int k = 0; k < 3; k++) seconds3[k] = ctx->create_s[k];
+    if (selections_replayed) *selections_replayed = ctx->create_selections;
     return FROG_OK;
 }
 

@@ -56,6 +56,12 @@ void frog_destroy(frog_ctx *ctx);
  * the stream a host framework issues its collectives against.  Default: a
  * stream created by frog_create. */
 int frog_set_stream(frog_ctx *ctx, void *hip_stream);
+/* Where frog_create's time went, in seconds: [0] the host-side layout build (Morton numbering, partner-major 4-byte records,
+ * tiles: all host cores), [1] device allocations, uploads and the first kernels until the model is resident, [2] the reservoir
+ * selections replayed ahead of time on the side stream (selections_replayed of them: Stats::addSample's mt19937 acceptance tests
+ * depend on nothing but the call count, stats.h:58-76, so a whole run's are produced here instead of beside the sweeps). */
+int frog_create_seconds(frog_ctx *ctx, double seconds3[3], int *selections_replayed);
+
 /* The stream the context's work is enqueued on and its device: what a caller needs to order its own collectives
  * (RCCL: include/frog_comm.h) against the library's kernels.  Either pointer may be NULL. */
 int frog_get_stream(frog_ctx *ctx, void **hip_stream, int *device);
