@@ -244,6 +244,7 @@ HIP_SYMBOLS = {
     "frog_transform_points_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32]),
     "frog_comm_unpack_slab_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]),
     "frog_step_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "frog_step_speculate": (C.c_int, [C.c_void_p]),
     "frog_cull_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_cull_stats_linear": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_stray_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -286,7 +286,8 @@ struct frog_ctx {
     frog::DevBuf<float4> coeff;               // [nOwned][G]
     frog::DevBuf<float4> grad;                // [nOwned][G] proposed coefficients (xyz), gradient weight (w)
     frog::DevBuf<float4> gradf;               // [nOwned][G] gradient lattice: sum w*sDisp xyz, sum w*sWeight
-    frog::DevBuf<double> gridsum;             // [3G]
+    frog::DevBuf<float4> grad_spare;          // a third lattice: the proposals of a step queued before the previous one's decision (frog_step_speculate)
+    frog::DevBuf<double> gridsum;             // [3G] (+ 4: frog_comm_mode)
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)
     frog::DevBuf<uint32_t> key_ptr;           // [nOwned*n_bricks*B^3 + 1] (image, brick, cell) -> perm range
     frog::DevBuf<uint32_t> key_cursor;
@@ -326,6 +327,9 @@ struct frog_ctx {
     double create_s[3] = { 0, 0, 0 };   // frog_create: host layout build, allocations + uploads + first kernels, reservoir selections replayed ahead
     int create_selections = 0;
     bool two_collectives = false;   // frog_comm_mode: the energy sums ride on the all-reduce of the proposal sums, the oversize count on the coordinate gather
+    bool finish_deformable = false; // ... and they decide a deformable step (frog_step_finish commits or rejects it)
+    bool speculated = false;        // frog_step_speculate has exchanged the lattices' roles ahead of the decision
+    bool spec_coeff_zero = false;
     double pending_seq = 0.0;       // sequence number of the scalars frog_comm_unpack_slab_step published and frog_step_finish has not read yet
     bool k11_f64 = false;           // FROG_K11_F64=1: the B-spline transform's weights and sums in f64 (rounds 1-4), for comparison
     frog::DevBuf<uint32_t> ref_own;           // [L_own] own point (internal numbering) of every half-link, reference order

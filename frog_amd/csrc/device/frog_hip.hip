@@ -1428,6 +1428,8 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    // a third lattice for contexts whose host queues the next step before this one's decision is known (frog_step_speculate)
+    if (ctx->two_collectives && !ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc((size_t)nO * G, (size_t)nO * G * reserve));
     FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G + 4, (3 * G + 4) * reserve));      // + 4: the energy sums' seat on the all-reduce (frog_comm_mode)
     FROG_HIP_CHECK(ctx->key_counts.alloc(n_keys, n_keys * reserve));
     FROG_HIP_CHECK(ctx->brick_ptr_scratch.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
@@ -2434,6 +2436,7 @@ int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_ro
         a.energy = ctx->energy.p; a.host_scalars = ctx->h_energy_dev;
         a.seq = (double)(++ctx->scalar_seq);
         ctx->pending_seq = a.seq;
+        ctx->finish_deformable = ctx->phase == 2;
     }
     const dim3 grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(div_up(longest, 256), 1), 1024), world_size);
     // the own rows' displacement against the culling list's snapshot: measured by the transform that wrote them into the slab
@@ -2451,6 +2454,27 @@ int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_ro
     return FROG_OK;
 }
 
+int frog_step_speculate(frog_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    if (ctx->pending_seq == 0.0 || !ctx->finish_deformable || ctx->phase != 2 || ctx->speculated)
+        return fail(FROG_E_STATE, "frog_step_speculate needs a deformable step whose scalars are on their way (frog_comm_unpack_slab_step)");
+    if (ctx->grad_spare.n != ctx->grad.n) {
+        // (frog_comm_mode was switched on after the lattice was made: the one allocation outside a set-up)
+        FROG_HIP_CHECK(ctx->grad_spare.alloc(ctx->grad.n, ctx->grad.cap));
+    }
+    // as if accepted (imageGroup.cxx:441-468): the proposal lattice becomes the coefficients, the spare one takes the next proposals;
+    // what is needed to undo it stays in spec_*
+    ctx->spec_coeff_zero = ctx->coeff_zero;
+    auto rotate = [](DevBuf<float4> &a, DevBuf<float4> &b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); std::swap(a.n, b.n); };
+    rotate(ctx->coeff, ctx->grad);              // coeff = proposal, grad = old coefficients
+    rotate(ctx->grad, ctx->grad_spare);         // grad = spare, spare = old coefficients
+    ctx->coeff_zero = false;
+    ctx->speculated = true;
+    ctx->phase = 0;
+    return FROG_OK;
+}
+
 int frog_step_finish(frog_ctx *ctx, double *E)
 {
     CTX_GUARD(ctx);
@@ -2460,16 +2484,27 @@ int frog_step_finish(frog_ctx *ctx, double *E)
     if (rc) return rc;
     if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // a rank's sweep found its culling list out of date
     const double e = std::sqrt(ctx->h_energy[0] / ctx->h_energy[1]), nbig = ctx->h_energy[2];
-    if (ctx->phase == 2) {
+    if (ctx->finish_deformable) {
         // updateDeformableTransforms' decision (imageGroup.cxx:434-439) and commit (:441-468), as frog_deformable_phase_c
+        ctx->finish_deformable = false;
         const bool rejected = ctx->opt.guarantee_diffeomorphism && nbig > 0;
-        if (!rejected) {
-            std::swap(ctx->coeff.p, ctx->grad.p);
-            std::swap(ctx->coeff.cap, ctx->grad.cap);
-            std::swap(ctx->coeff.n, ctx->grad.n);
-            ctx->coeff_zero = false;
+        auto rotate = [](DevBuf<float4> &a, DevBuf<float4> &b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); std::swap(a.n, b.n); };
+        if (ctx->speculated) {
+            ctx->speculated = false;
+            if (rejected) {
+                // undo frog_step_speculate: the lattices take their old roles; the phase A queued meanwhile worked on coordinates of
+                // a step that did not happen -- per-point sums, staged tiles, proposals in the spare lattice: nothing of it is read again
+                rotate(ctx->grad, ctx->grad_spare);
+                rotate(ctx->coeff, ctx->grad);
+                ctx->coeff_zero = ctx->spec_coeff_zero;
+                ctx->phase = 0;
+                ctx->xyz2_fresh = false; ctx->res_valid = false;
+            }
+        } else {
+            if (ctx->phase != 2) return fail(FROG_E_STATE, "frog_step_finish: no deformable step pending");
+            if (!rejected) { rotate(ctx->coeff, ctx->grad); ctx->coeff_zero = false; }
+            ctx->phase = 0;
         }
-        ctx->phase = 0;
         if (E) *E = rejected ? -1.0 : e;
         return FROG_OK;
     }

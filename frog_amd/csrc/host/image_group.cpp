@@ -194,7 +194,8 @@ void ImageGroup::runSharded()
         // two collectives per deformable iteration, one per linear iteration (include/frog_hip.h frog_comm_mode; rank_schedule.cpp
         // has the same flow); FROG_THREE_COLLECTIVES=1: the flow of rounds 2-4
         const bool two = !getenv("FROG_THREE_COLLECTIVES");
-        bool gathered = false;
+        const bool speculate = two && !getenv("FROG_NO_SPECULATION");      // the next step's phase A queued before this step's decision (frog_step_speculate)
+        bool gathered = false, phaseAQueued = false;
         ck(frog_comm_mode(c, two ? 1 : 0), "frog_comm_mode");
         auto transformPoints = [&](int apply) {
             if (two) {
@@ -289,15 +290,22 @@ void ImageGroup::runSharded()
                         cout << "Level " << level + 1 << "/" << deformableLevels << ", Iteration " << iteration + 1 << "/"
                              << deformableIterations << endl;
                     if (!(iteration % statIntervalUpdate)) updateStats();
-                    ck(frog_deformable_phase_a(c, alpha), "frog_deformable_phase_a");
+                    if (!phaseAQueued) ck(frog_deformable_phase_a(c, alpha), "frog_deformable_phase_a");
+                    phaseAQueued = false;
                     ck(g_comm.all_reduce(cm, FROG_BUF_GRIDSUM), "frog_comm_all_reduce");        // the shared common-space grid, :400-432
                     ck(frog_deformable_phase_b(c), "frog_deformable_phase_b");
                     double E = 0;
                     if (two) {
                         // the oversize count rides on the coordinate gather, the transform queued speculatively (frog_hip.h)
                         ck(g_comm.gather_points(cm, 0, 1, 0x4u), "frog_comm_gather_points");
+                        if (speculate && iteration + 1 < deformableIterations && (iteration + 1) % statIntervalUpdate != 0) {
+                            ck(frog_step_speculate(c), "frog_step_speculate");
+                            ck(frog_deformable_phase_a(c, alpha), "frog_deformable_phase_a");
+                            phaseAQueued = true;
+                        }
                         ck(frog_step_finish(c, &E), "frog_step_finish");
                         gathered = (float)E >= 0;
+                        if (!gathered) phaseAQueued = false;        // rejected: rolled back
                     } else {
                         ck(g_comm.all_reduce(cm, FROG_BUF_ENERGY), "frog_comm_all_reduce");         // energy sums + oversize count
                         ck(frog_deformable_phase_c(c, &E), "frog_deformable_phase_c");

@@ -28,6 +28,10 @@ struct Runner {
     // FROG_THREE_COLLECTIVES=1 keeps the flow of rounds 2-4 (three / two), for comparison.
     bool two = false;
     bool gathered = false;          // the step just finished has already transformed and gathered: the transformPoints() that follows it is done
+    // ... and the NEXT step's phase A is queued before this step's decision has reached the host (frog_step_speculate): the GPU
+    // does not wait for the host's read + launch latency once per iteration.  FROG_NO_SPECULATION=1 switches it off.
+    bool speculate = false;
+    bool phaseAQueued = false;      // the coming deformableStep finds its phase A already in the queue
     uint32_t ib = 0, ie = 0, nI = 0;
     int rc = 0;
 
@@ -94,12 +98,15 @@ struct Runner {
             for (int k = 0; k < 3; k++) la.dims[k] = info.dims[k];
         }
     }
-    double deformableStep(float alpha)
+    // next_plain: the iteration after this one, if this one is accepted, is an ordinary one (same level, no statistics refresh first)
+    double deformableStep(float alpha, bool next_plain)
     {
         double E = 0;
         if (rc) return E;
         if (whole) { ok(frog_deformable_step(c, alpha, &E)); return E; }
-        if (!ok(frog_deformable_phase_a(c, alpha))) return E;
+        const bool queued = phaseAQueued;
+        phaseAQueued = false;
+        if (!queued && !ok(frog_deformable_phase_a(c, alpha))) return E;
         if (cm && !ok(api->all_reduce(cm, FROG_BUF_GRIDSUM))) return E;        // the shared common-space grid, :400-432 (+ the energy sums when `two`)
         if (!ok(frog_deformable_phase_b(c))) return E;
         if (two) {
@@ -107,8 +114,13 @@ struct Runner {
             // the counts in the gather's trailers; decision and commit once they are added up.  A rejected step has left
             // speculative coordinates in the replicas: run()'s reject path re-bases and gathers before anything reads them.
             if (!ok(api->gather_points(cm, 0, 1, 0x4u))) return E;
+            if (speculate && next_plain) {
+                if (!ok(frog_step_speculate(c)) || !ok(frog_deformable_phase_a(c, alpha))) return E;
+                phaseAQueued = true;
+            }
             ok(frog_step_finish(c, &E));
             gathered = (float)E >= 0;
+            if (!gathered) phaseAQueued = false;        // rejected: frog_step_finish has rolled the speculation back
             return E;
         }
         if (cm && !ok(api->all_reduce(cm, FROG_BUF_ENERGY))) return E;         // energy sums + oversize count
@@ -167,6 +179,7 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
     }
     r.whole = !comm && r.ib == 0 && r.ie == r.nI;
     r.two = comm && !getenv("FROG_THREE_COLLECTIVES");
+    r.speculate = r.two && !getenv("FROG_NO_SPECULATION");
     if (comm) { const int rc = frog_comm_mode(ctx, r.two ? 1 : 0); if (rc) return rc; }
 
     // ---- untimed: linear set-up, first transform, (proxy: the other ranks' coordinates), warm-up iterations
@@ -221,7 +234,7 @@ extern "C" int frog_run_schedule(frog_ctx *ctx, frog_comm *comm, const frog_sche
         float alpha = plan->deformable_alpha;
         for (int iteration = 0; iteration < n && !r.rc; iteration++) {
             if (iteration % plan->stat_interval == 0) r.updateStats();
-            const double e = r.deformableStep(alpha);
+            const double e = r.deformableStep(alpha, iteration + 1 < n && (iteration + 1) % plan->stat_interval != 0);
             if (r.rc) break;
             if ((float)e < 0) {                                 // :97-115
                 if (diffeo == 0) alpha /= 2;

@@ -218,6 +218,13 @@ int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_ro
 /* Waits for the scalars.  After a deformable step: *E as frog_deformable_phase_c (-1 = rejected, nothing committed),
  * the proposal committed otherwise; after a linear step: *E. */
 int frog_step_finish(frog_ctx *ctx, double *E);
+/* The host's own latency out of the loop: between frog_comm_unpack_slab_step(sum_mask 0b0100) and frog_step_finish a host may
+ * call frog_step_speculate and then frog_deformable_phase_a for the NEXT iteration -- the step is taken as accepted (the proposal
+ * lattice becomes the coefficients, a third lattice takes the next proposals), so that the GPU has the next sweep in its queue
+ * while the scalars travel to the host.  frog_step_finish then confirms, or -- the step was rejected, 4 of 650 on the benchmark
+ * group -- gives the lattices their old roles back; the phase A queued meanwhile is void (*E = -1 as usual; continue with
+ * run()'s reject path).  Not across a statistics refresh or the end of a level: those need the decision first. */
+int frog_step_speculate(frog_ctx *ctx);
 
 /* updateStats, owned images only; afterwards all-reduce(sum) FROG_BUF_EM
  * (non-owned rows are zero) and call frog_stats_publish. */

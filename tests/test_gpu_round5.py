@@ -145,6 +145,12 @@ def test_two_collectives_give_the_files_of_three(tmp_path, ranks):
     _frog(two, "-ngl", str(ranks))
     _frog(three, "-ngl", str(ranks), env_extra={"FROG_THREE_COLLECTIVES": "1"})
     _same_files(two, three, pairs.n_images)
+    # ... and the next step's phase A queued ahead of the decision (frog_step_speculate, the default) changes nothing either
+    plain = tmp_path / "plain"
+    plain.mkdir()
+    pairs.write(plain / "pairs.bin")
+    _frog(plain, "-ngl", str(ranks), env_extra={"FROG_NO_SPECULATION": "1"})
+    _same_files(two, plain, pairs.n_images)
 
 
 def test_two_collectives_with_rejected_steps(tmp_path):
@@ -163,6 +169,7 @@ def test_two_collectives_with_rejected_steps(tmp_path):
     out1 = _frog(one, *flags)
     out2 = _frog(two, "-ngl", "3", *flags)
     _frog(three, "-ngl", "3", *flags, env_extra={"FROG_THREE_COLLECTIVES": "1"})
+    # (the default run above also had the NEXT step's phase A in the queue at every rejection: frog_step_finish rolled it back)
     n_rejected = out2.count("Iteration canceled")
     assert n_rejected >= 2 and n_rejected == out1.count("Iteration canceled"), (n_rejected, out1.count("Iteration canceled"))
     _same_files(two, three, pairs.n_images)
