@@ -170,13 +170,16 @@ def roofline_and_iteration(prof, cull_def, cull_lin, l_own, p_own, i_own, n_lin,
     roofline["device_source_hash"] = src_hash
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            tr = json.load(fh)
-        # keyed on the workload AND on the device sources the counters were collected with: stale after any kernel change
-        if (tr.get("kernel") == dom and tr.get("half_links_owned", tr.get("half_links_per_launch")) == l_own
-                and tr.get("measured_at") == src_hash):
-            roofline["traffic"] = tr["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = tr.get("source")
-            roofline["traffic_measured_at"] = tr.get("measured_at")
+            doc = json.load(fh)
+        # one entry per workload (cfg 3, cfg 5, ...: scripts/merge_traffic.py), keyed on the workload AND on the device sources
+        # the counters were collected with: stale after any kernel change
+        for tr in doc.get("entries", [doc]):
+            if (tr.get("kernel") == dom and tr.get("half_links_owned", tr.get("half_links_per_launch")) == l_own
+                    and tr.get("measured_at") == src_hash):
+                roofline["traffic"] = tr["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = tr.get("source")
+                roofline["traffic_measured_at"] = tr.get("measured_at")
+                break
     except (OSError, ValueError, KeyError):
         pass
     return roofline, iteration

@@ -877,7 +877,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, false>, (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, true, false>,
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, true>, (const void *)sweep_kernel<SWEEP_COUNT, true, false, false, false>,
             (const void *)scatter_kernel, (const void *)lattice_step_kernel<true>, (const void *)lattice_step_kernel<false>,
-            (const void *)transform_bspline_tile_kernel<float>, (const void *)transform_bspline_kernel<float>, (const void *)transform_zero_lattice_kernel,
+            (const void *)transform_bspline_tile_kernel<float>, (const void *)transform_bspline_kernel<float>, (const void *)transform_bspline_kernel<float, 2>, (const void *)transform_zero_lattice_kernel,
             (const void *)cp_center_kernel, (const void *)bounds_kernel, (const void *)bounds_final_kernel, (const void *)zero_buffers_kernel,
             (const void *)brick_count_kernel, (const void *)brick_place_kernel, (const void *)cell_order_kernel, (const void *)brick_chunks_kernel,
             (const void *)scan_block_sums_kernel, (const void *)scan_of_sums_kernel, (const void *)scan_apply_kernel,
@@ -1054,7 +1054,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
                 ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
-            auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : transform_bspline_kernel<float>;
+            auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : (ctx->geom.brick == 8 ? transform_bspline_kernel<float, 2> : transform_bspline_kernel<float>);
             kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,

@@ -153,8 +153,14 @@ __global__ __launch_bounds__(256) void transform_linear_kernel(float4 *pos, P3 *
 // the two buffers instead of copying one onto the other (the commit of :441-468 is a pointer exchange).
 // T: the type the weights and the 64-tap sums are formed in (bspline_axis): float on the product path, double behind
 // FROG_K11_F64=1 (the form of rounds 1-4, kept to measure the difference; the reference's bits live in k_reforder.hip.h).
-template <typename T>
-__global__ __launch_bounds__(256) void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
+// WAVES_MAX: resident wavefronts per SIMD the launch may use.  On the sparse fine lattices of a large group (cfg 5 levels 3-4: 1 to
+// 7.7 GB of coefficients, bricks of 8^3 cells) every wavefront in flight is 64 x 64 scattered 16-byte reads, and six of them per
+// SIMD (what the f32 form's 76 registers allow) evict each other's lines: capped at two, 0.96 -> 0.56 ms (level 3) and 2.95 ->
+// 1.96 ms (level 4); the f64 form's 220 registers had capped it by accident (0.68 / 2.18).  Small contexts on dense lattices (a
+// rank of eight of cfg 3: 16 us) are a few per cent faster uncapped.
+template <typename T, int WAVES_MAX = 8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WAVES_MAX)))
+void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
                                                                 const uint32_t *perm, uint32_t n_points,
                                                                 uint32_t image_begin, const GeomDev g, int apply,
                                                                 const P3 *snap, uint32_t *disp_part,
