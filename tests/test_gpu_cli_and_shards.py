@@ -503,9 +503,17 @@ def test_cli_sharded_host_over_a_one_device_rccl_communicator(tmp_path, small_pa
         d.mkdir()
         small_pairs.write(d / "pairs.bin")
     _run_frog(one)
-    out = _run_frog(sharded, "-ng", "1", env=dict(os.environ, FROG_SHARDED_ALWAYS="1"))
+    # FROG_COMM_EXERCISE_SINGLE_RANK: the one-rank communicator does not return early -- ncclAllGather in place on the slab,
+    # ncclAllReduce on the proposal sums (+ the energy sums behind them) and on the mixture table really run, on one rank
+    out = _run_frog(sharded, "-ng", "1", env=dict(os.environ, FROG_SHARDED_ALWAYS="1", FROG_COMM_EXERCISE_SINGLE_RANK="1"))
     assert "Images sharded over 1 GPUs" in out
     _compare_runs(one, sharded, small_pairs.n_images)
+    # the flow of rounds 2-4 (three collectives, in-place gather of FROG_BUF_XYZ2 through the slab) over the same communicator
+    three = tmp_path / "three"
+    three.mkdir()
+    small_pairs.write(three / "pairs.bin")
+    _run_frog(three, "-ng", "1", env=dict(os.environ, FROG_SHARDED_ALWAYS="1", FROG_COMM_EXERCISE_SINGLE_RANK="1", FROG_THREE_COLLECTIVES="1"))
+    _compare_runs(one, three, small_pairs.n_images)
 
 
 def test_native_communicator_single_rank_over_rccl():
@@ -531,10 +539,22 @@ assert lib.frog_comm_bind(h, eng._ctx, (C.c_uint32 * 2)(0, 4)) == 0
 assert lib.frog_comm_set_rows(h, (C.c_uint64 * 2)(0, 2400)) == 0
 assert lib.frog_comm_barrier(h) == 0, _abi.hip_lib().frog_last_error()
 assert lib.frog_comm_all_gather_xyz2(h) == 0 and lib.frog_comm_all_reduce(h, _abi.FROG_BUF_ENERGY) == 0
+# the padded gather with a step's scalars in its trailer, for real on the one rank (FROG_COMM_EXERCISE_SINGLE_RANK)
+import numpy as np
+eng.linear_init((0.5, 0.5, 0.5))
+assert lib.frog_comm_gather_points(h, 0, 0, 0) == 0, _abi.hip_lib().frog_last_error()
+before = eng.points()[1].copy() if hasattr(eng, "points") else None
+eng.update_stats_local(); eng.stats_publish()
+assert _abi.hip_lib().frog_comm_mode(eng._ctx, 1) == 0
+assert _abi.hip_lib().frog_linear_step_local(eng._ctx) == 0
+assert lib.frog_comm_gather_points(h, 0, 0, 0xB) == 0, _abi.hip_lib().frog_last_error()
+E = C.c_double()
+assert _abi.hip_lib().frog_step_finish(eng._ctx, C.byref(E)) == 0 and E.value > 0, _abi.hip_lib().frog_last_error()
 arr = (C.c_void_p * 1)(h); lib.frog_comm_destroy_all.restype = None; lib.frog_comm_destroy_all(1, arr)
 print("native comm ok")
 """
-    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, FROG_COMM_EXERCISE_SINGLE_RANK="1"))
     assert r.returncode == 0 and "native comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
