@@ -574,13 +574,42 @@ def run_preflight(rank, world, local_rank, transport, rdv):
             _abi.check(fn(), name)
         _abi.check(lib.frog_synchronize(ctx), "frog_synchronize")
         lat[name] = 1e6 * (time.perf_counter() - t0) / reps
-    everyone = rdv.gather_json("preflight", {"ok": ok, "lat": lat})
+    # the calls the native host's loop makes (round 5: two collectives per deformable iteration, one per linear one): a linear
+    # iteration whose transform goes straight into the gather's slab, the step's sums in the slots' trailers -- every rank must
+    # read the same finite E and end with the same replica of the coordinates
+    import zlib
+    flow = {"E": None, "crc": None}
+    try:
+        _abi.check(lib.frog_comm_mode(ctx, 1), "frog_comm_mode")
+        _abi.check(lib.frog_linear_init(ctx, (C.c_float * 3)(0.5, 0.5, 0.5)), "frog_linear_init")
+        _abi.check(cl.frog_comm_gather_points(comm, 0, 0, 0), "frog_comm_gather_points")
+        _abi.check(lib.frog_update_stats_local(ctx), "frog_update_stats_local")
+        _abi.check(cl.frog_comm_all_reduce(comm, _abi.FROG_BUF_EM), "frog_comm_all_reduce")
+        _abi.check(lib.frog_stats_publish(ctx), "frog_stats_publish")
+        _abi.check(lib.frog_linear_step_local(ctx), "frog_linear_step_local")
+        _abi.check(cl.frog_comm_gather_points(comm, 0, 0, 0xB), "frog_comm_gather_points")
+        e = C.c_double()
+        _abi.check(lib.frog_step_finish(ctx, C.byref(e)), "frog_step_finish")
+        xyz2 = np.empty((n_pts, 3), np.float32)
+        _abi.check(lib.frog_get_points(ctx, None, xyz2.ctypes.data_as(_abi.c_float_p)), "frog_get_points")
+        flow = {"E": e.value, "crc": zlib.crc32(xyz2.tobytes())}
+    except Exception as exc:            # reported, and the attempt counts as failed
+        flow["error"] = str(exc)[:300]
+        ok = False
+    everyone = rdv.gather_json("preflight", {"ok": ok, "lat": lat, "flow": flow})
+    flows = [x.get("flow", {}) for x in everyone]
+    same_flow = (all(f.get("E") is not None and np.isfinite(f["E"]) for f in flows)
+                 and len({f.get("E") for f in flows}) == 1 and len({f.get("crc") for f in flows}) == 1)
+    if not same_flow:
+        ok = False
+        everyone = [dict(x, ok=False) for x in everyone]
     arr = (C.c_void_p * 1)(comm)
     rdv.gather_json("done", {"rank": rank})
     cl.frog_comm_destroy_all(1, arr)
     lib.frog_destroy(ctx)
     good = all(x["ok"] for x in everyone)
-    line = {"preflight": transport, "known_answers": good, "latencies_rank0": lat} if rank == 0 else None
+    line = ({"preflight": transport, "known_answers": good, "latencies_rank0": lat, "linear_iteration_E": flows[0].get("E"),
+             "replicas_identical": len({f.get("crc") for f in flows}) == 1} if rank == 0 else None)
     return line, good
 
 
@@ -808,7 +837,7 @@ def orchestrate(args, argv, n, my_ranks, directory):
             pass
         if host == "preflight":
             if line:
-                rec.update({kk: line[kk] for kk in ("known_answers", "latencies_rank0") if kk in line})
+                rec.update({kk: line[kk] for kk in ("known_answers", "latencies_rank0", "linear_iteration_E", "replicas_identical") if kk in line})
             ok = ok and bool(line and line.get("known_answers"))
             rec["ok"] = ok
             if not ok:
