@@ -1,3 +1,6 @@
+#!/bin/bash
+# kt_variants_cfg5.sh -- on the GPU box: per-phase transform times of cfg 5 and of the one-of-eight shard proxy of cfg 3 under the default library and the
+# build variants frog_amd/lib/variants/libfrog_hip_{ptw2,ptw3,ptw4}.so (scripts/build_variant.sh: thread-per-point transform capped at 2 / 3 / 4 wavefronts per SIMD)
 L=frog_amd/lib
 cp $L/libfrog_hip.so $L/keep.so
 for name in default ptw2 ptw3 ptw4; do

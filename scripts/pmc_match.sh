@@ -1,3 +1,5 @@
+#!/bin/bash
+# pmc_match.sh -- on the GPU box: MFMA / wait / memory counters of match_mfma_kernel (bench_match.py --images 30) in two rocprofv3 --pmc passes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5_match_pmc; mkdir -p $O
 ARGS="bench_match.py --images 30 --cpu-jobs 0"
