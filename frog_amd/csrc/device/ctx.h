@@ -286,9 +286,6 @@ struct frog_ctx {
     frog::DevBuf<float4> coeff;               // [nOwned][G]
     frog::DevBuf<float4> grad;                // [nOwned][G] proposed coefficients (xyz), gradient weight (w)
     frog::DevBuf<float4> gradf;               // [nOwned][G] gradient lattice: sum w*sDisp xyz, sum w*sWeight
-    frog::DevBuf<float4> sc_w;                // [3][owned points, sorted] the scatter's weights wx, wy, wz per point (scatter_prepare_kernel)
-    frog::DevBuf<uint32_t> sc_cell;           // [owned points, sorted] the point's cell, packed
-    bool sc_pre = false;                      // the scatter reads them instead of forming them
     frog::DevBuf<float4> grad_spare;          // a third lattice: the proposals of a step queued before the previous one's decision (frog_step_speculate)
     frog::DevBuf<double> gridsum;             // [3G] (+ 4: frog_comm_mode)
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)

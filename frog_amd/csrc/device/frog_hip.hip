@@ -298,7 +298,6 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
         std::swap(ctx->perm.cap, ctx->perm_tmp.cap);
         std::swap(ctx->perm.n, ctx->perm_tmp.n);
         gather_positions_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos.p, ctx->perm.p, nPts, ctx->pos_b.p);
-        if (ctx->sc_pre) scatter_prepare_kernel<<<div_up(nPts, 256), 256, 0, s>>>(ctx->pos_b.p, nPts, gd, ctx->sc_w.p, ctx->sc_cell.p);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->pos_b_stale = false;
     }
@@ -350,8 +349,6 @@ static int join_setup_positions(frog_ctx *ctx)
     const uint32_t nPts = ctx->own_pt_end - ctx->own_pt_begin;
     if (ctx->pos_b_stale && nPts && ctx->pos_b.p && ctx->perm.p) {
         gather_positions_kernel<<<div_up(nPts, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->perm.p, nPts, ctx->pos_b.p);
-        if (ctx->sc_pre)        // re-based without a new lattice: the constants follow the positions
-            scatter_prepare_kernel<<<div_up(nPts, 256), 256, 0, ctx->stream>>>(ctx->pos_b.p, nPts, to_dev(ctx->geom), ctx->sc_w.p, ctx->sc_cell.p);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->pos_b_stale = false;
     }
@@ -879,7 +876,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         const void *kernels[] = {
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, false>, (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, true, false>,
             (const void *)sweep_kernel<SWEEP_DEFORMABLE, true, false, false, true>, (const void *)sweep_kernel<SWEEP_COUNT, true, false, false, false>,
-            (const void *)scatter_kernel, (const void *)scatter_prepare_kernel, (const void *)lattice_step_kernel<true>, (const void *)lattice_step_kernel<false>,
+            (const void *)scatter_kernel, (const void *)lattice_step_kernel<true>, (const void *)lattice_step_kernel<false>,
             (const void *)transform_bspline_tile_kernel<float>, (const void *)transform_bspline_kernel<float>, (const void *)transform_bspline_kernel<float, 2>, (const void *)transform_zero_lattice_kernel,
             (const void *)cp_center_kernel, (const void *)bounds_kernel, (const void *)bounds_final_kernel, (const void *)zero_buffers_kernel,
             (const void *)brick_count_kernel, (const void *)brick_place_kernel, (const void *)cell_order_kernel, (const void *)brick_chunks_kernel,
@@ -1442,17 +1439,6 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     if (ctx->perm.n != nPts) FROG_HIP_CHECK(ctx->perm.alloc(nPts));
     if (ctx->perm_tmp.n != nPts) FROG_HIP_CHECK(ctx->perm_tmp.alloc(nPts));
     if (ctx->pos_b.n != nPts) FROG_HIP_CHECK(ctx->pos_b.alloc(nPts));
-    // the scatter's per-point constants (k_grid.hip.h scatter_prepare_kernel): 64 bytes per owned point; a context that cannot
-    // have them goes on forming them in every step
-    static const bool no_pre = getenv("FROG_SCATTER_PRECOMPUTE") && atoi(getenv("FROG_SCATTER_PRECOMPUTE")) == 0;
-    ctx->sc_pre = !no_pre && nPts > 0;
-    if (ctx->sc_pre && (ctx->sc_w.n != 3 * (size_t)nPts || ctx->sc_cell.n != nPts)) {
-        if (ctx->sc_w.alloc(3 * (size_t)nPts) != hipSuccess || ctx->sc_cell.alloc(nPts) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->sc_w.release(); ctx->sc_cell.release();
-            ctx->sc_pre = false;
-        }
-    }
     if (ctx->perm_key.n != nPts) FROG_HIP_CHECK(ctx->perm_key.alloc(nPts));
     if (ctx->pos2_spec.n != ctx->P) FROG_HIP_CHECK(ctx->pos2_spec.alloc(ctx->P));
     FROG_HIP_CHECK(ctx->brick_slot_ptr.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
@@ -1734,8 +1720,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
             ctx->pos_b.p, ctx->point_sums.p, ctx->point_sums_stale ? ctx->group_sums.p : nullptr,
             ctx->own_pt_end - ctx->own_pt_begin, ctx->own_pt_begin, ctx->perm.p,
             reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p), ctx->brick_slot_ptr.p + (size_t)nO * gd.n_bricks,
-            ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p + ctx->stray_parity, gd, en,
-            ctx->sc_pre ? ctx->sc_w.p : nullptr, ctx->sc_pre ? ctx->sc_cell.p : nullptr);
+            ctx->gradf.p, ctx->scatter_stage.p, ctx->stray.p + ctx->stray_parity, gd, en);
         FROG_HIP_CHECK(hipGetLastError());
     }
     {

@@ -615,49 +615,6 @@ __global__ __launch_bounds__(256) void gather_positions_kernel(const float4 *pos
     if (s < n) pos_b[s] = pos[perm[s]];
 }
 
-// ---- the scatter's per-point constants, once per lattice --------------------------------------------------------------------
-// A point's cell and its twelve cubic weights depend on nothing but its re-based position, which does not change while a lattice
-// lives ("constant per grid").  The scatter's phase 1 used to form them in every iteration: three f64 divisions and three f64
-// weight polynomials per point, ~1 000 issue cycles per batch of 64 -- a third of what the one-wavefront block's SIMD spends on
-// the batch (the per-block trace after round 5's phase-2 work: phase 1 4.0 of a block's 26.9 us, and the launch is bound by SIMD
-// time, not by bytes).  Now the set-up leaves them in memory, in the sort's order: w[0..3] = wx, wy, wz as float4 planes of n
-// entries, cell = the packed (ic.x, ic.y, ic.z) -- 52 bytes per point and iteration of coalesced reads on a launch that moves a quarter
-// of what the HBM could.  Same expressions on the same inputs (scatter_cell, bspline_weights<double>, one rounding to f32): the
-// values phase 1 computed, bit for bit.
-// cell: the three components as signed 10-bit fields of one word (a lattice has a few hundred nodes per axis at most); bit 30 set: a
-// component does not fit (a point far outside the box) -- the scatter then forms cell and weights from the position as before
-constexpr uint32_t SC_CELL_UNPACKED = 1u << 30;
-__device__ __forceinline__ uint32_t pack_cell(const int ic[3])
-{
-    if (ic[0] < -512 || ic[0] > 511 || ic[1] < -512 || ic[1] > 511 || ic[2] < -512 || ic[2] > 511) return SC_CELL_UNPACKED;
-    return ((uint32_t)ic[0] & 0x3FFu) | (((uint32_t)ic[1] & 0x3FFu) << 10) | (((uint32_t)ic[2] & 0x3FFu) << 20);
-}
-__device__ __forceinline__ void unpack_cell(uint32_t c, int ic[3])
-{
-    ic[0] = (int)(c << 22) >> 22; ic[1] = (int)(c << 12) >> 22; ic[2] = (int)(c << 2) >> 22;
-}
-__global__ __launch_bounds__(256) void scatter_prepare_kernel(const float4 *pos_b, uint32_t n_points, const GeomDev g, float4 *w, uint32_t *cell)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_points) return;
-    const float4 v = pos_b[s];
-    const float in[3] = { v.x, v.y, v.z };
-    int ic[3]; float fr[3];
-    scatter_cell(in, g, ic, fr);
-    float w12[12];
-    #pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
-        double F[4];
-        bspline_weights(F, (double)fr[ax]);
-        #pragma unroll
-        for (int m = 0; m < 4; m++) w12[ax * 4 + m] = (float)F[m];
-    }
-    w[s] = make_float4(w12[0], w12[1], w12[2], w12[3]);
-    w[(size_t)n_points + s] = make_float4(w12[4], w12[5], w12[6], w12[7]);
-    w[2 * (size_t)n_points + s] = make_float4(w12[8], w12[9], w12[10], w12[11]);
-    cell[s] = pack_cell(ic);
-}
-
 // ---- the scatter's block table, built on the device (no host round trip inside a lattice set-up) ----------
 // A scatter block = (image, brick, run of <= SCATTER_CHUNK of the brick's points).  Brick k (image-major) holds the
 // points perm[ptr[k * keys_per_brick] .. ptr[(k + 1) * keys_per_brick]); it gets ceil(count / SCATTER_CHUNK) blocks,
@@ -1033,7 +990,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
                                                      const float4 *group_sums, uint32_t own_points, uint32_t own_pt_begin,
                                                      const uint32_t *perm, const ScatterBlock *blocks, const uint32_t *n_blocks,
                                                      float4 *gradf, float4 *stage, unsigned int *stray, const GeomDev g,
-                                                     const ScatterEnergy en, const float4 *pre_w, const uint32_t *pre_cell)
+                                                     const ScatterEnergy en)
 {
     // The first ENERGY_BLOCKS blocks of the grid add up the sweep's (sDistances, sWeights) tile partials instead -- a launch
     // of its own cost 7 us + two gaps of every iteration, and nothing in this kernel waits for the result.  Fixed slices,
@@ -1064,9 +1021,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
     // unconditional, from an index clamped into the block (see k_links.hip.h on loads under lane-dependent branches).
     const uint32_t s_last = blk.end - 1u;
     const auto load_index = [&](uint32_t s) -> uint32_t { return perm[min(s, s_last)]; };
-    // pre_w / pre_cell (scatter_prepare_kernel; null: formed here from the position, as until round 5): the point's weights and cell
-    struct PointConst { float4 wx /* the position when there are no constants */, wy, wz; uint32_t cell; };
-    const auto load_point = [&](uint32_t p, uint32_t s, float4 (&part)[N_XCD], PointConst &c) __attribute__((always_inline)) {
+    const auto load_point = [&](uint32_t p, uint32_t s, float4 (&part)[N_XCD], float4 &v) __attribute__((always_inline)) {
         if (group_sums) {                        // kernel-uniform
             const uint32_t li = p - own_pt_begin;
             #pragma unroll
@@ -1074,18 +1029,11 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
         } else {
             part[0] = point_sums[p];
         }
-        const uint32_t sc_ = min(s, s_last);
-        if (pre_w) {                             // kernel-uniform
-            c.wx = pre_w[sc_]; c.wy = pre_w[(size_t)own_points + sc_]; c.wz = pre_w[2 * (size_t)own_points + sc_];
-            c.cell = pre_cell[sc_];
-        } else {
-            c.wx = pos_b[sc_];                   // the position, in perm's order (the set-up's copy: coalesced)
-        }
+        v = pos_b[min(s, s_last)];                // the position, in perm's order (the set-up's copy: coalesced)
     };
     uint32_t p_cur = load_index(blk.begin + lane);
     uint32_t p_nxt = load_index(blk.begin + 64 + lane);
-    float4 part_cur[N_XCD];
-    PointConst v_cur;
+    float4 part_cur[N_XCD], v_cur;
     #pragma unroll
     for (int q = 1; q < N_XCD; q++) part_cur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     load_point(p_cur, blk.begin + lane, part_cur, v_cur);
@@ -1110,8 +1058,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
     int run_base = -1;
     for (uint32_t batch = blk.begin; batch < blk.end; batch += 64) {
         const uint32_t p_far = load_index(batch + 128 + lane);
-        float4 part_nxt[N_XCD];
-        PointConst v_nxt;
+        float4 part_nxt[N_XCD], v_nxt;
         #pragma unroll
         for (int q = 1; q < N_XCD; q++) part_nxt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         load_point(p_nxt, batch + 64 + lane, part_nxt, v_nxt);
@@ -1133,25 +1080,16 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
                 for (int q = 1; q < N_XCD; q++) { sm.x += part_cur[q].x; sm.y += part_cur[q].y; sm.z += part_cur[q].z; sm.w += part_cur[q].w; }
             }
             if (sm.w != 0.f) {                       // imageGroup.cxx:299
-                int ic[3];
+                const float in[3] = { v_cur.x, v_cur.y, v_cur.z };
+                int ic[3]; float fr[3];
+                scatter_cell(in, g, ic, fr);
+                double F[4];
                 float w12[12];
-                if (pre_w && !(v_cur.cell & SC_CELL_UNPACKED)) {
-                    unpack_cell(v_cur.cell, ic);
-                    w12[0] = v_cur.wx.x; w12[1] = v_cur.wx.y; w12[2] = v_cur.wx.z; w12[3] = v_cur.wx.w;
-                    w12[4] = v_cur.wy.x; w12[5] = v_cur.wy.y; w12[6] = v_cur.wy.z; w12[7] = v_cur.wy.w;
-                    w12[8] = v_cur.wz.x; w12[9] = v_cur.wz.y; w12[10] = v_cur.wz.z; w12[11] = v_cur.wz.w;
-                } else {
-                    const float4 pv = pre_w ? pos_b[min(batch + lane, s_last)] : v_cur.wx;       // (a cell that did not fit its word: hardly ever)
-                    const float in[3] = { pv.x, pv.y, pv.z };
-                    float fr[3];
-                    scatter_cell(in, g, ic, fr);
-                    double F[4];
+                #pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    bspline_weights(F, (double)fr[ax]);
                     #pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
-                        bspline_weights(F, (double)fr[ax]);
-                        #pragma unroll
-                        for (int m = 0; m < 4; m++) w12[ax * 4 + m] = (float)F[m];
-                    }
+                    for (int m = 0; m < 4; m++) w12[ax * 4 + m] = (float)F[m];
                 }
                 #pragma unroll
                 for (int j = 0; j < 4; j++)
