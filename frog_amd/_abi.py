@@ -251,6 +251,8 @@ HIP_SYMBOLS = {
     "frog_test_cull_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "frog_test_em_refit": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_test_inlier_probability": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_size_t, c_float_p, c_float_p]),
+    "frog_test_inlier_weight_pair": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_float, c_float_p, C.c_size_t, c_float_p,
+                                              C.POINTER(C.c_ubyte)]),
     "frog_test_bspline_weights": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "frog_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_profile_read": (C.c_int, [C.c_void_p, C.POINTER(FrogKernelTime), C.c_int]),

@@ -161,6 +161,15 @@ static_assert(TILE_POINTS <= 256, "own-point index must fit 8 bits of LinkRec::a
 struct EmDerived {
     float kq1, kq2, s1, s2;
 };
+// The deformable sweeps' weight (k_links.hip.h inlier_weight_pair): p = 1 / (1 + x2/x1 + eps/x1) with the eps term left out
+// is 1 / (1 + 2^(l + ds d2)), l = log2(kq2 / kq1), ds = s2 - s1 -- ONE exponential -- and min(pA, pB) is that function of the
+// LARGER of the two images' exponents: one exponential and one reciprocal per half-link instead of four and two.  Leaving
+// eps = 1e-10 out changes p by p eps / (x1 + x2 + eps), so the form is used for lo <= d2 <= hi only, a range on which the
+// image's mixture density x1 + x2 is certainly >= EM_FAST_DENSITY (k_stats.hip.h em_fast_of); outside it the sweep evaluates
+// inlier_probability as before.  An empty range (lo = +inf, hi = -inf) for mixtures the form is not derived for.
+struct EmFast {
+    float l, ds, lo, hi;
+};
 
 struct GridGeom {
     int dims[3];
@@ -229,6 +238,7 @@ struct frog_ctx {
     // statistics
     frog::DevBuf<float4> em;                  // [nI] c1,c2,ratio,0
     frog::DevBuf<frog::EmDerived> emd;        // [nI]
+    frog::DevBuf<frog::EmFast> emf;           // [nI] one-exponential form of the deformable sweeps' weight
     frog::DevBuf<float> samples;              // [nOwned][cap]
     frog::DevBuf<unsigned char> em_guess;     // [nOwned][4][EM_GUESS_BATCHES] exponents of the EM sums' trajectories, last fit (k_stats.hip.h)
     // Which ordinals a refresh keeps does not depend on the data (k_stats.hip.h: only on virtualSize, the capacity and the

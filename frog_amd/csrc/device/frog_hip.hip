@@ -121,7 +121,7 @@ static SweepArgs sweep_args(frog_ctx *ctx, uint32_t sub)
     a.sub = sub;
     a.n_groups = ctx->n_groups;
     for (uint32_t g = 0; g <= ctx->n_groups; g++) a.group_begin[g] = ctx->group_begin[g];
-    a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p; a.em = ctx->em.p;
+    a.tiles = ctx->tiles.p; a.recs = ctx->rec_format.narrow ? (const void *)ctx->recs32.p : (const void *)ctx->recs.p; a.pos2 = ctx->pos2.p; a.emd = ctx->emd.p; a.emf = ctx->emf.p; a.em = ctx->em.p;
     a.rec2_last = (uint32_t)(ctx->L_recs / 2 - 1);
     a.img_bits = ctx->rec_format.img_bits; a.lds_images = sweep_lds_images(ctx); a.poff = ctx->d_poff.p; a.point_last = (uint32_t)(ctx->P ? ctx->P - 1 : 0);
     a.n_tiles = ctx->n_tiles; a.threshold = ctx->opt.inlier_threshold;
@@ -489,6 +489,16 @@ void frog_destroy(frog_ctx *ctx)
     if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+#ifdef FROG_W1_COUNT
+    {
+        unsigned long long h[8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w1_count), sizeof h);
+        fprintf(stderr, "W1 steps %llu with-general %llu  lanes %llu general %llu skipped %llu general-below-lo %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+        std::vector<float4> em(ctx->nI); std::vector<frog::EmFast> ef(ctx->nI);
+        (void)hipMemcpy(em.data(), ctx->em.p, em.size() * 16, hipMemcpyDeviceToHost); (void)hipMemcpy(ef.data(), ctx->emf.p, ef.size() * 16, hipMemcpyDeviceToHost);
+        for (uint32_t i = 0; i < ctx->nI && i < 6; i++) fprintf(stderr, "  image %u c1 %g c2 %g r %g   l %g ds %g lo %g hi %g (d_hi %g)\n", i, em[i].x, em[i].y, em[i].z, ef[i].l, ef[i].ds, ef[i].lo, ef[i].hi, sqrt(ef[i].hi));
+    }
+#endif
 #ifdef FROG_SWEEP_TRACE
     if (const char *path = getenv("FROG_SWEEP_TRACE_FILE")) {
         std::vector<unsigned long long> h(8 * 8 * 16384);
@@ -718,6 +728,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     std::vector<float4> hem(c->nI, make_float4(10.f, 300.f, 0.5f, 0.f));
     CREATE_CHECK(c->em.upload(hem, s));
     CREATE_CHECK(c->emd.alloc(c->nI));
+    CREATE_CHECK(c->emf.alloc(c->nI));
     c->h_virtual.resize(c->n_owned());
     uint32_t cap = 1;
     for (uint32_t i = c->ib; i < c->ie; i++) {
@@ -783,7 +794,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->stray.alloc(3));
     CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 3 * sizeof(unsigned int), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
-    em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->nI);
+    em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold - THRESHOLD_BAND);
     CREATE_CHECK(hipGetLastError());
     // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
     if (const char *e = getenv("FROG_CULL")) c->cull_enabled = atoi(e) != 0;
@@ -812,7 +823,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (c->cull_enabled && (c->opt.inlier_threshold >= 1e-3f || c->cull_linear) && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
         if (int rc_ = cull_allocate(c)) { frog_destroy(c); return rc_; }
     }
-    stats_publish_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->emd.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
+    stats_publish_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     if (!getenv("FROG_LATTICE_LAZY")) {
@@ -984,7 +995,7 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
     ctx->xyz2_fresh = false; ctx->res_valid = false;
     ctx->disp_current = false; ctx->disp_spec = false; ctx->disp_others = false;
     ctx->cull_need_build = true; ctx->cull_check_due = true;
-    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
+    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1148,7 +1159,7 @@ int frog_stats_publish(frog_ctx *ctx)
     CTX_GUARD(ctx);
     // the weight constants of the new mixtures and, with them, the certified outlier cutoffs (k_cull.hip.h); the check before
     // the next sweep compares the cutoffs with the list's
-    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
+    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
                                                                        ctx->deformable ? 0 : 1);
     // Linear stage: the mixtures tighten from refresh to refresh as the images come together, and with them the distance
     // from which a weight is exactly zero -- a list built for the old cutoffs stays VALID but holds links it no longer
@@ -1520,7 +1531,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
             FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
             cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
         }
-        stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
+        stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->cull_need_build = true;
         ctx->cull_check_due = true;
@@ -2197,6 +2208,46 @@ int frog_test_inlier_probability(int device, const float em3[3], const float *d2
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpy(fast, df.p, n * sizeof(float), hipMemcpyDeviceToHost));
     FROG_HIP_CHECK(hipMemcpy(exact, de.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FROG_OK;
+}
+
+// what a deformable sweep step does with its d2 before the threshold band decides (k_links.hip.h): form 0 = the one-exponential
+// form inside the pair's range, 1 = the general form, 2 = the one-exponential form's value below threshold - band (an outlier
+// whatever its range)
+__global__ void test_weight_pair_kernel(const float4 emA, const float4 emB, float threshold, const float *d2, size_t n, float *weight,
+                                        unsigned char *form)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float theta = threshold - THRESHOLD_BAND;
+    const EmFast fA = em_fast_of(emA, theta);
+    EmFast fB = em_fast_of(emB, theta);
+    fB.lo = fmaxf(fB.lo, fA.lo); fB.hi = fminf(fB.hi, fA.hi);
+    bool in_range;
+    float w = inlier_weight_pair(d2[i], fA, fB, in_range);
+    unsigned char f = 0;
+    if (w < theta) f = 2;
+    else if (!in_range) { w = fminf(inlier_probability(d2[i], em_derived_of(emA)), inlier_probability(d2[i], em_derived_of(emB))); f = 1; }
+    weight[i] = w; form[i] = f;
+}
+
+int frog_test_inlier_weight_pair(int device, const float emA3[3], const float emB3[3], float threshold, const float *d2, size_t n,
+                                 float *weight, unsigned char *form)
+{
+    if (!emA3 || !emB3 || (n && (!d2 || !weight || !form))) return fail(FROG_E_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
+    FROG_HIP_CHECK(hipSetDevice(device));
+    if (!n) return FROG_OK;
+    DevBuf<float> dd, dw; DevBuf<unsigned char> df;
+    FROG_HIP_CHECK(dd.alloc(n)); FROG_HIP_CHECK(dw.alloc(n)); FROG_HIP_CHECK(df.alloc(n));
+    FROG_HIP_CHECK(hipMemcpy(dd.p, d2, n * sizeof(float), hipMemcpyHostToDevice));
+    test_weight_pair_kernel<<<div_up(n, 256), 256>>>(make_float4(emA3[0], emA3[1], emA3[2], 0.f), make_float4(emB3[0], emB3[1], emB3[2], 0.f),
+                                                      threshold, dd.p, n, dw.p, df.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpy(weight, dw.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    FROG_HIP_CHECK(hipMemcpy(form, df.p, n, hipMemcpyDeviceToHost));
     return FROG_OK;
 }
 

@@ -31,9 +31,15 @@
 namespace frog {
 
 enum { SWEEP_LINEAR = 0, SWEEP_DEFORMABLE = 1, SWEEP_COUNT = 2 };
+#ifndef FROG_W1
+#define FROG_W1 1       // 0: the deformable sweeps evaluate inlier_probability twice per half-link, as the other sweeps do (A/B builds)
+#endif
 // Prefetch pipeline of the sweep: the record stream runs CHUNK_AHEAD chunks (of two steps)
 // ahead of the arithmetic, the partner-point gather PT_AHEAD steps; the loop is unrolled over
 // one period of both rings.
+// (Deeper rings -- gathers three steps ahead, record chunks three, an eight-step body, 80 registers with two spilled -- were
+// measured in round 5: every sweep 10 % slower, 0.259 against 0.236 ms for the fused one.  More requests in flight do not help
+// a texture path that is the busy unit.)
 constexpr int CHUNK_RING = 3, CHUNK_AHEAD = 2;
 constexpr int PT_RING = 3, PT_AHEAD = 2;
 constexpr int BODY_STEPS = 6;
@@ -57,6 +63,7 @@ struct SweepArgs {
     uint32_t point_last;        // index of the last point of the model
     const P3 *pos2;
     const EmDerived *emd;
+    const EmFast *emf;          // deformable sweeps: the one-exponential form (inlier_weight_pair)
     const float4 *em;           // (c1, c2, ratio) per image: the exact re-evaluation near the inlier threshold
     uint32_t n_tiles;
     uint32_t rec2_last;         // index of the last record PAIR (16 bytes) of the context (prefetch clamp)
@@ -176,6 +183,42 @@ __device__ __forceinline__ float inlier_probability(float d2, const EmDerived e)
     return d2 < D2_FIX ? 1.0f : p;
 }
 
+// The deformable sweeps' weight, min(pA, pB), from ONE exponential and one reciprocal (ctx.h EmFast): without the `+ eps`
+// of its denominator p_k = 1 / (1 + 2^(l_k + ds_k d2)), a decreasing function of its exponent, so the smaller probability
+// is the one with the larger exponent -- whichever way each exponent depends on d2.  (The sweep spent a third of its vector
+// instructions on four exponentials and two divisions per half-link; measured)
+// What the missing eps costs, and where the form is used:
+//   * p_noeps >= p_eps always.  A weight below threshold - band in this form is therefore below it in the reference's form
+//     too (bound below): the link is an outlier in both, and nothing else about it is needed (imageGroup.cxx:268).  (The
+//     reference's `d < 0.1 -> 1` is no exception: em_fast_of gives an image constants only if its one-exponential value is
+//     above threshold - band for every d2 <= 0.01; such a link is then not dropped, is outside every range, and takes the
+//     general form, which has the rule.)
+//   * otherwise the weight's VALUE matters, and the form is used when d2 lies in both images' ranges [lo, hi]
+//     (k_stats.hip.h em_fast_of: there p_noeps - p_eps <= EM_FAST_EPS_DROP = 7e-6 = 117 e is certain); a lane outside them
+//     evaluates inlier_probability for both images, as the sweep always did (`in_range` false: also for a NaN distance, for
+//     d < 0.1, and for mixtures the form is not derived for, whose range is empty).
+// Error against the reference's form, in range (e = 2^-24; p_ref as analysed at inlier_probability above deviates from the
+// real-valued p_eps by p (1 - p) (9 + 2.5 u1 + 9 + 2.5 u2) e + 3e <= 0.25 (18 + 320) e + 3e = 88 e for u <= 64):
+//   l, ds     one rounding each of f64 values: the exponent E = l + ds d2 carries |l| e + |ds d2| e, and the fma one more
+//             rounding of E itself: dE <= (|l| + |ds d2| + |E|) e <= (2 |l| + 2 |ds| d2) e.  |l| <= 66 (em_fast_of gives no range
+//             otherwise; log2((1 - r) / r) + 3 log2(c2'/c1') for r in [1e-6, 1 - 1e-6] and c2/c1 <= 4e4); |ds| d2 <= 0.72 u1 <= 46:
+//             dE <= 224 e.
+//   2^E       v_exp_f32: 1 ulp; with dE: t = 2^E (1 + ln 2 dE + 2e) = 2^E (1 + 158 e)
+//   1 + t, v_rcp_f32 (1 ulp): 3e more on p.
+//   =>        |p_fast - p_noeps| <= p (1 - p) 158 e + 3e <= 43 e, 0 <= p_noeps - p_eps <= 117 e, |p_eps - p_ref| <= 88 e:
+//             |p_fast - p_ref| <= 248 e < INLIER_PROBABILITY_BOUND = 2^-16 = 256 e, the bound THRESHOLD_BAND relies on.
+//   outside the range only the one-sided statement is used: p_ref <= p_eps + 88 e <= p_noeps + 88 e <= p_fast + 131 e, so
+//             p_fast < threshold - 1e-4 puts p_ref below the threshold by 9e-5.
+// min(pA, pB): |min(a, b) - min(a', b')| <= max(|a - a'|, |b - b'|), and min(a, b) <= min(a', b') + c when a <= a' + c, b <= b' + c:
+// the same statements for the weight.  tests/test_gpu_round2.py::test_inlier_weight_pair_against_the_reference_build.
+// `b` carries the pair's range: [max(lo_a, lo_b), min(hi_a, hi_b)]
+__device__ __forceinline__ float inlier_weight_pair(float d2, const EmFast a, const EmFast b, bool &in_range)
+{
+    const float e = fmaxf(__builtin_fmaf(a.ds, d2, a.l), __builtin_fmaf(b.ds, d2, b.l));
+    in_range = d2 >= b.lo && d2 <= b.hi;                // false for a NaN distance and for empty ranges
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e));
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     #pragma unroll
@@ -198,6 +241,9 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // BUILD (deformable sweep, narrow records): while walking EVERY record of its range the wavefront also writes the culling
 // list for the coordinates it reads -- what cull_build_kernel does in a pass of its own (0.6 ms for 1e8 records: a record,
 // two coordinates and a distance per half-link, all of which this kernel has in hand anyway).
+#ifdef FROG_W1_COUNT
+__device__ unsigned long long g_w1_count[8];    // steps, steps with a lane in the general form, lanes, lanes in the general form, lanes skipped as outliers, general-form lanes below lo
+#endif
 #ifdef FROG_SWEEP_TRACE
 // per (block, wavefront) of the last fused steady-state launch: wall_clock64 at kernel entry, tile known, staging barrier passed,
 // first step done, walk done, final barrier passed, end; records walked (scripts/microbench/sweep_trace_an.py)
@@ -249,6 +295,9 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     const int lane = threadIdx.x & 63;
     unsigned char *tables = sweep_dyn_lds + (FUSED ? (size_t)wave * a.lds_images * (sizeof(EmDerived) + 2 * sizeof(uint32_t)) : (size_t)0);
     EmDerived *emd_s = reinterpret_cast<EmDerived *>(tables);
+    EmFast *emf_s = reinterpret_cast<EmFast *>(tables);            // W1: the deformable sweeps keep the one-exponential form here instead
+    static_assert(sizeof(EmFast) == sizeof(EmDerived), "the two tables share their place");
+    constexpr bool W1 = FROG_W1 && MODE == SWEEP_DEFORMABLE;
     uint32_t *img_base_s = reinterpret_cast<uint32_t *>(tables + (size_t)a.lds_images * sizeof(EmDerived));   // narrow records: first point of the group's images
     float *cut_s = reinterpret_cast<float *>(img_base_s + a.lds_images);      // BUILD: list cutoff of the group's images
     __shared__ uint32_t last_step_s[BUILD ? WAVES * TILE_POINTS : 1];         // BUILD: see cull_build_kernel
@@ -328,8 +377,20 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     const uint32_t g_first = a.group_begin[grp], g_count = a.group_begin[grp + 1] - g_first;
     // the group's tables: filled by the block (one group per block) or by the wavefront (FUSED: one group per wavefront)
     const uint32_t fill_id = FUSED ? (uint32_t)lane : threadIdx.x, fill_stride = FUSED ? 64u : 256u;
-    if (EMD_LDS)
-        for (uint32_t k = fill_id; k < g_count; k += fill_stride) emd_s[k] = a.emd[g_first + k];
+    if (EMD_LDS) {
+        if constexpr (W1) {
+            // FUSED: the partner's constants with the PAIR's range (a fused block has ONE own image, the same for every entry
+            // of its tables): two compares per step instead of four.  The per-group form's table serves four tiles, of any
+            // images: the ranges are intersected in the step.
+            const EmFast fO = a.emf[image];
+            for (uint32_t k = fill_id; k < g_count; k += fill_stride) {
+                EmFast f = a.emf[g_first + k];
+                if constexpr (FUSED) { f.lo = fmaxf(f.lo, fO.lo); f.hi = fminf(f.hi, fO.hi); }
+                emf_s[k] = f;
+            }
+        }
+        else { for (uint32_t k = fill_id; k < g_count; k += fill_stride) emd_s[k] = a.emd[g_first + k]; }
+    }
     if (!WIDE)
         for (uint32_t k = fill_id; k < a.lds_images; k += fill_stride) img_base_s[k] = k < g_count ? a.poff[g_first + k] : 0u;
     uint32_t *last_step = last_step_s + (BUILD ? wave * TILE_POINTS : 0);
@@ -344,6 +405,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
     bool dup = false;                   //        some step of the list holds one point twice
 
     const EmDerived eA = a.emd[image];
+    const EmFast fA = a.emf[image];
 
     double s[(MODE == SWEEP_LINEAR) ? LINEAR_SUMS : 2];
     #pragma unroll
@@ -387,7 +449,13 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
         constexpr bool ELECT = decltype(elect_c)::value;
         const uint32_t ia = own_of(rq);                 // own point inside the tile
         const P3 pa = { px[ia], px[ia + PLANE], px[ia + 2 * PLANE] };
-        const EmDerived eB = EMD_LDS ? emd_s[img_of(rq)] : a.emd[img_of(rq)];
+        EmDerived eB;
+        EmFast fB;
+        if constexpr (W1) {
+            fB = EMD_LDS ? emf_s[img_of(rq)] : a.emf[img_of(rq)];
+            if constexpr (!(EMD_LDS && FUSED)) { fB.lo = fmaxf(fB.lo, fA.lo); fB.hi = fminf(fB.hi, fA.hi); }  // else: done when the table was filled
+        }
+        else eB = EMD_LDS ? emd_s[img_of(rq)] : a.emd[img_of(rq)];
 
         const float dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
@@ -405,7 +473,31 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? FROG_FUSED_MIN_WAVES : 1
             built += (uint32_t)__popcll(m);
             if (!valid) return;
         }
-        float w = fminf(inlier_probability(d2, eA), inlier_probability(d2, eB));
+        float w;
+        if constexpr (W1) {
+            bool in_range;
+            w = inlier_weight_pair(d2, fA, fB, in_range);
+            asm volatile("" : "+v"(w));                     // formed by every lane, in front of the branch: the compiler otherwise moves it --
+                                                            // and the table read it starts with -- behind the range test, one more LDS round trip in the chain
+#ifdef FROG_W1_NOMID
+            in_range = true;
+#endif
+#ifdef FROG_W1_COUNT
+            if constexpr (FUSED && !BUILD) {
+                const bool skip = w < a.threshold - a.band, mid = !in_range && !skip;
+                const unsigned long long all = __ballot(true), mm = __ballot(mid), sk = __ballot(skip), lo_m = __ballot(mid && d2 < fB.lo);
+                if (lane == __builtin_ctzll(all)) {
+                    atomicAdd(&g_w1_count[0], 1ull); atomicAdd(&g_w1_count[1], mm ? 1ull : 0ull);
+                    atomicAdd(&g_w1_count[2], (unsigned long long)__popcll(all)); atomicAdd(&g_w1_count[3], (unsigned long long)__popcll(mm));
+                    atomicAdd(&g_w1_count[4], (unsigned long long)__popcll(sk)); atomicAdd(&g_w1_count[5], (unsigned long long)__popcll(lo_m));
+                }
+            }
+#endif
+            if (!in_range && !(w < a.threshold - a.band)) { // rare: far tails of the inlier component, d < 0.1, degenerate mixtures
+                const uint32_t imgB = img_of(rq) + (WIDE && !EMD_LDS ? 0u : g_first);
+                w = fminf(inlier_probability(d2, eA), inlier_probability(d2, a.emd[imgB]));
+            }
+        } else w = fminf(inlier_probability(d2, eA), inlier_probability(d2, eB));
         if constexpr (MODE != SWEEP_LINEAR) {
             // the threshold decision is taken on the reference's own arithmetic when it is close
             if (fabsf(w - a.threshold) < a.band) {

@@ -655,11 +655,94 @@ __device__ __forceinline__ EmDerived em_derived_of(const float4 e)
     return d;
 }
 
-__global__ void em_derive_kernel(const float4 *em, EmDerived *emd, uint32_t n_images)
+// ---- the one-exponential form of the deformable sweeps' weight (ctx.h EmFast, k_links.hip.h inlier_weight_pair) ----
+// Leaving the reference's `+ 1e-10` (stats.h:91) out of the denominator raises p = x1 / (x1 + x2 + eps) by
+//     D = eps x1 / (S (S + eps)) <= eps p^2 / x1,      S = x1 + x2, p = x1 / S,
+// and the form is used where D <= EM_FAST_EPS_DROP is certain.  Two sufficient conditions, both per image:
+//   (i)  x1 >= EM_FAST_DENSITY = eps / EM_FAST_EPS_DROP (p <= 1): an interval [lo1, hi1] of d2 around the inlier component's
+//        maximum (em_density_range);
+//   (ii) beyond hi1, for c1 < c2 (p and x1 both fall there): on a stretch [a, b], D <= eps p(a)^2 / x1(b); the range is
+//        extended stretch by stretch (0.25 % of d2 each) while that bound holds, up to the distance from which p stays below
+//        `theta` -- the sweep never asks for the range of a weight below theta = inlierThreshold - THRESHOLD_BAND (such a link is
+//        an outlier in either form: k_links.hip.h).
+constexpr double EM_FAST_EPS_DROP = 7e-6;
+constexpr double EM_FAST_DENSITY = 1e-10 / EM_FAST_EPS_DROP;
+constexpr float EM_FAST_D2_MIN = 0.0100001f;    // above D2_FIX (k_links.hip.h): `d < 0.1 -> 1` is left to the general form
+
+// [lo, hi] (in d2) on which x(d2) = kq d2 2^(s d2) >= T, for s < 0: x rises to its one maximum at d2 = -1 / (s ln 2) and falls.
+// Guess and verify: the ends are bisected with the hardware's f32 exponential, moved inwards by 1e-3, rounded to f32, and
+// ACCEPTED ONLY IF x, in f64, is >= T at both -- x has one maximum, so then it is >= T between them, whatever the quality of
+// the guess (a bad guess costs range, never correctness).
+__device__ inline bool em_density_range(double kq, double s, double T, float &lo_out, float &hi_out)
+{
+    if (!(kq > 0.0) || !(kq < 1e30) || !(s < 0.0) || !(s > -1e30)) return false;
+    const float kqf = (float)kq, sf = (float)s, Tf = (float)T;
+    const float peak = -1.0f / (sf * 0.69314718f);
+    auto xf = [&](float d2) { return kqf * d2 * __builtin_amdgcn_exp2f(sf * d2); };
+    if (!(peak > 0.0f) || !(peak < 1e30f) || !(xf(peak) >= Tf)) return false;
+    float a = 0.0f, b = peak;                           // rising side: x(a) < T <= x(b)
+    for (int k = 0; k < 40; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) b = m; else a = m; }
+    const float lo = b * 1.001f;
+    a = peak; b = peak;                                 // falling side: x(a) >= T > x(b)
+    for (int k = 0; k < 12 && xf(b) >= Tf; k++) { a = b; b *= 4.0f; }      // 2^(s d2) is 2^-1.44 at the maximum: gone after a few steps
+    if (xf(b) >= Tf) return false;
+    for (int k = 0; k < 40; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) a = m; else b = m; }
+    const float hi = a * 0.999f;
+    auto xd = [&](double d2) { return kq * d2 * exp2(s * d2); };
+    if (!(lo <= hi) || !(xd((double)lo) >= T) || !(xd((double)hi) >= T)) return false;
+    lo_out = lo; hi_out = hi;
+    return true;
+}
+
+// c1' = fl(c1 + eps), c2' = fl(c2 + eps) as stats.h:88-90 forms them;  x2 / x1 = ((1 - r) / r) (c1'/c2')^3 exp(d2 (1/c1'^2 - 1/c2'^2) / 2)
+__device__ inline EmFast em_fast_of(const float4 e, float theta)
+{
+    EmFast f;
+    // no range: the general form decides every link this image's exponent does not already rule out -- and with l = -inf it
+    // rules out none (the pair's exponent is then the other image's: an outlier by that image alone is an outlier)
+    f.l = -__builtin_inff(); f.ds = 0.f; f.lo = __builtin_inff(); f.hi = -__builtin_inff();
+    const float eps = 1e-10f;
+    const double c1 = (double)(e.x + eps), c2 = (double)(e.y + eps), r = (double)e.z;
+    if (!(c1 > 0.0) || !(c2 > 0.0) || !(c1 < 1e18) || !(c2 < 1e18) || !(r > 0.0) || !(r < 1.0)) return f;
+    const double c0 = 0.797884560802865, K = -0.72134752044448170368;
+    const double i1 = 1.0 / c1, i2 = 1.0 / c2;
+    const double kq1 = r * c0 * i1 * i1 * i1, kq2 = (1.0 - r) * c0 * i2 * i2 * i2;
+    const double s1 = K * i1 * i1, s2 = K * i2 * i2;
+    const double l = log2(kq2 / kq1), ds = s2 - s1;
+    if (!(fabs(l) <= 66.0) || !(fabs(ds) < 1e30)) return f;          // |l| <= 66: what the rounding analysis at inlier_weight_pair assumes
+    // `d < 0.1 -> 1` (stats.h:87) is the general form's: a link that close must reach it, i.e. must not be dropped for a
+    // one-exponential value below theta -- E = l + ds d2 <= log2(1 / theta - 1) with a margin, at both ends of [0, D2_MIN]
+    // (E is linear in d2).  Holds for every mixture with an inlier component worth the name (l = -19 on the benchmark group).
+    const double e_theta = log2(1.0 / (double)theta - 1.0) - 0.01;
+    if (!(l <= e_theta) || !(l + ds * (double)EM_FAST_D2_MIN <= e_theta)) return f;
+    float lo = 0.f, hi = 0.f;
+    if (!em_density_range(kq1, s1, EM_FAST_DENSITY, lo, hi)) return f;
+    // (ii): p(a)^2 / x1(b) with the hardware's f32 exponentials (1e-6 relative) against a bound taken 3 % short
+    if (ds > 0.0 && theta > 1e-3f && theta < 0.999f) {
+        const float lf = (float)l, dsf = (float)ds, kqf = (float)kq1, sf = (float)s1;
+        // p < theta 0.999 from here on: E = l + ds d2 > log2(1 / (0.999 theta) - 1)
+        const float d2_theta = (__builtin_log2f(1.0f / (0.999f * theta) - 1.0f) - lf) / dsf * 1.0001f;
+        float a = hi;
+        for (int k = 0; k < 512 && a < d2_theta; k++) {
+            const float b = a * 1.0025f;
+            const float pa = 1.0f / (1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dsf, a, lf)));
+            const float xb = kqf * b * __builtin_amdgcn_exp2f(sf * b);
+            if (!(1e-10f * pa * pa <= 0.97f * (float)EM_FAST_EPS_DROP * xb)) break;
+            a = b;
+        }
+        if (a > hi) hi = a * 0.9999f;                   // the last stretch accepted ends at a
+    }
+    f.l = (float)l; f.ds = (float)ds;
+    f.lo = fmaxf(lo, EM_FAST_D2_MIN); f.hi = hi;
+    return f;
+}
+
+__global__ void em_derive_kernel(const float4 *em, EmDerived *emd, EmFast *emf, uint32_t n_images, float theta)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_images) return;
     emd[i] = em_derived_of(em[i]);
+    emf[i] = em_fast_of(em[i], theta);
 }
 
 } // namespace frog

@@ -303,3 +303,20 @@ def device_inlier_probability(em, d2, device=0):
                                            dd.size, fast.ctypes.data_as(_abi.c_float_p),
                                            exact.ctypes.data_as(_abi.c_float_p)), "frog_test_inlier_probability")
     return fast, exact
+
+
+def device_inlier_weight_pair(em_a, em_b, d2, threshold=0.5, device=0):
+    """The deformable sweeps' weight of half-links between images with mixtures ``em_a`` and ``em_b`` for SQUARED distances
+    ``d2``, as a sweep step forms it before the threshold band decides: (weight, form) with form 0 = one exponential, inside the
+    pair's range, 1 = general form, 2 = one-exponential value below threshold - 1e-4 (dropped as an outlier)."""
+    lib = _abi.hip_lib()
+    a = np.ascontiguousarray(em_a, np.float32)
+    b = np.ascontiguousarray(em_b, np.float32)
+    dd = np.ascontiguousarray(d2, np.float32)
+    w = np.empty_like(dd)
+    form = np.empty(dd.size, np.uint8)
+    check(lib.frog_test_inlier_weight_pair(device, a.ctypes.data_as(_abi.c_float_p), b.ctypes.data_as(_abi.c_float_p),
+                                           float(threshold), dd.ctypes.data_as(_abi.c_float_p), dd.size,
+                                           w.ctypes.data_as(_abi.c_float_p), form.ctypes.data_as(_abi.C.POINTER(_abi.C.c_ubyte))),
+          "frog_test_inlier_weight_pair")
+    return w, form

@@ -275,6 +275,14 @@ int frog_cull_stats_linear(frog_ctx *ctx, uint64_t *lists_built, uint64_t *liste
 int frog_test_inlier_probability(int device, const float c1_c2_ratio[3], const float *d2, size_t n,
                                  float *fast, float *exact);
 
+/* Test hook: the DEFORMABLE sweeps' weight of a half-link between an image with mixture A and one with mixture B, for n squared
+ * distances, as a sweep step forms it before the threshold band decides: weight[i], and form[i] = 0 (one exponential for
+ * min(pA, pB), d2 inside the pair's range), 1 (the general form: `fast` of frog_test_inlier_probability for both images),
+ * 2 (the one-exponential value, below inlierThreshold - 1e-4: the sweep drops the link as an outlier without asking for its
+ * range).  tests/test_gpu_round2.py compares with the reference build of stats.cxx. */
+int frog_test_inlier_weight_pair(int device, const float c1_c2_ratio_a[3], const float c1_c2_ratio_b[3], float inlier_threshold,
+                                 const float *d2, size_t n, float *weight, unsigned char *form);
+
 /* Test hook: vtkBSplineTransformWeights (imageGroup.cxx:221-232) as the device's scatter and reference-order kernels
  * evaluate it: the four f64 weights of every fraction f[i] into out4n[4 i .. 4 i + 3].  tests/test_gpu_round5.py compares
  * them bit for bit with the reference's own function (oracle/_ref/libfrog_refweights.so). */

@@ -3,7 +3,7 @@ usage: sweep_trace_an.py trace.bin"""
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8, 8).astype(np.int64)      # [block][wave][slot]
-live = a[:, 0, 6] > 0
+live = (a[:, 0, 6] > 0) & (a[:, :, 3] > 0).all(axis=1)        # blocks whose eight wavefronts all stamped their first step
 a = a[live]
 t0 = a[:, :, 0].min()
 us = lambda x: x * 10e-3                                                              # 100 MHz wall clock
@@ -22,3 +22,10 @@ start = us(a[:, :, 0].min(axis=1) - t0); end = us(a[:, :, 6].max(axis=1) - t0)
 T = int(end.max() * 10) + 1
 occ = np.zeros(T + 1); np.add.at(occ, (start * 10).astype(int), 1); np.add.at(occ, (end * 10).astype(int), -1); occ = np.cumsum(occ)
 print("concurrent blocks: mean %.0f max %d; deciles" % (occ[:T].mean(), occ.max()), [int(b.mean()) for b in np.array_split(occ[:T], 10)])
+# where the spread inside a block comes from: records per range against walk time, wave by wave
+rec = a[:, :, 7].astype(float)
+print("records per range: mean %.0f  std over the 8 waves of a block (mean) %.0f  max/mean in a block %.3f" % (rec.mean(), rec.std(axis=1).mean(), (rec.max(axis=1) / rec.mean(axis=1)).mean()))
+print("walk us: std over the waves of a block (mean) %.2f   max/mean in a block %.3f" % (walk.std(axis=1).mean(), (walk.max(axis=1) / walk.mean(axis=1)).mean()))
+print("corr(walk, records) over all waves %.3f; inside a block (mean of per-block corr) %.3f" % (np.corrcoef(walk.ravel(), rec.ravel())[0, 1], np.nanmean([np.corrcoef(walk[b], rec[b])[0, 1] for b in range(0, len(a), 7)])))
+print("per wave index: mean records", rec.mean(axis=0).round(0), " mean walk us", walk.mean(axis=0).round(2))
+print("                mean entry->first step us", us(a[:, :, 3] - a[:, :, 0]).mean(axis=0).round(2), " wait at the last barrier us", us(a[:, :, 5] - a[:, :, 4]).mean(axis=0).round(2))

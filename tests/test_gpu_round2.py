@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from frog_amd import _abi
-from frog_amd.image_group import ImageGroup, device_inlier_probability
+from frog_amd.image_group import ImageGroup, device_inlier_probability, device_inlier_weight_pair
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup, Stats, ref_lib
 
@@ -76,6 +76,58 @@ def test_inlier_probability_against_the_reference_build():
     note("inlier_probability_exact_mismatches", f"{worst_exact} of {n_total}")
     assert worst_fast <= bound, worst_fast
     assert worst_exact == 0, f"{worst_exact} of {n_total} values differ from the reference build"
+
+
+def test_inlier_weight_pair_against_the_reference_build():
+    """The deformable sweeps' weight min(pA, pB) in its one-exponential form (k_links.hip.h inlier_weight_pair) against the
+    reference build's getInlierProbability for both images: inside the pair's range and in the general form the VALUE is
+    within INLIER_PROBABILITY_BOUND = 2^-16; a weight the sweep drops without asking for its range (form 2: below
+    threshold - 1e-4 in the one-exponential form) is below the threshold in the reference build too.  Mixtures: the
+    benchmark's (c1 3, c2 200), wide outlier components (the eps of stats.h:91 matters most there), a mixture with
+    c1 > c2 and degenerate ratios (no range: general form), and two thresholds."""
+    if ref_lib() is None:
+        pytest.fail("oracle/_ref/libfrog_refstats.so (the reference's stats.cxx) was not built")
+    bound = 2.0 ** -16
+    mixtures = [(3.0, 200.0, 0.7), (3.3, 205.0, 0.69), (0.8, 60.0, 0.5), (10.0, 300.0, 0.05), (2.0, 1000.0, 0.95),
+                (40.0, 300.0, 0.5), (5.0, 3.0, 0.5), (3.0, 200.0, 1e-6), (3.0, 200.0, 1.0 - 1e-6), (1e-3, 50.0, 0.5)]
+    rng = np.random.default_rng(7)
+    worst, worst_at, n_form = 0.0, None, np.zeros(3, np.int64)
+    for threshold in (0.5, 0.1):
+        for ia, ma in enumerate(mixtures):
+            for mb in mixtures[ia::3]:
+                ra, rb = Stats("ref"), Stats("ref")
+                ra.set_params(list(ma)); rb.set_params(list(mb))
+                cs = min(ma[0], mb[0])
+                d = np.concatenate([
+                    cs * np.geomspace(0.02, 60.0, 30000),
+                    np.linspace(0.0, 0.2, 1001),
+                    np.nextafter(np.float32(0.1), np.float32([0.0, 1.0])),
+                    rng.uniform(0.0, 5.0 * max(ma[1], mb[1]), 20000),
+                ]).astype(np.float32)
+                d2 = (d * d).astype(np.float32)
+                d2 = np.concatenate([d2, np.nextafter(np.float32(0.01), np.float32([0.0, 1.0])), np.float32([0.01])])
+                root = np.sqrt(d2)
+                want = np.minimum(ra.prob_n(root), rb.prob_n(root)).astype(np.float64)
+                # a dense stretch where the pair's weight crosses the threshold
+                k = int(np.argmin(np.abs(want[:30000] - threshold)))
+                dense = (d[k] + np.arange(-5000, 5000) * np.spacing(d[k])).astype(np.float32)
+                d2 = np.concatenate([d2, (dense * dense).astype(np.float32)])
+                root = np.sqrt(d2)
+                want = np.minimum(ra.prob_n(root), rb.prob_n(root)).astype(np.float64)
+                w, form = device_inlier_weight_pair(ma, mb, d2, threshold)
+                value = form < 2
+                assert np.all(np.isfinite(w[value]))
+                dev = np.abs(w[value].astype(np.float64) - want[value])
+                if dev.size and dev.max() > worst:
+                    worst, worst_at = float(dev.max()), (ma, mb, threshold, float(d2[value][int(np.argmax(dev))]), int(form[value][int(np.argmax(dev))]))
+                # dropped without a range: an outlier in the reference build as well, by a margin
+                assert np.all(want[form == 2] < threshold - 5e-5), (ma, mb, threshold)
+                assert np.all(w[form == 2] < threshold - 1e-4 + 1e-9)
+                n_form += np.bincount(form, minlength=3)[:3]
+    note("inlier_weight_pair_max_abs_dev", f"{worst} at {worst_at}")
+    note("inlier_weight_pair_forms_one_exp_general_dropped", n_form.tolist())
+    assert worst <= bound, (worst, worst_at)
+    assert n_form[0] > 0 and n_form[1] > 0 and n_form[2] > 0
 
 
 # ---- integer outputs, exactly -------------------------------------------------------------------------------
