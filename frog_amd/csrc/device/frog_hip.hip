@@ -823,7 +823,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (c->cull_enabled && (c->opt.inlier_threshold >= 1e-3f || c->cull_linear) && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
         if (int rc_ = cull_allocate(c)) { frog_destroy(c); return rc_; }
     }
-    stats_publish_kernel<<<div_up(c->nI, 64), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
+    stats_publish_kernel<<<dim3(div_up(c->nI, 64), 2), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     if (!getenv("FROG_LATTICE_LAZY")) {
@@ -995,7 +995,7 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
     ctx->xyz2_fresh = false; ctx->res_valid = false;
     ctx->disp_current = false; ctx->disp_spec = false; ctx->disp_others = false;
     ctx->cull_need_build = true; ctx->cull_check_due = true;
-    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
+    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1159,7 +1159,7 @@ int frog_stats_publish(frog_ctx *ctx)
     CTX_GUARD(ctx);
     // the weight constants of the new mixtures and, with them, the certified outlier cutoffs (k_cull.hip.h); the check before
     // the next sweep compares the cutoffs with the list's
-    stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
+    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
                                                                        ctx->deformable ? 0 : 1);
     // Linear stage: the mixtures tighten from refresh to refresh as the images come together, and with them the distance
     // from which a weight is exactly zero -- a list built for the old cutoffs stays VALID but holds links it no longer
@@ -1531,7 +1531,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
             FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
             cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
         }
-        stats_publish_kernel<<<div_up(ctx->nI, 64), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
+        stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->cull_need_build = true;
         ctx->cull_check_due = true;

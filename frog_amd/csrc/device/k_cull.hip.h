@@ -73,9 +73,11 @@ __global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, EmFast *e
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_images) return;
     const float4 e = em[i];
+    // grid.y = 2: the certified cutoff and the one-exponential form's ranges are two searches of some thousand dependent
+    // instructions each, per image, in front of the sweep that waits for both: side by side in different wavefronts
+    if (blockIdx.y == 1) { emf[i] = em_fast_of(e, threshold - THRESHOLD_BAND); return; }
     const EmDerived d = em_derived_of(e);
     emd[i] = d;
-    emf[i] = em_fast_of(e, threshold - THRESHOLD_BAND);
     cut_now[i] = linear ? cull_cutoff_linear_of(d) : cull_cutoff_of(e, threshold);
 }
 

@@ -681,12 +681,12 @@ __device__ inline bool em_density_range(double kq, double s, double T, float &lo
     auto xf = [&](float d2) { return kqf * d2 * __builtin_amdgcn_exp2f(sf * d2); };
     if (!(peak > 0.0f) || !(peak < 1e30f) || !(xf(peak) >= Tf)) return false;
     float a = 0.0f, b = peak;                           // rising side: x(a) < T <= x(b)
-    for (int k = 0; k < 40; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) b = m; else a = m; }
+    for (int k = 0; k < 26; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) b = m; else a = m; }    // f32: 24 bits
     const float lo = b * 1.001f;
     a = peak; b = peak;                                 // falling side: x(a) >= T > x(b)
     for (int k = 0; k < 12 && xf(b) >= Tf; k++) { a = b; b *= 4.0f; }      // 2^(s d2) is 2^-1.44 at the maximum: gone after a few steps
     if (xf(b) >= Tf) return false;
-    for (int k = 0; k < 40; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) a = m; else b = m; }
+    for (int k = 0; k < 26; k++) { const float m = 0.5f * (a + b); if (xf(m) >= Tf) a = m; else b = m; }
     const float hi = a * 0.999f;
     auto xd = [&](double d2) { return kq * d2 * exp2(s * d2); };
     if (!(lo <= hi) || !(xd((double)lo) >= T) || !(xd((double)hi) >= T)) return false;
