@@ -349,6 +349,9 @@ struct frog_ctx {
 
     // certified outlier culling of the deformable sweep (k_cull.hip.h)
     bool exact_weights = false;               // FROG_WEIGHT_EXACT=1 (test hook): inlier_probability_exact for every weight
+    bool general_weights = false;             // FROG_WEIGHT_GENERAL=1 (test hook): no image gets a range for the one-exponential form
+                                              // (k_stats.hip.h em_fast_of with theta = NaN), the deformable sweeps evaluate inlier_probability twice
+    float fast_theta() const { return general_weights ? __builtin_nanf("") : opt.inlier_threshold - 1e-4f; }
     bool cull_enabled = true;                 // FROG_CULL=0 turns it off (every sweep walks all records)
     bool cull_need_build = true;              // host side: (re)build the list before the next deformable sweep
     float cull_scale = 2.0f, cull_pad = 25.0f; // list cutoff = scale * certified cutoff + pad (the skin)

@@ -107,6 +107,8 @@ static unsigned sweep_blocks(const frog_ctx *ctx) { return div_up(ctx->n_tiles, 
 // Entries of the sweep's LDS tables (EM constants and first point of the partner group's images; dynamic LDS, 20 bytes
 // each): narrow records index them with an img_bits-wide field -- also the prefetched records past a range, which may
 // hold any value -- so 2^img_bits; wide records with the largest group's size; 0 when a group is too large for LDS.
+static_assert(THRESHOLD_BAND == 1e-4f, "ctx.h frog_ctx::fast_theta spells the band out");
+
 static uint32_t sweep_lds_images(const frog_ctx *ctx)
 {
     if (ctx->rec_format.narrow) return 1u << ctx->rec_format.img_bits;
@@ -794,7 +796,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     CREATE_CHECK(c->stray.alloc(3));
     CREATE_CHECK(hipMemsetAsync(c->stray.p, 0, 3 * sizeof(unsigned int), s));
     CREATE_CHECK(c->bounds_scratch.alloc((size_t)BOUNDS_BLOCKS * 6 + 6));
-    em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold - THRESHOLD_BAND);
+    em_derive_kernel<<<div_up(c->nI, 256), 256, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->fast_theta());
     CREATE_CHECK(hipGetLastError());
     // certified outlier culling (k_cull.hip.h): FROG_CULL=0 off; FROG_CULL_SKIN="scale,pad" sets the list cutoff
     if (const char *e = getenv("FROG_CULL")) c->cull_enabled = atoi(e) != 0;
@@ -803,6 +805,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!(c->cull_enabled && c->opt.inlier_threshold >= 1e-3f) && !c->fused_forced) c->fused_sweep = false;
     // test hook: every inlier weight through the form with the reference's own promotions (ten times the arithmetic)
     if (const char *e = getenv("FROG_WEIGHT_EXACT")) c->exact_weights = atoi(e) != 0;
+    if (const char *e = getenv("FROG_WEIGHT_GENERAL")) c->general_weights = atoi(e) != 0;
     // test hook: the solver loops in the reference's own order and arithmetic (k_reforder.hip.h); no list, no fast weight
     c->ref_order = o->reference_order != 0;                    // frog_options::reference_order (bin/frog -exact 1)
     if (const char *e = getenv("FROG_REFERENCE_ORDER")) c->ref_order = atoi(e) != 0;        // the tests' switch, overrides
@@ -823,7 +826,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (c->cull_enabled && (c->opt.inlier_threshold >= 1e-3f || c->cull_linear) && c->n_tiles > 0 && !getenv("FROG_CULL_LAZY")) {
         if (int rc_ = cull_allocate(c)) { frog_destroy(c); return rc_; }
     }
-    stats_publish_kernel<<<dim3(div_up(c->nI, 64), 2), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->cut_now.p, 1);
+    stats_publish_kernel<<<dim3(div_up(c->nI, 64), 2), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->fast_theta(), c->cut_now.p, 1);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
     if (!getenv("FROG_LATTICE_LAZY")) {
@@ -995,7 +998,7 @@ int frog_linear_init(frog_ctx *ctx, const float anchor_pos[3])
     ctx->xyz2_fresh = false; ctx->res_valid = false;
     ctx->disp_current = false; ctx->disp_spec = false; ctx->disp_others = false;
     ctx->cull_need_build = true; ctx->cull_check_due = true;
-    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 1);
+    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->fast_theta(), ctx->cut_now.p, 1);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1159,7 +1162,7 @@ int frog_stats_publish(frog_ctx *ctx)
     CTX_GUARD(ctx);
     // the weight constants of the new mixtures and, with them, the certified outlier cutoffs (k_cull.hip.h); the check before
     // the next sweep compares the cutoffs with the list's
-    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p,
+    stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->fast_theta(), ctx->cut_now.p,
                                                                        ctx->deformable ? 0 : 1);
     // Linear stage: the mixtures tighten from refresh to refresh as the images come together, and with them the distance
     // from which a weight is exactly zero -- a list built for the old cutoffs stays VALID but holds links it no longer
@@ -1531,7 +1534,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
             FROG_HIP_CHECK(hipMemsetAsync(ctx->lin_listed.p, 0, sizeof(unsigned long long), ctx->stream));
             cull_count_kernel<<<CULL_COUNT_BLOCKS, 256, 0, ctx->stream>>>(ctx->act_cnt.p, (uint32_t)ctx->act_cnt.n, ctx->lin_listed.p);
         }
-        stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->cut_now.p, 0);
+        stats_publish_kernel<<<dim3(div_up(ctx->nI, 64), 2), 64, 0, ctx->stream>>>(ctx->em.p, ctx->emd.p, ctx->emf.p, ctx->nI, ctx->opt.inlier_threshold, ctx->fast_theta(), ctx->cut_now.p, 0);
         FROG_HIP_CHECK(hipGetLastError());
         ctx->cull_need_build = true;
         ctx->cull_check_due = true;

@@ -68,14 +68,14 @@ __global__ void cull_cutoff_kernel(const float4 *em, uint32_t n_images, float th
 // and its certified cutoff (two launches of 5 + 12 us each with a gap between them, at every statistics refresh)
 // `linear`: the cutoff of the LINEAR stage's list instead (cull_cutoff_linear_of below)
 __device__ inline float cull_cutoff_linear_of(const EmDerived d);
-__global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, EmFast *emf, uint32_t n_images, float threshold, float *cut_now, int linear)
+__global__ void stats_publish_kernel(const float4 *em, EmDerived *emd, EmFast *emf, uint32_t n_images, float threshold, float theta, float *cut_now, int linear)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_images) return;
     const float4 e = em[i];
     // grid.y = 2: the certified cutoff and the one-exponential form's ranges are two searches of some thousand dependent
     // instructions each, per image, in front of the sweep that waits for both: side by side in different wavefronts
-    if (blockIdx.y == 1) { emf[i] = em_fast_of(e, threshold - THRESHOLD_BAND); return; }
+    if (blockIdx.y == 1) { emf[i] = em_fast_of(e, theta); return; }      // theta = threshold - THRESHOLD_BAND, or NaN: no ranges (test hook)
     const EmDerived d = em_derived_of(e);
     emd[i] = d;
     cut_now[i] = linear ? cull_cutoff_linear_of(d) : cull_cutoff_of(e, threshold);

@@ -171,10 +171,16 @@ def test_rim_deviations_with_the_fast_and_with_the_exact_weight(monkeypatch):
     monkeypatch.setenv("FROG_WEIGHT_EXACT", "1")
     exact = free_run(pairs, 50, 3, 40)
     monkeypatch.delenv("FROG_WEIGHT_EXACT")
+    # ... and a third time with the deformable sweeps' one-exponential form switched off (FROG_WEIGHT_GENERAL=1: no image gets
+    # a range, every weight is min of two inlier_probability values as before round 5's second session): the same bars
+    monkeypatch.setenv("FROG_WEIGHT_GENERAL", "1")
+    general = free_run(pairs, 50, 3, 40)
+    monkeypatch.delenv("FROG_WEIGHT_GENERAL")
     raw_f = max(d["raw"] for d in fast["lattices"]); raw_x = max(d["raw"] for d in exact["lattices"])
-    note("rim_deviation_fast_vs_exact_weights", f"raw fast {raw_f:.2e} exact {raw_x:.2e} field fast "
-         f"{max(d['field'] for d in fast['lattices']):.2e} exact {max(d['field'] for d in exact['lattices']):.2e}")
-    for r in (fast, exact):
+    note("rim_deviation_fast_vs_exact_weights", f"raw fast {raw_f:.2e} exact {raw_x:.2e} general {max(d['raw'] for d in general['lattices']):.2e} field fast "
+         f"{max(d['field'] for d in fast['lattices']):.2e} exact {max(d['field'] for d in exact['lattices']):.2e} "
+         f"general {max(d['field'] for d in general['lattices']):.2e}; E fast {fast['E']:.2e} general {general['E']:.2e}")
+    for r in (fast, exact, general):
         for d in r["lattices"]:
             assert d["weighted"] <= REL and d["field"] <= REL and d["raw"] <= 1e-3       # measured 3.4e-4 / 5.6e-6
 
