@@ -8,10 +8,16 @@ default flags of run.sh (-d 1, -d2 1).  Keypoints are resident in HBM before the
 the timed region covers all pairing kernels, the per-query decisions and the return of the
 pair lists to the host.
 
-Prints ONE JSON line.  `roofline` here is the f32-input MFMA roofline: the dominant kernel is the
-matrix-core filter of frog_amd/csrc/device/match.hip (one (D + 2)-term product per (query,
-candidate) pair that passes the sign and scale tests, 2 FLOP per term) against 256 CUs x 4 SIMDs x
-64 FLOP/clk x 2.4 GHz.
+Prints ONE JSON line.  `roofline`: the dominant kernel is the matrix-core filter of
+frog_amd/csrc/device/match.hip -- one (D + 2)-term product per (query, candidate) pair that passes the
+sign and scale tests, 2 FLOP per term.  `frac` prices those ALGORITHMIC FLOPs against the f32-input
+MFMA peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz = 157 TFLOP/s), the unit an exact-f32 product
+would need and the figure of rounds 1-4.  Since round 5 the filter runs on the bf16 cores as three
+products of (hi, lo) splits (match_mfma16_kernel: 3 (D + 2) terms padded to a multiple of 16 per pair,
+with a proven error bound): `issued` gives the FLOPs the instructions actually perform and their
+fraction of the dense bf16 peak (2.5 PFLOP/s) -- small, because the pass is no longer bound by the
+matrix cores but by operand traffic and the two kernels around the filter.  FROG_MATCH_F32=1 runs the
+f32 chain.
 """
 import argparse
 import json
@@ -56,6 +62,12 @@ def main():
     # per (query, candidate) pair that passes the sign and scale tests.
     flops = 2.0 * (args.dim + 2) * nd
     peak = 256 * 4 * 64 * 2.4e9
+    bf16 = not os.environ.get("FROG_MATCH_F32") and not os.environ.get("FROG_MATCH_VALU") and args.dim <= 64
+    dp = 48 if args.dim <= 48 else 64
+    k3 = (3 * (dp + 2) + 15) // 16 * 16
+    issued = {"form": "bf16 x 3 (v_mfma_f32_32x32x16_bf16)", "flops": 2.0 * k3 * nd, "peak_tflops": 2500.0,
+              "frac_of_bf16_peak": 2.0 * k3 * nd / (ms * 1e-3) / 2.5e15} if bf16 else \
+             {"form": "f32 chain (v_mfma_f32_32x32x2_f32)", "flops": flops, "peak_tflops": peak / 1e12, "frac_of_f32_peak": flops / (ms * 1e-3) / peak}
     out = {
         "metric": "image pairs matched/sec (20 000 x 20 000 keypoints, 48-D)",
         "value": len(jobs) / elapsed, "unit": "image pairs/s", "n_gpus": 1, "higher_is_better": True,
@@ -63,8 +75,10 @@ def main():
         "config": {"workload": f"{args.images} images x {args.points} keypoints x {args.dim} floats, {len(jobs)} image pairs, "
                                f"-d {args.threshold} -d2 1", "matches": n_pairs,
                    "candidate_pairs": float(sum(imgs[a].n * imgs[b].n for a, b in jobs)), "distances_evaluated": nd},
-        "roofline": {"bound": "mfma", "kernel": "match_mfma_kernel", "achieved": flops / (ms * 1e-3) / 1e12,
+        "roofline": {"bound": "mfma", "kernel": "match_mfma16_kernel" if bf16 else "match_mfma_kernel", "achieved": flops / (ms * 1e-3) / 1e12,
                      "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak, "traffic": None,
+                     "frac_rule": "algorithmic FLOPs (2 (D + 2) per pair that passes the filters) / f32-input MFMA peak, as in rounds 1-4",
+                     "issued": issued,
                      "note": "ms = all kernels of the run (range search, MFMA filter, exact verification)"},
         "setup_seconds": {"generate": t_gen, "upload": t_upload},
     }

@@ -36,6 +36,10 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 extern "C" const char *frog_last_error(void);
 namespace frog { void set_last_error(const std::string &s); }
@@ -54,6 +58,9 @@ struct DevImage {
     float *xyz = nullptr;               // [n][3]
     float *norm = nullptr;              // |descriptor|^2 (f64 sum rounded to f32), for the MFMA filter
     float *mf = nullptr;                // extended vectors in MFMA operand order: [ceil(n/32)][(dp+2)/2][64]
+    uint16_t *mfa16 = nullptr, *mfb16 = nullptr;   // bf16 (hi, lo) splits of the extended vectors in the operand order of
+                                        // v_mfma_f32_32x32x16_bf16, candidate form and query form: [ceil(n/32)][steps16][64][8]
+    bool bf16_ok = false;               // every entry splits without overflow (|v| < 2^126): the bf16 filter's bound holds
     float norm_max = 0.f;
     bool finite = true;                 // every descriptor value is finite
     uint32_t *orig = nullptr;           // sorted position -> index in the caller's order
@@ -70,6 +77,7 @@ struct MatchArgs {
     uint32_t nq, nc, splits;
     uint32_t hmax_stride;               // entries per query of the half-tile maxima: 2 * tiles of the candidate image
     float anat;
+    float mf_eps;                       // the matrix-core filter's error bound in use (MF_EPS or MF_EPS_BF16), relative to |q|^2 + |c|^2
     Partial *partial;                   // [splits][nq]
     unsigned long long *n_dist;         // distances evaluated (statistics)
 };
@@ -399,6 +407,153 @@ __global__ __launch_bounds__(MATCH_BLOCK * 2 / G) void match_mfma_kernel(const M
         atomicAdd(a.n_dist + STAT_BASE + STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, 64ull * MF_TILE * (t_end - t_begin));
 }
 
+// ---- the same filter on the bf16 matrix cores (16 x the f32 rate) -------------------------------------------------------
+// Every entry v of an extended vector is split  v = vh + vl + vr,  vh = bf16(v), vl = bf16(v - vh) (round to nearest even;
+// v - vh is exact in f32), |vl| <= 2^-8 |v|, |vr| <= 2^-16 |v|.  With DE = D + 2 entries per vector the candidate operand is
+// the K-vector [ch | cl | ch] and the query operand [qh' | qh' | ql'] (q' = the query's vector with its last two entries
+// exchanged, as in the f32 form), 3 DE products per pair:  sum_k (ch qh' + cl qh' + ch ql')_k  -- what is left out per entry is
+// cl ql' + cr q' + c qr' - cr qr', at most 3.0001 * 2^-16 |c_k| |q'_k| (0 for the entries that are 1: 1 = bf16(1)).
+// Error of the product P against the real -d^2/2, S = |q|^2 + |c|^2, u = 2^-24:
+//   splits        sum_k |c_k q_k| <= S / 2 over the D descriptor entries: 1.5 * 2^-16 S; the two half norms: 2^-16 S / 2
+//                                                                                              -> 2.0 * 2^-16 S = 3.05e-5 S
+//   accumulation  the products of two bf16 values are exact in f32; each of the K3 = 3 DE of them (160 or 208 with padding) is
+//                 taken to enter the f32 accumulation with an error of at most 2 u (truncating adders allowed for) of the sum
+//                 of the magnitudes so far, at most 1.01 S: 2 u K3 1.01 S                       -> 1.9e-5 S (2.5e-5 at D = 64)
+//                 (an assumption about v_mfma_f32_32x32x16_bf16's internal adder, which the ISA document does not describe;
+//                 tests/test_gpu_match.py::test_bf16_filter_products_within_the_bound measures the products against f64
+//                 for random, cancelling and large-norm vectors: observed maximum in DESIGN.md section 10)
+//   stored norms  f64 sums rounded to f32: u S / 2; the reference distance's own roundings: 2 (D + 3) u S in d, half in P
+// together |P - (-d_ref / 2)| <= 5.3e-5 S (5.9e-5 at D = 64), i.e. |-2 P - d_ref| <= 1.2e-4 S; MF_EPS_BF16 = 2^-12 = 2.44e-4
+// leaves a factor 2.  A wider bound only lets more half tiles through to the exact verification (typically still two per query:
+// 2.4e-4 S is far below the gaps between a query's nearest descriptors); it never changes a pair.
+// A block stages the candidate tile (10 or 13 KB) in LDS once for its four wavefronts (double buffered, one barrier per
+// tile): at this rate each wavefront reading its own copy through the L1 would need twice the L1's 64 B per clock.
+constexpr float MF_EPS_BF16 = 1.0f / 4096.0f;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int mf16_steps(int D) { return (3 * (D + 2) + 15) / 16; }
+
+template <int D, bool ANAT>
+__global__ __launch_bounds__(MATCH_BLOCK) void match_mfma16_kernel(const MatchArgs a, const uint2 *ranges, const QRange *qr,
+                                                                   const uint4 *q_mfb, const uint4 *c_mfa, float *hmax)
+{
+    constexpr int G = 2;                            // query groups of 32 per wavefront
+    constexpr int STEPS = mf16_steps(D);            // matrix instructions per 32 x 32 tile (K = 16 each)
+    constexpr int TILE16 = STEPS * 64;              // uint4 per operand tile
+    __shared__ uint4 ctile[2][TILE16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t g0 = (blockIdx.x * MATCH_BLOCK + wave * 32 * G) / MF_TILE;
+    const uint32_t n_qgroups = (a.nq + MF_TILE - 1) / MF_TILE;
+    // (no early return: every wavefront of the block takes part in the staging and its barriers)
+    uint4 b[G][STEPS];
+    float qx[G], qy[G], qz[G];
+    uint32_t qfirst[G], qcount[G], qidx[G];
+    bool qvalid[G];
+    #pragma unroll
+    for (int g = 0; g < G; g++) {
+        const uint32_t grp = min(g0 + g, n_qgroups - 1);
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) b[g][s2] = q_mfb[((size_t)grp * STEPS + s2) * 64 + lane];
+        const uint32_t qi = (g0 + g) * MF_TILE + j;
+        qidx[g] = qi;
+        qvalid[g] = (g0 + g) < n_qgroups && qi < a.nq;
+        const QRange r = qvalid[g] ? qr[qi] : QRange{ 0, 0 };
+        qfirst[g] = r.first; qcount[g] = r.last - r.first;
+        qx[g] = qy[g] = qz[g] = 0.f;
+        if (ANAT && qvalid[g]) { qx[g] = a.q_xyz[3 * (size_t)qi]; qy[g] = a.q_xyz[3 * (size_t)qi + 1]; qz[g] = a.q_xyz[3 * (size_t)qi + 2]; }
+    }
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t t_first = rg.x / MF_TILE, t_last = (rg.y + MF_TILE - 1) / MF_TILE;
+    const uint32_t per = (t_last - t_first + a.splits - 1) / a.splits;
+    const uint32_t t_begin = min(t_last, t_first + blockIdx.y * per), t_end = min(t_last, t_begin + per);
+    if (t_begin >= t_end) return;                   // block-uniform
+
+    constexpr int PER_THREAD = (TILE16 + MATCH_BLOCK - 1) / MATCH_BLOCK;
+    uint4 stage[PER_THREAD];
+    auto fetch = [&](uint32_t t) {
+        const uint4 *src = c_mfa + (size_t)t * TILE16;
+        #pragma unroll
+        for (int k = 0; k < PER_THREAD; k++) {
+            const int e = (int)threadIdx.x + k * MATCH_BLOCK;
+            stage[k] = e < TILE16 ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto park = [&](int buf) {
+        #pragma unroll
+        for (int k = 0; k < PER_THREAD; k++) {
+            const int e = (int)threadIdx.x + k * MATCH_BLOCK;
+            if (e < TILE16) ctile[buf][e] = stage[k];
+        }
+    };
+    fetch(t_begin);
+    park(0);
+    __syncthreads();
+    for (uint32_t t = t_begin; t < t_end; t++) {
+        const int buf = (int)((t - t_begin) & 1u);
+        if (t + 1 < t_end) fetch(t + 1);            // in flight while this tile is multiplied
+        f32x16 acc[G];
+        #pragma unroll
+        for (int g = 0; g < G; g++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[g][r] = 0.f;
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) {
+            const uint4 av = ctile[buf][s2 * 64 + lane];
+            #pragma unroll
+            for (int g = 0; g < G; g++)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[g][s2]), acc[g], 0, 0, 0);
+        }
+        const uint32_t base = t * MF_TILE + 4 * h;
+        #pragma unroll
+        for (int g = 0; g < G; g++) {
+            float hm = -INFINITY;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t c = base + (uint32_t)((r & 3) + 8 * (r >> 2));   // row of the product = candidate
+                bool pass = (c - qfirst[g]) < qcount[g];                        // sign and scale tests, match.cpp:270-275
+                if (ANAT) {                                                     // :278-291
+                    const uint32_t cc = min(c, a.nc - 1);
+                    const float ex = qx[g] - a.c_xyz[3 * (size_t)cc], ey = qy[g] - a.c_xyz[3 * (size_t)cc + 1], ez = qz[g] - a.c_xyz[3 * (size_t)cc + 2];
+                    pass = pass && !(sqrtf(ex * ex + ey * ey + ez * ez) > a.anat);
+                }
+                hm = fmaxf(hm, pass ? acc[g][r] : -INFINITY);
+            }
+            if (qvalid[g]) hmax[(size_t)qidx[g] * a.hmax_stride + t * 2 + h] = hm;
+        }
+        if (t + 1 < t_end) park(buf ^ 1);           // the other buffer: last read one barrier ago
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicAdd(a.n_dist + STAT_BASE + STAT_SLOTS + (blockIdx.x + blockIdx.y) % STAT_SLOTS, 64ull * MF_TILE * (MATCH_BLOCK / 64) * (t_end - t_begin));
+}
+
+// test hook: the 32 x 32 products of one candidate group and one query group, f32 chain (form 0) or bf16 splits (form 1)
+template <int D>
+__global__ __launch_bounds__(64) void match_products_kernel(const float *q_mf, const float *c_mf, const uint4 *q_mfb, const uint4 *c_mfa,
+                                                            int form, float *out /*[32 candidates][32 queries]*/)
+{
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    f32x16 acc;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    if (form == 0) {
+        constexpr int STEPS = (D + 2) / 2;
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) {
+            const float bq = s2 < STEPS - 1 ? q_mf[s2 * 64 + lane] : q_mf[s2 * 64 + (lane ^ 32)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c_mf[s2 * 64 + lane], bq, acc, 0, 0, 0);
+        }
+    } else {
+        constexpr int STEPS = mf16_steps(D);
+        #pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c_mfa[s2 * 64 + lane]), __builtin_bit_cast(bf16x8, q_mfb[s2 * 64 + lane]), acc, 0, 0, 0);
+    }
+    #pragma unroll
+    for (int r = 0; r < 16; r++) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = acc[r];
+}
+
 constexpr int SCAN_BLOCK = 64;          // one wavefront = 4 query teams
 constexpr int SCAN_HITS = 64;           // half tiles listed per query before the slow path
 
@@ -439,7 +594,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void match_scan_kernel(const MatchArgs 
     }
     // -2 x product approximates the distance to MF_EPS * (|q|^2 + |c|^2): every candidate whose exact distance is at most
     // the second smallest exact distance has a product >= (second largest product) - MF_EPS * (|q|^2 + max |c|^2)
-    const float thr = t2 - MF_EPS * (q_norm[qc] + c_norm_max);      // -inf when fewer than two half tiles hold a candidate
+    // (1e-30: products of bf16 splits below the normal range may be flushed; nothing for descriptors of any real size)
+    const float thr = t2 - a.mf_eps * (q_norm[qc] + c_norm_max) - 1e-30f;      // -inf when fewer than two half tiles hold a candidate
     // per team: its 16 candidate rows, D/4 + 1 float4 apart: the odd stride spreads the rows over all banks
     constexpr int ROW4 = D / 4 + 1;
     __shared__ float4 rows[SCAN_BLOCK / 16][16 * ROW4];
@@ -797,6 +953,39 @@ static int run_all(frog_matcher *m, const uint16_t *first, const uint16_t *secon
     return FROG_OK;
 }
 
+// bf16 splits of one f32 value (round to nearest even; finite inputs below 2^126 in magnitude: no overflow on the way up)
+static inline uint16_t bf16_bits(float f)
+{
+    uint32_t u; std::memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_value(uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+// the two bf16 operand arrays of `n` points (k_mfma16: candidate form [ch | cl | ch], query form [qh' | qh' | ql']) from the
+// padded descriptors and their squared norms; false when an entry is too large to split
+static bool build_bf16_operands(const float *pad, const float *nrm, uint32_t n, uint32_t dp, std::vector<uint16_t> &fa, std::vector<uint16_t> &fb)
+{
+    const uint32_t de = dp + 2, steps = (uint32_t)mf16_steps((int)dp), groups = (n + 31) / 32;
+    fa.assign((size_t)groups * steps * 64 * 8, 0); fb.assign(fa.size(), 0);
+    std::vector<float> ec(de), eq(de);
+    const float big = 8.5070592e37f;        // 2^126
+    for (uint32_t p = 0; p < n; p++) {
+        for (uint32_t k = 0; k < dp; k++) ec[k] = eq[k] = pad[(size_t)p * dp + k];
+        ec[dp] = -0.5f * nrm[p]; ec[dp + 1] = 1.0f;
+        eq[dp] = 1.0f; eq[dp + 1] = -0.5f * nrm[p];
+        for (uint32_t k = 0; k < de; k++) if (!(std::fabs(ec[k]) < big)) return false;
+        for (uint32_t kk = 0; kk < 3 * de; kk++) {
+            const uint32_t k = kk % de, part = kk / de;
+            const uint16_t ch = bf16_bits(ec[k]), cl = bf16_bits(ec[k] - bf16_value(ch));
+            const uint16_t qh = bf16_bits(eq[k]), ql = bf16_bits(eq[k] - bf16_value(qh));
+            const size_t at = ((((size_t)(p / 32) * steps + kk / 16) * 64) + ((kk % 16) / 8) * 32 + (p & 31)) * 8 + kk % 8;
+            fa[at] = part == 1 ? cl : ch;
+            fb[at] = part == 2 ? ql : qh;
+        }
+    }
+    return true;
+}
+
 extern "C" {
 
 void frog_match_options_default(frog_match_options *o)
@@ -822,6 +1011,8 @@ void frog_matcher_destroy(frog_matcher *m)
         if (d.pos) (void)hipFree(d.pos);
         if (d.norm) (void)hipFree(d.norm);
         if (d.mf) (void)hipFree(d.mf);
+        if (d.mfa16) (void)hipFree(d.mfa16);
+        if (d.mfb16) (void)hipFree(d.mfb16);
     }
     if (m->n_dist) (void)hipFree(m->n_dist);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -860,6 +1051,7 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     for (hipStream_t &e : m->extra) CCHECK(hipStreamCreate(&e));
     CCHECK(hipMalloc((void **)&m->n_dist, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long)));
     std::vector<float> pad, lo, hi, sg, sc, xyz, nrm, mfv;
+    std::vector<uint16_t> fa16, fb16;
     for (uint32_t i = 0; i < n_images; i++) {
         const frog_keypoints &k = images[i];
         DevImage &d = m->img[i];
@@ -905,6 +1097,16 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
             CCHECK(hipMalloc((void **)&d.mf, mfv.size() * sizeof(float)));
             CCHECK(hipMemcpy(d.mf, mfv.data(), mfv.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        if (m->dp <= 64 && d.finite) {
+            d.bf16_ok = build_bf16_operands(pad.data(), nrm.data(), k.n, m->dp, fa16, fb16);
+            if (d.bf16_ok) {
+                if (fa16.empty()) { fa16.assign((size_t)mf16_steps((int)m->dp) * 64 * 8, 0); fb16 = fa16; }    // an image without keypoints
+                CCHECK(hipMalloc((void **)&d.mfa16, fa16.size() * sizeof(uint16_t)));
+                CCHECK(hipMalloc((void **)&d.mfb16, fb16.size() * sizeof(uint16_t)));
+                CCHECK(hipMemcpy(d.mfa16, fa16.data(), fa16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                CCHECK(hipMemcpy(d.mfb16, fb16.data(), fb16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            }
+        }
         CCHECK(hipMalloc((void **)&d.desc, n * m->dp * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.sign, n * sizeof(float)));
         CCHECK(hipMalloc((void **)&d.scale, n * sizeof(float)));
@@ -928,6 +1130,49 @@ int frog_matcher_create(const frog_keypoints *images, uint32_t n_images, int dev
     }
 #undef CCHECK
     *out = m;
+    return FROG_OK;
+}
+
+// Test hook: the matrix-core filter's products for 32 candidates x 32 queries (descriptors of `dim` = 48 or 64 values, row
+// major), through the same operand builders and instruction sequences as the filter kernels: form 0 = the f32 chain,
+// 1 = three products of bf16 splits.  out[c * 32 + q] approximates -|q - c|^2 / 2; bound[0] = the bound the scan kernel uses
+// for that form (relative to |q|^2 + |c|^2, on -2 x product).  tests/test_gpu_match.py compares with f64.
+int frog_match_test_products(int device, const float *cand, const float *query, uint32_t dim, int form, float *out, float *bound)
+{
+    if (!cand || !query || !out || (dim != 48 && dim != 64) || (form != 0 && form != 1)) return fail(FROG_E_INVALID, "bad arguments to frog_match_test_products");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(FROG_E_NODEVICE, "no HIP device");
+    if (device < 0 || device >= count) return fail(FROG_E_INVALID, "bad device index");
+    MCHECK(hipSetDevice(device));
+    const uint32_t steps = (dim + 2) / 2, steps16 = (uint32_t)mf16_steps((int)dim);
+    std::vector<float> nc(32), nq(32), mfc((size_t)steps * 64, 0.f), mfq((size_t)steps * 64, 0.f);
+    auto norms = [&](const float *d, std::vector<float> &n) {
+        for (int p = 0; p < 32; p++) { double sum = 0; for (uint32_t c = 0; c < dim; c++) sum += (double)d[p * dim + c] * d[p * dim + c]; n[p] = (float)sum; }
+    };
+    norms(cand, nc); norms(query, nq);
+    auto f32_form = [&](const float *d, const std::vector<float> &n, std::vector<float> &mf) {
+        for (uint32_t p = 0; p < 32; p++)
+            for (uint32_t k = 0; k < dim + 2; k++)
+                mf[((size_t)(k / 2)) * 64 + (k & 1) * 32 + p] = k < dim ? d[p * dim + k] : (k == dim ? -0.5f * n[p] : 1.0f);
+    };
+    f32_form(cand, nc, mfc); f32_form(query, nq, mfq);
+    std::vector<uint16_t> ca, cb, qa, qb;
+    if (!build_bf16_operands(cand, nc.data(), 32, dim, ca, cb) || !build_bf16_operands(query, nq.data(), 32, dim, qa, qb))
+        return fail(FROG_E_INVALID, "descriptor entries too large for the bf16 split");
+    float *d_mfc = nullptr, *d_mfq = nullptr, *d_out = nullptr; uint16_t *d_ca = nullptr, *d_qb = nullptr;
+    auto release = [&]() { (void)hipFree(d_mfc); (void)hipFree(d_mfq); (void)hipFree(d_out); (void)hipFree(d_ca); (void)hipFree(d_qb); };
+#define TCHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { frog::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_)); release(); return FROG_E_HIP; } } while (0)
+    TCHECK(hipMalloc((void **)&d_mfc, mfc.size() * 4)); TCHECK(hipMalloc((void **)&d_mfq, mfq.size() * 4)); TCHECK(hipMalloc((void **)&d_out, 1024 * 4));
+    TCHECK(hipMalloc((void **)&d_ca, (size_t)steps16 * 64 * 16)); TCHECK(hipMalloc((void **)&d_qb, (size_t)steps16 * 64 * 16));
+    TCHECK(hipMemcpy(d_mfc, mfc.data(), mfc.size() * 4, hipMemcpyHostToDevice)); TCHECK(hipMemcpy(d_mfq, mfq.data(), mfq.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(d_ca, ca.data(), (size_t)steps16 * 64 * 16, hipMemcpyHostToDevice)); TCHECK(hipMemcpy(d_qb, qb.data(), (size_t)steps16 * 64 * 16, hipMemcpyHostToDevice));
+    if (dim == 48) match_products_kernel<48><<<1, 64>>>(d_mfq, d_mfc, (const uint4 *)d_qb, (const uint4 *)d_ca, form, d_out);
+    else match_products_kernel<64><<<1, 64>>>(d_mfq, d_mfc, (const uint4 *)d_qb, (const uint4 *)d_ca, form, d_out);
+    TCHECK(hipGetLastError());
+    TCHECK(hipMemcpy(out, d_out, 1024 * 4, hipMemcpyDeviceToHost));
+#undef TCHECK
+    release();
+    if (bound) *bound = form ? MF_EPS_BF16 : MF_EPS;
     return FROG_OK;
 }
 
@@ -992,7 +1237,17 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
         rc = run_all(m, first, second, n_jobs, o, ja, jb);
         return rc ? rc : hand_over();
     }
+    std::vector<std::thread> collectors;
+    std::atomic<size_t> launched{0};
+    std::atomic<bool> stop{false}, failed{false};
+    std::atomic<bool> slot_free[RING];
+    std::mutex mtx;
+    std::condition_variable cv_launched, cv_slot;
     auto cleanup = [&]() {
+        { std::lock_guard<std::mutex> lk(mtx); stop.store(true); }     // an error on the way: the collectors give up where they are
+        cv_launched.notify_all(); cv_slot.notify_all();
+        for (std::thread &t : collectors) if (t.joinable()) t.join();
+        collectors.clear();
         if (partial) (void)hipFree(partial);
         if (qrange) (void)hipFree(qrange);
         if (hmax) (void)hipFree(hmax);
@@ -1014,7 +1269,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     RCHECK(hipMalloc((void **)&ranges, (size_t)RING * q_blocks_max * sizeof(uint2)));
     RCHECK(hipMalloc((void **)&d_out, (size_t)RING * max_n * sizeof(int)));
     RCHECK(hipHostMalloc((void **)&h_out, (size_t)RING * max_n * sizeof(int)));
-    for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
+    for (int r = 0; r < RING; r++) RCHECK(hipEventCreateWithFlags(&done[r], hipEventDisableTiming | hipEventBlockingSync));
     RCHECK(hipEventCreate(&t0));
     RCHECK(hipEventCreate(&t1));
     RCHECK(hipMemsetAsync(m->n_dist, 0, (STAT_BASE + 3 * STAT_SLOTS) * sizeof(unsigned long long), m->stream));
@@ -1023,31 +1278,68 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     for (int k = 1; k < n_streams; k++) RCHECK(hipStreamWaitEvent(m->extra[k - 1], t0, 0));
 
     // upstream's `match` variable lives across the queries of one ComputeMatches call
-    std::vector<int> by_query;
-    auto collect = [&](size_t pi) {
+    auto collect = [&](size_t pi, std::vector<int> &by_query, std::vector<uint32_t> &ta, std::vector<uint32_t> &tb) {
         const Pass &ps = passes[pi];
         const int *res = h_out + (size_t)(pi % RING) * max_n;
         const DevImage &Q = m->img[ps.query];
         const uint32_t nq = Q.n;
         by_query.resize(nq);
         for (uint32_t s = 0; s < nq; s++) by_query[Q.h_orig[s]] = res[s];     // back to the caller's query order
+        // into the thread's own buffers first: the jobs' vectors sit side by side in memory, and two threads appending to
+        // neighbouring jobs would hand the cache line of their headers back and forth at every push_back
+        ta.clear(); tb.clear();
         int stale = 0;                                  // `int match = 0;`, match.cpp:259
         for (uint32_t q = 0; q < nq; q++) {
             int v = by_query[q];
             if (v <= -3) { stale = -(v + 3); continue; }
             if (v == -1) continue;
             if (v >= 0) stale = v; else v = stale;      // -2: accepted, no candidate
-            if (ps.sym) { ja[ps.job].push_back(q); jb[ps.job].push_back((uint32_t)v); }     // make_pair(i, match)
-            else { ja[ps.job].push_back((uint32_t)v); jb[ps.job].push_back(q); }           // make_pair(match, i)
+            if (ps.sym) { ta.push_back(q); tb.push_back((uint32_t)v); }     // make_pair(i, match)
+            else { ta.push_back((uint32_t)v); tb.push_back(q); }           // make_pair(match, i)
         }
+        ja[ps.job].insert(ja[ps.job].end(), ta.begin(), ta.end());
+        jb[ps.job].insert(jb[ps.job].end(), tb.begin(), tb.end());
     };
+
+    // Turning a pass's result codes into its job's pair list is a walk over the queries in the caller's order (the `match`
+    // that survives from query to query) -- ~90 us of host time per pass of 20 000 queries, more than the device needs for the
+    // pass since the filter moved to the bf16 cores.  Collector threads do it beside the thread that queues the work: a job's
+    // passes (forward, then -sym's reverse) always go to the same thread, in order; a ring slot is reused once its pass has
+    // been collected.
+    static const int n_collectors = getenv("FROG_MATCH_COLLECTORS") ? std::min(8, std::max(1, atoi(getenv("FROG_MATCH_COLLECTORS")))) : 3;
+    for (int r = 0; r < RING; r++) slot_free[r].store(true);
+    for (int k = 0; k < n_collectors; k++)
+        collectors.emplace_back([&, k]() {
+            (void)hipSetDevice(m->device);
+            std::vector<int> by_query;
+            std::vector<uint32_t> ta, tb;
+            for (size_t pi = 0; pi < passes.size(); pi++) {
+                if ((int)(passes[pi].job % (uint32_t)n_collectors) != k) continue;
+                {
+                    std::unique_lock<std::mutex> lk(mtx);           // asleep until the pass is in the queue: a spinning collector
+                    cv_launched.wait(lk, [&] { return launched.load() > pi || stop.load(); });     // takes a core from the queueing thread
+                }
+                if (stop.load()) return;
+                const int slot = (int)(pi % RING);
+                if (hipEventSynchronize(done[slot]) != hipSuccess) { failed.store(true); stop.store(true); cv_slot.notify_all(); return; }
+                collect(pi, by_query, ta, tb);
+                { std::lock_guard<std::mutex> lk(mtx); slot_free[slot].store(true); }
+                cv_slot.notify_all();
+            }
+        });
 
     for (size_t pi = 0; pi < passes.size(); pi++) {
         const int slot = (int)(pi % RING);
-        if (pi >= RING) {
-            RCHECK(hipEventSynchronize(done[slot]));
-            collect(pi - RING);
+        {
+            std::unique_lock<std::mutex> lk(mtx);
+            cv_slot.wait(lk, [&] { return slot_free[slot].load() || stop.load(); });
         }
+        if (failed.load()) { frog::set_last_error("hipEventSynchronize failed in a collector thread"); cleanup(); return FROG_E_HIP; }
+        slot_free[slot].store(false);
+        struct Launched {                               // at the end of the iteration, also on `continue`
+            std::atomic<size_t> &n; size_t v; std::mutex &m; std::condition_variable &cv;
+            ~Launched() { { std::lock_guard<std::mutex> lk(m); n.store(v); } cv.notify_all(); }
+        } mark{ launched, pi + 1, mtx, cv_launched };
         const Pass &ps = passes[pi];
         const DevImage &Q = m->img[ps.query], &C = m->img[ps.cand];
         const uint32_t nq = Q.n;
@@ -1064,13 +1356,20 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
             a.nq = nq; a.nc = C.n; a.splits = splits; a.anat = o->anat;
             a.partial = partial + (size_t)slot * splits_max * max_n;
             a.n_dist = m->n_dist;
+            a.mf_eps = MF_EPS;
             uint2 *rg = ranges + (size_t)slot * q_blocks_max;
             const bool mfma = hmax != nullptr && Q.finite && C.finite && C.n > 0;
             if (mfma) {
                 // candidate tiles per block: few = even load over the 256 CUs (the query blocks' ranges differ a lot in
                 // length), many = the block's 256 queries are loaded as operands less often.  Measured, image pairs/s
                 // at 20 000 x 20 000: 2 tiles 1584, 4: 2059, 8: 2249, 16: 2110
-                static const uint32_t tiles_per_block = getenv("FROG_MATCH_TILES") ? (uint32_t)std::max(1, atoi(getenv("FROG_MATCH_TILES"))) : 8u;
+                // The bf16 form (round 5) multiplies a tile five times faster and pays the same for its block's query operands:
+                // 64 tiles per block (image pairs/s with 4 / 8 / 16 / 32 / 64 / 128: 7 957 / 8 606 / 8 475 / 8 474 / 9 209 / 8 562;
+                // the blocks of a pass no longer fill the chip -- 158 of them -- but four streams of passes do)
+                static const int tiles_env = getenv("FROG_MATCH_TILES") ? std::max(1, atoi(getenv("FROG_MATCH_TILES"))) : 0;
+                static const bool force_f32 = getenv("FROG_MATCH_F32") != nullptr;
+                const bool bf16 = !force_f32 && Q.bf16_ok && C.bf16_ok;
+                const uint32_t tiles_per_block = tiles_env ? (uint32_t)tiles_env : (bf16 ? 64u : 8u);
                 a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + tiles_per_block - 1) / tiles_per_block));
                 QRange *qr = qrange + (size_t)slot * max_n;
                 float *hm = hmax + (size_t)slot * hmax_slot;
@@ -1082,9 +1381,13 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 // SIMD instead of 3); measured the same within noise (5 971 vs 5 982 image pairs/s), so 2 stays the default
                 static const int mf_groups = getenv("FROG_MATCH_GROUPS") && atoi(getenv("FROG_MATCH_GROUPS")) == 4 ? 4 : 2;
                 match_qrange_kernel<<<q_blocks, MATCH_BLOCK, 0, st>>>(a, qr, rg);
+                // the bf16 matrix cores by default (16 x the f32 rate, a wider but proven bound: match_mfma16_kernel);
+                // FROG_MATCH_F32=1 keeps the f32 chain (A/B, tests)
+                a.mf_eps = bf16 ? MF_EPS_BF16 : MF_EPS;
 #define MF_LAUNCH(DD, AA)                                                                                               \
                 do {                                                                                                    \
-                    if (mf_groups == 4) match_mfma_kernel<DD, AA, 4><<<mgrid, MATCH_BLOCK / 2, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm); \
+                    if (bf16) match_mfma16_kernel<DD, AA><<<mgrid, MATCH_BLOCK, 0, st>>>(a, rg, qr, (const uint4 *)Q.mfb16, (const uint4 *)C.mfa16, hm); \
+                    else if (mf_groups == 4) match_mfma_kernel<DD, AA, 4><<<mgrid, MATCH_BLOCK / 2, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm); \
                     else match_mfma_kernel<DD, AA, 2><<<mgrid, MATCH_BLOCK, 0, st>>>(a, rg, qr, Q.mf, C.mf, hm);       \
                     match_scan_kernel<DD, AA><<<(nq + SCAN_BLOCK / 16 - 1) / (SCAN_BLOCK / 16), SCAN_BLOCK, 0, st>>>(a, rg, qr, Q.norm, C.norm_max, hm, \
                                                                                        o->threshold, o->dist2second, dst); \
@@ -1124,7 +1427,9 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     }
     RCHECK(hipEventRecord(t1, m->stream));
     RCHECK(hipStreamSynchronize(m->stream));
-    for (size_t pi = passes.size() > RING ? passes.size() - RING : 0; pi < passes.size(); pi++) collect(pi);
+    for (std::thread &t : collectors) t.join();         // every pass has been queued: they run to the end of the list
+    collectors.clear();
+    if (failed.load()) { frog::set_last_error("hipEventSynchronize failed in a collector thread"); cleanup(); return FROG_E_HIP; }
     float ms = 0;
     RCHECK(hipEventElapsedTime(&ms, t0, t1));
     std::vector<unsigned long long> stat(STAT_BASE + 3 * STAT_SLOTS, 0ull);

@@ -154,3 +154,18 @@ def read_keypoints(path):
 def write_keypoints(path, kp):
     v = kp.view()
     check(_abi.host_lib().frog_keypoints_write(str(path).encode(), C.byref(v)), "frog_keypoints_write")
+
+
+def filter_products(cand, query, form, device=0):
+    """The matrix-core filter's approximate -|q - c|^2 / 2 for 32 candidates x 32 queries (rows of 48 or 64 floats):
+    form 0 = f32 chain, 1 = bf16 splits.  Returns (products[32 candidates][32 queries], bound relative to |q|^2 + |c|^2 on
+    -2 x product)."""
+    lib = _abi.hip_lib()
+    c = np.ascontiguousarray(cand, np.float32)
+    q = np.ascontiguousarray(query, np.float32)
+    assert c.shape == q.shape and c.shape[0] == 32 and c.shape[1] in (48, 64)
+    out = np.empty((32, 32), np.float32)
+    bound = C.c_float(0)
+    check(lib.frog_match_test_products(device, c.ctypes.data_as(_abi.c_float_p), q.ctypes.data_as(_abi.c_float_p), c.shape[1],
+                                       int(form), out.ctypes.data_as(_abi.c_float_p), C.byref(bound)), "frog_match_test_products")
+    return out, float(bound.value)

@@ -77,6 +77,12 @@ void frog_match_free(void *p);
 
 /* HIP-event time of the pairing kernels of the last frog_matcher_run (ms) and the number of
  * (query, candidate) descriptor distances it evaluated. */
+/* Test hook: the matrix-core filter's approximate -|q - c|^2 / 2 for 32 candidates x 32 queries (dim = 48 or 64, row-major
+ * descriptors), out[c * 32 + q]: form 0 = the f32 instruction chain, 1 = three products of bf16 (hi, lo) splits -- through the
+ * operand builders and instruction sequences the filter kernels use.  *bound = the relative bound (on -2 x product, in units
+ * of |q|^2 + |c|^2) the verification stage allows for that form. */
+int frog_match_test_products(int device, const float *cand, const float *query, uint32_t dim, int form, float *out, float *bound);
+
 int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *distances);
 
 #ifdef __cplusplus

@@ -9,6 +9,15 @@ from oracle.oracle_api import match_run
 pytestmark = pytest.mark.gpu
 
 
+def note(name, value):
+    """Numbers worth keeping from a GPU run (gpurun_out/test_numbers.txt travels back with the call)."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "test_numbers.txt"), "a") as fh:
+            fh.write(f"{name} {value}\n")
+
+
 def same(got, want):
     assert len(got) == len(want)
     for k, ((ga, gb), (wa, wb)) in enumerate(zip(got, want)):
@@ -117,6 +126,66 @@ def test_matrix_core_filter_corner_cases(monkeypatch):
             monkeypatch.delenv("FROG_MATCH_VALU")
             same(got, want); same(vec, want)
             assert len(want[0][0]) > 100 or imgs is base
+
+
+def test_bf16_filter_products_within_the_bound():
+    """match.hip match_mfma16_kernel: -|q - c|^2 / 2 from three products of bf16 (hi, lo) splits on the bf16 matrix cores.
+    The verification stage allows |-2 P - d| <= 2^-12 (|q|^2 + |c|^2); the derivation (5.3e-5 on P, 1.2e-4 on -2 P) assumes
+    something about the instruction's internal f32 accumulation that the ISA document does not state, so the products are
+    MEASURED here against f64, through the kernels' own operand builder and instruction sequence: unit-norm descriptors,
+    norms of 1e-3 and 37, near-identical pairs (the distance is what is left of a cancellation of three terms of size S/2),
+    descriptors of mixed magnitudes, one-hot descriptors, both descriptor lengths -- and the f32 chain beside it."""
+    from frog_amd.match import filter_products
+    rng = np.random.default_rng(5)
+    f = np.float32
+    worst = {0: 0.0, 1: 0.0}
+    for dim in (48, 64):
+        cases = []
+        for scale in (1.0, 1e-3, 37.0):
+            c = rng.normal(size=(32, dim)); c /= np.linalg.norm(c, axis=1, keepdims=True)
+            q = rng.normal(size=(32, dim)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+            cases.append(((c * scale).astype(f), (q * scale).astype(f)))
+        c = np.abs(rng.normal(size=(32, dim))); c /= np.linalg.norm(c, axis=1, keepdims=True)          # SURF-like: non-negative
+        cases.append((c.astype(f), (c + 1e-4 * rng.normal(size=(32, dim))).astype(f)))                 # near-identical
+        cases.append((c.astype(f), c[::-1].astype(f)))
+        m = (rng.normal(size=(32, dim)) * 10.0 ** rng.integers(-6, 3, size=(32, dim))).astype(f)       # mixed magnitudes
+        cases.append((m, (m * (1 + 1e-3 * rng.normal(size=m.shape))).astype(f)))
+        hot = np.zeros((32, dim), f); hot[np.arange(32), rng.integers(0, dim, 32)] = f(3.0)
+        cases.append((hot, hot[rng.permutation(32)]))
+        ones = np.full((32, dim), f(1.0) + f(2.0) ** -9, f)                                            # every entry half way between two bf16 values
+        cases.append((ones, (ones * f(1.001)).astype(f)))
+        for cand, query in cases:
+            d = ((cand.astype(np.float64)[:, None, :] - query.astype(np.float64)[None, :, :]) ** 2).sum(axis=2)
+            S = (cand.astype(np.float64) ** 2).sum(axis=1)[:, None] + (query.astype(np.float64) ** 2).sum(axis=1)[None, :]
+            for form in (0, 1):
+                P, bound = filter_products(cand, query, form)
+                err = np.abs(-2.0 * P.astype(np.float64) - d) / S
+                worst[form] = max(worst[form], float(err.max()))
+                assert err.max() <= 0.5 * bound, (dim, form, float(err.max()), bound)      # half the bound: the other half is head-room
+    note("filter_products_max_error_over_S_f32_bf16", f"{worst[0]:.3e} {worst[1]:.3e} (bounds 3.05e-05 2.44e-04)")
+
+
+def test_bf16_and_f32_filters_give_the_exact_kernels_pairs(monkeypatch):
+    """The default filter is the bf16 one; FROG_MATCH_F32=1 keeps the f32 chain, FROG_MATCH_VALU=1 no filter at all: the three
+    pair lists are the oracle's, on a group with duplicates and near-ties and for 64-value descriptors (13 steps of K = 16)."""
+    base = synthetic_keypoints(3, 3000, seed=29)
+    rows = [k.rows() for k in base]
+    rng = np.random.default_rng(3)
+    rows[1][:500, 6:] = rows[0][rng.integers(0, 3000, 500), 6:] + np.float32(2e-4) * rng.normal(size=(500, 48)).astype(np.float32)
+    rows[2][:300, 6:] = rows[0][7, 6:]
+    imgs = [Keypoints.from_rows(r) for r in rows]
+    wide = [Keypoints(k.xyz, k.scale, k.laplacian, k.response, np.concatenate([k.desc, k.desc[:, :16] * np.float32(0.5)], axis=1)) for k in imgs]
+    for group in (imgs, wide):
+        jobs = [(0, 1), (0, 2), (1, 2)]
+        opts = dict(threshold=1e9, dist2second=0.95, sym=1)
+        want = match_run(group, jobs, **opts)
+        for env in ({}, {"FROG_MATCH_F32": "1"}, {"FROG_MATCH_VALU": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = Matcher(group).run(jobs, **opts)
+            for k in env:
+                monkeypatch.delenv(k)
+            same(got, want)
 
 
 def test_scale_ratio_boundary_and_filters():
