@@ -130,6 +130,42 @@ def test_inlier_weight_pair_against_the_reference_build():
     assert n_form[0] > 0 and n_form[1] > 0 and n_form[2] > 0
 
 
+def test_inlier_weight_pair_random_mixtures():
+    """scripts/fuzz_weight_pair.py in small: 60 random pairs of mixtures (c1 over four decades, c2 / c1 from 0.5 to 1000, ratios
+    down to 1e-6 and up to 1 - 1e-6) and thresholds from 0.01 to 0.99 -- VALUES within 2^-16 of the reference build, no link that
+    the reference build calls an inlier dropped.  (400 pairs, same generator: worst 7.1e-6.)"""
+    if ref_lib() is None:
+        pytest.fail("oracle/_ref/libfrog_refstats.so (the reference's stats.cxx) was not built")
+    rng = np.random.default_rng(123)
+    worst = 0.0
+    for _ in range(60):
+        def mix():
+            c1 = float(np.float32(10.0 ** rng.uniform(-2, 2)))
+            c2 = float(np.float32(c1 * 10.0 ** rng.uniform(-0.3, 3)))
+            r = float(np.float32(rng.choice([rng.uniform(0.01, 0.99), 10.0 ** rng.uniform(-6, -2), 1 - 10.0 ** rng.uniform(-6, -2)])))
+            return (c1, c2, r)
+        ma, mb = mix(), mix()
+        thr = float(rng.choice([0.5, 0.5, 0.1, 0.9, 0.01, 0.99]))
+        ra, rb = Stats("ref"), Stats("ref")
+        ra.set_params(list(ma)); rb.set_params(list(mb))
+        d = np.concatenate([min(ma[0], mb[0]) * np.geomspace(0.01, 80.0, 20000), rng.uniform(0, 5 * max(ma[1], mb[1]), 5000),
+                            np.linspace(0, 0.3, 301)]).astype(np.float32)
+        d2 = (d * d).astype(np.float32)
+        want = np.minimum(ra.prob_n(np.sqrt(d2)), rb.prob_n(np.sqrt(d2))).astype(np.float64)
+        k = int(np.argmin(np.abs(want - thr)))
+        dense = (d[k] + np.arange(-2000, 2000) * np.spacing(d[k])).astype(np.float32)
+        d2 = np.concatenate([d2, (dense * dense).astype(np.float32)])
+        want = np.minimum(ra.prob_n(np.sqrt(d2)), rb.prob_n(np.sqrt(d2))).astype(np.float64)
+        w, form = device_inlier_weight_pair(ma, mb, d2, thr)
+        value = form < 2
+        assert np.all(np.isfinite(w[value])), (ma, mb, thr)
+        if value.any():
+            worst = max(worst, float(np.max(np.abs(w[value].astype(np.float64) - want[value]))))
+        assert not np.any(want[form == 2] >= thr), (ma, mb, thr)
+    note("inlier_weight_pair_random_mixtures_max_abs_dev", worst)
+    assert worst <= 2.0 ** -16, worst
+
+
 # ---- integer outputs, exactly -------------------------------------------------------------------------------
 
 def lockstep_to_deformable(pairs, iters=20, **opt):
