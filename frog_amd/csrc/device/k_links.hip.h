@@ -6,17 +6,20 @@
 // loads of two steps at a time, the partner point gathered as a 12-byte load from the packed xyz2
 // table, the own point and the partner image's constants read from LDS; a block only ever
 // touches the coordinates of ONE partner group, which stay in its XCD's L2.  Nothing here is
-// GEMM shaped: it is a gather + weighted reduction, no MFMA.  What bounds it (rocprofv3, DESIGN.md
-// section 4): the ~64 cache-line requests a CU's L1 keeps in flight and, about equally, vector-ALU
-// issue (most of a step's instructions are the two inlier probabilities).
+// GEMM shaped: it is a gather + weighted reduction, no MFMA.  What bounds it (rocprofv3 and the A/B builds of
+// DESIGN.md sections 4, 4j): the texture path's rate for a step's 64 scattered 12-byte gathers.  Not the vector ALU --
+// the deformable sweeps' weight went from two inlier probabilities (a third of a step's vector instructions) to one
+// exponential in round 5 for 2 % -- and not the number of loads in flight (one more step of run-ahead: 10 % slower).
 //
 // Arithmetic contract (reference lines in the comments):
 //   dist2, dist  -- f32, no FMA contraction, correctly rounded sqrt: bit-exact
 //                   with the reference, so `d < 0.1` and the sample values agree.
-//   inlier weight -- f32 from d2 with precomputed constants, v_exp_f32 and div_fast below: within 2^-16 of the
-//                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92), bound derived at
-//                   inlier_probability; weights within 1e-4 of the inlier threshold are recomputed with the
-//                   reference's own arithmetic, so no decision depends on the fast form.
+//   inlier weight -- f32 from d2 with precomputed constants: linear and counting sweeps v_exp_f32 and div_fast for
+//                   each image's probability (inlier_probability), deformable sweeps ONE exponential for the smaller
+//                   of the two inside certified ranges (inlier_weight_pair); either way within 2^-16 of the
+//                   reference's mixed f32/f64 getInlierProbability (stats.h:84-92), bounds derived at the two
+//                   functions; weights within 1e-4 of the inlier threshold are recomputed with the
+//                   reference's own arithmetic, so no decision depends on a fast form.
 //   linear sums  -- f32 products, f64 accumulation (imageGroup.cxx:1102-1117);
 //                   per-tile partials reduced in a fixed order (deterministic).
 //   deformable   -- f32 products and f32 per-point running sums in partner order,
