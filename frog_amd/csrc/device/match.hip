@@ -1240,8 +1240,13 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
         };
         const size_t n_fill = offset[n_jobs] > (1u << 22) ? std::min<size_t>(4, n_jobs) : 1;
         std::vector<std::thread> fillers;
-        for (size_t t = 1; t < n_fill; t++) fillers.emplace_back(fill, n_jobs * t / n_fill, n_jobs * (t + 1) / n_fill);
-        fill(0, n_jobs / n_fill);
+        size_t done_to = n_jobs / n_fill;             // jobs [0, done_to) are this thread's; a slice whose thread cannot be started joins them
+        std::vector<std::pair<size_t, size_t>> mine{ { 0, done_to } };
+        for (size_t t = 1; t < n_fill; t++) {
+            const size_t k0 = n_jobs * t / n_fill, k1 = n_jobs * (t + 1) / n_fill;
+            try { fillers.emplace_back(fill, k0, k1); } catch (...) { mine.push_back({ k0, k1 }); }
+        }
+        for (const auto &r : mine) fill(r.first, r.second);
         for (std::thread &t : fillers) t.join();
         return FROG_OK;
     };
@@ -1321,7 +1326,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     static const int n_collectors = getenv("FROG_MATCH_COLLECTORS") ? std::min(8, std::max(1, atoi(getenv("FROG_MATCH_COLLECTORS")))) : 3;
     for (int r = 0; r < RING; r++) slot_free[r].store(true);
     for (int k = 0; k < n_collectors; k++)
-        collectors.emplace_back([&, k]() {
+        try { collectors.emplace_back([&, k]() {
             (void)hipSetDevice(m->device);
             std::vector<int> by_query;
             std::vector<uint32_t> ta, tb;
@@ -1338,7 +1343,11 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 { std::lock_guard<std::mutex> lk(mtx); slot_free[slot].store(true); }
                 cv_slot.notify_all();
             }
-        });
+        }); } catch (...) {                             // no thread to be had: nothing has been queued yet
+            frog::set_last_error("cannot start a collector thread");
+            cleanup();
+            return FROG_E_NOMEM;
+        }
 
     for (size_t pi = 0; pi < passes.size(); pi++) {
         const int slot = (int)(pi % RING);
