@@ -142,7 +142,10 @@ def roofline_and_iteration(prof, cull_def, cull_lin, l_own, p_own, i_own, n_lin,
                 "bytes_per_steady_launch": 20.0 * walked + 12.0 * p_own,
                 "steady_launches": {"launches": int(launches), "avg_launch_ms": ms / launches if launches else None},
                 "frac_algorithmic_equiv": (alg_bytes * all_launches / (all_ms * 1e-3) / 1e9 / 8000.0) if all_launches else None,
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "timed_launches": "HIP events on the launch's own dispatch packet, live in the timed region: every launch (--kernel-times) / "
+                                  "every list-writing launch and one steady launch in four, avg_launch_ms = launches x the mean of the "
+                                  "timed ones (default; FROG_BENCH_PROFILE=2 times every sweep: 1.6 % slower line, same averages)"}
     if bl:
         roofline["list_writing_launches"] = {"launches": int(bl), "avg_launch_ms": bms / bl, "walks": "every half-link"}
     if listed[0]:
@@ -327,7 +330,7 @@ def native_plan(args, n_lin, per_level, profile, time_comm, warmup=None):
     plan.stat_interval = 10
     plan.deformable_alpha = 0.02
     plan.anchor[0] = plan.anchor[1] = plan.anchor[2] = 0.5
-    plan.profile = profile
+    plan.profile = int(os.environ.get("FROG_BENCH_PROFILE", profile))        # experiment switch (0: no event on any launch, 2: on every sweep)
     plan.time_comm = int(time_comm)
     return plan
 
@@ -386,7 +389,9 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     cl, comm = None, None
     if world > 1:
         cl, comm = create_native_comm(rdv, transport, ctx, shards, pairs.point_offset, local_rank)
-    plan = native_plan(args, n_lin, per_level, 1 if args.kernel_times else 2, world > 1)
+    # mode 3: HIP events on every list-writing sweep and on one steady sweep in four (frog_profile_enable): an event-carrying
+    # launch starts ~6 us late and holds its successor back -- with all of them timed that was 1.6 % of this line
+    plan = native_plan(args, n_lin, per_level, 1 if args.kernel_times else 3, world > 1)
     if proxy is not None:
         plan.proxy_xyz2 = proxy[0].ctypes.data
         plan.proxy_em = proxy[1].ctypes.data
@@ -659,7 +664,7 @@ def run_torch(args, rank, world, local_rank, backend, rdv):
         grp.updateLinearTransforms()
         grp.transformPoints()
         it += 1
-    engine.profile_enable(1 if args.kernel_times else 2)
+    engine.profile_enable(1 if args.kernel_times else 3)
     phase_s, phase_k = {}, {}
     prof = {n: [0.0, 0] for n in _abi.FROG_K_NAMES}
 

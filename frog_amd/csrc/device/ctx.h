@@ -387,7 +387,11 @@ struct frog_ctx {
 
     // live timing
     bool point_sums_stale = false;             // the last deformable step left the per-point sums as N_XCD partial sums
-    int profiling = 0;                         // 0 off, 1 every kernel group, 2 the two half-link sweeps only
+    int profiling = 0;                         // 0 off, 1 every kernel group, 2 the half-link sweeps only (3 = 2 with every fourth steady launch timed)
+    int profile_stride = 1;                    // mode 2: every launch of a steady sweep carries events; mode 3: one in four
+    uint64_t span_seen[FROG_K_COUNT_] = {};    // launches of the group since frog_profile_read(reset), timed or not
+    double timed_ms[FROG_K_COUNT_] = {};       // ... the timed ones: their sum and count
+    uint64_t timed_n[FROG_K_COUNT_] = {};
     struct TimedSpan { hipEvent_t a, b; int slot; };
     std::vector<TimedSpan> spans;             // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;

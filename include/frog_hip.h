@@ -316,13 +316,15 @@ enum {
     FROG_K_COUNT_
 };
 typedef struct frog_kernel_time {
-    double   ms_total;      /* sum of hipEventElapsedTime over the launches */
-    uint64_t launches;
+    double   ms_total;      /* launches x the mean hipEventElapsedTime of the timed launches (= their sum when all are timed) */
+    uint64_t launches;      /* all launches of the group, timed or not */
 } frog_kernel_time;
 /* on = 1: every launch of the kernels above is bracketed by a pair of hipEvents recorded on the
  * context's stream.  The markers keep consecutive kernels from overlapping their tails and
- * ramp-ups: measured 6 % of the iteration rate with all seven groups bracketed.  on = 2 brackets
- * the half-link sweeps only (the kernels a roofline is quoted for): < 1 %.  on = 0: off. */
+ * ramp-ups: measured 6 % of the iteration rate with all seven groups bracketed.  on = 2 puts events on
+ * the half-link sweeps only (the kernels a roofline is quoted for), on their own dispatch packets: 1.6 % -- such a launch starts
+ * ~6 us late and holds its successor back ~5.  on = 3: as 2 with events on every list-writing sweep and on ONE steady sweep
+ * in four (the steady launches of a level are alike to 1 %): 0.4 %.  on = 0: off. */
 int frog_profile_enable(frog_ctx *ctx, int on);
 /* Waits for the stream, adds up the recorded pairs into out[FROG_K_COUNT_];
  * reset != 0 clears the accumulators afterwards. */
