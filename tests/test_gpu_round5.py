@@ -174,3 +174,31 @@ def test_two_collectives_with_rejected_steps(tmp_path):
     assert n_rejected >= 2 and n_rejected == out1.count("Iteration canceled"), (n_rejected, out1.count("Iteration canceled"))
     _same_files(two, three, pairs.n_images)
     _compare_runs(one, two, pairs.n_images)
+
+
+# ---- sampled timing of the sweeps (frog_profile_enable(ctx, 3)) ------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_sampled_sweep_timing_counts_every_launch():
+    """frog_profile_enable(ctx, 3): HIP events on every list-writing sweep and on one steady sweep in four; frog_profile_read
+    reports ALL launches of a group at the mean of the timed ones.  Against mode 2 (every sweep timed) on the same schedule: the
+    same launch counts, average launch times within 10 % (they agree to 0.1 % on the benchmark group; this one is small and its
+    launches are short), no other group reported -- and identical results (timing does not touch the arithmetic)."""
+    pairs = Pairs.synthetic(12, 4000, 1500, seed=9)
+    out = {}
+    for mode in (2, 3):
+        g = ImageGroup(pairs)
+        g.linearIterations, g.deformableLevels, g.deformableIterations = 12, 2, 18
+        g.profile_enable(mode)
+        E = g.run()
+        out[mode] = (g.profile_read(), E, g.points()[1].copy())
+    k2, k3 = out[2][0], out[3][0]
+    for name in ("sweep_linear", "sweep_deformable", "sweep_build", "sweep_linear_build"):
+        assert k2[name][1] == k3[name][1], (name, k2[name], k3[name])
+        if k2[name][1]:
+            a2, a3 = k2[name][0] / k2[name][1], k3[name][0] / k3[name][1]
+            assert abs(a2 - a3) <= 0.10 * a2, (name, a2, a3)
+    assert k3["sweep_deformable"][1] >= 30 and k3["sweep_linear"][1] >= 8
+    for name in ("scatter", "lattice", "transform", "stats"):
+        assert k2[name][1] == 0 and k3[name][1] == 0
+    assert out[2][1] == out[3][1] and np.array_equal(out[2][2], out[3][2])
