@@ -2,9 +2,14 @@
 // TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and the cpu_baseline leg of the
 // benches may use it; the product (libfrog_hip.so) never does.
 //
-// PARITY UNPINNED: match.cpp needs boost (filesystem, iostreams) and the transform reader's
-// VTK, none of which exist in this image, so the reference's `match` cannot be built and its
-// repository holds no test vectors for it.  What is restated, line by line:
+// PARITY PINNED (round 6) for ComputeMatches and `norm`: match.cpp as a whole cannot be built here (its main needs boost
+// filesystem / iostreams and the VTK transform reader), but `struct Point` (:28-48), the scalar `norm` (:243-251) and
+// ComputeMatches (:255-336) are std-only, so `make -C oracle ref` compiles exactly those, cut out of the file where it lies, into
+// oracle/_ref/libfrog_refmatch.so (ref_match_api.cpp).  tests/test_match_oracle_ref.py: this restatement returns the reference
+// build's pair lists on every option set (-d, -d2, -anat, -sym, -all, ties, exact duplicates, empty images, six descriptor
+// lengths), its norm has the same bits, and tests/golden/match_golden.json holds the reference build's answers for where
+// oracle/_ref is absent; the hand-worked cases of tests/test_match_oracle.py run against both.  The pair LOOP of main (:616-660,
+// which image pairs, in which order, -sym appended) stays a restatement: main is what cannot be built.  What is restated:
 //   norm (scalar build)          match.cpp:242-251
 //   ComputeMatches               match.cpp:255-336
 //   the pair loop of main        match.cpp:616-660

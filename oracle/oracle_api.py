@@ -415,6 +415,56 @@ def match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, al
     return [(a[int(offset[k]):int(offset[k + 1])], b[int(offset[k]):int(offset[k + 1])]) for k in range(n)]
 
 
+_ref_match = None
+
+
+def ref_match_lib():
+    """The reference's own ComputeMatches / scalar norm / struct Point (match/match.cpp:28-48, :243-251, :255-336), cut out by
+    oracle/Makefile into oracle/_ref/libfrog_refmatch.so; None when it was not built."""
+    global _ref_match
+    if _ref_match is None:
+        path = os.path.join(_HERE, "_ref", "libfrog_refmatch.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.refmatch_compute.restype = C.c_long
+        L.refmatch_compute.argtypes = ([C.c_uint32] + [C.c_void_p] * 4) * 2 + [C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_float,
+                                                                              C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        L.refmatch_norm.restype = C.c_float
+        L.refmatch_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        assert L.refmatch_sizeof_point_id() == 4            # INT_PTIDS, the reference's default build
+        _ref_match = L
+    return _ref_match
+
+
+def ref_match_run(images, jobs, threshold=0.22, dist2second=1.0, anat=0.0, sym=0, all=0):
+    """match_run's interface over the REFERENCE build: per job ComputeMatches(first, second, ...) as main calls it
+    (match.cpp:642), with `sym` the reverse direction ComputeMatches(second, first, ..., true) appended (match.cpp:644-648)."""
+    L = ref_match_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libfrog_refmatch.so not built")
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+
+    def one(cand, qry, is_sym):
+        arrs = [f32(cand.xyz), f32(cand.scale), f32(cand.laplacian), f32(cand.desc), f32(qry.xyz), f32(qry.scale),
+                f32(qry.laplacian), f32(qry.desc)]
+        dim = arrs[3].shape[1] if arrs[3].ndim == 2 else arrs[7].shape[1]
+        cap = max(1, cand.n * qry.n if all else qry.n)
+        a, b = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        n = L.refmatch_compute(cand.n, *[x.ctypes.data for x in arrs[:4]], qry.n, *[x.ctypes.data for x in arrs[4:]], dim,
+                               threshold, dist2second, int(all), anat, int(is_sym), a.ctypes.data, b.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return a[:n], b[:n]
+    out = []
+    for first, second in jobs:
+        a, b = one(images[first], images[second], False)
+        if sym:
+            a2, b2 = one(images[second], images[first], True)
+            a, b = np.concatenate([a, a2]), np.concatenate([b, b2])
+        out.append((a, b))
+    return out
+
+
 # ---- transform chains (oracle/chain_oracle.cpp) --------------------------------------------
 def chain_apply(links, points, jacobian=False):
     """Forward evaluation (and Jacobians) of a chain of frog_amd.chain.Link on the CPU."""

@@ -107,8 +107,15 @@ def lattice_deviation(g, ref, k, i, pts, weights):
     # the same on a regular lattice of points over the bounding box of the image's points (what a resampler evaluates)
     lo, hi = pts.min(axis=0).astype(np.float64), pts.max(axis=0).astype(np.float64)
     dense = np.stack(np.meshgrid(*[np.linspace(lo[d], hi[d], DENSE_PER_AXIS) for d in range(3)], indexing="ij"), axis=-1).reshape(-1, 3)
+    worst = int(np.argmax(err))
+    hit = idx == worst
+    own_support, n_hit = float(wt[hit].sum()), int(np.count_nonzero(hit.any(axis=1)))
     return {"raw": float(np.max(err)), "weighted": float(np.max(err * weights)), "field": dev_d, "dense": field_dev(dense),
-            "weak": int(np.count_nonzero(weights < 1.0)), "nodes": len(rc)}
+            "weak": int(np.count_nonzero(weights < 1.0)), "nodes": len(rc),
+            # where the largest raw deviation sits, and how well the group's data determine that node (1 = fully)
+            "raw_node": worst, "raw_node_weight": float(weights[worst]),
+            # ... and this image's own support there: sum of its points' basis weights, and how many of its points reach the node
+            "raw_node_support": own_support, "raw_node_points": n_hit}
 
 
 def compare_lattice(g, ref, k, i, pts, weights):

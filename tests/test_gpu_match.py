@@ -60,6 +60,33 @@ def test_match_all_identical_to_oracle(opts):
         assert all((b == 0).all() if opts.get("sym") else (a == 0).all() for a, b in got)
 
 
+@pytest.mark.parametrize("opts", [dict(threshold=1.0), dict(threshold=0.6, dist2second=0.8), dict(threshold=1.0, anat=30.0, sym=1),
+                                  dict(threshold=1e10), dict(all=1, threshold=0.9, sym=1), dict(all=1, threshold=1.2, anat=40.0)])
+def test_pairs_identical_to_the_reference_build(opts):
+    """The device's pair lists against the REFERENCE's own ComputeMatches (oracle/_ref/libfrog_refmatch.so: match.cpp:255-336
+    with its scalar norm and struct Point, compiled as they are; oracle/ref_match_api.cpp) -- no restatement in between."""
+    from oracle import oracle_api
+    if oracle_api.ref_match_lib() is None:
+        pytest.skip("oracle/_ref/libfrog_refmatch.so not built (reference tree absent)")
+    imgs = synthetic_keypoints(4, 1500, seed=17)
+    imgs[2] = Keypoints.from_rows(imgs[2].rows()[:777])
+    imgs[3] = Keypoints.from_rows(imgs[3].rows()[:33])
+    jobs = all_pairs(4) + [(3, 0)]
+    want = oracle_api.ref_match_run(imgs, jobs, **opts)
+    same(Matcher(imgs).run(jobs, **opts), want)
+    assert sum(len(a) for a, _ in want) > 100
+
+
+def test_pairs_identical_to_the_golden_fixture_of_the_reference_build():
+    """tests/golden/match_golden.json (generated from the reference build by tests/golden/make_match_golden.py)."""
+    from test_match_oracle_ref import golden
+    imgs, jobs, cases = golden()
+    m = Matcher(imgs)
+    for case in cases:
+        want = [(np.array(a, np.uint32), np.array(b, np.uint32)) for a, b in case["pairs"]]
+        same(m.run(jobs, **case["options"]), want)
+
+
 @pytest.mark.parametrize("dim", [8, 100])
 def test_match_all_descriptor_lengths_and_empty_images(dim):
     imgs = synthetic_keypoints(3, 300, dim=dim, seed=dim)

@@ -261,7 +261,11 @@ def fast_against_reference_order(pairs, li, dl, di, monkeypatch, images, **opt):
         d = {"raw": 0.0, "weighted": 0.0, "field": 0.0}
         for i in images:
             r = lattice_deviation(fast.g, adapter, k, i, snaps[k][po[i]:po[i + 1]], w)
-            for key in d:
+            if r["raw"] >= d["raw"]:
+                d["raw_image"] = int(i)
+                for key in ("raw_node", "raw_node_weight", "raw_node_support", "raw_node_points"):
+                    d[key] = r[key]
+            for key in ("raw", "weighted", "field"):
                 d[key] = max(d[key], r[key])
             d["weak"], d["nodes"] = r["weak"], r["nodes"]
         d["dense_field"], d["max_disp"] = dense_field_deviation(fast.g, ref.g, k, images, snaps[k])

@@ -1,10 +1,22 @@
 """Pairing oracle (oracle/match_oracle.cpp) against hand-worked cases of
-ComputeMatches (match/match.cpp:255-336).  The reference's `match` cannot be built here
-(boost, VTK): these known-answer cases are what pins the restatement."""
+ComputeMatches (match/match.cpp:255-336) -- and, since round 6, the same cases against the REFERENCE's own ComputeMatches
+(oracle/_ref/libfrog_refmatch.so: the std-only pieces of match.cpp compiled as they are, oracle/ref_match_api.cpp), so the
+hand-worked answers are checked against upstream's code too.  tests/test_match_oracle_ref.py compares the two on whole
+synthetic groups and on a committed fixture."""
 import numpy as np
+import pytest
 
 from frog_amd.match import Keypoints, all_pairs
-from oracle.oracle_api import match_run
+from oracle import oracle_api
+
+
+@pytest.fixture(params=["oracle", "reference"])
+def match_run(request):
+    if request.param == "oracle":
+        return oracle_api.match_run
+    if oracle_api.ref_match_lib() is None:
+        pytest.skip("oracle/_ref/libfrog_refmatch.so not built (reference tree absent)")
+    return oracle_api.ref_match_run
 
 
 def kp(desc, scale=None, sign=None, xyz=None):
@@ -16,7 +28,7 @@ def kp(desc, scale=None, sign=None, xyz=None):
                      np.zeros(n, np.float32), desc)
 
 
-def test_nearest_and_ratio_test():
+def test_nearest_and_ratio_test(match_run):
     # image 0 = candidates, image 1 = queries (ComputeMatches(points2 = first, points1 = second));
     # all values exactly representable, so the f32 arithmetic is exact
     cand = kp([[0, 0], [1, 0], [0, 4]])
@@ -44,14 +56,14 @@ def test_nearest_and_ratio_test():
     assert a.tolist() == []
 
 
-def test_single_candidate_has_no_second():
+def test_single_candidate_has_no_second(match_run):
     cand = kp([[0, 0]])
     qry = kp([[0.3, 0.4]])
     (a, b), = match_run([cand, qry], [(0, 1)], threshold=0.6, dist2second=0.5)
     assert a.tolist() == [0] and b.tolist() == [0]          # d2 == FLT_MAX accepts whatever the ratio
 
 
-def test_sign_and_scale_filters():
+def test_sign_and_scale_filters(match_run):
     cand = kp([[0, 0], [0, 0.01]], scale=np.array([1.0, 1.0], np.float32), sign=np.array([1.0, -1.0], np.float32))
     qry = kp([[0, 0.01], [0, 0.01], [0, 0.01]], scale=np.array([1.0, 1.31, 1 / 1.31], np.float32),
              sign=np.array([-1.0, 1.0, 1.0], np.float32))
@@ -64,7 +76,7 @@ def test_sign_and_scale_filters():
     assert b.tolist() == [0]
 
 
-def test_anatomical_test_and_sym():
+def test_anatomical_test_and_sym(match_run):
     xyz_c = np.array([[0, 0, 0], [100, 0, 0]], np.float32)
     cand = kp([[0, 0], [0, 0.2]], xyz=xyz_c)
     qry = kp([[0, 0.19]], xyz=np.array([[1, 0, 0]], np.float32))
@@ -77,7 +89,7 @@ def test_anatomical_test_and_sym():
     assert a.tolist() == [1, 0, 1] and b.tolist() == [0, 0, 0]
 
 
-def test_stale_match_variable_quirk():
+def test_stale_match_variable_quirk(match_run):
     # `match` is declared outside the query loop (match.cpp:259): a query without any candidate that
     # still passes the tests (needs sqrt(FLT_MAX) < threshold) re-emits the previous query's match
     cand = kp([[0, 0], [1, 1]], sign=np.array([1.0, 1.0], np.float32))
@@ -92,7 +104,7 @@ def test_job_order_and_all_pairs():
     assert all_pairs(3) == [(0, 1), (0, 2), (1, 2)]
 
 
-def test_match_all_pushes_the_running_match_variable():
+def test_match_all_pushes_the_running_match_variable(match_run):
     """matchAll (match.cpp:297-302), worked by hand.  Candidates in 1-D at 0, 10, 3, 0.25, 9; threshold 1 (on sqrt(dist)).
     query 0 at 0:   cand 0: |0| < 1 -> push `match` (= 0, the initial value, :259); cand 1: 10 far -> d1 = 100, match = 1;
                     cand 2: 3 far, 9 < 100 -> match = 2; cand 3: 0.25 < 1 -> push 2; cand 4: 9 far, 81 > 9 -> match stays 2.
