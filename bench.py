@@ -224,7 +224,9 @@ def make_line(args, world, k, elapsed, host, collectives, pairs, levels, n_lin, 
                                f"levels, -g 100 -gd 1 -si 10",
                    "schedule": {"linear": n_lin, "deformable_per_level": per_level},
                    "parallelism": f"images sharded over {world} GPU(s)", "grids_per_level": grids,
-                   "final_E": final_e},
+                   "final_E": final_e,
+                   **({"mode": "-exact 1 (frog_options::reference_order): the reference's own order and arithmetic, bit-equal to the oracle"}
+                      if getattr(args, "exact", False) else {})},
         "roofline": roofline,
         "iteration": iteration,
         "kernels_ms": {n: {"total_ms": v[0], "launches": int(v[1])} for n, v in prof.items() if v[1]},
@@ -350,6 +352,8 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     t_gen = time.perf_counter() - t0
     n_lin, per_level = schedule(steps, levels)
     opts = _abi.FrogOptions.default(max_levels_hint=levels)      # what a host knows before it starts: -dl
+    if args.exact:
+        opts.reference_order = 1
     proxy = None
     if args.shard_of:
         if world != 1:
@@ -478,9 +482,44 @@ def run_native(args, rank, world, local_rank, transport, rdv):
         arr = (C.c_void_p * 1)(comm)
         cl.frog_comm_destroy_all(1, arr)
     lib.frog_destroy(ctx)
+    if (world == 1 and rank == 0 and line is not None and not args.shard_of and not args.exact and not args.no_exact_mode
+            and (args.exact_mode or (not args.no_cpu_baseline and args.config == 3))):
+        line["exact_mode"] = exact_mode(args, pairs, levels, n_lin, per_level, local_rank)
     if end_to_end_pending:
         line["end_to_end"] = end_to_end(pairs, levels)
     return line, (world == 1 or len({x["hash"] for x in everyone}) == 1)
+
+
+def exact_mode(args, pairs, levels, n_lin, per_level, local_rank):
+    """The same schedule once more through bin/frog -exact 1 = frog_options::reference_order: the device path in the reference's
+    own order and arithmetic, whose every per-point sum, gradient image, lattice, matrix and coordinate is bit-equal to the oracle
+    (tests/test_gpu_reference_order.py) -- the mode inside north_star's literal "transform parameters within 1e-4".  Measured after
+    the timed region, like cpu_baseline; same frog_run_schedule loop, same warm-up, no kernel events."""
+    from frog_amd import _abi
+    try:
+        lib, host = _abi.hip_lib(), _abi.host_lib()
+        opts = _abi.FrogOptions.default(max_levels_hint=levels)
+        opts.reference_order = 1
+        ctx = C.c_void_p()
+        t0 = time.perf_counter()
+        _abi.check(lib.frog_create(C.byref(pairs.model), C.byref(opts), local_rank, 0, pairs.n_images, C.byref(ctx)), "frog_create")
+        t_create = time.perf_counter() - t0
+        try:
+            res = _abi.FrogScheduleResult()
+            _abi.check(host.frog_run_schedule(ctx, None, C.byref(native_plan(args, n_lin, per_level, 0, False)), C.byref(res)), "frog_run_schedule")
+        finally:
+            lib.frog_destroy(ctx)
+        k = n_lin + sum(per_level)
+        tags = ["linear"] + [f"level{l}" for l in range(levels)]
+        return {"value": k / res.elapsed_s, "unit": "iterations/s", "ms_per_step": 1e3 * res.elapsed_s / k, "steps": k,
+                "final_E": res.final_E, "grids_per_level": [int(g) for g in res.grids_per_level[:levels]],
+                "phase_iterations_per_s": {t: (n_lin if i == 0 else per_level[i - 1]) / res.phase_s[i]
+                                           for i, t in enumerate(tags) if (n_lin if i == 0 else per_level[i - 1]) and res.phase_s[i] > 0},
+                "create_s": t_create,
+                "mode": "bin/frog -exact 1 (frog_options::reference_order): the reference's own order and arithmetic on the device, "
+                        "bit-equal to the oracle; the per-lattice chain builds (DESIGN.md 2c) are inside the timed region"}
+    except Exception as exc:                # noqa: BLE001 -- an add-on: the measured line is printed whatever happens here
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def end_to_end(pairs, levels):
@@ -923,6 +962,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the bin/frog whole-process run after the timed region (N = 1)")
     ap.add_argument("--end-to-end", action="store_true", help="run it even with --no-cpu-baseline / another --config")
+    ap.add_argument("--exact", action="store_true",
+                    help="time bin/frog -exact 1 = frog_options::reference_order instead of the product kernels: the device path in the "
+                         "reference's own order and arithmetic, bit-equal to the oracle (DESIGN.md 2a); the line says so in config.mode")
+    ap.add_argument("--no-exact-mode", action="store_true", help="skip the -exact 1 run of the same schedule after the timed region (N = 1)")
+    ap.add_argument("--exact-mode", action="store_true", help="run it even with --no-cpu-baseline / another --config")
     ap.add_argument("--kernel-times", action="store_true",
                     help="HIP-event times of every kernel group, not only of the half-link sweeps (costs ~6 %% of the rate)")
     ap.add_argument("--child", choices=("preflight", "native", "torch"), default=None, help=argparse.SUPPRESS)

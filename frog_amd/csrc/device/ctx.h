@@ -346,6 +346,31 @@ struct frog_ctx {
     frog::DevBuf<float> ref_w, ref_d;         // [L_own] weight and distance of every half-link (linear step)
     frog::DevBuf<uint64_t> ref_img_link;      // [nOwned + 1] first half-link of every owned image (relative, reference order)
     frog::DevBuf<double> ref_pt_energy;       // [ownP][2] energy terms of every owned point (deformable step)
+    // reference-order scatter as one chain per (image, control point) (k_refchain.hip.h), built once per lattice
+    frog::DevBuf<uint16_t> ref_link_img;      // [L_own] image of every half-link's partner (static; ref_own is static too since round 6)
+    // ... the rows of half-links side by side for the deformable per-point sums (k_refchain.hip.h), built once per context
+    bool rr_valid = false;
+    uint32_t rr_n_groups = 0;
+    frog::DevBuf<uint32_t> rr_slot_row, rr_group_len, rr_ent;
+    frog::DevBuf<uint16_t> rr_ent_img;
+    frog::DevBuf<uint64_t> rr_group_ptr;
+    bool rc_valid = false;                    // the chains below belong to the current lattice and the current `pos`
+    bool ref_literal = false;                   // FROG_REF_LITERAL=1: the literal form (ref_scatter_kernel), for comparison
+    uint32_t rc_n_groups = 0, rc_n_gnodes = 0;
+    hipStream_t ref_stream = nullptr;         // the energy chains of a deformable step run here, beside the scatter
+    hipEvent_t ref_fork = nullptr, ref_join = nullptr;
+    bool ref_join_pending = false;
+    bool rc_by_row = false;                   // the chains' entries name owned rows (ref_row_sums) instead of points (point_sums)
+    frog::DevBuf<float4> ref_row_sums;        // [ownP] the per-point sums once more, by owned row in reference order
+    int rc_unroll = 8;                        // entries per step of the chain kernel on this lattice (8 or 16)
+    frog::DevBuf<uint64_t> rc_keys, rc_keys_alt;      // [64 ownP] sort buffers
+    frog::DevBuf<unsigned char> rc_temp;              // hipCUB scratch
+    frog::DevBuf<uint32_t> rc_node_ptr;               // [gnodes + 1] first sorted entry of every (image, control point)
+    frog::DevBuf<uint32_t> rc_len, rc_len_sorted, rc_iota, rc_slot_node, rc_slot_of_node;   // chain lengths; slot <-> control point
+    frog::DevBuf<uint32_t> rc_group_len;              // [groups] padded chain length of the group
+    frog::DevBuf<uint64_t> rc_group_size, rc_group_ptr;   // [groups + 1] seats of the group, their exclusive sum
+    frog::DevBuf<uint32_t> rc_ent;                    // [seats] point (internal numbering) or RC_PAD
+    frog::DevBuf<double> rc_wt;                       // [seats] the tap's f64 weight
 
     // certified outlier culling of the deformable sweep (k_cull.hip.h)
     bool exact_weights = false;               // FROG_WEIGHT_EXACT=1 (test hook): inlier_probability_exact for every weight

@@ -11,6 +11,7 @@
 #include "k_cull.hip.h"
 #include "k_ransac.hip.h"
 #include "k_reforder.hip.h"
+#include "k_refchain.hip.h"
 #include "similarity.h"
 
 #include <atomic>
@@ -402,15 +403,70 @@ static int produce_selection(frog_ctx *c)
 static int ref_alloc(frog_ctx *ctx)
 {
     if (ctx->ref_img_link.p) return FROG_OK;
-    const uint32_t nO = ctx->n_owned();
+    const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
     std::vector<uint64_t> il(nO + 1);
     for (uint32_t i = 0; i <= nO; i++) il[i] = ctx->img_link_begin[ctx->ib + i];
     FROG_HIP_CHECK(ctx->ref_img_link.upload(il, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     FROG_HIP_CHECK(ctx->ref_own.alloc(std::max<size_t>(1, ctx->L_own)));
+    FROG_HIP_CHECK(ctx->ref_link_img.alloc(std::max<size_t>(1, ctx->L_own)));
+    FROG_HIP_CHECK(ctx->ref_pt_energy.alloc(2 * (size_t)std::max(1u, nRows)));
+    FROG_HIP_CHECK(ctx->ref_row_sums.alloc(std::max(1u, nRows)));
+    if (!ctx->ref_stream && !getenv("FROG_REF_ONE_STREAM")) {
+        FROG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->ref_stream, hipStreamNonBlocking));
+        FROG_HIP_CHECK(hipEventCreateWithFlags(&ctx->ref_fork, hipEventDisableTiming));
+        FROG_HIP_CHECK(hipEventCreateWithFlags(&ctx->ref_join, hipEventDisableTiming));
+    }
     FROG_HIP_CHECK(ctx->ref_w.alloc(std::max<size_t>(1, ctx->L_own)));
     FROG_HIP_CHECK(ctx->ref_d.alloc(std::max<size_t>(1, ctx->L_own)));
-    FROG_HIP_CHECK(ctx->ref_pt_energy.alloc(2 * (size_t)std::max(1u, ctx->own_pt_end - ctx->own_pt_begin)));
+    // per half-link, static: the own point and the partner's image (pos.w never changes)
+    if (nRows)
+        ref_link_static_kernel<<<div_up(nRows, 256), 256, 0, ctx->stream>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
+                                                                          ctx->ref_own.p, ctx->ref_link_img.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+// The rows of half-links side by side (k_refchain.hip.h), once per context.
+static int ref_rows_build(frog_ctx *ctx)
+{
+    if (ctx->rr_valid) return FROG_OK;
+    hipStream_t s = ctx->stream;
+    const uint32_t nRows = ctx->own_pt_end - ctx->own_pt_begin;
+    const uint32_t n_groups = div_up(std::max(1u, nRows), 64u);
+    const size_t n_slots = (size_t)n_groups * 64;
+    DevBuf<uint32_t> len, len_sorted, iota;
+    DevBuf<uint64_t> group_size;
+    DevBuf<unsigned char> temp;
+    FROG_HIP_CHECK(len.alloc(n_slots)); FROG_HIP_CHECK(len_sorted.alloc(n_slots)); FROG_HIP_CHECK(iota.alloc(n_slots));
+    FROG_HIP_CHECK(ctx->rr_slot_row.alloc(n_slots)); FROG_HIP_CHECK(ctx->rr_group_len.alloc(n_groups));
+    FROG_HIP_CHECK(group_size.alloc((size_t)n_groups + 1)); FROG_HIP_CHECK(ctx->rr_group_ptr.alloc((size_t)n_groups + 1));
+    size_t t1 = 0, t2 = 0;
+    FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t1, len.p, len_sorted.p, iota.p, ctx->rr_slot_row.p, n_slots, 0, 32, s));
+    FROG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, group_size.p, ctx->rr_group_ptr.p, (size_t)n_groups + 1, s));
+    FROG_HIP_CHECK(temp.alloc(std::max<size_t>(16, std::max(t1, t2))));
+    FROG_HIP_CHECK(hipMemsetAsync(len.p, 0, n_slots * sizeof(uint32_t), s));
+    FROG_HIP_CHECK(hipMemsetAsync(iota.p, 0xFF, n_slots * sizeof(uint32_t), s));          // slots past the last row: RC_PAD
+    if (nRows) ref_rows_len_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, nRows, len.p, iota.p);
+    size_t tb = temp.n;
+    FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(temp.p, tb, len.p, len_sorted.p, iota.p, ctx->rr_slot_row.p, n_slots, 0, 32, s));
+    FROG_HIP_CHECK(hipMemsetAsync(group_size.p, 0, ((size_t)n_groups + 1) * sizeof(uint64_t), s));
+    ref_rows_group_kernel<<<div_up(n_groups, 256), 256, 0, s>>>(len_sorted.p, n_groups, ctx->rr_group_len.p, group_size.p);
+    tb = temp.n;
+    FROG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, group_size.p, ctx->rr_group_ptr.p, (size_t)n_groups + 1, s));
+    uint64_t seats = 0;
+    FROG_HIP_CHECK(hipMemcpyAsync(&seats, ctx->rr_group_ptr.p + n_groups, sizeof seats, hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    FROG_HIP_CHECK(ctx->rr_ent.alloc(std::max<uint64_t>(1, seats)));
+    FROG_HIP_CHECK(ctx->rr_ent_img.alloc(std::max<uint64_t>(1, seats)));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rr_ent.p, 0xFF, std::max<uint64_t>(1, seats) * sizeof(uint32_t), s));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rr_ent_img.p, 0, std::max<uint64_t>(1, seats) * sizeof(uint16_t), s));
+    ref_rows_fill_kernel<<<n_groups, 64, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->pos.p, ctx->rr_slot_row.p, ctx->rr_group_ptr.p,
+                                                ctx->rr_ent.p, ctx->rr_ent_img.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipStreamSynchronize(s));            // the scratch buffers above die with this scope
+    ctx->rr_n_groups = n_groups;
+    ctx->rr_valid = true;
     return FROG_OK;
 }
 
@@ -420,11 +476,23 @@ static int ref_linear_step(frog_ctx *ctx)
     { const int rc = ref_alloc(ctx); if (rc) return rc; }
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
-    if (nRows)
-        ref_link_terms_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
-                                                                 ctx->pos2.p, ctx->em.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p);
-    ref_linear_chain_kernel<<<nO, 64, 0, s>>>(ctx->ref_img_link.p, ctx->ref_link.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p, ctx->pos2.p,
-                                              ctx->ib, ctx->mat.p, ctx->opt.linear_alpha, ctx->opt.use_scale, ctx->img_energy.p);
+    if (ctx->ref_literal) {
+        if (nRows)
+            ref_link_terms_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
+                                                                     ctx->pos2.p, ctx->em.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p);
+        ref_linear_chain_kernel<<<nO, 64, 0, s>>>(ctx->ref_img_link.p, ctx->ref_link.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p, ctx->pos2.p,
+                                                  ctx->ib, ctx->mat.p, ctx->opt.linear_alpha, ctx->opt.use_scale, ctx->img_energy.p);
+    } else if (nO) {
+        uint64_t longest = 0;
+        for (uint32_t i = ctx->ib; i < ctx->ie; i++) longest = std::max(longest, ctx->img_link_begin[i + 1] - ctx->img_link_begin[i]);
+        if (longest)
+            ref_link_weights_kernel<<<dim3(div_up(longest, 64 * RW_UNROLL), nO), 64, 0, s>>>(ctx->ref_img_link.p, ctx->ref_link.p, ctx->ref_own.p,
+                                                                                            ctx->ref_link_img.p, ctx->pos2.p, ctx->em.p, ctx->emd.p,
+                                                                                            ctx->ib, ctx->ref_w.p, ctx->ref_d.p);
+        ref_linear_chain2_kernel<<<nO, 64 * (RL_PRODUCERS + 1), 0, s>>>(ctx->ref_img_link.p, ctx->ref_link.p, ctx->ref_own.p, ctx->ref_w.p, ctx->ref_d.p,
+                                                                       ctx->pos2.p, ctx->ib, ctx->mat.p, ctx->opt.linear_alpha,
+                                                                       ctx->opt.use_scale, ctx->img_energy.p);
+    }
     ref_energy_total_kernel<<<1, 1, 0, s>>>(ctx->img_energy.p, nO, ctx->energy.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
@@ -436,14 +504,32 @@ static int ref_point_sums(frog_ctx *ctx, bool with_energy)
     { const int rc = ref_alloc(ctx); if (rc) return rc; }
     hipStream_t s = ctx->stream;
     const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
-    if (nRows)
+    if (nRows && ctx->ref_literal) {
         ref_point_sums_kernel<<<div_up(nRows, 256), 256, 0, s>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
                                                                  ctx->pos2.p, ctx->em.p, ctx->opt.inlier_threshold, ctx->point_sums.p,
                                                                  with_energy ? ctx->ref_pt_energy.p : nullptr);
+    } else if (nRows) {
+        const int rc = ref_rows_build(ctx);
+        if (rc) return rc;
+        ref_point_sums_rows_kernel<<<ctx->rr_n_groups, 64, 0, s>>>(ctx->rr_ent.p, ctx->rr_ent_img.p, ctx->rr_group_ptr.p, ctx->rr_group_len.p,
+                                                                  ctx->rr_slot_row.p, ctx->new_of_old.p, ctx->pos.p, ctx->pos2.p, ctx->em.p,
+                                                                  ctx->emd.p, ctx->opt.inlier_threshold, ctx->point_sums.p, ctx->n_hard ? nullptr : ctx->ref_row_sums.p,
+                                                                  with_energy ? ctx->ref_pt_energy.p : nullptr);
+    }
     ctx->point_sums_stale = false;
     if (with_energy) {
-        ref_image_energy_kernel<<<nO, 64, 0, s>>>(ctx->ref_pt_energy.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, ctx->img_energy.p);
-        ref_energy_total_kernel<<<1, 1, 0, s>>>(ctx->img_energy.p, nO, ctx->energy.p);
+        // The energy's two chains per image (20 000 dependent f64 additions each at cfg 3: 0.19 ms on 100 of 256 CUs) need nothing
+        // the scatter produces and produce nothing it needs: on a stream of their own beside it, joined by ref_deformable_phase_a.
+        hipStream_t se = s;
+        if (!ctx->ref_literal && !ctx->n_hard && ctx->ref_stream) {
+            FROG_HIP_CHECK(hipEventRecord(ctx->ref_fork, s));
+            FROG_HIP_CHECK(hipStreamWaitEvent(ctx->ref_stream, ctx->ref_fork, 0));
+            se = ctx->ref_stream;
+        }
+        if (ctx->ref_literal) ref_image_energy_kernel<<<nO, 64, 0, se>>>(ctx->ref_pt_energy.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, ctx->img_energy.p);
+        else ref_image_energy2_kernel<<<nO, RE_STEP, 0, se>>>(ctx->ref_pt_energy.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, ctx->img_energy.p);
+        ref_energy_total_kernel<<<1, 1, 0, se>>>(ctx->img_energy.p, nO, ctx->energy.p);
+        if (se != s) { FROG_HIP_CHECK(hipEventRecord(ctx->ref_join, se)); ctx->ref_join_pending = true; }
     }
     if (ctx->n_hard) {                                          // landmark constraints, imageGroup.cxx:280-295, :520-533
         hard_links_kernel<<<div_up(ctx->n_hard, 64), 64, 0, s>>>(ctx->pos2.p, ctx->point_sums.p, ctx->hl_point.p, ctx->hl_ptr.p,
@@ -452,6 +538,90 @@ static int ref_point_sums(frog_ctx *ctx, bool with_energy)
         if (with_energy) hard_energy_kernel<<<1, 1, 0, s>>>(ctx->hl_partial.p, ctx->n_hard, ctx->energy.p);
     }
     FROG_HIP_CHECK(hipGetLastError());
+    return FROG_OK;
+}
+
+// The chains of the reference-order scatter for the current lattice (k_refchain.hip.h): once per lattice, on `stream`.
+static int ref_chain_build(frog_ctx *ctx)
+{
+    if (ctx->rc_valid) return FROG_OK;
+    hipStream_t s = ctx->stream;
+    static const bool trace = getenv("FROG_REF_TRACE") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (trace) std::fprintf(stderr, "[ref_chain_build] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+    };
+    const GeomDev gd = to_dev(ctx->geom);
+    const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
+    const uint64_t n_gnodes64 = (uint64_t)nO * (uint64_t)gd.n_cp, n_keys = (uint64_t)nRows * 64;
+    if (n_gnodes64 >= 0xFFFFFF00ull || n_keys >= 0xFFFFFF00ull) return fail(FROG_E_INVALID, "reference-order scatter: lattice or group too large for 32-bit chain indices");
+    const uint32_t n_gnodes = (uint32_t)n_gnodes64;
+    const uint32_t n_groups = div_up(std::max(1u, n_gnodes), (uint32_t)RC_GROUP);
+    uint32_t max_img_pts = 1;
+    for (uint32_t i = ctx->ib; i < ctx->ie; i++) max_img_pts = std::max(max_img_pts, ctx->poff[i + 1] - ctx->poff[i]);
+    auto bits_for = [](uint64_t v) { int b = 1; while ((v >> b) != 0) b++; return b; };      // values 0 .. v
+    const int rbits = bits_for(max_img_pts - 1), gbits = bits_for(n_gnodes);
+    if (6 + rbits + gbits > 64) return fail(FROG_E_INVALID, "reference-order scatter: key does not fit 64 bits");
+    ctx->rc_n_groups = n_groups; ctx->rc_n_gnodes = n_gnodes;
+    FROG_HIP_CHECK(ctx->rc_keys.alloc(std::max<uint64_t>(1, n_keys)));
+    FROG_HIP_CHECK(ctx->rc_keys_alt.alloc(std::max<uint64_t>(1, n_keys)));
+    FROG_HIP_CHECK(ctx->rc_node_ptr.alloc((size_t)n_gnodes + 2));
+    const size_t n_slots = (size_t)n_groups * RC_GROUP;
+    FROG_HIP_CHECK(ctx->rc_len.alloc(n_slots)); FROG_HIP_CHECK(ctx->rc_len_sorted.alloc(n_slots));
+    FROG_HIP_CHECK(ctx->rc_iota.alloc(n_slots)); FROG_HIP_CHECK(ctx->rc_slot_node.alloc(n_slots));
+    FROG_HIP_CHECK(ctx->rc_slot_of_node.alloc(n_slots));
+    FROG_HIP_CHECK(ctx->rc_group_len.alloc(n_groups));
+    FROG_HIP_CHECK(ctx->rc_group_size.alloc((size_t)n_groups + 1)); FROG_HIP_CHECK(ctx->rc_group_ptr.alloc((size_t)n_groups + 1));
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, t1, ctx->rc_keys.p, ctx->rc_keys_alt.p, (size_t)n_keys, 6, 6 + rbits + gbits, s));
+    FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t2, ctx->rc_len.p, ctx->rc_len_sorted.p, ctx->rc_iota.p, ctx->rc_slot_node.p, n_slots, 0, 32, s));
+    FROG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t3, ctx->rc_group_size.p, ctx->rc_group_ptr.p, (size_t)n_groups + 1, s));
+    FROG_HIP_CHECK(ctx->rc_temp.alloc(std::max<size_t>(16, std::max(t1, std::max(t2, t3)))));
+    mark("allocations + size queries");
+    size_t tb = ctx->rc_temp.n;
+    if (nRows)
+        ref_chain_keys_kernel<<<div_up(nRows, 4), 256, 0, s>>>(ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, nRows, ctx->ib, ctx->own_pt_begin, gd,
+                                                              n_gnodes, rbits, ctx->rc_keys.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    if (n_keys) FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(ctx->rc_temp.p, tb, ctx->rc_keys.p, ctx->rc_keys_alt.p, (size_t)n_keys, 6, 6 + rbits + gbits, s));
+    const uint64_t *sorted = ctx->rc_keys_alt.p;
+    ref_chain_bounds_kernel<<<(unsigned)((n_keys + 1 + 255) / 256), 256, 0, s>>>(sorted, n_keys, rbits, n_gnodes, ctx->rc_node_ptr.p);
+    // slots past the last control point: length 0, pointing nowhere (the chain kernel does not write them)
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_len.p, 0, n_slots * sizeof(uint32_t), s));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_iota.p, 0xFF, n_slots * sizeof(uint32_t), s));
+    if (n_gnodes) ref_chain_len_kernel<<<div_up(n_gnodes, 256), 256, 0, s>>>(ctx->rc_node_ptr.p, n_gnodes, ctx->rc_len.p, ctx->rc_iota.p);
+    tb = ctx->rc_temp.n;
+    FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->rc_temp.p, tb, ctx->rc_len.p, ctx->rc_len_sorted.p, ctx->rc_iota.p, ctx->rc_slot_node.p, n_slots, 0, 32, s));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_group_size.p, 0, ((size_t)n_groups + 1) * sizeof(uint64_t), s));
+    // long chains (coarse lattices: few control points, thousands of entries each) fetch 16 entries per step, others 8
+    ctx->rc_unroll = n_keys / std::max<uint64_t>(1, n_gnodes) >= 256 ? 16 : 8;
+    // ... and look the sums up by owned row (see ref_chain_fill_kernel); landmark constraints edit the sums by point afterwards: by point then
+    static const int by_row_min = getenv("FROG_REF_BY_ROW_MIN") ? atoi(getenv("FROG_REF_BY_ROW_MIN")) : 300;
+    ctx->rc_by_row = !ctx->n_hard && !ctx->ref_literal && n_keys / std::max<uint64_t>(1, n_gnodes) >= (uint64_t)by_row_min;
+    ref_chain_group_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(ctx->rc_len_sorted.p, (uint32_t)n_slots, n_groups, (uint32_t)ctx->rc_unroll, ctx->rc_group_len.p,
+                                                                                  ctx->rc_group_size.p, ctx->rc_slot_node.p, ctx->rc_slot_of_node.p);
+    tb = ctx->rc_temp.n;
+    FROG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->rc_temp.p, tb, ctx->rc_group_size.p, ctx->rc_group_ptr.p, (size_t)n_groups + 1, s));
+    FROG_HIP_CHECK(hipGetLastError());
+    // the layout's size decides two allocations: one round trip per lattice
+    uint64_t seats = 0;
+    uint32_t n_entries = 0;
+    FROG_HIP_CHECK(hipMemcpyAsync(&seats, ctx->rc_group_ptr.p + n_groups, sizeof seats, hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipMemcpyAsync(&n_entries, ctx->rc_node_ptr.p + n_gnodes, sizeof n_entries, hipMemcpyDeviceToHost, s));
+    mark("kernels queued");
+    FROG_HIP_CHECK(hipStreamSynchronize(s));
+    mark("sorted, sizes on the host");
+    FROG_HIP_CHECK(ctx->rc_ent.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
+    FROG_HIP_CHECK(ctx->rc_wt.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
+    FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_ent.p, 0xFF, std::max<uint64_t>(1, seats) * sizeof(uint32_t), s));
+    if (n_entries)
+        ref_chain_fill_kernel<<<div_up(n_entries, 256), 256, 0, s>>>(sorted, n_entries, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_of_node.p, ctx->rc_group_ptr.p,
+                                                                    ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
+                                                                    ctx->rc_by_row ? 1 : 0, ctx->rc_ent.p, ctx->rc_wt.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    mark("layout allocated, fill queued");
+    if (trace) std::fprintf(stderr, "[ref_chain_build] %u control points, %u entries, %llu seats, %d entries per step\n", n_gnodes, n_entries, (unsigned long long)seats, ctx->rc_unroll);
+    ctx->rc_valid = true;
     return FROG_OK;
 }
 
@@ -467,10 +637,23 @@ static int ref_deformable_phase_a(frog_ctx *ctx, float alpha)
     if (rc) return rc;
     rc = join_setup(ctx);                       // the set-up's stream zeroes and sorts: wait before gradf is touched
     if (rc) return rc;
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, (size_t)nO * gd.n_cp * sizeof(float4), s));       // Fill(0), :249
-    ref_scatter_kernel<<<nO, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
-                                         ctx->gradf.p);
+    if (ctx->ref_literal) {
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->gradf.p, 0, (size_t)nO * gd.n_cp * sizeof(float4), s));       // Fill(0), :249
+        ref_scatter_kernel<<<nO, 64, 0, s>>>(ctx->pos.p, ctx->point_sums.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
+                                             ctx->gradf.p);
+    } else {
+        rc = ref_chain_build(ctx);
+        if (rc) return rc;
+        const float4 *sums = ctx->rc_by_row ? ctx->ref_row_sums.p : ctx->point_sums.p;
+        if (ctx->rc_unroll == 16)
+            ref_chain_kernel<16><<<ctx->rc_n_groups, 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
+                                                                sums, ctx->gradf.p);
+        else
+            ref_chain_kernel<8><<<ctx->rc_n_groups, 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
+                                                               sums, ctx->gradf.p);
+    }
     ref_cp_step_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->gradf.p, ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
+    if (ctx->ref_join_pending) { FROG_HIP_CHECK(hipStreamWaitEvent(s, ctx->ref_join, 0)); ctx->ref_join_pending = false; }      // the energy sums (ref_point_sums)
     if (ctx->two_collectives) energy_fold_kernel<<<1, 1, 0, s>>>(ctx->energy.p, ctx->gridsum.p + 3 * (size_t)gd.n_cp);      // as lattice_step_kernel
     FROG_HIP_CHECK(hipGetLastError());
     ctx->centered_in_a = false;                 // phase B subtracts the mean (cp_center_kernel: :417-428 as written)
@@ -521,6 +704,9 @@ void frog_destroy(frog_ctx *ctx)
     }
 #endif
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ref_stream) { (void)hipStreamSynchronize(ctx->ref_stream); (void)hipStreamDestroy(ctx->ref_stream); }
+    if (ctx->ref_fork) (void)hipEventDestroy(ctx->ref_fork);
+    if (ctx->ref_join) (void)hipEventDestroy(ctx->ref_join);
     if (ctx->setup_stream) { (void)hipStreamSynchronize(ctx->setup_stream); (void)hipStreamDestroy(ctx->setup_stream); }
     if (ctx->setup_fork) (void)hipEventDestroy(ctx->setup_fork);
     if (ctx->setup_join) (void)hipEventDestroy(ctx->setup_join);
@@ -816,6 +1002,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (const char *e = getenv("FROG_REFERENCE_ORDER")) c->ref_order = atoi(e) != 0;        // the tests' switch, overrides
     if (const char *e = getenv("FROG_K11_F64")) c->k11_f64 = atoi(e) != 0;
     if (c->ref_order) { c->cull_enabled = false; c->exact_weights = true; c->fused_sweep = false; }
+    c->ref_literal = getenv("FROG_REF_LITERAL") != nullptr;
     if (const char *e = getenv("FROG_CULL_LINEAR")) c->cull_linear = atoi(e) != 0;
     if (const char *e = getenv("FROG_CULL_SKIN_LINEAR")) {
         float a = 0, b = 0;
@@ -1091,7 +1278,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
     // the forms that do not write the trailer themselves (fresh lattice, reference-order mode)
     if (trailer) slab_trailer_kernel<<<1, 1, 0, ctx->stream>>>(ctx->energy.p, trailer);
     FROG_HIP_CHECK(hipGetLastError());
-    if (apply) ctx->pos_b_stale = true;         // pos has new values: pos_b (its copy in perm's order) is out of date
+    if (apply) { ctx->pos_b_stale = true; ctx->rc_valid = false; }      // pos has new values: pos_b (its copy in perm's order) and the reference-order chains are out of date
     return FROG_OK;
 }
 
@@ -1495,7 +1682,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
 {
     CTX_GUARD(ctx);
     if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
-    ctx->xyz2_fresh = false; ctx->res_valid = false;
+    ctx->xyz2_fresh = false; ctx->res_valid = false; ctx->rc_valid = false;
     int rc = join_setup(ctx);                   // a set-up right behind a set-up
     if (rc) return rc;
     rc = retire_current_grid(ctx);
@@ -2033,6 +2220,7 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
 int frog_set_hard_links(frog_ctx *ctx, const uint64_t *point, const uint64_t *partner, size_t n, float weight2)
 {
     CTX_GUARD(ctx);
+    ctx->rc_valid = false;            // the reference-order chains look the sums up by row only without landmark constraints
     if (n && (!point || !partner)) return fail(FROG_E_INVALID, "null argument");
     // keep the links of owned points, grouped by point in first-appearance order, link order preserved
     std::vector<uint32_t> pts, ptr(1, 0), prt;

@@ -1,0 +1,98 @@
+"""Round 6: (1) the product path against reference-order mode over cfg 3's WHOLE default schedule inside the suite (VERDICT r5
+item 1), with the form of the B-spline transform that moved the raw coefficients named by a test; (2) reference-order mode's
+fast kernels (one chain per control point, rows of half-links side by side, a producer / consumer linear chain) against the
+literal forms of rounds 4-5, bit for bit."""
+import numpy as np
+import pytest
+
+from frog_amd.pairs import Pairs
+import test_gpu_reference_order as T
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- (1) product path vs reference-order mode, cfg 3, -li 50 -dl 3 -di 200 ------------------------------------------------------
+# Bisected in round 6 (scripts/bisect_parity.sh, profiles/r06_parity_bisect.txt): of round 5's two arithmetic
+# changes the scatter's fused multiply-add moves NOTHING (cells fma / two roundings agree to three digits on every lattice), the
+# f32 form of the B-spline transform (K11) moves the raw coefficients of ONE rim node (second level-2 lattice, image 45 node 6037:
+# support 5.7e-8 from a single point, node weight 1.9e-20) from 2.0e-4 to 4.2e-3 of max|c| and the whole chain on a dense lattice
+# from 6.0e-7 to 3.0e-6.  The f64 form costs 5 % of the 650-step line (0.056 / 0.057 / 0.085 against 0.037 / 0.040 / 0.062 ms per
+# launch), so the f32 form stays the default and its bars are the measured values x 3; FROG_K11_F64=1 holds round 4's bars.
+BARS = {
+    #        raw      dense   field   weighted  chain   E
+    "f32": (1.3e-2, 1.0e-4, 1.0e-4, 1.5e-5, 1.0e-5, 1e-6),      # measured 4.2e-3, 3.3e-5, 3.4e-5, 5.0e-6, 3.0e-6, 7.0e-8
+    "f64": (1.0e-3, 1.0e-4, 1.0e-4, 1.5e-5, 2.0e-6, 1e-6),      # measured 2.0e-4, 1.4e-5, 2.8e-5, 3.9e-6, 6.0e-7, 7.0e-8
+}
+
+
+@pytest.mark.parametrize("k11", ["f32", "f64"])
+def test_fast_path_against_reference_order_config3_whole_default_schedule(monkeypatch, k11):
+    """BASELINE.json configs[2] at its size over the reference's whole default schedule: 650 accepted iterations, 65 refreshes,
+    the guard's rejections (1 / 2 / 4 lattices per level).  Same guard decisions (lockstep asserts them at every step), census
+    equal, and per lattice the bars above -- a ten-fold regression of any of them fails here, not in a script."""
+    monkeypatch.setenv("FROG_K11_F64", "1" if k11 == "f64" else "0")
+    pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
+    r = T.fast_against_reference_order(pairs, 50, 3, 200, monkeypatch, range(0, 100, 9))
+    T.report(f"fast_vs_reference_order_cfg3_whole_schedule_{k11}", r)
+    raw, dense, field, weighted, chain, e = BARS[k11]
+    assert r["grids"] == [1, 2, 4]
+    for k, d in enumerate(r["lattices"]):
+        assert d["raw"] <= raw and d["dense_field"] <= dense and d["field"] <= field and d["weighted"] <= weighted, (k, d)
+    assert r["E"] < e and r["matrices"] < 1e-6 and r["xyz"] < 1e-6 and r["chain"]["rel"] <= chain
+    assert r["census"] == 0            # the two runs' final inlier census, half-link for half-link (equal in every run so far)
+
+
+# ---- (2) reference-order mode: the fast forms against the literal ones ------------------------------------------------------------
+
+def run_reference_order(pairs, monkeypatch, li, dl, di, images, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("FROG_REFERENCE_ORDER", "1")
+    s = T.Side(pairs)
+    monkeypatch.delenv("FROG_REFERENCE_ORDER")
+    for k in env:
+        monkeypatch.delenv(k)
+    trace = []
+
+    def check(tag, sides, e=None, infos=None):
+        kind = tag if isinstance(tag, str) else tag[0]
+        if kind == "step":
+            info = s.grid(images[0], s.num_grids() - 1)[0]
+            n_cp = info.dims[0] * info.dims[1] * info.dims[2]
+            trace.append(("sums", s.point_sums().copy()))
+            trace.append(("grad", np.stack([s.gradient_raw(i, n_cp) for i in images])))
+        elif kind in ("linear", "deformable"):
+            trace.append((kind, s.xyz2().copy(), s.matrices().copy(), float(e[0])))
+    grids = T.lockstep([s], li, dl, di, check)
+    lattices = [np.stack([s.grid(i, k)[1] for i in images]) for k in range(s.num_grids())]
+    return grids, trace, lattices
+
+
+def same_trace(a, b):
+    assert a[0] == b[0]
+    assert len(a[1]) == len(b[1])
+    for x, y in zip(a[1], b[1]):
+        assert x[0] == y[0]
+        for u, v in zip(x[1:], y[1:]):
+            assert np.array_equal(u, v), x[0]
+    for u, v in zip(a[2], b[2]):
+        assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("group", ["small", "ragged", "cfg5_shaped"])
+def test_reference_order_fast_forms_equal_the_literal_forms(monkeypatch, group):
+    """bin/frog -exact 1 with its round-6 kernels (k_refchain.hip.h: one chain per control point; the rows of half-links side by
+    side; the linear chain fed by producer wavefronts) against FROG_REF_LITERAL=1 (ref_scatter_kernel, one wavefront per image
+    with a barrier per point; a thread per point over the reference-order CSR; terms and chain in two kernels): per-point sums,
+    gradient images, coordinates, matrices, energies and every lattice bit for bit, free-running with regrids."""
+    if group == "small":
+        pairs, sched, images = Pairs.synthetic(6, 3000, 1500, seed=7), (12, 3, 25), list(range(6))
+    elif group == "ragged":
+        from test_gpu_parity import ragged_pairs
+        pairs = ragged_pairs()
+        sched, images = (8, 2, 6), list(range(pairs.n_images))
+    else:
+        pairs, sched, images = Pairs.synthetic(40, 20000, 16667, seed=2, partners_per_image=20), (4, 5, 2), list(range(0, 40, 7))
+    fast = run_reference_order(pairs, monkeypatch, *sched, images)
+    literal = run_reference_order(pairs, monkeypatch, *sched, images, FROG_REF_LITERAL="1")
+    same_trace(fast, literal)
