@@ -8,16 +8,16 @@ default flags of run.sh (-d 1, -d2 1).  Keypoints are resident in HBM before the
 the timed region covers all pairing kernels, the per-query decisions and the return of the
 pair lists to the host.
 
-Prints ONE JSON line.  `roofline`: the dominant kernel is the matrix-core filter of
-frog_amd/csrc/device/match.hip -- one (D + 2)-term product per (query, candidate) pair that passes the
-sign and scale tests, 2 FLOP per term.  `frac` prices those ALGORITHMIC FLOPs against the f32-input
-MFMA peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz = 157 TFLOP/s), the unit an exact-f32 product
-would need and the figure of rounds 1-4.  Since round 5 the filter runs on the bf16 cores as three
-products of (hi, lo) splits (match_mfma16_kernel: 3 (D + 2) terms padded to a multiple of 16 per pair,
-with a proven error bound): `issued` gives the FLOPs the instructions actually perform and their
-fraction of the dense bf16 peak (2.5 PFLOP/s) -- small, because the pass is no longer bound by the
-matrix cores but by operand traffic and the two kernels around the filter.  FROG_MATCH_F32=1 runs the
-f32 chain.
+Prints ONE JSON line.  `roofline`: the dominant kernel is the matrix-core filter of frog_amd/csrc/device/match.hip.  Which form
+ran is asked of the library (frog_matcher_last_forms), not re-derived from the environment.  `frac` = the FLOPs the instructions
+PERFORM over the dense peak of the unit they run on: since round 5 the filter is three products of bf16 (hi, lo) splits
+(match_mfma16_kernel: 3 (D + 2) terms padded to a multiple of 16 per (query, candidate) pair, v_mfma_f32_32x32x16_bf16) against
+the dense bf16 peak of 2.5 PFLOP/s -- about 0.15: the pass is not bound by the matrix cores but by its tile loop (operand fetch ->
+LDS -> barrier with one four-wavefront block per CU) and the two kernels around the filter, and `bound` says so.
+`f32_equivalent` keeps the figure of rounds 1-5 as a labelled second field: ALGORITHMIC FLOPs (one (D + 2)-term product per pair
+that passes the sign and scale tests, 2 FLOP per term) over the f32-input MFMA peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz =
+157 TFLOP/s), the unit an exact-f32 product would need -- a speed-up over that unit, not a utilisation of anything.
+FROG_MATCH_F32=1 runs the f32 chain, whose `frac` is against that f32 peak.
 """
 import argparse
 import json
@@ -57,17 +57,20 @@ def main():
     elapsed = time.perf_counter() - t0
     ms, nd = m.last_stats()
     n_pairs = int(sum(len(a) for a, _ in res))
-    # roofline of the dominant kernel (match_mfma_kernel): f32-input MFMA, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md) =
-    # 256 CUs x 4 SIMDs x 64 x 2.4 GHz = 157.3 TFLOP/s.  Algorithmic FLOPs: one (D + 2)-term product (2 FLOP per term)
-    # per (query, candidate) pair that passes the sign and scale tests.
+    # Algorithmic FLOPs: one (D + 2)-term product (2 FLOP per term) per (query, candidate) pair that passes the sign and scale
+    # tests.  f32-input MFMA peak: 64 FLOP/clk/SIMD (MI355X_MICROARCH.md) = 256 CUs x 4 SIMDs x 64 x 2.4 GHz = 157.3 TFLOP/s.
     flops = 2.0 * (args.dim + 2) * nd
-    peak = 256 * 4 * 64 * 2.4e9
-    bf16 = not os.environ.get("FROG_MATCH_F32") and not os.environ.get("FROG_MATCH_VALU") and args.dim <= 64
+    peak_f32 = 256 * 4 * 64 * 2.4e9
+    n_valu, n_f32, n_bf16 = m.last_forms()
+    form = "bf16" if n_bf16 >= max(n_f32, n_valu) and n_bf16 else ("f32" if n_f32 >= n_valu and n_f32 else "valu")
     dp = 48 if args.dim <= 48 else 64
     k3 = (3 * (dp + 2) + 15) // 16 * 16
-    issued = {"form": "bf16 x 3 (v_mfma_f32_32x32x16_bf16)", "flops": 2.0 * k3 * nd, "peak_tflops": 2500.0,
-              "frac_of_bf16_peak": 2.0 * k3 * nd / (ms * 1e-3) / 2.5e15} if bf16 else \
-             {"form": "f32 chain (v_mfma_f32_32x32x2_f32)", "flops": flops, "peak_tflops": peak / 1e12, "frac_of_f32_peak": flops / (ms * 1e-3) / peak}
+    if form == "bf16":
+        issued_flops, peak, kernel, bound = 2.0 * k3 * nd, 2.5e15, "match_mfma16_kernel (v_mfma_f32_32x32x16_bf16 x 3 splits)", "tile-loop"
+    elif form == "f32":
+        issued_flops, peak, kernel, bound = flops, peak_f32, "match_mfma_kernel (v_mfma_f32_32x32x2_f32)", "mfma"
+    else:
+        issued_flops, peak, kernel, bound = flops, 157.3e12 / 2, "match_kernel (vector ALU, exact)", "valu"
     out = {
         "metric": "image pairs matched/sec (20 000 x 20 000 keypoints, 48-D)",
         "value": len(jobs) / elapsed, "unit": "image pairs/s", "n_gpus": 1, "higher_is_better": True,
@@ -75,10 +78,17 @@ def main():
         "config": {"workload": f"{args.images} images x {args.points} keypoints x {args.dim} floats, {len(jobs)} image pairs, "
                                f"-d {args.threshold} -d2 1", "matches": n_pairs,
                    "candidate_pairs": float(sum(imgs[a].n * imgs[b].n for a, b in jobs)), "distances_evaluated": nd},
-        "roofline": {"bound": "mfma", "kernel": "match_mfma16_kernel" if bf16 else "match_mfma_kernel", "achieved": flops / (ms * 1e-3) / 1e12,
-                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak, "traffic": None,
-                     "frac_rule": "algorithmic FLOPs (2 (D + 2) per pair that passes the filters) / f32-input MFMA peak, as in rounds 1-4",
-                     "issued": issued,
+        "roofline": {"bound": bound, "kernel": kernel, "achieved": issued_flops / (ms * 1e-3) / 1e12,
+                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": issued_flops / (ms * 1e-3) / peak, "traffic": None,
+                     "frac_rule": "r06: FLOPs the issued matrix instructions perform / dense peak of the unit they run on (bf16: 2.5 PFLOP/s); "
+                                  "rounds 1-5 quoted f32_equivalent.frac here",
+                     "bound_note": "bf16 form: a third of the kernel is matrix work, the rest its tile loop (fetch -> LDS -> barrier, one "
+                                   "four-wavefront block per CU) and the per-candidate tests: DESIGN.md section 10" if form == "bf16" else None,
+                     "passes_by_form": {"valu": n_valu, "f32_mfma": n_f32, "bf16_mfma": n_bf16},
+                     "f32_equivalent": {"frac": flops / (ms * 1e-3) / peak_f32, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+                                        "peak_tflops": peak_f32 / 1e12,
+                                        "rule": "algorithmic FLOPs (2 (D + 2) per pair that passes the filters) / f32-input MFMA peak: "
+                                                "how many exact-f32 units the pass is worth, not a utilisation"},
                      "note": "ms = all kernels of the run (range search, MFMA filter, exact verification)"},
         "setup_seconds": {"generate": t_gen, "upload": t_upload},
     }

@@ -221,6 +221,7 @@ HIP_SYMBOLS = {
                                    C.POINTER(c_u32_p)]),
     "frog_match_free": (None, [C.c_void_p]),
     "frog_matcher_last_stats": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "frog_matcher_last_forms": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "frog_match_test_products": (C.c_int, [C.c_int, c_float_p, c_float_p, C.c_uint32, C.c_int, c_float_p, c_float_p]),
     "frog_get_points2_subset": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, c_float_p]),
     "frog_set_hard_links": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t, C.c_float]),

@@ -340,6 +340,7 @@ struct frog_ctx {
     bool finish_deformable = false; // ... and they decide a deformable step (frog_step_finish commits or rejects it)
     bool speculated = false;        // frog_step_speculate has exchanged the lattices' roles ahead of the decision
     bool spec_coeff_zero = false;
+    bool scalars_by_copy = false;   // the scalars of the pending step come by hipMemcpyAsync + energy_copied (no device-visible pinned block)
     double pending_seq = 0.0;       // sequence number of the scalars frog_comm_unpack_slab_step published and frog_step_finish has not read yet
     bool k11_f64 = false;           // FROG_K11_F64=1: the B-spline transform's weights and sums in f64 (rounds 1-4), for comparison
     frog::DevBuf<uint32_t> ref_own;           // [L_own] own point (internal numbering) of every half-link, reference order

@@ -2574,7 +2574,7 @@ __global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *po
 {
     __shared__ uint32_t sh[4];
     const uint32_t r = blockIdx.y;
-    if (a.host_scalars && blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
+    if (a.sum_mask && blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
         // the ranks' trailers in rank order: integers (oversize counts, flags) add exactly; the energy sums of a linear step
         // in the same order on every rank, so every rank prints the same E
         for (int k = 0; k < 4; k++) {
@@ -2585,10 +2585,12 @@ __global__ __launch_bounds__(256) void unpack_slab_kernel(const P3 *slab, P3 *po
             a.energy[k] = sum;
         }
         __threadfence();
-        #pragma unroll
-        for (int k = 0; k < 4; k++) __hip_atomic_store(&a.host_scalars[k], a.energy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();
-        __hip_atomic_store(&a.host_scalars[7], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.host_scalars) {               // null: the host gets them by copy + event (frog_comm_unpack_slab_step)
+            #pragma unroll
+            for (int k = 0; k < 4; k++) __hip_atomic_store(&a.host_scalars[k], a.energy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&a.host_scalars[7], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     uint32_t m = 0;
     if (r != a.self) {
@@ -2678,7 +2680,6 @@ int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_ro
     CTX_GUARD(ctx);
     if (!slab || !row_begin || world_size < 1 || world_size > (uint32_t)UNPACK_MAX_RANKS || self >= world_size || sum_mask > 15u)
         return fail(FROG_E_INVALID, "bad slab arguments");
-    if (sum_mask && !ctx->h_energy_dev) return fail(FROG_E_STATE, "no host-visible scalar block");
     UnpackArgs a{};
     uint64_t longest = 0;
     for (uint32_t r = 0; r <= world_size; r++) a.row_begin[r] = row_begin[r];
@@ -2710,6 +2711,13 @@ int frog_comm_unpack_slab_step(frog_ctx *ctx, const void *slab, uint64_t slot_ro
     // (the own slot's rows are measured twice when `measure`: once by the transform, once here -- a maximum does not mind)
     if (measure) { ctx->disp_n = ctx->disp_own_n + grid.x * grid.y; ctx->disp_others = true; }
     else { ctx->disp_current = false; ctx->disp_others = false; }      // measured by the check before the next sweep
+    // No device-visible address of the pinned scalar block (hipHostGetDevicePointer failed, or FROG_SCALARS_COPY=1): the summed
+    // scalars reach the host by copy + event, as in frog_deformable_phase_c, and frog_step_finish waits for the event.
+    ctx->scalars_by_copy = sum_mask && !ctx->h_energy_dev;
+    if (ctx->scalars_by_copy) {
+        FROG_HIP_CHECK(hipMemcpyAsync(ctx->h_energy, ctx->energy.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FROG_HIP_CHECK(hipEventRecord(ctx->energy_copied, ctx->stream));
+    }
     return FROG_OK;
 }
 
@@ -2738,7 +2746,9 @@ int frog_step_finish(frog_ctx *ctx, double *E)
 {
     CTX_GUARD(ctx);
     if (ctx->pending_seq == 0.0) return fail(FROG_E_STATE, "frog_step_finish without frog_comm_unpack_slab_step(sum_mask != 0)");
-    const int rc = wait_step_scalars(ctx, ctx->pending_seq);
+    int rc = FROG_OK;
+    if (ctx->scalars_by_copy) { ctx->scalars_by_copy = false; FROG_HIP_CHECK(hipEventSynchronize(ctx->energy_copied)); }
+    else rc = wait_step_scalars(ctx, ctx->pending_seq);
     ctx->pending_seq = 0.0;
     if (rc) return rc;
     if (ctx->h_energy[3] > 0) ctx->cull_need_build = true;       // a rank's sweep found its culling list out of date

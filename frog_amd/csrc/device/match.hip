@@ -858,6 +858,7 @@ struct frog_matcher {
     hipStream_t extra[3] = { nullptr, nullptr, nullptr };   // image pairs rotate over stream + extra[]: one pair's tail overlaps the next pairs' start
     unsigned long long *n_dist = nullptr;
     double last_ms = 0, last_dist = 0, last_computed = 0, last_fallback = 0;
+    uint64_t last_forms[3] = { 0, 0, 0 };      // passes of the last run by form: exact vector kernel / f32 matrix-core filter / bf16 matrix-core filter
 };
 
 // frog_matcher_run with o->all (see match_all_kernel).  Passes run one after the other: the second launch of a pass needs the
@@ -952,6 +953,7 @@ static int run_all(frog_matcher *m, const uint16_t *first, const uint16_t *secon
     ACHECK(hipEventElapsedTime(&ms, t0, t1));
 #undef ACHECK
     m->last_ms = ms; m->last_dist = distances; m->last_computed = distances; m->last_fallback = 0;
+    m->last_forms[0] = n_jobs; m->last_forms[1] = m->last_forms[2] = 0;      // matchAll: the exact vector kernels only
     cleanup();
     return FROG_OK;
 }
@@ -1179,6 +1181,13 @@ int frog_match_test_products(int device, const float *cand, const float *query, 
     return FROG_OK;
 }
 
+int frog_matcher_last_forms(const frog_matcher *m, uint64_t passes_by_form[3])
+{
+    if (!m || !passes_by_form) return FROG_E_INVALID;
+    for (int k = 0; k < 3; k++) passes_by_form[k] = m->last_forms[k];
+    return FROG_OK;
+}
+
 int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *distances)
 {
     if (!m) return FROG_E_INVALID;
@@ -1218,6 +1227,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
     // FROG_MATCH_VALU=1 keeps every pass on the exact vector-ALU kernel (test hook; also taken for descriptors
     // longer than 64 values or with non-finite entries, where the MFMA filter's error bound means nothing)
     const bool force_valu = getenv("FROG_MATCH_VALU") != nullptr;
+    m->last_forms[0] = m->last_forms[1] = m->last_forms[2] = 0;
     uint2 *ranges = nullptr;
     int *d_out = nullptr, *h_out = nullptr;
     hipEvent_t done[RING] = {}, t0 = nullptr, t1 = nullptr;
@@ -1380,6 +1390,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
             a.mf_eps = MF_EPS;
             uint2 *rg = ranges + (size_t)slot * q_blocks_max;
             const bool mfma = hmax != nullptr && Q.finite && C.finite && C.n > 0;
+            if (!mfma) m->last_forms[0]++;
             if (mfma) {
                 // candidate tiles per block: few = even load over the 256 CUs (the query blocks' ranges differ a lot in
                 // length), many = the block's 256 queries are loaded as operands less often.  Measured, image pairs/s
@@ -1390,6 +1401,7 @@ int frog_matcher_run(frog_matcher *m, const uint16_t *first, const uint16_t *sec
                 static const int tiles_env = getenv("FROG_MATCH_TILES") ? std::max(1, atoi(getenv("FROG_MATCH_TILES"))) : 0;
                 static const bool force_f32 = getenv("FROG_MATCH_F32") != nullptr;
                 const bool bf16 = !force_f32 && Q.bf16_ok && C.bf16_ok;
+                m->last_forms[bf16 ? 2 : 1]++;
                 const uint32_t tiles_per_block = tiles_env ? (uint32_t)tiles_env : (bf16 ? 64u : 8u);
                 a.splits = std::max(1u, std::min(splits_max, (C.n / 5 / MF_TILE + tiles_per_block - 1) / tiles_per_block));
                 QRange *qr = qrange + (size_t)slot * max_n;

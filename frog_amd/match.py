@@ -130,6 +130,12 @@ class Matcher:
         check(self._lib.frog_matcher_last_stats(self._h, C.byref(ms), C.byref(nd)), "frog_matcher_last_stats")
         return ms.value, nd.value
 
+    def last_forms(self):
+        """Passes of the last run by form: (exact vector kernel, f32 matrix-core filter, bf16 matrix-core filter)."""
+        f = (C.c_uint64 * 3)()
+        check(self._lib.frog_matcher_last_forms(self._h, f), "frog_matcher_last_forms")
+        return int(f[0]), int(f[1]), int(f[2])
+
 
 def read_keypoints(path):
     """A surf3d keypoint file (.csv / .csv.gz / .bin) as match.cpp reads it."""

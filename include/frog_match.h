@@ -84,6 +84,11 @@ void frog_match_free(void *p);
 int frog_match_test_products(int device, const float *cand, const float *query, uint32_t dim, int form, float *out, float *bound);
 
 int frog_matcher_last_stats(const frog_matcher *m, double *kernel_ms, double *distances);
+/* Passes (ComputeMatches calls: one per job, two with -sym) of the last frog_matcher_run by the form that ran them:
+ * [0] the exact vector-ALU kernel alone (FROG_MATCH_VALU, -all, descriptors longer than 64 or non-finite), [1] the f32
+ * matrix-core filter (v_mfma_f32_32x32x2_f32) + exact verification, [2] the bf16 matrix-core filter (three products of (hi, lo)
+ * splits, v_mfma_f32_32x32x16_bf16) + exact verification.  What bench_match.py's `issued` figures are taken from. */
+int frog_matcher_last_forms(const frog_matcher *m, uint64_t passes_by_form[3]);
 
 #ifdef __cplusplus
 }

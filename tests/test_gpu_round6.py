@@ -96,3 +96,22 @@ def test_reference_order_fast_forms_equal_the_literal_forms(monkeypatch, group):
     fast = run_reference_order(pairs, monkeypatch, *sched, images)
     literal = run_reference_order(pairs, monkeypatch, *sched, images, FROG_REF_LITERAL="1")
     same_trace(fast, literal)
+
+
+# ---- (3) two collectives per iteration without a device-visible scalar block -----------------------------------------
+
+def test_two_collectives_flow_with_the_scalars_by_copy(tmp_path):
+    """FROG_SCALARS_COPY=1 = the state a failed hipHostGetDevicePointer leaves: frog_comm_unpack_slab_step used to return
+    FROG_E_STATE there, i.e. every multi-rank run aborted at its first linear iteration.  Now the summed scalars reach the host by
+    hipMemcpyAsync + event and frog_step_finish waits for the event: same files as the default hand-off, rejections included."""
+    from test_gpu_round5 import _frog, _same_files
+    pairs = Pairs.synthetic(9, 3000, 1200, seed=4)
+    direct, copy = tmp_path / "direct", tmp_path / "copy"
+    for d in (direct, copy):
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+    flags = ("-ngl", "3", "-gm", "0.004")
+    out = _frog(direct, *flags)
+    _frog(copy, *flags, env_extra={"FROG_SCALARS_COPY": "1"})
+    assert out.count("Iteration canceled") >= 2
+    _same_files(direct, copy, pairs.n_images)
