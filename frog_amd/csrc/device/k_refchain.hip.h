@@ -14,8 +14,8 @@
 //      inside a group); per entry the point (internal numbering) and the tap's f64 weight wx[i] wy[j] wz[k], formed by the same
 //      expressions ref_scatter_kernel evaluated per point and iteration;
 // and per iteration ref_chain_kernel: thread = (image, control point, component), running its chain with the reference's arithmetic.  Same
-// values added in the same order into every control point: the gradient lattice has ref_scatter_kernel's bits (and the
-// oracle's: tests/test_gpu_reference_order.py compares after every step), FROG_REF_LITERAL=1 keeps the literal form
+// values added in the same order into every control point: the gradient lattice has ref_scatter_kernel's bits (and those of the
+// tests' CPU restatement of the reference: tests/test_gpu_reference_order.py compares after every step), FROG_REF_LITERAL=1 keeps the literal form
 // for comparison (tests/test_gpu_round6.py).
 #pragma once
 
