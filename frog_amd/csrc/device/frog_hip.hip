@@ -1250,7 +1250,7 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
         if (tiled) {
             // one wavefront per scatter block, the brick's coefficients in LDS (k_grid.hip.h)
             const GeomDev gd = to_dev(ctx->geom);
-            const size_t E = (size_t)gd.brick + 3, lds = E * E * E * sizeof(float4);
+            const size_t lds = (size_t)K11_TILE_ENTRIES * sizeof(float4);      // brick == 4 (checked above): the strided 7^3 tile
             auto kernel = ctx->k11_f64 ? transform_bspline_tile_kernel<double> : transform_bspline_tile_kernel<float>;
             kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
                 ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),

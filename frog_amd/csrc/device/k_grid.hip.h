@@ -708,6 +708,22 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
 #ifndef FROG_K11_F32_UNROLL
 #define FROG_K11_F32_UNROLL 1          // z-planes of the f32 form unrolled together
 #endif
+// Strides of the tile's rows and planes in LDS, in float4 entries (bricks of 4^3 cells: a 7 x 7 x 7 tile), packed by default.
+// Round 6 built the conflict-free layout for VERDICT r5 item 6 -- rows 12 apart, planes 96: the entry of cell (cx, cy, cz) is then
+// cx - 4 cy mod 16 whatever cz, so any 16 consecutive cells of the points' sort order read 16 different groups of four banks, for
+// every tap -- and measured it against the packed one on one box (-DFROG_K11_TILE_SY=12 -DFROG_K11_TILE_SZ=96,
+// profiles/r06_ab_experiments.txt): level 2 0.0628 against 0.0627 ms, level 0 0.0394 against 0.0364 (the tile grows from 5.5 to
+// 10.3 KB: 15 resident blocks per CU instead of 16).  Bank conflicts of the tap reads are not what level 2 pays; DESIGN.md
+// section 8 row 33.
+#ifndef FROG_K11_TILE_SY
+#define FROG_K11_TILE_SY 7
+#endif
+#ifndef FROG_K11_TILE_SZ
+#define FROG_K11_TILE_SZ 49
+#endif
+constexpr int K11_SY = FROG_K11_TILE_SY, K11_SZ = FROG_K11_TILE_SZ;
+constexpr int K11_TILE_ENTRIES = 6 * K11_SZ + 6 * K11_SY + 7;      // bricks of 4^3 cells (the tiled form is not used with others)
+static_assert(K11_SY >= 7 && K11_SZ >= 7 * K11_SY, "tile rows / planes overlap");
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROG_TRANSFORM_WAVES)))
 void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const float4 *coeff,
@@ -750,11 +766,12 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
     const int dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
     const float4 *cf = coeff + (size_t)img * g.n_cp;
     for (int k = lane; k < n_tile; k += 64) {
-        const int x = cp0[0] + k % E, y = cp0[1] + (k / E) % E, z = cp0[2] + k / (E * E);
+        const int tx = k % E, ty = (k / E) % E, tz = k / (E * E);
+        const int x = cp0[0] + tx, y = cp0[1] + ty, z = cp0[2] + tz;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
         if (x < dx && y < dy && z < dz) c = cf[(size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z)];
         c.w = 0.f;                                      // the pad the f32 form sums along with x, y, z (fma4)
-        tile4[k] = c;
+        tile4[tx + K11_SY * ty + K11_SZ * tz] = c;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -775,7 +792,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
         const int l0 = i0[0] - cp0[0], l1 = i0[1] - cp0[1], l2 = i0[2] - cp0[2];
         T disp[3] = { 0, 0, 0 };
         if (l0 >= 0 && l1 >= 0 && l2 >= 0 && l0 + 3 < E && l1 + 3 < E && l2 + 3 < E) {
-            const int base = l0 + E * (l1 + E * l2);
+            const int base = l0 + K11_SY * l1 + K11_SZ * l2;
             if constexpr (sizeof(T) == 4) {
                 const f32x4 *tile = reinterpret_cast<const f32x4 *>(tile4);
                 f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
@@ -785,7 +802,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
                     #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         f32x4 vy = { 0.f, 0.f, 0.f, 0.f };
-                        const int row = base + E * (j + E * k);
+                        const int row = base + K11_SY * j + K11_SZ * k;
                         #pragma unroll
                         for (int i = 0; i < 4; i++) vy = fma4(tile[row + i], F[0][i], vy);
                         vz = fma4(vy, F[1][j], vz);
@@ -802,7 +819,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     T vy[3] = { 0, 0, 0 };
-                    const int row = base + E * (j + E * k);
+                    const int row = base + K11_SY * j + K11_SZ * k;
                     #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const T f = F[0][i];
