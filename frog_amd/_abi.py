@@ -175,6 +175,7 @@ class FrogMatchOptions(C.Structure):
 
 
 HIP_SYMBOLS = {
+    "frog_device_warm": (C.c_int, [C.c_int]),
     "frog_device_count": (C.c_int, []),
     "frog_last_error": (C.c_char_p, []),
     "frog_create": (C.c_int, [C.POINTER(FrogModel), C.POINTER(FrogOptions), C.c_int, C.c_uint32, C.c_uint32,

@@ -671,6 +671,13 @@ int frog_device_count(void)
     return n;
 }
 
+int frog_device_warm(int device)
+{
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return FROG_E_NODEVICE; }
+    (void)hipFree(nullptr);
+    return FROG_OK;
+}
+
 const char *frog_last_error(void) { return g_last_error.c_str(); }
 
 void frog_destroy(frog_ctx *ctx)

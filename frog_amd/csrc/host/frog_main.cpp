@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 #include <omp.h>
 
@@ -94,9 +95,16 @@ int main(int argc, char *argv[])
         cout << "-ngl number   : the same with n contexts on ONE device and host-staged collectives (rehearsal)" << endl;
         cout << "-q 0/1        : do not print one line per iteration. Default : " << group.quiet << endl;
         cout << "-exact 0/1    : every solver loop in the reference's own order and arithmetic (bit-equal to the CPU path's" << endl
-             << "                coefficients; about 100 times slower). Default : " << group.exact << endl;
+             << "                coefficients; about 10 times slower: 265 instead of 2 500 iterations/s on the 100-image" << endl
+             << "                benchmark group). Default : " << group.exact << endl;
         return 1;
     }
+
+    // The HIP runtime's first call (device discovery, the code objects of libfrog_hip.so) costs 0.15-0.25 s: started here, beside
+    // readPairs, instead of inside frog_create behind it.  -dev is looked up ahead of the flag loop for this alone.
+    int warmDevice = 0;
+    for (int i = 2; i + 1 < argc; i++) if (strcmp(argv[i], "-dev") == 0) warmDevice = atoi(argv[i + 1]);
+    std::thread warm([warmDevice] { (void)frog_device_warm(warmDevice); });
 
     cout << "Reading : " << argv[1] << endl;
     group.readPairs(argv[1]);
@@ -154,6 +162,7 @@ int main(int argc, char *argv[])
         argumentsIndex += increment;
     }
 
+    warm.join();
     group.run();
     auto end = std::chrono::system_clock::now();
     cout << "Iteration loops : " << group.loopIterations << " iterations in " << group.loopSeconds << "s" << endl;

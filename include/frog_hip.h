@@ -40,6 +40,9 @@ typedef struct frog_ctx frog_ctx;
 /* ---- life cycle ----------------------------------------------------------- */
 
 int frog_device_count(void);
+/* Initialises the HIP runtime on `device` (the first HIP call of a process: device discovery, code objects) and returns.  A host
+ * may call it from a thread of its own while it reads its input (bin/frog does, beside readPairs); frog_create works without it. */
+int frog_device_warm(int device);
 /* Message for the last non-OK status returned on this thread. */
 const char *frog_last_error(void);
 
