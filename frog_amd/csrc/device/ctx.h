@@ -180,10 +180,18 @@ struct GridGeom {
     int brick;              // cells per brick edge (8 or 4)
     int nbricks[3];
     int n_bricks;           // per image
+    // Layout of the lattices coeff / grad / gradf / grad_spare (k_grid.hip.h lat()): image-major [image][node], or -- `blocked`,
+    // fine lattices of many images -- [node / 16][image][node % 16]: the lattice step works through ALL images of 16 nodes at a time,
+    // and image-major those are 256-byte pieces 16 n_cp bytes apart (cfg 5 level 4: 500 pieces 14.7 MB apart per pass)
+    bool blocked = false;
+    uint32_t lat_images = 0;    // owned images the lattices are laid out for
+    size_t lat_entries() const { return blocked ? (size_t)((n_cp + 15) / 16) * 16 * lat_images : (size_t)lat_images * (size_t)n_cp; }
 };
 
 struct GridRecord {         // a finished or current lattice of the chain
     frog_grid_info info;
+    bool blocked = false;       // layout of `kept` (GridGeom::blocked when the lattice was retired)
+    uint32_t lat_images = 0;
     std::shared_ptr<DevBuf<float4>> kept;   // [owned images][G] coefficients, filled (device copy) when the lattice is retired
     bool retired = false;
 };
@@ -323,6 +331,7 @@ struct frog_ctx {
     frog::DevBuf<uint32_t> perm_key;          // (image, brick, cell) key of every sorted slot
     frog::DevBuf<float4> scatter_stage;       // [scatter blocks][(B+3)^3] tiles of the last scatter
     frog::DevBuf<uint32_t> brick_slot_ptr;    // [owned images * bricks + 1] staging slots per (image, brick)
+    frog::DevBuf<float4> extract_tmp;         // one image's lattice, contiguous (frog_get_grid / frog_get_gradient)
     frog::DevBuf<uint32_t> subset_idx;        // frog_get_points2_subset scratch
     frog::DevBuf<float> subset_out;
     std::vector<float4> h_res_sums, h_res_pos; // frog_residual_sums: owned rows, internal numbering

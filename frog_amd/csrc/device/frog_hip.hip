@@ -1621,6 +1621,16 @@ static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], c
     if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
     g.n_bricks = (int)nb;
     if ((size_t)nO * nb * (size_t)(g.brick * g.brick * g.brick) >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
+    // Lattice layout (ctx.h GridGeom::blocked, k_grid.hip.h lat()): image-major, or blocks of 16 nodes across the owned images.
+    // The lattice step reads and writes every (image, node) pair, 16 nodes of all images per block: image-major those are
+    // 256-byte pieces n_cp * 16 bytes apart.  FROG_LATTICE_BLOCKED=0 / 1 forces one form (A/B, tests); reference-order mode keeps
+    // image-major (its kernels index that way).
+    g.lat_images = nO;
+    {
+        static const char *e = getenv("FROG_LATTICE_BLOCKED");
+        g.blocked = e ? atoi(e) != 0 : (nO >= 32u && (size_t)nO * G >= ((size_t)1 << 24));
+        if (ctx->ref_order) g.blocked = false;
+    }
     return FROG_OK;
 }
 
@@ -1638,11 +1648,12 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     const size_t n_bricks_total = (size_t)nO * g.n_bricks;
     const size_t max_blocks = std::max<size_t>(1, scatter_max_blocks((uint32_t)n_bricks_total, nPts));
     const size_t E = (size_t)g.brick + 3;
-    FROG_HIP_CHECK(ctx->coeff.alloc((size_t)nO * G, (size_t)nO * G * reserve));
-    FROG_HIP_CHECK(ctx->grad.alloc((size_t)nO * G, (size_t)nO * G * reserve));
-    FROG_HIP_CHECK(ctx->gradf.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    const size_t LG = std::max(g.lat_entries(), (size_t)nO * G);       // entries of one lattice in its layout (blocked: nodes padded to 16)
+    FROG_HIP_CHECK(ctx->coeff.alloc(LG, LG * reserve));
+    FROG_HIP_CHECK(ctx->grad.alloc(LG, LG * reserve));
+    FROG_HIP_CHECK(ctx->gradf.alloc(LG, LG * reserve));
     // a third lattice for contexts whose host queues the next step before this one's decision is known (frog_step_speculate)
-    if (ctx->two_collectives && !ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc((size_t)nO * G, (size_t)nO * G * reserve));
+    if (ctx->two_collectives && !ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G + 4, (3 * G + 4) * reserve));      // + 4: the energy sums' seat on the all-reduce (frog_comm_mode)
     FROG_HIP_CHECK(ctx->key_counts.alloc(n_keys, n_keys * reserve));
     FROG_HIP_CHECK(ctx->brick_ptr_scratch.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
@@ -1668,8 +1679,8 @@ static int retire_current_grid(frog_ctx *ctx)
 {
     if (ctx->grids.empty() || ctx->grids.back().retired) return FROG_OK;
     GridRecord &gr = ctx->grids.back();
-    const size_t G = (size_t)ctx->geom.n_cp;
-    const size_t n = (size_t)ctx->n_owned() * G;
+    const size_t n = ctx->geom.lat_entries();           // in the layout it stands in (frog_get_grid extracts an image from it)
+    gr.blocked = ctx->geom.blocked; gr.lat_images = ctx->geom.lat_images;
     // the finished lattice stays on the device (a copy on the stream: no host round trip inside the
     // regrid path; 43 MB per lattice at level 2 of the 100-image group); frog_get_grid reads it back on demand
     gr.kept = std::make_shared<DevBuf<float4>>();
@@ -1977,7 +1988,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     if (ctx->centered_in_a) { ctx->phase = 2; return FROG_OK; }       // phase A already removed the group's own mean
     Span span(ctx, FROG_K_LATTICE);
     // :398: the group mean is removed only when no image is fixed
-    cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), g.n_cp, ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
+    cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), to_dev(g), ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
                                                         (double)maxD * g.spacing[2], ctx->energy.p,
                                                         ctx->two_collectives ? ctx->gridsum.p + 3 * (size_t)g.n_cp : nullptr);
@@ -2218,7 +2229,17 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
     const size_t nfl = std::min(cap, 3 * G);
     const float4 *src = gr.retired ? gr.kept->p : ctx->coeff.p;
     std::vector<float4> h(G);
-    FROG_HIP_CHECK(hipMemcpyAsync(h.data(), src + li * G, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    {
+        // the image's nodes out of the lattice's layout (image-major or blocked: k_grid.hip.h lat()) into a contiguous run
+        GridGeom lg{};
+        lg.n_cp = (int)G;
+        lg.blocked = gr.retired ? gr.blocked : ctx->geom.blocked;
+        lg.lat_images = gr.retired ? gr.lat_images : ctx->geom.lat_images;
+        FROG_HIP_CHECK(ctx->extract_tmp.alloc(G));
+        lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(src, to_dev(lg), (uint32_t)li, ctx->extract_tmp.p);
+        FROG_HIP_CHECK(hipGetLastError());
+        FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->extract_tmp.p, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    }
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < nfl; i++) { const float4 &v = h[i / 3]; coeffs[i] = (i % 3 == 0) ? v.x : (i % 3 == 1) ? v.y : v.z; }
     return FROG_OK;
@@ -2345,7 +2366,10 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
     if (image < ctx->ib || image >= ctx->ie) return fail(FROG_E_INVALID, "image not owned by this context");
     const size_t G = (size_t)ctx->geom.n_cp;
     const size_t n = std::min(cap, 4 * G);
-    FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->gradf.p + (size_t)(image - ctx->ib) * G, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FROG_HIP_CHECK(ctx->extract_tmp.alloc(G));
+    lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(ctx->gradf.p, to_dev(ctx->geom), image - ctx->ib, ctx->extract_tmp.p);
+    FROG_HIP_CHECK(hipGetLastError());
+    FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->extract_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FROG_OK;
 }

@@ -23,11 +23,23 @@ struct GeomDev {
     int brick;
     int nbricks[3];
     int n_bricks;
+    // lattice layout (ctx.h GridGeom::blocked): entry of (image, node) = (node >> lat_sh) * lat_blk + image * lat_img + (node & lat_mask)
+    int lat_sh;
+    uint32_t lat_mask;
+    size_t lat_blk, lat_img;
 };
+
+// entry of control point `node` of owned image `img` in coeff / grad / gradf / grad_spare
+__host__ __device__ __forceinline__ size_t lat(const GeomDev &g, uint32_t img, uint32_t node)
+{
+    return (size_t)(node >> g.lat_sh) * g.lat_blk + (size_t)img * g.lat_img + (size_t)(node & g.lat_mask);
+}
 
 inline GeomDev to_dev(const GridGeom &g)
 {
     GeomDev d;
+    if (g.blocked) { d.lat_sh = 4; d.lat_mask = 15u; d.lat_blk = (size_t)16 * g.lat_images; d.lat_img = 16; }
+    else { d.lat_sh = 31; d.lat_mask = 0x7FFFFFFFu; d.lat_blk = 0; d.lat_img = (size_t)g.n_cp; }
     for (int k = 0; k < 3; k++) { d.dims[k] = g.dims[k]; d.origin[k] = g.origin[k]; d.spacing[k] = g.spacing[k]; d.inv_spacing[k] = 1.0 / g.spacing[k]; d.nbricks[k] = g.nbricks[k]; }
     d.n_cp = g.n_cp; d.brick = g.brick; d.n_bricks = g.n_bricks;
     return d;
@@ -178,7 +190,7 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
     const uint32_t s = valid ? s_raw : n_points - 1;
     const uint32_t p = perm[s];
     const float4 v = pos_b[s];                  // = pos[p], as the lattice's set-up gathered it (coalesced here)
-    const float4 *cf = coeff + (size_t)(__float_as_int(v.w) - (int)image_begin) * g.n_cp;
+    const uint32_t img = (uint32_t)(__float_as_int(v.w) - (int)image_begin);
     const float in[3] = { v.x, v.y, v.z };
     T F[3][4];
     int i0[3];
@@ -191,7 +203,7 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
         // all 64 taps exist -- always the case for the group's own points (the lattice covers 1.2x
         // their bounding box): no per-tap test, so the 16 loads of a z-slab are issued together
         // instead of one row at a time behind a branch (the kernel waits on memory 79 % of the time)
-        const float4 *base = cf + (size_t)i0[0] + (size_t)dx * ((size_t)i0[1] + (size_t)dy * i0[2]);
+        const uint32_t base = (uint32_t)i0[0] + (uint32_t)dx * ((uint32_t)i0[1] + (uint32_t)dy * (uint32_t)i0[2]);
         if constexpr (sizeof(T) == 4) {
             f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
             #pragma unroll
@@ -199,9 +211,9 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
                 float4 c[4][4];
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float4 *row = base + (size_t)dx * ((size_t)j + (size_t)dy * k);
+                    const uint32_t row = base + (uint32_t)dx * ((uint32_t)j + (uint32_t)dy * (uint32_t)k);
                     #pragma unroll
-                    for (int i = 0; i < 4; i++) c[j][i] = row[i];
+                    for (int i = 0; i < 4; i++) c[j][i] = coeff[lat(g, img, row + i)];
                 }
                 f32x4 vz = { 0.f, 0.f, 0.f, 0.f };
                 #pragma unroll
@@ -220,9 +232,9 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
             float4 c[4][4];
             #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float4 *row = base + (size_t)dx * ((size_t)j + (size_t)dy * k);
+                const uint32_t row = base + (uint32_t)dx * ((uint32_t)j + (uint32_t)dy * (uint32_t)k);
                 #pragma unroll
-                for (int i = 0; i < 4; i++) c[j][i] = row[i];
+                for (int i = 0; i < 4; i++) c[j][i] = coeff[lat(g, img, row + i)];
             }
             T vz[3] = { 0, 0, 0 };
             #pragma unroll
@@ -248,11 +260,11 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
                 const int y = i0[1] + j;
                 if (y < 0 || y >= dy) continue;
                 T vy[3] = { 0, 0, 0 };
-                const float4 *row = cf + (size_t)dx * ((size_t)y + (size_t)dy * z);
+                const uint32_t row = (uint32_t)dx * ((uint32_t)y + (uint32_t)dy * (uint32_t)z);
                 for (int i = 0; i < 4; i++) {
                     const int x = i0[0] + i;
                     if (x < 0 || x >= dx) continue;
-                    const float4 c = row[x];
+                    const float4 c = coeff[lat(g, img, row + (uint32_t)x)];
                     const T f = F[0][i];
                     vy[0] = fma((T)c.x, f, vy[0]); vy[1] = fma((T)c.y, f, vy[1]); vy[2] = fma((T)c.z, f, vy[2]);
                 }
@@ -764,12 +776,11 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
     const int bz = bidx / g.nbricks[1];
     const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
     const int dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
-    const float4 *cf = coeff + (size_t)img * g.n_cp;
     for (int k = lane; k < n_tile; k += 64) {
         const int tx = k % E, ty = (k / E) % E, tz = k / (E * E);
         const int x = cp0[0] + tx, y = cp0[1] + ty, z = cp0[2] + tz;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
-        if (x < dx && y < dy && z < dz) c = cf[(size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z)];
+        if (x < dx && y < dy && z < dz) c = coeff[lat(g, img, (uint32_t)x + (uint32_t)dx * ((uint32_t)y + (uint32_t)dy * (uint32_t)z))];
         c.w = 0.f;                                      // the pad the f32 form sums along with x, y, z (fma4)
         tile4[tx + K11_SY * ty + K11_SZ * tz] = c;
     }
@@ -841,11 +852,11 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
                     const int y = i0[1] + j;
                     if (y < 0 || y >= dy) continue;
                     T vy[3] = { 0, 0, 0 };
-                    const float4 *row = cf + (size_t)dx * ((size_t)y + (size_t)dy * z);
+                    const uint32_t row = (uint32_t)dx * ((uint32_t)y + (uint32_t)dy * (uint32_t)z);
                     for (int i = 0; i < 4; i++) {
                         const int x = i0[0] + i;
                         if (x < 0 || x >= dx) continue;
-                        const float4 c = row[x];
+                        const float4 c = coeff[lat(g, img, row + (uint32_t)x)];
                         const T f = F[0][i];
                         vy[0] = fma((T)c.x, f, vy[0]); vy[1] = fma((T)c.y, f, vy[1]); vy[2] = fma((T)c.z, f, vy[2]);
                     }
@@ -1064,7 +1075,6 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
     const int bz = bidx / g.nbricks[1];
     // first control point of the brick: cell c (1-based) uses control points c-1..c+2
     const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
-    float4 *gimg = gradf + (size_t)img * g.n_cp;
 
     const int ti = lane & 3, tj = (lane >> 2) & 3, tk = lane >> 4;
     const int tap_off = ti + E * (tj + E * tk);
@@ -1126,7 +1136,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
                         const int gx = ic[0] - 1 + i, gy = ic[1] - 1 + j, gz = ic[2] - 1 + k;
                         if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
                         const float w = wxy[4 * j + i] * wz[k];
-                        float *dst = reinterpret_cast<float *>(gimg + ((size_t)gx + (size_t)g.dims[0] * ((size_t)gy + (size_t)g.dims[1] * gz)));
+                        float *dst = reinterpret_cast<float *>(gradf + lat(g, img, (uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz)));
                         atomicAdd(dst + 0, w * sm.x); atomicAdd(dst + 1, w * sm.y);
                         atomicAdd(dst + 2, w * sm.z); atomicAdd(dst + 3, w * sm.w);
                     }
@@ -1381,7 +1391,7 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
         const uint32_t img = i0 + il;
         float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (img < a.n_owned && cp < g.n_cp) {
-            const size_t o = (size_t)img * g.n_cp + cp;
+            const size_t o = lat(g, img, (uint32_t)cp);
             const float4 c4 = a.coeff[o];                       // needed last, asked for first
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             // (a per-image box of the non-empty bricks used to trim the candidates: one more memory round trip in front of
@@ -1486,7 +1496,7 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
             v.x = (float)((double)v.x - mx);
             v.y = (float)((double)v.y - my);
             v.z = (float)((double)v.z - mz);
-            a.grad[(size_t)img * g.n_cp + cp] = v;
+            a.grad[lat(g, img, (uint32_t)cp)] = v;
             cnt += ((double)fabsf(v.x) > a.lim[0]) + ((double)fabsf(v.y) > a.lim[1]) + ((double)fabsf(v.z) > a.lim[2]);
         };
         if (kept) {
@@ -1496,7 +1506,7 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
                 if (img < a.n_owned) centre(img, keep[pass]);
             }
         } else {
-            for (uint32_t img = il; img < a.n_owned; img += LS_IC) centre(img, a.grad[(size_t)img * g.n_cp + cp]);
+            for (uint32_t img = il; img < a.n_owned; img += LS_IC) centre(img, a.grad[lat(g, img, (uint32_t)cp)]);
         }
     }
     // oversize count -> energy[2] (zeroed by energy_reduce_kernel earlier in the step): integers added as f64 are exact and
@@ -1512,10 +1522,11 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
 constexpr int CP_BATCH = 10;
 
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
-__global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, int n_cp, uint32_t n_images,
+__global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, const GeomDev g, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
                                                         double *energy, const double *energy_tail)
 {
+    const int n_cp = g.n_cp;
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
     // two collectives per iteration: the all-reduced energy sums and list flag come back from behind the proposal sums
     // (lattice_step_kernel put them there); energy[2], which the other threads count into, is not touched
@@ -1529,14 +1540,14 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
         for (uint32_t i0 = 0; i0 < n_owned; i0 += CP_BATCH) {
             float4 v[CP_BATCH];
             #pragma unroll
-            for (int b = 0; b < CP_BATCH; b++) v[b] = grad[(size_t)min(i0 + b, n_owned - 1) * n_cp + cp];
+            for (int b = 0; b < CP_BATCH; b++) v[b] = grad[lat(g, min(i0 + b, n_owned - 1), (uint32_t)cp)];
             #pragma unroll
             for (int b = 0; b < CP_BATCH; b++) {
                 if (i0 + b >= n_owned) break;
                 v[b].x = (float)((double)v[b].x - mx);
                 v[b].y = (float)((double)v[b].y - my);
                 v[b].z = (float)((double)v[b].z - mz);
-                grad[(size_t)(i0 + b) * n_cp + cp] = v[b];
+                grad[lat(g, i0 + b, (uint32_t)cp)] = v[b];
                 cnt += ((double)fabsf(v[b].x) > lim_x) + ((double)fabsf(v[b].y) > lim_y) + ((double)fabsf(v[b].z) > lim_z);
             }
         }
@@ -1546,6 +1557,13 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += (unsigned int)__shfl_down((int)cnt, off, 64);
     if ((threadIdx.x & 63) == 0 && cnt) unsafeAtomicAdd(&energy[2], (double)cnt);
+}
+
+// One image's lattice out of coeff / gradf / a retired lattice into a contiguous array (the getters; layouts: lat())
+__global__ __launch_bounds__(256) void lattice_extract_kernel(const float4 *src, const GeomDev g, uint32_t img, float4 *dst)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < (uint32_t)g.n_cp) dst[n] = src[lat(g, img, n)];
 }
 
 } // namespace frog

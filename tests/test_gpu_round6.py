@@ -115,3 +115,22 @@ def test_two_collectives_flow_with_the_scalars_by_copy(tmp_path):
     _frog(copy, *flags, env_extra={"FROG_SCALARS_COPY": "1"})
     assert out.count("Iteration canceled") >= 2
     _same_files(direct, copy, pairs.n_images)
+
+
+# ---- (4) the lattices in blocks of 16 nodes across the images (k_grid.hip.h lat()) ----------------------------------------------------
+
+@pytest.mark.parametrize("flags", [(), ("-ngl", "3"), ("-gm", "0.004")])
+def test_blocked_lattice_layout_gives_the_same_files(tmp_path, flags):
+    """FROG_LATTICE_BLOCKED=1 (the layout fine lattices of many images get by themselves: [node / 16][image][node % 16]) against
+    image-major on a group that would never choose it: identical measures.csv and transforms -- the layout moves entries, no
+    arithmetic -- for one context, three sharded contexts (phase B by cp_center_kernel, the speculative third lattice) and a run whose
+    guard rejects steps (retired lattices read back through their own layout)."""
+    from test_gpu_round5 import _frog, _same_files
+    pairs = Pairs.synthetic(9, 3000, 1200, seed=4)
+    plain, blocked = tmp_path / "plain", tmp_path / "blocked"
+    for d in (plain, blocked):
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+    _frog(plain, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0"})
+    _frog(blocked, *flags, env_extra={"FROG_LATTICE_BLOCKED": "1"})
+    _same_files(plain, blocked, pairs.n_images)
