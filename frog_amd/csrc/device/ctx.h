@@ -314,6 +314,7 @@ struct frog_ctx {
     frog::DevBuf<unsigned char> scatter_blocks_tmp; // the same blocks in brick order
     frog::DevBuf<uint32_t> len_hist;          // [2][SCATTER_CHUNK + 1] block-length histogram, cursors
     uint32_t n_scatter_blocks = 0;            // launch grid of the scatter: an upper bound of the block count
+    uint32_t scatter_chunk = 384;             // points per scatter block of this context (<= SCATTER_CHUNK; frog_create)
     frog::DevBuf<float> bounds_scratch;       // [BOUNDS_BLOCKS][6] per-block min xyz, max xyz
     frog::DevBuf<unsigned int> stray;         // [0], [1]: points the scatter of an even / odd step found outside every brick (their taps went to
                                               // gradf), [2]: running total

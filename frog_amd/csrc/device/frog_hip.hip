@@ -239,9 +239,9 @@ __global__ void scratch_warm_kernel(unsigned int *out, int n)
 }
 
 // upper bound of the scatter's block count: every non-empty brick ends with at most one partial block
-static uint32_t scatter_max_blocks(uint32_t n_bricks_total, uint32_t n_points)
+static uint32_t scatter_max_blocks(uint32_t n_bricks_total, uint32_t n_points, uint32_t chunk)
 {
-    return std::min(n_bricks_total, n_points) + n_points / SCATTER_CHUNK;
+    return std::min(n_bricks_total, n_points) + n_points / chunk;
 }
 
 // Device work of a lattice set-up (frog_deformable_setup_bounds) for the geometry in ctx->geom, on stream s.
@@ -312,8 +312,8 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
     // block table (k_grid.hip.h): blocks per brick -> staging slots (scan) -> blocks in brick order -> longest first.
     // Its length stays on the device (brick_slot_ptr[n_bricks_total]); the scatter is launched with an upper bound:
     // every non-empty brick ends with at most one partial block
-    const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts);
-    brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, chunks.p);
+    const uint32_t max_blocks = scatter_max_blocks(n_bricks_total, nPts, ctx->scatter_chunk);
+    brick_chunks_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, n_bricks_total, keys_per_brick, ctx->scatter_chunk, chunks.p);
     FROG_HIP_CHECK(hipGetLastError());
     rc = exclusive_scan(chunks.p, n_bricks_total, ctx->brick_slot_ptr.p, ctx->key_cursor.p /* scratch: the placement is done */);
     if (rc) return rc;
@@ -322,11 +322,11 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
     uint32_t *len_hist = ctx->len_hist.p, *len_cursor = ctx->len_hist.p + (SCATTER_CHUNK + 1);
     const uint32_t *n_blocks_dev = ctx->brick_slot_ptr.p + n_bricks_total;
     block_fill_kernel<<<div_up(n_bricks_total, 256), 256, 0, s>>>(ctx->key_ptr.p, ctx->brick_slot_ptr.p, n_bricks_total, keys_per_brick,
-                                                                 blk_tmp, len_hist);
+                                                                 ctx->scatter_chunk, blk_tmp, len_hist);
     static_assert(SCATTER_CHUNK + 1 <= 1024, "block_len_base_kernel: one thread per block length");
     block_len_base_kernel<<<1, (SCATTER_CHUNK + 1 + 63) / 64 * 64, 0, s>>>(len_hist, len_cursor);
     if (max_blocks)
-        block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, len_cursor, blk);
+        block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, ctx->scatter_chunk, len_cursor, blk);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -776,6 +776,16 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     c->poff.assign(m->point_offset, m->point_offset + c->nI + 1);
     c->P = c->poff[c->nI];
     c->own_pt_begin = c->poff[c->ib]; c->own_pt_end = c->poff[c->ie];
+    {
+        // Points per scatter block (k_grid.hip.h): SCATTER_CHUNK for every context.  Round 6 tried shorter blocks for contexts that
+        // own few points (a rank of eight of the benchmark group has 625 blocks of 384 for 1 024 SIMDs, its scatter lasts one block's
+        // 31 us): with 128 the scatter took 18 us -- and the lattice step, which adds a brick's staged tiles slot by slot, 40 instead
+        // of 21 (level 0; 30 / 19 and 33 / 26 on levels 1 and 2): 7 287 against 7 365 rank-iterations/s, and a brick's points are summed
+        // per block, so shardings would no longer agree to the bit.  The switch stays for experiments.
+        uint32_t chunk = (uint32_t)SCATTER_CHUNK;
+        if (const char *e = getenv("FROG_SCATTER_CHUNK_POINTS")) chunk = std::min<uint32_t>((uint32_t)SCATTER_CHUNK, std::max<uint32_t>(64u, (uint32_t)atoi(e) / 64u * 64u));
+        c->scatter_chunk = chunk;
+    }
     if (c->P >= 0x7FFFFFFFull) { delete c; return fail(FROG_E_INVALID, "more than 2^31-1 points"); }
 
     Layout lay;
@@ -1061,7 +1071,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
                 if (make_geometry(c, finest, mn, mx, gh, ih) == FROG_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                     gh.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)gh.n_cp * 5 / 4);
                     const size_t nO = c->n_owned(), nPts = c->own_pt_end - c->own_pt_begin;
-                    const size_t blocks = scatter_max_blocks((uint32_t)std::min<size_t>(0xFFFFFFFFu, nO * (size_t)gh.n_bricks), (uint32_t)nPts);
+                    const size_t blocks = scatter_max_blocks((uint32_t)std::min<size_t>(0xFFFFFFFFu, nO * (size_t)gh.n_bricks), (uint32_t)nPts, c->scatter_chunk);
                     const size_t E = (size_t)gh.brick + 3;
                     size_t arena_h = 0;
                     for (int l = 0; l <= finest; l++) {
@@ -1646,7 +1656,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     const size_t reserve = ((size_t)nO * G * 64 * sizeof(float4) <= ((size_t)2 << 30)) ? 64 : (((size_t)nO * G * 8 * sizeof(float4) <= ((size_t)2 << 30)) ? 8 : 1);
     const size_t n_keys = (size_t)nO * g.n_bricks * (size_t)(g.brick * g.brick * g.brick);
     const size_t n_bricks_total = (size_t)nO * g.n_bricks;
-    const size_t max_blocks = std::max<size_t>(1, scatter_max_blocks((uint32_t)n_bricks_total, nPts));
+    const size_t max_blocks = std::max<size_t>(1, scatter_max_blocks((uint32_t)n_bricks_total, nPts, ctx->scatter_chunk));
     const size_t E = (size_t)g.brick + 3;
     const size_t LG = std::max(g.lat_entries(), (size_t)nO * G);       // entries of one lattice in its layout (blocked: nodes padded to 16)
     FROG_HIP_CHECK(ctx->coeff.alloc(LG, LG * reserve));
@@ -1722,7 +1732,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
     const size_t n_keys64 = (size_t)nO * nb * keys_per_brick;
     if (n_keys64 >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
-    ctx->n_scatter_blocks = scatter_max_blocks(nO * (uint32_t)nb, nPts);
+    ctx->n_scatter_blocks = scatter_max_blocks(nO * (uint32_t)nb, nPts, ctx->scatter_chunk);
     ctx->coeff_zero = true;
     // The device work of the set-up -- zeroing, the sort of the points, the block table -- is queued on the set-up stream,
     // behind what `stream` holds NOW (the re-based coordinates, the copy of the finished lattice, the last readers of the old
@@ -1805,7 +1815,7 @@ static int cull_allocate_buffers(frog_ctx *ctx)
         for (uint32_t i = 0; i < ctx->nI; i++) blocks += div_up(ctx->poff[i + 1] - ctx->poff[i], CULL_BLOCK_POINTS);
         // one slot per producer block: cull_disp_kernel's, or the B-spline transform's (at most one block per point + one per
         // SCATTER_CHUNK points in its tiled form)
-        FROG_HIP_CHECK(ctx->disp_part.alloc(std::max<size_t>(blocks, (size_t)ctx->P + ctx->P / SCATTER_CHUNK + 16)));
+        FROG_HIP_CHECK(ctx->disp_part.alloc(std::max<size_t>(blocks, (size_t)ctx->P + ctx->P / ctx->scatter_chunk + 16)));
     }
     FROG_HIP_CHECK(ctx->cull_state.alloc(2));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->cull_state.p, 0, ctx->cull_state.bytes(), s));

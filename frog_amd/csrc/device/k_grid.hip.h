@@ -648,16 +648,18 @@ struct ScatterBlock {
 };
 
 // chunks[k] = number of scatter blocks of brick k
-__global__ void brick_chunks_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t *chunks)
+// `chunk` (<= SCATTER_CHUNK): points per block of THIS context (frog_ctx::scatter_chunk) -- a context that owns few points cuts
+// its bricks into shorter blocks, so that they fill the chip instead of queueing as a few long ones
+__global__ void brick_chunks_kernel(const uint32_t *ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t chunk, uint32_t *chunks)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_bricks_total) return;
     const uint32_t n = ptr[(size_t)(k + 1) * keys_per_brick] - ptr[(size_t)k * keys_per_brick];
-    chunks[k] = (n + SCATTER_CHUNK - 1) / SCATTER_CHUNK;
+    chunks[k] = (n + chunk - 1) / chunk;
 }
 
 // blocks in brick order + histogram of their lengths (len_hist[SCATTER_CHUNK + 1], zeroed by the caller)
-__global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr, uint32_t n_bricks_total, uint32_t keys_per_brick,
+__global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr, uint32_t n_bricks_total, uint32_t keys_per_brick, uint32_t chunk,
                                   ScatterBlock *blocks, uint32_t *len_hist)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,16 +668,16 @@ __global__ void block_fill_kernel(const uint32_t *ptr, const uint32_t *slot_ptr,
     if (k < n_bricks_total) {
         const uint32_t b = ptr[(size_t)k * keys_per_brick], e = ptr[(size_t)(k + 1) * keys_per_brick];
         uint32_t slot = slot_ptr[k];
-        const uint32_t step = SCATTER_CHUNK;
+        const uint32_t step = chunk;
         for (uint32_t b0 = b; b0 < e; b0 += step, slot++) {
             const uint32_t e0 = min(b0 + step, e);
             blocks[slot] = ScatterBlock{ k, b0, e0, slot };
-            if (e0 - b0 == (uint32_t)SCATTER_CHUNK) full++; else atomicAdd(&len_hist[e0 - b0], 1u);
+            if (e0 - b0 == chunk) full++; else atomicAdd(&len_hist[e0 - b0], 1u);
         }
     }
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) full += (uint32_t)__shfl_down((int)full, off, 64);
-    if ((threadIdx.x & 63) == 0 && full) atomicAdd(&len_hist[SCATTER_CHUNK], full);
+    if ((threadIdx.x & 63) == 0 && full) atomicAdd(&len_hist[chunk], full);
 }
 
 // first position of every length in the longest-first order; one block of SCATTER_CHUNK + 1 <= 1024 threads
@@ -693,7 +695,7 @@ __global__ void block_len_base_kernel(const uint32_t *len_hist, uint32_t *len_cu
     if (t <= SCATTER_CHUNK) len_cursor[t] = sh[t];
 }
 
-__global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_blocks, uint32_t *len_cursor, ScatterBlock *sorted)
+__global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_blocks, uint32_t chunk, uint32_t *len_cursor, ScatterBlock *sorted)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < *n_blocks;
@@ -701,13 +703,13 @@ __global__ void block_sort_kernel(const ScatterBlock *blocks, const uint32_t *n_
     if (live) b = blocks[i];
     // the full blocks of a wavefront take their places with ONE atomic (see block_fill_kernel); which full block goes where
     // among the full ones is arbitrary either way
-    const bool is_full = live && b.end - b.begin == (uint32_t)SCATTER_CHUNK;
+    const bool is_full = live && b.end - b.begin == chunk;
     const unsigned long long m = __ballot(is_full);
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (m) {
         const int leader = (int)__ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&len_cursor[SCATTER_CHUNK], (uint32_t)__popcll(m));
+        if (lane == leader) base = atomicAdd(&len_cursor[chunk], (uint32_t)__popcll(m));
         base = (uint32_t)__shfl((int)base, leader, 64);
     }
     if (is_full) sorted[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
