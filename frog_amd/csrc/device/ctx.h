@@ -185,6 +185,13 @@ struct GridGeom {
     // and image-major those are 256-byte pieces 16 n_cp bytes apart (cfg 5 level 4: 500 pieces 14.7 MB apart per pass)
     bool blocked = false;
     uint32_t lat_images = 0;    // owned images the lattices are laid out for
+    // `sparse`: entries are kept for ACTIVE (image, node) pairs only -- the nodes in the 4^3 stencil of any of the image's points
+    // (frog_ctx::lat_mask: per node a bit set over the owned images, mask_words words).  `pos` stands still while a lattice stands,
+    // so the set is fixed for the lattice's life; a pair outside it never receives a gradient and is never read by the transform
+    // of the image's points: its coefficient is 0 minus the node's means so far, the SAME float for every such image of the node
+    // (frog_ctx::ucoeff).  The lattice step then touches 43 % of the pairs of cfg 5's finest lattice instead of all of them.
+    bool sparse = false;
+    uint32_t mask_words = 0;
     size_t lat_entries() const { return blocked ? (size_t)((n_cp + 15) / 16) * 16 * lat_images : (size_t)lat_images * (size_t)n_cp; }
 };
 
@@ -192,6 +199,10 @@ struct GridRecord {         // a finished or current lattice of the chain
     frog_grid_info info;
     bool blocked = false;       // layout of `kept` (GridGeom::blocked when the lattice was retired)
     uint32_t lat_images = 0;
+    bool sparse = false;        // `kept` holds the active pairs only: kept_mask / kept_u say which, and what the others are
+    uint32_t mask_words = 0;
+    std::shared_ptr<DevBuf<uint32_t>> kept_mask;
+    std::shared_ptr<DevBuf<float4>> kept_u;
     std::shared_ptr<DevBuf<float4>> kept;   // [owned images][G] coefficients, filled (device copy) when the lattice is retired
     bool retired = false;
 };
@@ -305,6 +316,10 @@ struct frog_ctx {
     frog::DevBuf<float4> grad;                // [nOwned][G] proposed coefficients (xyz), gradient weight (w)
     frog::DevBuf<float4> gradf;               // [nOwned][G] gradient lattice: sum w*sDisp xyz, sum w*sWeight
     frog::DevBuf<float4> grad_spare;          // a third lattice: the proposals of a step queued before the previous one's decision (frog_step_speculate)
+    // sparse lattices (GridGeom::sparse): the active pairs, and per node the value of its inactive pairs -- companions of coeff / grad /
+    // grad_spare, exchanged with them
+    frog::DevBuf<uint32_t> lat_mask;          // [G][mask_words]
+    frog::DevBuf<float4> ucoeff, ugrad, ugrad_spare;   // [G]
     frog::DevBuf<double> gridsum;             // [3G] (+ 4: frog_comm_mode)
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)
     frog::DevBuf<uint32_t> key_ptr;           // [nOwned*n_bricks*B^3 + 1] (image, brick, cell) -> perm range

@@ -264,6 +264,10 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
         add(ctx->gradf.p, ctx->gradf.bytes()); add(ctx->coeff.p, ctx->coeff.bytes()); add(ctx->grad.p, ctx->grad.bytes());
         add(ctx->gridsum.p, ctx->gridsum.bytes()); add(ctx->key_counts.p, ctx->key_counts.bytes());
         add(ctx->len_hist.p, ctx->len_hist.bytes());
+        if (g.sparse) {
+            add(ctx->lat_mask.p, ctx->lat_mask.bytes()); add(ctx->ucoeff.p, ctx->ucoeff.bytes()); add(ctx->ugrad.p, ctx->ugrad.bytes());
+            add(ctx->ugrad_spare.p, ctx->ugrad_spare.bytes());
+        }
         if (z.n) {
             zero_buffers_kernel<<<z.first_block[z.n], 256, 0, s>>>(z);
             FROG_HIP_CHECK(hipGetLastError());
@@ -327,6 +331,8 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
     block_len_base_kernel<<<1, (SCATTER_CHUNK + 1 + 63) / 64 * 64, 0, s>>>(len_hist, len_cursor);
     if (max_blocks)
         block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, ctx->scatter_chunk, len_cursor, blk);
+    if (g.sparse && nPts && max_blocks)         // the active (image, node) pairs of the new lattice, block by block
+        lattice_mask_kernel<<<max_blocks, 64, 0, s>>>(ctx->pos_b.p, blk, n_blocks_dev, gd, ctx->lat_mask.p);
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1631,15 +1637,24 @@ static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], c
     if (nb * nO >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many bricks");
     g.n_bricks = (int)nb;
     if ((size_t)nO * nb * (size_t)(g.brick * g.brick * g.brick) >= 0x7FFFFFFFull) return fail(FROG_E_INVALID, "too many lattice cells");
-    // Lattice layout (ctx.h GridGeom::blocked, k_grid.hip.h lat()): image-major, or blocks of 16 nodes across the owned images.
-    // The lattice step reads and writes every (image, node) pair, 16 nodes of all images per block: image-major those are
-    // 256-byte pieces n_cp * 16 bytes apart.  FROG_LATTICE_BLOCKED=0 / 1 forces one form (A/B, tests); reference-order mode keeps
-    // image-major (its kernels index that way).
+    // Lattice layout and storage of the finest lattices of many images (ctx.h GridGeom::blocked / sparse, k_grid.hip.h lat()):
+    //   blocked: blocks of 16 nodes across the owned images instead of image-major (the lattice step works through ALL images of
+    //            16 nodes at a time);
+    //   sparse:  entries only for the (image, node) pairs some point of the image reaches -- the others of a node share one value.
+    // Measured on cfg 5's level 4 (500 images x 9e5 nodes, `scripts/cfg5_level4_traffic.sh`): the
+    // lattice step 8.09 -> 6.71 ms with 41 -> 28 GB moved; the B-spline transform + 3 %; the set of active pairs costs 10 ms per
+    // lattice to find.  Worth it from about seven iterations per lattice on, on lattices of >= 2^27 pairs; smaller ones (cfg 5's
+    // level 3: 7e7 pairs; everything of cfg 3) keep the plain form, where the step is bound by latency, not bytes.
+    // FROG_LATTICE_BLOCKED / FROG_LATTICE_SPARSE = 0 / 1 force a form (A/B, tests); reference-order mode keeps the plain one.
     g.lat_images = nO;
     {
         static const char *e = getenv("FROG_LATTICE_BLOCKED");
-        g.blocked = e ? atoi(e) != 0 : (nO >= 32u && (size_t)nO * G >= ((size_t)1 << 24));
-        if (ctx->ref_order) g.blocked = false;
+        static const char *es = getenv("FROG_LATTICE_SPARSE");
+        const bool fine = nO >= 32u && (size_t)nO * G >= ((size_t)1 << 27);
+        g.blocked = e ? atoi(e) != 0 : fine;
+        g.sparse = es ? atoi(es) != 0 : fine;
+        if (ctx->ref_order) g.blocked = g.sparse = false;
+        g.mask_words = (nO + 31u) / 32u;
     }
     return FROG_OK;
 }
@@ -1664,6 +1679,11 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->gradf.alloc(LG, LG * reserve));
     // a third lattice for contexts whose host queues the next step before this one's decision is known (frog_step_speculate)
     if (ctx->two_collectives && !ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc(LG, LG * reserve));
+    if (g.sparse) {
+        FROG_HIP_CHECK(ctx->lat_mask.alloc(G * g.mask_words, G * g.mask_words * reserve));
+        FROG_HIP_CHECK(ctx->ucoeff.alloc(G, G * reserve)); FROG_HIP_CHECK(ctx->ugrad.alloc(G, G * reserve));
+        FROG_HIP_CHECK(ctx->ugrad_spare.alloc(G, G * reserve));
+    }
     FROG_HIP_CHECK(ctx->gridsum.alloc(3 * G + 4, (3 * G + 4) * reserve));      // + 4: the energy sums' seat on the all-reduce (frog_comm_mode)
     FROG_HIP_CHECK(ctx->key_counts.alloc(n_keys, n_keys * reserve));
     FROG_HIP_CHECK(ctx->brick_ptr_scratch.alloc(n_bricks_total + 1, (n_bricks_total + 1) * reserve));
@@ -1702,6 +1722,16 @@ static int retire_current_grid(frog_ctx *ctx)
         FROG_HIP_CHECK(gr.kept->alloc_async(std::max<size_t>(1, n), ctx->stream));
     }
     if (n) FROG_HIP_CHECK(hipMemcpyAsync(gr.kept->p, ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    gr.sparse = ctx->geom.sparse; gr.mask_words = ctx->geom.mask_words;
+    if (gr.sparse) {                            // which pairs `kept` holds, and what the others are
+        const size_t G = (size_t)ctx->geom.n_cp;
+        gr.kept_mask = std::make_shared<DevBuf<uint32_t>>();
+        gr.kept_u = std::make_shared<DevBuf<float4>>();
+        FROG_HIP_CHECK(gr.kept_mask->alloc_async(std::max<size_t>(1, G * gr.mask_words), ctx->stream));
+        FROG_HIP_CHECK(gr.kept_u->alloc_async(std::max<size_t>(1, G), ctx->stream));
+        FROG_HIP_CHECK(hipMemcpyAsync(gr.kept_mask->p, ctx->lat_mask.p, G * gr.mask_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        FROG_HIP_CHECK(hipMemcpyAsync(gr.kept_u->p, ctx->ucoeff.p, G * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     gr.retired = true;
     return FROG_OK;
 }
@@ -1965,6 +1995,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p;
         la.gradf = ctx->gradf.p; la.stray = ctx->stray.p + ctx->stray_parity;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
+        la.mask = ctx->lat_mask.p; la.ucoeff = ctx->ucoeff.p; la.ugrad = ctx->ugrad.p;
         la.energy_tail = ctx->two_collectives && !ctx->whole_group() ? ctx->gridsum.p + 3 * (size_t)gd.n_cp : nullptr;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
@@ -2001,7 +2032,8 @@ int frog_deformable_phase_b(frog_ctx *ctx)
     cp_center_kernel<<<div_up(g.n_cp, 256), 256, 0, s>>>(ctx->grad.p, ctx->n_owned(), to_dev(g), ctx->nf ? 0u : ctx->nI, ctx->gridsum.p,
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
                                                         (double)maxD * g.spacing[2], ctx->energy.p,
-                                                        ctx->two_collectives ? ctx->gridsum.p + 3 * (size_t)g.n_cp : nullptr);
+                                                        ctx->two_collectives ? ctx->gridsum.p + 3 * (size_t)g.n_cp : nullptr,
+                                                        ctx->lat_mask.p, ctx->ucoeff.p, ctx->ugrad.p);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->phase = 2;
     return FROG_OK;
@@ -2044,6 +2076,7 @@ int frog_deformable_phase_c(frog_ctx *ctx, double *E)
         std::swap(ctx->coeff.p, ctx->grad.p);
         std::swap(ctx->coeff.cap, ctx->grad.cap);
         std::swap(ctx->coeff.n, ctx->grad.n);
+        std::swap(ctx->ucoeff.p, ctx->ugrad.p); std::swap(ctx->ucoeff.cap, ctx->ugrad.cap); std::swap(ctx->ucoeff.n, ctx->ugrad.n);   // (sparse lattices: their companions)
         ctx->coeff_zero = false;
     }
     ctx->phase = 0;
@@ -2245,8 +2278,12 @@ int frog_get_grid(frog_ctx *ctx, uint32_t image, int k, frog_grid_info *info, fl
         lg.n_cp = (int)G;
         lg.blocked = gr.retired ? gr.blocked : ctx->geom.blocked;
         lg.lat_images = gr.retired ? gr.lat_images : ctx->geom.lat_images;
+        lg.sparse = gr.retired ? gr.sparse : ctx->geom.sparse;
+        lg.mask_words = gr.retired ? gr.mask_words : ctx->geom.mask_words;
+        const uint32_t *mask = !lg.sparse ? nullptr : (gr.retired ? gr.kept_mask->p : ctx->lat_mask.p);
+        const float4 *u = !lg.sparse ? nullptr : (gr.retired ? gr.kept_u->p : ctx->ucoeff.p);
         FROG_HIP_CHECK(ctx->extract_tmp.alloc(G));
-        lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(src, to_dev(lg), (uint32_t)li, ctx->extract_tmp.p);
+        lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(src, to_dev(lg), (uint32_t)li, mask, u, ctx->extract_tmp.p);
         FROG_HIP_CHECK(hipGetLastError());
         FROG_HIP_CHECK(hipMemcpyAsync(h.data(), ctx->extract_tmp.p, G * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -2377,7 +2414,11 @@ int frog_get_gradient(frog_ctx *ctx, uint32_t image, float *out, size_t cap)
     const size_t G = (size_t)ctx->geom.n_cp;
     const size_t n = std::min(cap, 4 * G);
     FROG_HIP_CHECK(ctx->extract_tmp.alloc(G));
-    lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(ctx->gradf.p, to_dev(ctx->geom), image - ctx->ib, ctx->extract_tmp.p);
+    {
+        GridGeom lg = ctx->geom;
+        lg.sparse = false;                      // the gradient lattice has an entry for every pair (only stray points write it)
+        lattice_extract_kernel<<<div_up(G, 256), 256, 0, ctx->stream>>>(ctx->gradf.p, to_dev(lg), image - ctx->ib, nullptr, nullptr, ctx->extract_tmp.p);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     FROG_HIP_CHECK(hipMemcpyAsync(out, ctx->extract_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FROG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -2777,6 +2818,7 @@ int frog_step_speculate(frog_ctx *ctx)
     auto rotate = [](DevBuf<float4> &a, DevBuf<float4> &b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); std::swap(a.n, b.n); };
     rotate(ctx->coeff, ctx->grad);              // coeff = proposal, grad = old coefficients
     rotate(ctx->grad, ctx->grad_spare);         // grad = spare, spare = old coefficients
+    rotate(ctx->ucoeff, ctx->ugrad); rotate(ctx->ugrad, ctx->ugrad_spare);      // (sparse lattices: their companions)
     ctx->coeff_zero = false;
     ctx->speculated = true;
     ctx->phase = 0;
@@ -2806,13 +2848,14 @@ int frog_step_finish(frog_ctx *ctx, double *E)
                 // a step that did not happen -- per-point sums, staged tiles, proposals in the spare lattice: nothing of it is read again
                 rotate(ctx->grad, ctx->grad_spare);
                 rotate(ctx->coeff, ctx->grad);
+                rotate(ctx->ugrad, ctx->ugrad_spare); rotate(ctx->ucoeff, ctx->ugrad);
                 ctx->coeff_zero = ctx->spec_coeff_zero;
                 ctx->phase = 0;
                 ctx->xyz2_fresh = false; ctx->res_valid = false;
             }
         } else {
             if (ctx->phase != 2) return fail(FROG_E_STATE, "frog_step_finish: no deformable step pending");
-            if (!rejected) { rotate(ctx->coeff, ctx->grad); ctx->coeff_zero = false; }
+            if (!rejected) { rotate(ctx->coeff, ctx->grad); rotate(ctx->ucoeff, ctx->ugrad); ctx->coeff_zero = false; }
             ctx->phase = 0;
         }
         if (E) *E = rejected ? -1.0 : e;

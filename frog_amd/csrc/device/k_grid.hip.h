@@ -27,7 +27,14 @@ struct GeomDev {
     int lat_sh;
     uint32_t lat_mask;
     size_t lat_blk, lat_img;
+    uint32_t mask_words;        // > 0: the lattice keeps entries of ACTIVE (image, node) pairs only (ctx.h GridGeom::sparse): words per node
 };
+
+// Sparse lattices (ctx.h GridGeom::sparse): is (image, node) an active pair?  mask = [node][mask_words] bit sets over the owned images.
+__device__ __forceinline__ bool lat_active(const uint32_t *mask, const GeomDev &g, uint32_t img, uint32_t node)
+{
+    return (mask[(size_t)node * g.mask_words + (img >> 5)] >> (img & 31u)) & 1u;
+}
 
 // entry of control point `node` of owned image `img` in coeff / grad / gradf / grad_spare
 __host__ __device__ __forceinline__ size_t lat(const GeomDev &g, uint32_t img, uint32_t node)
@@ -40,6 +47,7 @@ inline GeomDev to_dev(const GridGeom &g)
     GeomDev d;
     if (g.blocked) { d.lat_sh = 4; d.lat_mask = 15u; d.lat_blk = (size_t)16 * g.lat_images; d.lat_img = 16; }
     else { d.lat_sh = 31; d.lat_mask = 0x7FFFFFFFu; d.lat_blk = 0; d.lat_img = (size_t)g.n_cp; }
+    d.mask_words = g.sparse ? g.mask_words : 0u;
     for (int k = 0; k < 3; k++) { d.dims[k] = g.dims[k]; d.origin[k] = g.origin[k]; d.spacing[k] = g.spacing[k]; d.inv_spacing[k] = 1.0 / g.spacing[k]; d.nbricks[k] = g.nbricks[k]; }
     d.n_cp = g.n_cp; d.brick = g.brick; d.n_bricks = g.n_bricks;
     return d;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
 // of its own with a few microseconds of idle stream in front of it).  A block clears ZERO_BLOCK_BYTES of one buffer with
 // 16-byte stores (the buffers are hipMalloc'ed: aligned); sizes are multiples of 4 bytes, the last words of a buffer go
 // one by one.
-constexpr int ZERO_MAX = 8;
+constexpr int ZERO_MAX = 12;
 constexpr unsigned ZERO_BLOCK_BYTES = 256 * 16 * 8;
 struct ZeroList {
     uint32_t *p[ZERO_MAX];
@@ -1355,6 +1363,10 @@ struct LatticeStepArgs {
     float alpha;
     double lim[3];
     double *energy;
+    // sparse lattices: the active pairs' bit sets, the value every inactive pair of a node holds (standing / proposed)
+    const uint32_t *mask;
+    const float4 *ucoeff;
+    float4 *ugrad;
 };
 
 // CPB: control points per block (LS_CPB, or LS_CPB_SMALL for lattices of so few nodes that blocks of LS_CPB would leave most
@@ -1388,11 +1400,32 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
     float4 keep[LS_KEEP];
     const bool kept = CENTER && a.n_owned <= (uint32_t)(LS_KEEP * LS_IC);
 
+    // Sparse lattices: which of this thread's pairs are active, for all the passes it keeps in registers -- asked for up front, side
+    // by side: behind a load of its own at the head of every pass's chain the passes ran one after the other (a wait in front of
+    // each pass's branch; cfg 5 level 4: a third of the bytes gone and a tenth of the time)
+    uint32_t act = ~0u;
+    float4 u_node = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.mask_words && cp < g.n_cp) {
+        u_node = a.ucoeff[cp];
+        if (kept) {
+            act = 0u;
+            #pragma unroll
+            for (int pass = 0; pass < LS_KEEP; pass++) {
+                const uint32_t img = (uint32_t)pass * LS_IC + il;
+                if (img < a.n_owned) act |= (lat_active(a.mask, g, img, (uint32_t)cp) ? 1u : 0u) << pass;
+            }
+        }
+    }
     // steps 1-2 for this thread's (image i0 + il, control point): the proposal (0 for threads without one)
     auto propose = [&](uint32_t i0, bool store) {
         const uint32_t img = i0 + il;
         float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (img < a.n_owned && cp < g.n_cp) {
+        if (img < a.n_owned && cp < g.n_cp && g.mask_words && !(kept ? (act >> (i0 / LS_IC)) & 1u : (uint32_t)lat_active(a.mask, g, img, (uint32_t)cp))) {
+            // no point of this image reaches the node while the lattice stands: gw = 0, the proposal is the standing value -- the
+            // one every such pair of the node holds (they started at 0 together and only ever had the node's mean subtracted)
+            n4 = u_node;
+            n4.w = -1.0f;                               // marks the pair for centre(): nothing of it is stored
+        } else if (img < a.n_owned && cp < g.n_cp) {
             const size_t o = lat(g, img, (uint32_t)cp);
             const float4 c4 = a.coeff[o];                       // needed last, asked for first
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1495,6 +1528,7 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
     if (cp < g.n_cp) {
         const double mx = mean[c][0], my = mean[c][1], mz = mean[c][2];
         auto centre = [&](uint32_t img, float4 v) {
+            if (g.mask_words && v.w < 0.0f) return;     // an inactive pair (propose): the node's shared value stands for it, below
             v.x = (float)((double)v.x - mx);
             v.y = (float)((double)v.y - my);
             v.z = (float)((double)v.z - mz);
@@ -1508,7 +1542,20 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
                 if (img < a.n_owned) centre(img, keep[pass]);
             }
         } else {
-            for (uint32_t img = il; img < a.n_owned; img += LS_IC) centre(img, a.grad[lat(g, img, (uint32_t)cp)]);
+            for (uint32_t img = il; img < a.n_owned; img += LS_IC) {
+                if (g.mask_words && !lat_active(a.mask, g, img, (uint32_t)cp)) continue;
+                centre(img, a.grad[lat(g, img, (uint32_t)cp)]);
+            }
+        }
+        if (g.mask_words && il == 0) {
+            // the inactive pairs of the node, all at once: their shared value minus the mean (the same (float)((double) v - mean) each
+            // of them would get), and as many oversize coefficients as there are such pairs
+            float4 u = u_node;
+            u.x = (float)((double)u.x - mx); u.y = (float)((double)u.y - my); u.z = (float)((double)u.z - mz);
+            a.ugrad[cp] = u;
+            uint32_t n_active = 0;
+            for (uint32_t w = 0; w < g.mask_words; w++) n_active += (uint32_t)__popc(a.mask[(size_t)cp * g.mask_words + w]);
+            cnt += (a.n_owned - n_active) * (((double)fabsf(u.x) > a.lim[0]) + ((double)fabsf(u.y) > a.lim[1]) + ((double)fabsf(u.z) > a.lim[2]));
         }
     }
     // oversize count -> energy[2] (zeroed by energy_reduce_kernel earlier in the step): integers added as f64 are exact and
@@ -1526,7 +1573,8 @@ constexpr int CP_BATCH = 10;
 // (imageGroup.cxx:417-428); gridsum holds the sum over ALL images.
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, const GeomDev g, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
-                                                        double *energy, const double *energy_tail)
+                                                        double *energy, const double *energy_tail,
+                                                        const uint32_t *mask, const float4 *ucoeff, float4 *ugrad)
 {
     const int n_cp = g.n_cp;
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1546,12 +1594,21 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
             #pragma unroll
             for (int b = 0; b < CP_BATCH; b++) {
                 if (i0 + b >= n_owned) break;
+                if (g.mask_words && !lat_active(mask, g, i0 + b, (uint32_t)cp)) continue;      // inactive: the node's shared value, below
                 v[b].x = (float)((double)v[b].x - mx);
                 v[b].y = (float)((double)v[b].y - my);
                 v[b].z = (float)((double)v[b].z - mz);
                 grad[lat(g, i0 + b, (uint32_t)cp)] = v[b];
                 cnt += ((double)fabsf(v[b].x) > lim_x) + ((double)fabsf(v[b].y) > lim_y) + ((double)fabsf(v[b].z) > lim_z);
             }
+        }
+        if (g.mask_words) {                 // as lattice_step_kernel<CENTER>: the inactive pairs of the node at once
+            float4 u = ucoeff[cp];
+            u.x = (float)((double)u.x - mx); u.y = (float)((double)u.y - my); u.z = (float)((double)u.z - mz);
+            ugrad[cp] = u;
+            uint32_t n_active = 0;
+            for (uint32_t w = 0; w < g.mask_words; w++) n_active += (uint32_t)__popc(mask[(size_t)cp * g.mask_words + w]);
+            cnt += (n_owned - n_active) * (((double)fabsf(u.x) > lim_x) + ((double)fabsf(u.y) > lim_y) + ((double)fabsf(u.z) > lim_z));
         }
     }
     // the count goes to energy[2] as a double (so that one f64 all-reduce carries it); energy_reduce_kernel zeroed it
@@ -1562,10 +1619,74 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
 }
 
 // One image's lattice out of coeff / gradf / a retired lattice into a contiguous array (the getters; layouts: lat())
-__global__ __launch_bounds__(256) void lattice_extract_kernel(const float4 *src, const GeomDev g, uint32_t img, float4 *dst)
+__global__ __launch_bounds__(256) void lattice_extract_kernel(const float4 *src, const GeomDev g, uint32_t img, const uint32_t *mask,
+                                                              const float4 *u, float4 *dst)
 {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < (uint32_t)g.n_cp) dst[n] = src[lat(g, img, n)];
+    if (n >= (uint32_t)g.n_cp) return;
+    dst[n] = (g.mask_words && !lat_active(mask, g, img, n)) ? u[n] : src[lat(g, img, n)];
+}
+
+// Active pairs of a sparse lattice: (image, node) for every node in the 4^3 stencil of any of the image's points -- the cell of a
+// point comes from `pos`, which does not change while the lattice stands, so the set is the lattice's for life: no other pair ever
+// receives a gradient (gw = 0: the proposal is the standing value, imageGroup.cxx:346-375) or is read by the transform of the
+// image's points.  One wavefront per scatter block (image, brick, run of the brick's points): the block's nodes are collected
+// in an LDS bit set over the brick's (B + 3)^3 tile and go to the mask with one atomic per node -- a thread per point with 64
+// atomics each took 11 ms per lattice on cfg 5's finest level (every bit set by 1.3 points on average, all of them through L2).
+// The mask was zeroed; pos_b = the positions in perm's order.
+__global__ __launch_bounds__(64) void lattice_mask_kernel(const float4 *pos_b, const ScatterBlock *blocks, const uint32_t *n_blocks,
+                                                          const GeomDev g, uint32_t *mask)
+{
+    __shared__ uint32_t bits[(BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX + 31) / 32];
+    if (blockIdx.x >= *n_blocks) return;
+    const int lane = threadIdx.x;
+    const ScatterBlock blk = blocks[blockIdx.x];
+    const int E = g.brick + 3, n_tile = E * E * E;
+    for (int k = lane; k < (n_tile + 31) / 32; k += 64) bits[k] = 0u;
+    const uint32_t img = blk.key / g.n_bricks;
+    uint32_t bidx = blk.key - img * g.n_bricks;
+    const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
+    const int by = bidx % g.nbricks[1];
+    const int bz = bidx / g.nbricks[1];
+    const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
+    const uint32_t bit = 1u << (img & 31u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t sidx = blk.begin + lane; sidx < blk.end; sidx += 64) {
+        const float4 v = pos_b[sidx];
+        const float in[3] = { v.x, v.y, v.z };
+        int ic[3]; float fr[3];
+        scatter_cell(in, g, ic, fr);
+        // ... and the cell as the transforms find it (bspline_axis: the f64 quotient, by division or by the reciprocal): a point within
+        // an ulp of a cell face sits one cell further there, and the transform reads that stencil
+        int lo[3], hi[3];
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int c1 = (int)floor(((double)in[k] - g.origin[k]) / g.spacing[k]), c2 = (int)floor(((double)in[k] - g.origin[k]) * g.inv_spacing[k]);
+            lo[k] = min(ic[k], min(c1, c2)) - 1;
+            hi[k] = max(ic[k], max(c1, c2)) + 2;
+        }
+        for (int gz = lo[2]; gz <= hi[2]; gz++) for (int gy = lo[1]; gy <= hi[1]; gy++) for (int gx = lo[0]; gx <= hi[0]; gx++) {
+            if (gx < 0 || gy < 0 || gz < 0 || gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
+            const int lx = gx - cp0[0], ly = gy - cp0[1], lz = gz - cp0[2];
+            if (lx >= 0 && ly >= 0 && lz >= 0 && lx < E && ly < E && lz < E) {
+                const int t = lx + E * (ly + E * lz);
+                atomicOr(&bits[t >> 5], 1u << (t & 31));
+            } else {                            // a stray point, or a stencil across a face of the brick's tile: straight to the mask
+                uint32_t *w = mask + (size_t)((uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz)) * g.mask_words + (img >> 5);
+                if (!(*w & bit)) atomicOr(w, bit);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < n_tile; t += 64) {
+        if (!((bits[t >> 5] >> (t & 31)) & 1u)) continue;
+        const int gx = cp0[0] + t % E, gy = cp0[1] + (t / E) % E, gz = cp0[2] + t / (E * E);
+        if (gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
+        uint32_t *w = mask + (size_t)((uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz)) * g.mask_words + (img >> 5);
+        if (!(*w & bit)) atomicOr(w, bit);
+    }
 }
 
 } // namespace frog

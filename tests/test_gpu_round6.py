@@ -117,20 +117,23 @@ def test_two_collectives_flow_with_the_scalars_by_copy(tmp_path):
     _same_files(direct, copy, pairs.n_images)
 
 
-# ---- (4) the lattices in blocks of 16 nodes across the images (k_grid.hip.h lat()) ----------------------------------------------------
+# ---- (4) fine lattices of many images: blocks of 16 nodes across the images, entries for active pairs only (k_grid.hip.h) ------------
 
 @pytest.mark.parametrize("flags", [(), ("-ngl", "3"), ("-gm", "0.004")])
-def test_blocked_lattice_layout_gives_the_same_files(tmp_path, flags):
-    """FROG_LATTICE_BLOCKED=1 (the layout fine lattices of many images get by themselves: [node / 16][image][node % 16]) against
-    image-major on a group that would never choose it: identical measures.csv and transforms -- the layout moves entries, no
-    arithmetic -- for one context, three sharded contexts (phase B by cp_center_kernel, the speculative third lattice) and a run whose
-    guard rejects steps (retired lattices read back through their own layout)."""
+@pytest.mark.parametrize("forms", [{"FROG_LATTICE_BLOCKED": "1"}, {"FROG_LATTICE_SPARSE": "1"}, {"FROG_LATTICE_BLOCKED": "1", "FROG_LATTICE_SPARSE": "1"}])
+def test_blocked_and_sparse_lattices_give_the_same_files(tmp_path, flags, forms):
+    """The two forms lattices of >= 2^27 (image, node) pairs get by themselves (cfg 5's finest level), forced on a group that would
+    never choose them, against the plain form: FROG_LATTICE_BLOCKED=1 ([node / 16][image][node % 16] instead of image-major: moves
+    entries, no arithmetic) and FROG_LATTICE_SPARSE=1 (entries for the pairs some point of the image reaches; every other pair of a
+    node holds the same float -- 0 minus the node's means so far -- kept once per node).  Identical measures.csv and transforms for
+    one context, three sharded contexts (phase B by cp_center_kernel, the speculative third lattice and its companion) and a run whose
+    guard rejects steps (retired lattices read back through their own layout, mask and shared values)."""
     from test_gpu_round5 import _frog, _same_files
     pairs = Pairs.synthetic(9, 3000, 1200, seed=4)
-    plain, blocked = tmp_path / "plain", tmp_path / "blocked"
-    for d in (plain, blocked):
+    plain, other = tmp_path / "plain", tmp_path / "other"
+    for d in (plain, other):
         d.mkdir()
         pairs.write(d / "pairs.bin")
-    _frog(plain, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0"})
-    _frog(blocked, *flags, env_extra={"FROG_LATTICE_BLOCKED": "1"})
-    _same_files(plain, blocked, pairs.n_images)
+    _frog(plain, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0", "FROG_LATTICE_SPARSE": "0"})
+    _frog(other, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0", "FROG_LATTICE_SPARSE": "0", **forms})
+    _same_files(plain, other, pairs.n_images)
