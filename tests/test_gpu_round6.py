@@ -137,3 +137,31 @@ def test_blocked_and_sparse_lattices_give_the_same_files(tmp_path, flags, forms)
     _frog(plain, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0", "FROG_LATTICE_SPARSE": "0"})
     _frog(other, *flags, env_extra={"FROG_LATTICE_BLOCKED": "0", "FROG_LATTICE_SPARSE": "0", **forms})
     _same_files(plain, other, pairs.n_images)
+
+
+# ---- (5) the scatter's hand-scheduled DPP statement against the plain form ---------------------------------------------
+
+def test_scatter_quad_form_equals_the_point_by_point_form_bit_for_bit(tmp_path):
+    """The scatter's phase 2 reads four points' weights per LDS instruction and hands the sums round the quad with v_fmac_f32_dpp
+    inside an asm statement (k_grid.hip.h FROG_FMAC4_DPP: the compiler's hazard recogniser does not look inside).  Against a build
+    without it (`make variants`: -DFROG_SCATTER_QUADS=0, frog_amd/lib/variants/libfrog_hip_noquads.so): the same schedule in two
+    processes, coordinates, energies and every lattice identical."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    variant = os.path.join(os.path.dirname(here), "frog_amd", "lib", "variants", "libfrog_hip_noquads.so")
+    if not os.path.exists(variant):
+        pytest.skip("frog_amd/lib/variants/libfrog_hip_noquads.so not built (make -C frog_amd/csrc variants)")
+    outs = []
+    for lib in (None, "variants/libfrog_hip_noquads.so"):
+        env = dict(os.environ)
+        env.pop("FROG_HIP_LIB", None)
+        if lib:
+            env["FROG_HIP_LIB"] = lib
+        out = tmp_path / ("quads.npz" if lib is None else "plain.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "run_lattices.py"), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 6
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
