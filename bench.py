@@ -419,6 +419,7 @@ def run_native(args, rank, world, local_rank, transport, rdv):
     prof = {n: [res.kernels[i].ms_total, int(res.kernels[i].launches)] for i, n in enumerate(_abi.FROG_K_NAMES)}
     tags = ["linear"] + [f"level{l}" for l in range(levels)]
     phase_s = {t: res.phase_s[i] for i, t in enumerate(tags) if i == 0 or per_level[i - 1]}
+    was_proxy = bool(args.shard_of)
     if args.shard_of and not args.kernel_times:
         args.shard_of = None            # no per-kernel table to print: the plain line
     if args.kernel_times:
@@ -471,10 +472,10 @@ def run_native(args, rank, world, local_rank, transport, rdv):
                              "sweep_ms_total": [x["sweep_ms"] for x in everyone], "comm_est_ms_total": [x["comm_est_ms"] for x in everyone],
                              "note": "per rank over the timed region: wall time, sum of the bracketed kernels' device time "
                                      "(all groups with --kernel-times, else the half-link sweeps), estimated device time of the collectives"}
-        if world == 1 and not args.no_cpu_baseline and args.config == 3 and not args.shard_of:
+        if world == 1 and not args.no_cpu_baseline and args.config == 3 and not was_proxy:
             line["cpu_baseline"] = cpu_baseline(pairs, n_lin, per_level, 10)
     # (with the CPU baseline, i.e. on the full default line: the A/B scripts pass --no-cpu-baseline and get neither)
-    end_to_end_pending = (world == 1 and rank == 0 and line is not None and not args.shard_of and not args.no_end_to_end
+    end_to_end_pending = (world == 1 and rank == 0 and line is not None and not was_proxy and not args.no_end_to_end
                           and (args.end_to_end or (not args.no_cpu_baseline and args.config == 3)))
     if comm:
         if world > 1:
@@ -482,7 +483,7 @@ def run_native(args, rank, world, local_rank, transport, rdv):
         arr = (C.c_void_p * 1)(comm)
         cl.frog_comm_destroy_all(1, arr)
     lib.frog_destroy(ctx)
-    if (world == 1 and rank == 0 and line is not None and not args.shard_of and not args.exact and not args.no_exact_mode
+    if (world == 1 and rank == 0 and line is not None and not was_proxy and not args.exact and not args.no_exact_mode
             and (args.exact_mode or (not args.no_cpu_baseline and args.config == 3))):
         line["exact_mode"] = exact_mode(args, pairs, levels, n_lin, per_level, local_rank)
     if end_to_end_pending:

@@ -1678,7 +1678,9 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     FROG_HIP_CHECK(ctx->grad.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->gradf.alloc(LG, LG * reserve));
     // a third lattice for contexts whose host queues the next step before this one's decision is known (frog_step_speculate)
-    if (ctx->two_collectives && !ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc(LG, LG * reserve));
+    // (every context that owns a sub-range, whichever flow its host will choose: frog_create sizes the head-room before any host
+    // can call frog_comm_mode -- ADVICE r5 -- and one lattice more per rank is cheap: cfg 5, rank of eight, 0.95 GB)
+    if (!ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc(LG, LG * reserve));
     if (g.sparse) {
         FROG_HIP_CHECK(ctx->lat_mask.alloc(G * g.mask_words, G * g.mask_words * reserve));
         FROG_HIP_CHECK(ctx->ucoeff.alloc(G, G * reserve)); FROG_HIP_CHECK(ctx->ugrad.alloc(G, G * reserve));
@@ -2732,6 +2734,11 @@ int frog_comm_mode(frog_ctx *ctx, int two_collectives)
     CTX_GUARD(ctx);
     if (ctx->phase != 0) return fail(FROG_E_STATE, "frog_comm_mode inside a deformable step");
     ctx->two_collectives = two_collectives != 0;
+    // the third lattice of the speculative flow is part of lattice_alloc's head-room only when the mode is known there; a mode
+    // switched on with a lattice already standing takes it here, outside any iteration (it used to be allocated inside
+    // frog_step_speculate, between two steps of the timed loop)
+    if (ctx->two_collectives && !ctx->whole_group() && ctx->grad.p && ctx->grad_spare.n != ctx->grad.n)
+        FROG_HIP_CHECK(ctx->grad_spare.alloc(ctx->grad.n, ctx->grad.cap));
     return FROG_OK;
 }
 
