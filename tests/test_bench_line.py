@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_a_bench_n1*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_a_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06_bench_n1*.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
