@@ -13,8 +13,12 @@
 //     read-modify-write (:301-338); the control-point step and the image-order f64 proposal sums (:346-375, :400-419);
 //   * the B-spline transform without fused multiply-adds (vtkBSplineTransform as restated in DESIGN.md section 2).
 // Its results are compared with the tests' CPU restatement of the reference by np.array_equal (tests/test_gpu_reference_order.py); the product path
-// is then compared with THIS mode on the device, at sizes the CPU restatement cannot reach in a test.  Speed is irrelevant
-// here: a chain is walked by one lane, a scatter by one wavefront per image with a barrier per point.
+// is then compared with THIS mode on the device, at sizes the CPU restatement cannot reach in a test.
+// The kernels of this file are the LITERAL forms (rounds 4-5: a chain walked by one lane, the scatter by one wavefront per image
+// with a barrier per point; 22 iterations/s on the benchmark group).  Since round 6 the mode runs through k_refchain.hip.h --
+// only what the reference's order really binds is kept serial: 265 iterations/s, the same bits -- and these stay behind
+// FROG_REF_LITERAL=1 as what the new forms are held against (tests/test_gpu_round6.py); the control-point step, the B-spline
+// transform and the update of an image's matrix from its sums are used by both.
 #pragma once
 
 #include "ctx.h"
