@@ -186,7 +186,7 @@ struct GridGeom {
     bool blocked = false;
     uint32_t lat_images = 0;    // owned images the lattices are laid out for
     // `sparse`: entries are kept for ACTIVE (image, node) pairs only -- the nodes in the 4^3 stencil of any of the image's points
-    // (frog_ctx::lat_mask: per node a bit set over the owned images, mask_words words).  `pos` stands still while a lattice stands,
+    // (frog_ctx::lat_mask: per owned image a bit per node, mask_words words).  `pos` stands still while a lattice stands,
     // so the set is fixed for the lattice's life; a pair outside it never receives a gradient and is never read by the transform
     // of the image's points: its coefficient is 0 minus the node's means so far, the SAME float for every such image of the node
     // (frog_ctx::ucoeff).  The lattice step then touches 43 % of the pairs of cfg 5's finest lattice instead of all of them.
@@ -318,7 +318,8 @@ struct frog_ctx {
     frog::DevBuf<float4> grad_spare;          // a third lattice: the proposals of a step queued before the previous one's decision (frog_step_speculate)
     // sparse lattices (GridGeom::sparse): the active pairs, and per node the value of its inactive pairs -- companions of coeff / grad /
     // grad_spare, exchanged with them
-    frog::DevBuf<uint32_t> lat_mask;          // [G][mask_words]
+    frog::DevBuf<uint32_t> lat_mask;          // [owned images][mask_words]: a bit per node
+    frog::DevBuf<uint32_t> lat_inactive;      // [G] owned images for which the node is inactive
     frog::DevBuf<float4> ucoeff, ugrad, ugrad_spare;   // [G]
     frog::DevBuf<double> gridsum;             // [3G] (+ 4: frog_comm_mode)
     frog::DevBuf<uint32_t> perm;              // owned points sorted by (image, brick)

@@ -331,8 +331,10 @@ static int queue_setup_kernels(frog_ctx *ctx, hipStream_t s)
     block_len_base_kernel<<<1, (SCATTER_CHUNK + 1 + 63) / 64 * 64, 0, s>>>(len_hist, len_cursor);
     if (max_blocks)
         block_sort_kernel<<<div_up(max_blocks, 256), 256, 0, s>>>(blk_tmp, n_blocks_dev, ctx->scatter_chunk, len_cursor, blk);
-    if (g.sparse && nPts && max_blocks)         // the active (image, node) pairs of the new lattice, block by block
-        lattice_mask_kernel<<<max_blocks, 64, 0, s>>>(ctx->pos_b.p, blk, n_blocks_dev, gd, ctx->lat_mask.p);
+    if (g.sparse) {                             // the active (image, node) pairs of the new lattice, block by block; per node how many images lack it
+        if (nPts && max_blocks) lattice_mask_kernel<<<max_blocks, 64, 0, s>>>(ctx->pos_b.p, blk, n_blocks_dev, gd, ctx->lat_mask.p);
+        lattice_inactive_kernel<<<div_up((size_t)gd.n_cp, 256), 256, 0, s>>>(ctx->lat_mask.p, nO, gd, ctx->lat_inactive.p);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     return FROG_OK;
 }
@@ -1083,7 +1085,11 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
                     for (int l = 0; l <= finest; l++) {
                         GridGeom gl{};
                         frog_grid_info il{};
-                        if (make_geometry(c, l, mn, mx, gl, il) == FROG_OK) arena_h += 3 * ((nO * (size_t)gl.n_cp * 5 / 4 + 63) / 64 * 64);
+                        if (make_geometry(c, l, mn, mx, gl, il) == FROG_OK) {
+                            arena_h += 3 * ((nO * (size_t)gl.n_cp * 5 / 4 + 63) / 64 * 64);
+                            // a sparse lattice retires with its bit maps and shared values (retire_current_grid): room for them too
+                            if (gl.sparse) arena_h += 3 * (((nO * (size_t)gl.mask_words + 3) / 4 + (size_t)gl.n_cp) * 5 / 4 + 128);
+                        }
                     }
                     const size_t need = (3 * nO * (size_t)gh.n_cp + blocks * E * E * E + arena_h) * sizeof(float4)
                                         + 3 * nO * (size_t)gh.n_bricks * (size_t)(gh.brick * gh.brick * gh.brick) * sizeof(uint32_t);
@@ -1642,9 +1648,9 @@ static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], c
     //            16 nodes at a time);
     //   sparse:  entries only for the (image, node) pairs some point of the image reaches -- the others of a node share one value.
     // Measured on cfg 5's level 4 (500 images x 9e5 nodes, `scripts/cfg5_level4_traffic.sh`): the
-    // lattice step 8.09 -> 6.71 ms with 41 -> 28 GB moved; the B-spline transform + 3 %; the set of active pairs costs 10 ms per
-    // lattice to find.  Worth it from about seven iterations per lattice on, on lattices of >= 2^27 pairs; smaller ones (cfg 5's
-    // level 3: 7e7 pairs; everything of cfg 3) keep the plain form, where the step is bound by latency, not bytes.
+    // lattice step 8.09 -> 6.7 ms with 41 -> 28 GB moved; the B-spline transform + 3 %; the set of active pairs costs 1.9 ms per
+    // lattice to find; bench.py --config 5: 168.5 -> 175 it/s.  Lattices of >= 2^27 pairs; smaller ones (cfg 5's level 3: 7e7 pairs;
+    // everything of cfg 3) keep the plain form, where the step is bound by latency, not bytes, and both forms cost a few per cent.
     // FROG_LATTICE_BLOCKED / FROG_LATTICE_SPARSE = 0 / 1 force a form (A/B, tests); reference-order mode keeps the plain one.
     g.lat_images = nO;
     {
@@ -1654,7 +1660,7 @@ static int make_geometry(const frog_ctx *ctx, int level, const double mins[3], c
         g.blocked = e ? atoi(e) != 0 : fine;
         g.sparse = es ? atoi(es) != 0 : fine;
         if (ctx->ref_order) g.blocked = g.sparse = false;
-        g.mask_words = (nO + 31u) / 32u;
+        g.mask_words = (uint32_t)((G + 31) / 32) + 1u;          // per image: a bit per node (+ 1: a tile row may be written through the word behind its last bit)
     }
     return FROG_OK;
 }
@@ -1682,7 +1688,8 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     // can call frog_comm_mode -- ADVICE r5 -- and one lattice more per rank is cheap: cfg 5, rank of eight, 0.95 GB)
     if (!ctx->whole_group()) FROG_HIP_CHECK(ctx->grad_spare.alloc(LG, LG * reserve));
     if (g.sparse) {
-        FROG_HIP_CHECK(ctx->lat_mask.alloc(G * g.mask_words, G * g.mask_words * reserve));
+        FROG_HIP_CHECK(ctx->lat_mask.alloc((size_t)nO * g.mask_words, (size_t)nO * g.mask_words * reserve));
+        FROG_HIP_CHECK(ctx->lat_inactive.alloc(G, G * reserve));
         FROG_HIP_CHECK(ctx->ucoeff.alloc(G, G * reserve)); FROG_HIP_CHECK(ctx->ugrad.alloc(G, G * reserve));
         FROG_HIP_CHECK(ctx->ugrad_spare.alloc(G, G * reserve));
     }
@@ -1725,13 +1732,21 @@ static int retire_current_grid(frog_ctx *ctx)
     }
     if (n) FROG_HIP_CHECK(hipMemcpyAsync(gr.kept->p, ctx->coeff.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     gr.sparse = ctx->geom.sparse; gr.mask_words = ctx->geom.mask_words;
-    if (gr.sparse) {                            // which pairs `kept` holds, and what the others are
+    if (gr.sparse) {                            // which pairs `kept` holds, and what the others are: in the arena behind it when there is room
         const size_t G = (size_t)ctx->geom.n_cp;
+        const size_t mask_words = (size_t)ctx->n_owned() * gr.mask_words;
+        const size_t mask_room = ((mask_words + 3) / 4 + 63) / 64 * 64, u_room = (G + 63) / 64 * 64;      // in float4 entries
         gr.kept_mask = std::make_shared<DevBuf<uint32_t>>();
         gr.kept_u = std::make_shared<DevBuf<float4>>();
-        FROG_HIP_CHECK(gr.kept_mask->alloc_async(std::max<size_t>(1, G * gr.mask_words), ctx->stream));
-        FROG_HIP_CHECK(gr.kept_u->alloc_async(std::max<size_t>(1, G), ctx->stream));
-        FROG_HIP_CHECK(hipMemcpyAsync(gr.kept_mask->p, ctx->lat_mask.p, G * gr.mask_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->retired_arena.p && ctx->retired_used + mask_room + u_room <= ctx->retired_arena.cap) {
+            gr.kept_mask->borrow(reinterpret_cast<uint32_t *>(ctx->retired_arena.p + ctx->retired_used), mask_words);
+            gr.kept_u->borrow(ctx->retired_arena.p + ctx->retired_used + mask_room, G);
+            ctx->retired_used += mask_room + u_room;
+        } else {
+            FROG_HIP_CHECK(gr.kept_mask->alloc_async(std::max<size_t>(1, mask_words), ctx->stream));
+            FROG_HIP_CHECK(gr.kept_u->alloc_async(std::max<size_t>(1, G), ctx->stream));
+        }
+        FROG_HIP_CHECK(hipMemcpyAsync(gr.kept_mask->p, ctx->lat_mask.p, mask_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         FROG_HIP_CHECK(hipMemcpyAsync(gr.kept_u->p, ctx->ucoeff.p, G * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     }
     gr.retired = true;
@@ -1997,7 +2012,7 @@ int frog_deformable_phase_a(frog_ctx *ctx, float alpha)
         la.stage = ctx->scatter_stage.p; la.brick_slot_ptr = ctx->brick_slot_ptr.p;
         la.gradf = ctx->gradf.p; la.stray = ctx->stray.p + ctx->stray_parity;
         la.coeff = ctx->coeff.p; la.grad = ctx->grad.p; la.gridsum = ctx->gridsum.p;
-        la.mask = ctx->lat_mask.p; la.ucoeff = ctx->ucoeff.p; la.ugrad = ctx->ugrad.p;
+        la.mask = ctx->lat_mask.p; la.n_inactive = ctx->lat_inactive.p; la.ucoeff = ctx->ucoeff.p; la.ugrad = ctx->ugrad.p;
         la.energy_tail = ctx->two_collectives && !ctx->whole_group() ? ctx->gridsum.p + 3 * (size_t)gd.n_cp : nullptr;
         la.n_owned = nO; la.n_images = ctx->nf ? 0u : ctx->nI; la.alpha = alpha;          // :398: no mean removal with fixed images
         for (int k = 0; k < 3; k++) la.lim[k] = (double)ctx->opt.max_displacement_ratio * ctx->geom.spacing[k];
@@ -2035,7 +2050,7 @@ int frog_deformable_phase_b(frog_ctx *ctx)
                                                         (double)maxD * g.spacing[0], (double)maxD * g.spacing[1],
                                                         (double)maxD * g.spacing[2], ctx->energy.p,
                                                         ctx->two_collectives ? ctx->gridsum.p + 3 * (size_t)g.n_cp : nullptr,
-                                                        ctx->lat_mask.p, ctx->ucoeff.p, ctx->ugrad.p);
+                                                        ctx->lat_mask.p, ctx->lat_inactive.p, ctx->ucoeff.p, ctx->ugrad.p);
     FROG_HIP_CHECK(hipGetLastError());
     ctx->phase = 2;
     return FROG_OK;

@@ -27,13 +27,13 @@ struct GeomDev {
     int lat_sh;
     uint32_t lat_mask;
     size_t lat_blk, lat_img;
-    uint32_t mask_words;        // > 0: the lattice keeps entries of ACTIVE (image, node) pairs only (ctx.h GridGeom::sparse): words per node
+    uint32_t mask_words;        // > 0: the lattice keeps entries of ACTIVE (image, node) pairs only (ctx.h GridGeom::sparse): words per IMAGE
 };
 
-// Sparse lattices (ctx.h GridGeom::sparse): is (image, node) an active pair?  mask = [node][mask_words] bit sets over the owned images.
+// Sparse lattices (ctx.h GridGeom::sparse): is (image, node) an active pair?  mask = [owned image][mask_words]: a bit per node.
 __device__ __forceinline__ bool lat_active(const uint32_t *mask, const GeomDev &g, uint32_t img, uint32_t node)
 {
-    return (mask[(size_t)node * g.mask_words + (img >> 5)] >> (img & 31u)) & 1u;
+    return (mask[(size_t)img * g.mask_words + (node >> 5)] >> (node & 31u)) & 1u;
 }
 
 // entry of control point `node` of owned image `img` in coeff / grad / gradf / grad_spare
@@ -1372,6 +1372,7 @@ struct LatticeStepArgs {
     double *energy;
     // sparse lattices: the active pairs' bit sets, the value every inactive pair of a node holds (standing / proposed)
     const uint32_t *mask;
+    const uint32_t *n_inactive;     // [G] owned images for which the node is inactive
     const float4 *ucoeff;
     float4 *ugrad;
 };
@@ -1560,9 +1561,7 @@ __global__ __launch_bounds__(CPB * LS_IC) void lattice_step_kernel(const Lattice
             float4 u = u_node;
             u.x = (float)((double)u.x - mx); u.y = (float)((double)u.y - my); u.z = (float)((double)u.z - mz);
             a.ugrad[cp] = u;
-            uint32_t n_active = 0;
-            for (uint32_t w = 0; w < g.mask_words; w++) n_active += (uint32_t)__popc(a.mask[(size_t)cp * g.mask_words + w]);
-            cnt += (a.n_owned - n_active) * (((double)fabsf(u.x) > a.lim[0]) + ((double)fabsf(u.y) > a.lim[1]) + ((double)fabsf(u.z) > a.lim[2]));
+            cnt += a.n_inactive[cp] * (((double)fabsf(u.x) > a.lim[0]) + ((double)fabsf(u.y) > a.lim[1]) + ((double)fabsf(u.z) > a.lim[2]));
         }
     }
     // oversize count -> energy[2] (zeroed by energy_reduce_kernel earlier in the step): integers added as f64 are exact and
@@ -1581,7 +1580,7 @@ constexpr int CP_BATCH = 10;
 __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ grad, uint32_t n_owned, const GeomDev g, uint32_t n_images,
                                                         const double *gridsum, double lim_x, double lim_y, double lim_z,
                                                         double *energy, const double *energy_tail,
-                                                        const uint32_t *mask, const float4 *ucoeff, float4 *ugrad)
+                                                        const uint32_t *mask, const uint32_t *n_inactive, const float4 *ucoeff, float4 *ugrad)
 {
     const int n_cp = g.n_cp;
     const int cp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1613,9 +1612,7 @@ __global__ __launch_bounds__(256) void cp_center_kernel(float4 *__restrict__ gra
             float4 u = ucoeff[cp];
             u.x = (float)((double)u.x - mx); u.y = (float)((double)u.y - my); u.z = (float)((double)u.z - mz);
             ugrad[cp] = u;
-            uint32_t n_active = 0;
-            for (uint32_t w = 0; w < g.mask_words; w++) n_active += (uint32_t)__popc(mask[(size_t)cp * g.mask_words + w]);
-            cnt += (n_owned - n_active) * (((double)fabsf(u.x) > lim_x) + ((double)fabsf(u.y) > lim_y) + ((double)fabsf(u.z) > lim_z));
+            cnt += n_inactive[cp] * (((double)fabsf(u.x) > lim_x) + ((double)fabsf(u.y) > lim_y) + ((double)fabsf(u.z) > lim_z));
         }
     }
     // the count goes to energy[2] as a double (so that one f64 all-reduce carries it); energy_reduce_kernel zeroed it
@@ -1637,26 +1634,35 @@ __global__ __launch_bounds__(256) void lattice_extract_kernel(const float4 *src,
 // Active pairs of a sparse lattice: (image, node) for every node in the 4^3 stencil of any of the image's points -- the cell of a
 // point comes from `pos`, which does not change while the lattice stands, so the set is the lattice's for life: no other pair ever
 // receives a gradient (gw = 0: the proposal is the standing value, imageGroup.cxx:346-375) or is read by the transform of the
-// image's points.  One wavefront per scatter block (image, brick, run of the brick's points): the block's nodes are collected
-// in an LDS bit set over the brick's (B + 3)^3 tile and go to the mask with one atomic per node -- a thread per point with 64
-// atomics each took 11 ms per lattice on cfg 5's finest level (every bit set by 1.3 points on average, all of them through L2).
-// The mask was zeroed; pos_b = the positions in perm's order.
+// image's points.  One wavefront per scatter block (image, brick, run of the brick's points): the block's nodes are collected in
+// an LDS bit set over the brick's (B + 3)^3 tile and go to the image's bit map ROW BY ROW -- a tile row is E consecutive nodes,
+// i.e. E consecutive bits: one or two atomics.  (A thread per point with 64 atomics each took 11 ms per lattice on cfg 5's finest
+// level; node-major bit sets over the images, one atomic per set node: 9.7.)  The mask was zeroed; pos_b = the positions in
+// perm's order.
+__device__ __forceinline__ void lat_mask_set(uint32_t *words, uint32_t first_bit, uint32_t bits)      // bits: <= 32 consecutive, from first_bit on
+{
+    const uint32_t w = first_bit >> 5, off = first_bit & 31u;
+    const uint32_t lo = bits << off, hi = off ? bits >> (32u - off) : 0u;
+    if (lo && (words[w] & lo) != lo) atomicOr(&words[w], lo);
+    if (hi && (words[w + 1] & hi) != hi) atomicOr(&words[w + 1], hi);
+}
+
 __global__ __launch_bounds__(64) void lattice_mask_kernel(const float4 *pos_b, const ScatterBlock *blocks, const uint32_t *n_blocks,
                                                           const GeomDev g, uint32_t *mask)
 {
-    __shared__ uint32_t bits[(BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX + 31) / 32];
+    __shared__ uint32_t bits[(BRICK_CP_MAX * BRICK_CP_MAX * BRICK_CP_MAX + 31) / 32 + 1];
     if (blockIdx.x >= *n_blocks) return;
     const int lane = threadIdx.x;
     const ScatterBlock blk = blocks[blockIdx.x];
     const int E = g.brick + 3, n_tile = E * E * E;
-    for (int k = lane; k < (n_tile + 31) / 32; k += 64) bits[k] = 0u;
+    for (int k = lane; k < (n_tile + 31) / 32 + 1; k += 64) bits[k] = 0u;
     const uint32_t img = blk.key / g.n_bricks;
     uint32_t bidx = blk.key - img * g.n_bricks;
     const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
     const int by = bidx % g.nbricks[1];
     const int bz = bidx / g.nbricks[1];
     const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
-    const uint32_t bit = 1u << (img & 31u);
+    uint32_t *words = mask + (size_t)img * g.mask_words;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (uint32_t sidx = blk.begin + lane; sidx < blk.end; sidx += 64) {
@@ -1679,21 +1685,34 @@ __global__ __launch_bounds__(64) void lattice_mask_kernel(const float4 *pos_b, c
             if (lx >= 0 && ly >= 0 && lz >= 0 && lx < E && ly < E && lz < E) {
                 const int t = lx + E * (ly + E * lz);
                 atomicOr(&bits[t >> 5], 1u << (t & 31));
-            } else {                            // a stray point, or a stencil across a face of the brick's tile: straight to the mask
-                uint32_t *w = mask + (size_t)((uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz)) * g.mask_words + (img >> 5);
-                if (!(*w & bit)) atomicOr(w, bit);
+            } else {                            // a stray point, or a stencil across a face of the brick's tile: straight to the bit map
+                lat_mask_set(words, (uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz), 1u);
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < n_tile; t += 64) {
-        if (!((bits[t >> 5] >> (t & 31)) & 1u)) continue;
-        const int gx = cp0[0] + t % E, gy = cp0[1] + (t / E) % E, gz = cp0[2] + t / (E * E);
-        if (gx >= g.dims[0] || gy >= g.dims[1] || gz >= g.dims[2]) continue;
-        uint32_t *w = mask + (size_t)((uint32_t)gx + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz)) * g.mask_words + (img >> 5);
-        if (!(*w & bit)) atomicOr(w, bit);
+    for (int row = lane; row < E * E; row += 64) {          // tile row (ly, lz): nodes cp0x .. cp0x + E - 1 of lattice row (gy, gz)
+        const int ly = row % E, lz = row / E;
+        const int gy = cp0[1] + ly, gz = cp0[2] + lz;
+        if (gy >= g.dims[1] || gz >= g.dims[2]) continue;
+        const int t0 = E * row;
+        const unsigned long long two = (unsigned long long)bits[t0 >> 5] | ((unsigned long long)bits[(t0 >> 5) + 1] << 32);
+        uint32_t rb = (uint32_t)(two >> (t0 & 31)) & ((1u << E) - 1u);
+        const int in_x = g.dims[0] - cp0[0];                // nodes of the row inside the lattice
+        if (in_x < E) rb &= (1u << max(in_x, 0)) - 1u;
+        if (rb) lat_mask_set(words, (uint32_t)cp0[0] + (uint32_t)g.dims[0] * ((uint32_t)gy + (uint32_t)g.dims[1] * (uint32_t)gz), rb);
     }
+}
+
+// n_inactive[node] = owned images for which the node is inactive (the guard's count of a node's shared value, lattice_step_kernel)
+__global__ __launch_bounds__(256) void lattice_inactive_kernel(const uint32_t *mask, uint32_t n_owned, const GeomDev g, uint32_t *n_inactive)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (uint32_t)g.n_cp) return;
+    uint32_t active = 0;
+    for (uint32_t img = 0; img < n_owned; img++) active += (mask[(size_t)img * g.mask_words + (n >> 5)] >> (n & 31u)) & 1u;
+    n_inactive[n] = n_owned - active;
 }
 
 } // namespace frog
