@@ -39,7 +39,9 @@ __device__ __forceinline__ bool lat_active(const uint32_t *mask, const GeomDev &
 // entry of control point `node` of owned image `img` in coeff / grad / gradf / grad_spare
 __host__ __device__ __forceinline__ size_t lat(const GeomDev &g, uint32_t img, uint32_t node)
 {
-    return (size_t)(node >> g.lat_sh) * g.lat_blk + (size_t)img * g.lat_img + (size_t)(node & g.lat_mask);
+    // (the test is on a kernel argument: uniform, a scalar branch -- the image-major form keeps the two-instruction index it always had)
+    return g.lat_blk ? (size_t)(node >> g.lat_sh) * g.lat_blk + (size_t)img * g.lat_img + (size_t)(node & g.lat_mask)
+                     : (size_t)img * g.lat_img + (size_t)node;
 }
 
 inline GeomDev to_dev(const GridGeom &g)
