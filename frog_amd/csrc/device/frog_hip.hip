@@ -597,12 +597,12 @@ static int ref_chain_build(frog_ctx *ctx)
     // slots past the last control point: length 0, pointing nowhere (the chain kernel does not write them)
     FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_len.p, 0, n_slots * sizeof(uint32_t), s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_iota.p, 0xFF, n_slots * sizeof(uint32_t), s));
-    if (n_gnodes) ref_chain_len_kernel<<<div_up(n_gnodes, 256), 256, 0, s>>>(ctx->rc_node_ptr.p, n_gnodes, ctx->rc_len.p, ctx->rc_iota.p);
+    // long chains (coarse lattices: few control points, thousands of entries each) fetch 16 entries per step, others 8
+    ctx->rc_unroll = n_keys / std::max<uint64_t>(1, n_gnodes) >= 256 ? 16 : 8;
+    if (n_gnodes) ref_chain_len_kernel<<<div_up(n_gnodes, 256), 256, 0, s>>>(ctx->rc_node_ptr.p, n_gnodes, (uint32_t)ctx->rc_unroll, ctx->rc_len.p, ctx->rc_iota.p);
     tb = ctx->rc_temp.n;
     FROG_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->rc_temp.p, tb, ctx->rc_len.p, ctx->rc_len_sorted.p, ctx->rc_iota.p, ctx->rc_slot_node.p, n_slots, 0, 32, s));
     FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_group_size.p, 0, ((size_t)n_groups + 1) * sizeof(uint64_t), s));
-    // long chains (coarse lattices: few control points, thousands of entries each) fetch 16 entries per step, others 8
-    ctx->rc_unroll = n_keys / std::max<uint64_t>(1, n_gnodes) >= 256 ? 16 : 8;
     // ... and look the sums up by owned row (see ref_chain_fill_kernel); landmark constraints edit the sums by point afterwards: by point then
     static const int by_row_min = getenv("FROG_REF_BY_ROW_MIN") ? atoi(getenv("FROG_REF_BY_ROW_MIN")) : 300;
     ctx->rc_by_row = !ctx->n_hard && !ctx->ref_literal && n_keys / std::max<uint64_t>(1, n_gnodes) >= (uint64_t)by_row_min;
