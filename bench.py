@@ -495,10 +495,13 @@ def exact_mode(args, pairs, levels, n_lin, per_level, local_rank):
     """The same schedule once more through bin/frog -exact 1 = frog_options::reference_order: the device path in the reference's
     own order and arithmetic, whose every per-point sum, gradient image, lattice, matrix and coordinate is bit-equal to the oracle
     (tests/test_gpu_reference_order.py) -- the mode inside north_star's literal "transform parameters within 1e-4".  Measured after
-    the timed region, like cpu_baseline; same frog_run_schedule loop, same warm-up, no kernel events."""
+    the timed region, like cpu_baseline; same frog_run_schedule loop, same warm-up, no kernel events.  When the line's schedule is
+    a short one (the round-end driver's 20 steps: a lattice's chains are built for five iterations), the mode is also timed over the
+    reference's default schedule for the configuration (`default_schedule`: what DESIGN.md 2c and the README quote)."""
     from frog_amd import _abi
-    try:
-        lib, host = _abi.hip_lib(), _abi.host_lib()
+    lib, host = _abi.hip_lib(), _abi.host_lib()
+
+    def run(lin, per):
         opts = _abi.FrogOptions.default(max_levels_hint=levels)
         opts.reference_order = 1
         ctx = C.c_void_p()
@@ -507,18 +510,24 @@ def exact_mode(args, pairs, levels, n_lin, per_level, local_rank):
         t_create = time.perf_counter() - t0
         try:
             res = _abi.FrogScheduleResult()
-            _abi.check(host.frog_run_schedule(ctx, None, C.byref(native_plan(args, n_lin, per_level, 0, False)), C.byref(res)), "frog_run_schedule")
+            _abi.check(host.frog_run_schedule(ctx, None, C.byref(native_plan(args, lin, per, 0, False)), C.byref(res)), "frog_run_schedule")
         finally:
             lib.frog_destroy(ctx)
-        k = n_lin + sum(per_level)
+        k = lin + sum(per)
         tags = ["linear"] + [f"level{l}" for l in range(levels)]
         return {"value": k / res.elapsed_s, "unit": "iterations/s", "ms_per_step": 1e3 * res.elapsed_s / k, "steps": k,
                 "final_E": res.final_E, "grids_per_level": [int(g) for g in res.grids_per_level[:levels]],
-                "phase_iterations_per_s": {t: (n_lin if i == 0 else per_level[i - 1]) / res.phase_s[i]
-                                           for i, t in enumerate(tags) if (n_lin if i == 0 else per_level[i - 1]) and res.phase_s[i] > 0},
-                "create_s": t_create,
-                "mode": "bin/frog -exact 1 (frog_options::reference_order): the reference's own order and arithmetic on the device, "
-                        "bit-equal to the oracle; the per-lattice chain builds (DESIGN.md 2c) are inside the timed region"}
+                "phase_iterations_per_s": {t: (lin if i == 0 else per[i - 1]) / res.phase_s[i]
+                                           for i, t in enumerate(tags) if (lin if i == 0 else per[i - 1]) and res.phase_s[i] > 0},
+                "create_s": t_create}
+    try:
+        out = run(n_lin, per_level)
+        out["mode"] = ("bin/frog -exact 1 (frog_options::reference_order): the reference's own order and arithmetic on the device, "
+                       "bit-equal to the oracle; the per-lattice chain builds (DESIGN.md 2c) are inside the timed region")
+        d_lin, d_per = schedule(50 + 200 * levels, levels)           # -li 50 -di 200 per level
+        if args.config == 3 and (d_lin, list(d_per)) != (n_lin, list(per_level)):
+            out["default_schedule"] = run(d_lin, d_per)
+        return out
     except Exception as exc:                # noqa: BLE001 -- an add-on: the measured line is printed whatever happens here
         return {"error": f"{type(exc).__name__}: {exc}"}
 

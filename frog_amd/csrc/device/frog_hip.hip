@@ -408,6 +408,7 @@ static int produce_selection(frog_ctx *c)
 }
 
 // ---- FROG_REFERENCE_ORDER=1 (k_reforder.hip.h): launch sequences ---------------------------------------------
+static int ref_rows_build(frog_ctx *ctx);
 static int ref_alloc(frog_ctx *ctx)
 {
     if (ctx->ref_img_link.p) return FROG_OK;
@@ -432,7 +433,8 @@ static int ref_alloc(frog_ctx *ctx)
         ref_link_static_kernel<<<div_up(nRows, 256), 256, 0, ctx->stream>>>(ctx->ref_rowptr.p, ctx->ref_link.p, ctx->new_of_old.p, nRows, ctx->pos.p,
                                                                           ctx->ref_own.p, ctx->ref_link_img.p);
     FROG_HIP_CHECK(hipGetLastError());
-    return FROG_OK;
+    // the other table that depends on the model alone: the rows of half-links side by side (the deformable stage's per-point sums)
+    return ctx->ref_literal ? FROG_OK : ref_rows_build(ctx);
 }
 
 // The rows of half-links side by side (k_refchain.hip.h), once per context.
@@ -611,21 +613,29 @@ static int ref_chain_build(frog_ctx *ctx)
     tb = ctx->rc_temp.n;
     FROG_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->rc_temp.p, tb, ctx->rc_group_size.p, ctx->rc_group_ptr.p, (size_t)n_groups + 1, s));
     FROG_HIP_CHECK(hipGetLastError());
-    // the layout's size decides two allocations: one round trip per lattice
+    // the layout's size decides two allocations and the fill's grid: one round trip per lattice
     uint64_t seats = 0;
-    uint32_t n_entries = 0;
+    uint32_t n_entries = 0, longest = 0;
     FROG_HIP_CHECK(hipMemcpyAsync(&seats, ctx->rc_group_ptr.p + n_groups, sizeof seats, hipMemcpyDeviceToHost, s));
     FROG_HIP_CHECK(hipMemcpyAsync(&n_entries, ctx->rc_node_ptr.p + n_gnodes, sizeof n_entries, hipMemcpyDeviceToHost, s));
+    FROG_HIP_CHECK(hipMemcpyAsync(&longest, ctx->rc_group_len.p, sizeof longest, hipMemcpyDeviceToHost, s));      // the first group's: sorted descending
     mark("kernels queued");
     FROG_HIP_CHECK(hipStreamSynchronize(s));
     mark("sorted, sizes on the host");
     FROG_HIP_CHECK(ctx->rc_ent.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
     FROG_HIP_CHECK(ctx->rc_wt.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
-    FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_ent.p, 0xFF, std::max<uint64_t>(1, seats) * sizeof(uint32_t), s));
-    if (n_entries)
-        ref_chain_fill_kernel<<<div_up(n_entries, 256), 256, 0, s>>>(sorted, n_entries, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_of_node.p, ctx->rc_group_ptr.p,
-                                                                    ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
-                                                                    ctx->rc_by_row ? 1 : 0, ctx->rc_ent.p, ctx->rc_wt.p);
+    const unsigned j_tiles = div_up(std::max(1u, longest), 64u);
+    if (n_entries && !ctx->ref_literal && j_tiles <= 65535u) {
+        ref_chain_fill_tiled_kernel<<<dim3(n_groups, j_tiles), 256, 0, s>>>(sorted, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_node.p, ctx->rc_group_ptr.p,
+                                                                           ctx->rc_group_len.p, ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib,
+                                                                           ctx->own_pt_begin, gd, ctx->rc_by_row ? 1 : 0, ctx->rc_ent.p, ctx->rc_wt.p);
+    } else {
+        FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_ent.p, 0xFF, std::max<uint64_t>(1, seats) * sizeof(uint32_t), s));
+        if (n_entries)
+            ref_chain_fill_kernel<<<div_up(n_entries, 256), 256, 0, s>>>(sorted, n_entries, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_of_node.p, ctx->rc_group_ptr.p,
+                                                                        ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib, ctx->own_pt_begin, gd,
+                                                                        ctx->rc_by_row ? 1 : 0, ctx->rc_ent.p, ctx->rc_wt.p);
+    }
     FROG_HIP_CHECK(hipGetLastError());
     mark("layout allocated, fill queued");
     if (trace) std::fprintf(stderr, "[ref_chain_build] %u control points, %u entries, %llu seats, %d entries per step\n", n_gnodes, n_entries, (unsigned long long)seats, ctx->rc_unroll);

@@ -129,6 +129,58 @@ __global__ __launch_bounds__(256) void ref_chain_fill_kernel(const uint64_t *key
     wt[seat] = w;
 }
 
+// The same fill through LDS: block = (group of RC_GROUP chains, 64 consecutive entries of each).  The sorted keys of a chain are
+// consecutive (a wavefront reads 64 of them side by side), the seats of a group's entry j are consecutive across its chains (the
+// block writes the tile entry-major): both sides in whole lines.  A thread per sorted key wrote its seat RC_GROUP entries from its
+// neighbour's -- 128 M partial-line writes, 9.6 ms per level-0 lattice.  Also writes the padding (RC_PAD), so nothing is cleared first.
+__global__ __launch_bounds__(256) void ref_chain_fill_tiled_kernel(const uint64_t *keys, int rbits, const uint32_t *node_ptr, const uint32_t *slot_node,
+                                                                   const uint64_t *group_ptr, const uint32_t *group_len, const float4 *pos,
+                                                                   const uint32_t *new_of_old, const uint32_t *poff, uint32_t image_begin,
+                                                                   uint32_t own_pt_begin, const GeomDev g, int by_row, uint32_t *ent, double *wt)
+{
+    __shared__ uint32_t s_ent[RC_GROUP][65];
+    __shared__ double s_wt[RC_GROUP][65];
+    const uint32_t grp = blockIdx.x, j0 = blockIdx.y * 64u, n = group_len[grp];
+    if (j0 >= n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    #pragma unroll
+    for (int c = wave; c < RC_GROUP; c += 4) {
+        const uint32_t gnode = slot_node[(size_t)grp * RC_GROUP + c];
+        uint32_t e_out = RC_PAD;
+        double w_out = 0.0;
+        if (gnode != RC_PAD) {
+            const uint32_t b = node_ptr[gnode], len = node_ptr[gnode + 1] - b, j = j0 + (uint32_t)lane;
+            if (j < len) {
+                const uint64_t key = keys[(size_t)b + j];
+                const int tap = (int)(key & 63u);
+                const uint32_t ordinal = (uint32_t)((key >> 6) & ((1ull << rbits) - 1ull));
+                const uint32_t image = image_begin + gnode / (uint32_t)g.n_cp;
+                const uint32_t row = poff[image] - own_pt_begin + ordinal;
+                const uint32_t p = new_of_old[row];
+                const float4 v = pos[p];
+                const float in[3] = { v.x, v.y, v.z };
+                double W[3][4];
+                #pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float coord = (float)(((double)in[k] - g.origin[k]) / g.spacing[k]);
+                    const float fl = floorf(coord);
+                    bspline_weights(W[k], (double)(coord - fl));
+                }
+                w_out = W[0][tap & 3] * W[1][(tap >> 2) & 3] * W[2][tap >> 4];
+                e_out = by_row ? row : p;
+            }
+        }
+        s_ent[c][lane] = e_out;
+        s_wt[c][lane] = w_out;
+    }
+    __syncthreads();
+    const size_t base = (size_t)group_ptr[grp] + (size_t)j0 * RC_GROUP;
+    for (uint32_t idx = threadIdx.x; idx < 64u * RC_GROUP; idx += 256u) {
+        const uint32_t j = idx / RC_GROUP, c = idx % RC_GROUP;
+        if (j0 + j < n) { ent[base + idx] = s_ent[c][j]; wt[base + idx] = s_wt[c][j]; }
+    }
+}
+
 // The scatter: thread = one component of one control point of one image (slot order; lane = 4 slot + component), its chain in
 // point order with the arithmetic of imageGroup.cxx:330-337 -- f64 product, f64 sum, rounded to f32 after every addition -- points
 // without sums skipped (:299).  Every control point is written (an empty chain leaves the Fill(0) of :249).
