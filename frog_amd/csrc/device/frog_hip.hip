@@ -552,6 +552,16 @@ static int ref_point_sums(frog_ctx *ctx, bool with_energy)
 }
 
 // The chains of the reference-order scatter for the current lattice (k_refchain.hip.h): once per lattice, on `stream`.
+// One workgroup per group of RC_GROUP chains.  A launch is one AQL packet whose grid is 32-bit WORK-ITEMS per dimension: cfg 5's
+// finest lattice has 3.4e7 groups, x 256 threads = 8.8e9 -- the launch returned no error and the groups past 2^32 / 256 were
+// never filled (round 6: found by scripts/diag_exact_forms.py at full size).  So: at most 2^22 workgroups in x, the rest in the
+// second dimension; the kernels bound-check blockIdx.y * gridDim.x + blockIdx.x against the group count.
+static inline dim3 rc_grid(uint32_t n_groups)
+{
+    const uint32_t gx = std::min(std::max(1u, n_groups), 1u << 22);
+    return dim3(gx, div_up(std::max(1u, n_groups), gx));
+}
+
 static int ref_chain_build(frog_ctx *ctx)
 {
     if (ctx->rc_valid) return FROG_OK;
@@ -564,7 +574,7 @@ static int ref_chain_build(frog_ctx *ctx)
     const GeomDev gd = to_dev(ctx->geom);
     const uint32_t nO = ctx->n_owned(), nRows = ctx->own_pt_end - ctx->own_pt_begin;
     const uint64_t n_gnodes64 = (uint64_t)nO * (uint64_t)gd.n_cp, n_keys = (uint64_t)nRows * 64;
-    if (n_gnodes64 >= 0xFFFFFF00ull || n_keys >= 0xFFFFFF00ull) return fail(FROG_E_INVALID, "reference-order scatter: lattice or group too large for 32-bit chain indices");
+    if (n_gnodes64 >= 0xFFFF0000ull || n_keys >= 0xFFFF0000ull) return fail(FROG_E_INVALID, "reference-order scatter: lattice or group too large for 32-bit chain indices");
     const uint32_t n_gnodes = (uint32_t)n_gnodes64;
     const uint32_t n_groups = div_up(std::max(1u, n_gnodes), (uint32_t)RC_GROUP);
     uint32_t max_img_pts = 1;
@@ -622,13 +632,25 @@ static int ref_chain_build(frog_ctx *ctx)
     mark("kernels queued");
     FROG_HIP_CHECK(hipStreamSynchronize(s));
     mark("sorted, sizes on the host");
+    if (trace) {
+        DevBuf<unsigned long long> chk;
+        FROG_HIP_CHECK(chk.alloc(4));
+        FROG_HIP_CHECK(hipMemsetAsync(chk.p, 0, 4 * sizeof(unsigned long long), s));
+        ref_chain_check_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(ctx->rc_node_ptr.p, ctx->rc_slot_node.p, ctx->rc_group_len.p, (uint32_t)n_slots, chk.p);
+        unsigned long long h[4];
+        FROG_HIP_CHECK(hipMemcpyAsync(h, chk.p, sizeof h, hipMemcpyDeviceToHost, s));
+        FROG_HIP_CHECK(hipStreamSynchronize(s));
+        std::fprintf(stderr, "[ref_chain_build] check: %llu chains longer than their group, %llu empty slots (expected %llu), control points sum %llu (expected %llu)\n",
+                     h[0], h[1], (unsigned long long)(n_slots - n_gnodes), h[2], (unsigned long long)n_gnodes * (n_gnodes - 1) / 2);
+    }
     FROG_HIP_CHECK(ctx->rc_ent.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
     FROG_HIP_CHECK(ctx->rc_wt.alloc(std::max<uint64_t>(1, seats), std::max<uint64_t>(1, seats + seats / 4)));
     const unsigned j_tiles = div_up(std::max(1u, longest), 64u);
     if (n_entries && !ctx->ref_literal && j_tiles <= 65535u) {
-        ref_chain_fill_tiled_kernel<<<dim3(n_groups, j_tiles), 256, 0, s>>>(sorted, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_node.p, ctx->rc_group_ptr.p,
-                                                                           ctx->rc_group_len.p, ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib,
-                                                                           ctx->own_pt_begin, gd, ctx->rc_by_row ? 1 : 0, ctx->rc_ent.p, ctx->rc_wt.p);
+        const dim3 gg = rc_grid(n_groups);
+        ref_chain_fill_tiled_kernel<<<dim3(gg.x, j_tiles, gg.y), 256, 0, s>>>(sorted, rbits, ctx->rc_node_ptr.p, ctx->rc_slot_node.p, ctx->rc_group_ptr.p,
+                                                                             ctx->rc_group_len.p, ctx->pos.p, ctx->new_of_old.p, ctx->d_poff.p, ctx->ib,
+                                                                             ctx->own_pt_begin, gd, ctx->rc_by_row ? 1 : 0, n_groups, ctx->rc_ent.p, ctx->rc_wt.p);
     } else {
         FROG_HIP_CHECK(hipMemsetAsync(ctx->rc_ent.p, 0xFF, std::max<uint64_t>(1, seats) * sizeof(uint32_t), s));
         if (n_entries)
@@ -664,11 +686,11 @@ static int ref_deformable_phase_a(frog_ctx *ctx, float alpha)
         if (rc) return rc;
         const float4 *sums = ctx->rc_by_row ? ctx->ref_row_sums.p : ctx->point_sums.p;
         if (ctx->rc_unroll == 16)
-            ref_chain_kernel<16><<<ctx->rc_n_groups, 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
-                                                                sums, ctx->gradf.p);
+            ref_chain_kernel<16><<<rc_grid(ctx->rc_n_groups), 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
+                                                                         sums, ctx->rc_n_groups, ctx->gradf.p);
         else
-            ref_chain_kernel<8><<<ctx->rc_n_groups, 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
-                                                               sums, ctx->gradf.p);
+            ref_chain_kernel<8><<<rc_grid(ctx->rc_n_groups), 64, 0, s>>>(ctx->rc_ent.p, ctx->rc_wt.p, ctx->rc_group_ptr.p, ctx->rc_group_len.p, ctx->rc_slot_node.p,
+                                                                        sums, ctx->rc_n_groups, ctx->gradf.p);
     }
     ref_cp_step_kernel<<<div_up(gd.n_cp, 256), 256, 0, s>>>(ctx->gradf.p, ctx->coeff.p, ctx->grad.p, nO, gd.n_cp, alpha, ctx->gridsum.p);
     if (ctx->ref_join_pending) { FROG_HIP_CHECK(hipStreamWaitEvent(s, ctx->ref_join, 0)); ctx->ref_join_pending = false; }      // the energy sums (ref_point_sums)

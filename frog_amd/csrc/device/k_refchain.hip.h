@@ -95,6 +95,18 @@ __global__ __launch_bounds__(256) void ref_chain_group_kernel(const uint32_t *le
     if (t < n_slots && slot_node[t] != RC_PAD) slot_of_node[slot_node[t]] = t;
 }
 
+// Debug (FROG_REF_TRACE=1): chains longer than their group's padded length, slots without a control point, the sum of the slots' control points
+__global__ __launch_bounds__(256) void ref_chain_check_kernel(const uint32_t *node_ptr, const uint32_t *slot_node, const uint32_t *group_len, uint32_t n_slots,
+                                                              unsigned long long *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots) return;
+    const uint32_t gn = slot_node[t];
+    if (gn == RC_PAD) { atomicAdd(&out[1], 1ull); return; }
+    atomicAdd(&out[2], (unsigned long long)gn);
+    if (node_ptr[gn + 1] - node_ptr[gn] > group_len[t / RC_GROUP]) atomicAdd(&out[0], 1ull);
+}
+
 // Entry e of the sorted keys -> its seat in the chain layout: the point (internal numbering) and the tap's weight
 // w = wx[i] * wy[j] * wz[k] in f64 from the weights of the f32 fraction (imageGroup.cxx:311-322), as ref_scatter_kernel forms them.
 __global__ __launch_bounds__(256) void ref_chain_fill_kernel(const uint64_t *keys, uint32_t n_entries, int rbits, const uint32_t *node_ptr,
@@ -136,11 +148,14 @@ __global__ __launch_bounds__(256) void ref_chain_fill_kernel(const uint64_t *key
 __global__ __launch_bounds__(256) void ref_chain_fill_tiled_kernel(const uint64_t *keys, int rbits, const uint32_t *node_ptr, const uint32_t *slot_node,
                                                                    const uint64_t *group_ptr, const uint32_t *group_len, const float4 *pos,
                                                                    const uint32_t *new_of_old, const uint32_t *poff, uint32_t image_begin,
-                                                                   uint32_t own_pt_begin, const GeomDev g, int by_row, uint32_t *ent, double *wt)
+                                                                   uint32_t own_pt_begin, const GeomDev g, int by_row, uint32_t n_groups,
+                                                                   uint32_t *ent, double *wt)
 {
     __shared__ uint32_t s_ent[RC_GROUP][65];
     __shared__ double s_wt[RC_GROUP][65];
-    const uint32_t grp = blockIdx.x, j0 = blockIdx.y * 64u, n = group_len[grp];
+    const uint32_t grp = blockIdx.z * gridDim.x + blockIdx.x;   // rc_grid(): a launch holds < 2^32 work-items per dimension
+    if (grp >= n_groups) return;
+    const uint32_t j0 = blockIdx.y * 64u, n = group_len[grp];
     if (j0 >= n) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     #pragma unroll
@@ -193,13 +208,15 @@ __global__ __launch_bounds__(256) void ref_chain_fill_tiled_kernel(const uint64_
 // level 0 still took 2.9 us, one round trip; 16 there).
 template <int RC_UNROLL>
 __global__ __launch_bounds__(64) void ref_chain_kernel(const uint32_t *ent, const double *wt, const uint64_t *group_ptr, const uint32_t *group_len,
-                                                       const uint32_t *slot_node, const float4 *point_sums, float4 *gradf)
+                                                       const uint32_t *slot_node, const float4 *point_sums, uint32_t n_groups, float4 *gradf)
 {
     const int t = threadIdx.x >> 2, c = threadIdx.x & 3;
-    const uint32_t slot = blockIdx.x * RC_GROUP + t;
-    const uint32_t n = group_len[blockIdx.x];                   // a multiple of RC_UNROLL
-    const uint32_t *ge = ent + group_ptr[blockIdx.x] + t;
-    const double *gw = wt + group_ptr[blockIdx.x] + t;
+    const uint32_t grp = blockIdx.y * gridDim.x + blockIdx.x;   // rc_grid()
+    if (grp >= n_groups) return;
+    const uint32_t slot = grp * RC_GROUP + t;
+    const uint32_t n = group_len[grp];                          // a multiple of RC_UNROLL
+    const uint32_t *ge = ent + group_ptr[grp] + t;
+    const double *gw = wt + group_ptr[grp] + t;
     const float *sums = reinterpret_cast<const float *>(point_sums) + c;
     float g = 0.f;
     if (n) {

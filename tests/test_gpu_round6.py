@@ -98,6 +98,19 @@ def test_reference_order_fast_forms_equal_the_literal_forms(monkeypatch, group):
     same_trace(fast, literal)
 
 
+def test_reference_order_fast_forms_equal_the_literal_forms_at_config5_size(monkeypatch):
+    """The same at BASELINE.json configs[4]'s size, -li 2 -dl 5 -di 1: its finest lattice has 5.5e8 (image, control point) pairs =
+    3.4e7 groups of chains, and a launch of one 256-thread workgroup per group is 8.8e9 work-items in x -- more than the 32-bit
+    grid of a dispatch packet.  The launch reported no error and left the groups past 2^24 unfilled (found at full size by
+    scripts/diag_exact_forms.py; the 40-image group above cannot see it).  rc_grid() folds the groups into two grid dimensions."""
+    pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
+    images = list(range(0, 500, 71))
+    fast = run_reference_order(pairs, monkeypatch, 2, 5, 1, images)
+    literal = run_reference_order(pairs, monkeypatch, 2, 5, 1, images, FROG_REF_LITERAL="1")
+    assert fast[0] == [1, 1, 1, 1, 1]
+    same_trace(fast, literal)
+
+
 # ---- (3) two collectives per iteration without a device-visible scalar block (ADVICE r5) -----------------------------------------
 
 def test_two_collectives_flow_with_the_scalars_by_copy(tmp_path):
