@@ -71,7 +71,10 @@ def cpu_baseline(pairs, n_lin, per_level, stat_interval, repeats=3):
     the mean of each kind), extrapolated to the timed schedule."""
     from frog_amd import _abi
     from oracle.oracle_api import OracleGroup, lib
-    cores = lib().frogo_get_max_threads()
+    # as many threads as CPUs the process may use (a container's quota counts: 256 threads on a 16-CPU share are throttled
+    # together and the baseline reads five times too slow), OMP_NUM_THREADS respected when it asks for fewer
+    cores = min(lib().frogo_get_max_threads(), _abi.usable_cpus())
+    lib().frogo_set_threads(cores)
     ref = OracleGroup(pairs.model, _abi.FrogOptions.default())
     ref.setup_stats()
     ref.linear_init()
@@ -841,7 +844,8 @@ def orchestrate(args, argv, n, my_ranks, directory):
     env_base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
     if "OMP_NUM_THREADS" not in os.environ or os.environ.get("FROG_BENCH_UNDER_TORCHRUN") == "1":
         # torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset; frog_create builds its layout on the host threads
-        env_base["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or n) // n))
+        from frog_amd._abi import usable_cpus
+        env_base["OMP_NUM_THREADS"] = str(max(1, usable_cpus() // n))
     # a healthy attempt takes 5-20 s (the torch host up to two minutes more on a fresh box: its first `import torch`); the
     # worst case of a whole run -- preflight passes, the native RCCL attempt hangs, fallback -- stays near five minutes
     timeouts = {"preflight": float(os.environ.get("FROG_BENCH_PREFLIGHT_TIMEOUT", "90")),

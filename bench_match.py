@@ -95,11 +95,13 @@ def main():
     if args.cpu_jobs:
         from oracle.oracle_api import lib, match_run
         sample = jobs[:args.cpu_jobs]
+        from frog_amd._abi import usable_cpus
+        cores = min(lib().frogo_match_get_max_threads(), usable_cpus())      # the CPUs the process may use, not the machine's
         t0 = time.perf_counter()
-        ref = match_run(imgs, sample, threshold=args.threshold)
+        ref = match_run(imgs, sample, threshold=args.threshold, threads=cores)
         t_cpu = time.perf_counter() - t0
         same = all(np.array_equal(a, c) and np.array_equal(b, d) for (a, b), (c, d) in zip(res[:len(sample)], ref))
-        out["cpu_baseline"] = {"value": len(sample) / t_cpu, "unit": "image pairs/s", "cores": lib().frogo_match_get_max_threads(),
+        out["cpu_baseline"] = {"value": len(sample) / t_cpu, "unit": "image pairs/s", "cores": cores,
                                "kind": "port", "sample": f"the first {len(sample)} image pairs with the oracle "
                                "(oracle/match_oracle.cpp; one thread per image pair, as upstream's omp loop)",
                                "identical_pairs": bool(same)}

@@ -12,6 +12,45 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 
 
+def usable_cpus():
+    """CPUs this process may run on: the affinity mask capped by the cgroup quota (csrc/common/usable_cpus.h, the same rule).
+    On the GPU boxes os.cpu_count() says 256 and cpu.max says 16: 256 OpenMP threads there are throttled together."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def quota(d):
+        try:
+            with open(os.path.join(d, "cpu.max")) as fh:
+                q, p = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+        except (OSError, ValueError):
+            pass
+        try:
+            with open(os.path.join(d, "cpu.cfs_quota_us")) as fh:
+                q = float(fh.read())
+            with open(os.path.join(d, "cpu.cfs_period_us")) as fh:
+                p = float(fh.read())
+            return q / p if q > 0 and p > 0 else None
+        except (OSError, ValueError):
+            return None
+    dirs = ["/sys/fs/cgroup", "/sys/fs/cgroup/cpu"]
+    try:
+        with open("/proc/self/cgroup") as fh:
+            for line in fh:
+                _, ctrl, path = line.rstrip("\n").split(":", 2)
+                root = "/sys/fs/cgroup" if ctrl == "" else ("/sys/fs/cgroup/cpu" if "cpu" in ctrl.split(",") or "cpuacct" in ctrl.split(",") else None)
+                while root and len(path) > 1:
+                    dirs.append(root + path)
+                    path = path.rsplit("/", 1)[0] or "/"
+    except (OSError, ValueError):
+        pass
+    for d in dirs:
+        q = quota(d)
+        if q and q > 0:
+            n = min(n, max(1, math.ceil(q - 1e-9)))
+    return max(1, n)
+
+
 def device_source_hash():
     """sha256 (first 16 hex digits) over the HIP sources of the registration kernels (everything under csrc/device
     except the matcher, the transform chains and the collectives library), in name order: what a PMC measurement under
@@ -57,7 +96,8 @@ class FrogOptions(C.Structure):
                 ("n_fixed_images", C.c_int32),
                 ("max_levels_hint", C.c_int32),
                 ("reference_order", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("selections_in_background", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
     @classmethod
     def default(cls, **kw):

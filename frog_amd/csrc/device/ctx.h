@@ -74,7 +74,7 @@ template <class T> struct DevBuf {
         n = count; cap = count;
         return e;
     }
-    hipError_t upload(const std::vector<T> &v, hipStream_t s)
+    template <class A> hipError_t upload(const std::vector<T, A> &v, hipStream_t s)
     {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;

@@ -36,6 +36,12 @@ using namespace frog;
         FROG_HIP_CHECK(hipSetDevice((ctx)->device));                      \
     } while (0)
 
+// This library's host loops (prep.h, the RANSAC batches) run on the LLVM OpenMP runtime.  At its first use that runtime maps the
+// machine's topology for its affinity interface -- 40-120 ms on a 256-CPU host, measured as "numbering" taking 0.04-0.12 s instead
+// of 0.005 -- which nothing here uses (no thread is ever bound).  Switched off when the library is loaded, before the runtime's
+// first call, unless the user has said something about KMP_AFFINITY themselves.
+__attribute__((constructor)) static void frog_openmp_defaults() { setenv("KMP_AFFINITY", "disabled", 0); }
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // FROG_ROCTX=1: a roctx range around every kernel group (the names of FROG_K_*), for `rocprofv3 --marker-trace`.  The
@@ -1167,7 +1173,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     // side stream (80 replays are 0.12 s of one-block-per-image work that would otherwise run beside the first iterations)
     for (int k = 0; k + 1 < c->sel_ring; k++)
         if (int rc_ = produce_selection(c)) { frog_destroy(c); return rc_; }
-    if (hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
+    if (!c->opt.selections_in_background && hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
     c->create_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_resident).count();
     c->create_selections = c->sel_ring > 0 ? c->sel_ring - 1 : 0;
 #undef CREATE_CHECK

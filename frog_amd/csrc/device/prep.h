@@ -29,15 +29,32 @@
 #pragma once
 
 #include "ctx.h"
+#include "../common/usable_cpus.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <utility>
 #include <omp.h>
 
-// Host threads of the layout build: what OpenMP offers, but at most 64 -- on a 256-thread host, with one
-// process per GPU, eight uncapped pools would be 2048 threads for a job that takes half a second.
-inline int host_threads() { const int n = omp_get_max_threads(); return n < 1 ? 1 : (n > 64 ? 64 : n); }
+// Host threads of the layout build: frog::host_threads() (common/usable_cpus.h) -- what OpenMP offers, capped by the CPUs the
+// process may use (affinity mask, cgroup quota) and by 64: on a 256-thread host, with one process per GPU, eight uncapped pools
+// would be 2048 threads for a job that takes half a second.
 
 namespace frog {
+
+// Arrays with an entry per half-link (0.4 GB each for the benchmark group) are sized once and written in full on all host
+// threads: resize() must not zero them on one (the three fills were 0.15 s of frog_create's 0.29 s of layout build).
+template <class T> struct noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = noinit_alloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using Bulk = std::vector<T, noinit_alloc<T>>;
 
 struct Layout {
     // Internal point numbering: inside every image the points are renumbered along a
@@ -53,12 +70,12 @@ struct Layout {
     // its 4 MiB L2 -- also for false matches, whose partner points are uniformly random.
     std::vector<uint32_t> group_begin;      // [n_groups + 1]
     std::vector<Tile> tiles;
-    std::vector<LinkRec> recs;              // wide records, or
-    std::vector<uint32_t> recs32;           // narrow records (RecFormat)
+    Bulk<LinkRec> recs;                     // wide records, or
+    Bulk<uint32_t> recs32;                  // narrow records (RecFormat)
     RecFormat format{};
     std::vector<uint32_t> img_tile_ptr;     // [nI + 1]
     std::vector<uint64_t> ref_rowptr;       // owned rows, relative to first owned link
-    std::vector<uint32_t> ref_link;         // partner global index, reference order
+    Bulk<uint32_t> ref_link;                // partner global index, reference order
     std::vector<uint64_t> img_link_begin;   // [nI + 1] (relative, owned images only meaningful)
 };
 
@@ -92,7 +109,11 @@ inline void build_numbering(const frog_model &m, Layout &out)
         float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
         for (uint32_t p = b; p < e; p++)
             for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], m.xyz[3 * (size_t)p + k]); mx[k] = std::max(mx[k], m.xyz[3 * (size_t)p + k]); }
-        std::vector<std::pair<uint32_t, uint32_t>> key(e - b);
+        // (Morton key, old index) ascending = a stable sort by key of the points in index order: three counting passes of 10 bits
+        // (std::sort of 20 000 pairs was 1.3 ms per image -- with a hundred images over sixteen threads the slowest stage of the
+        // layout build)
+        const uint32_t n_pts = e - b;
+        std::vector<std::pair<uint32_t, uint32_t>> key(n_pts), tmp(n_pts);
         for (uint32_t p = b; p < e; p++) {
             uint32_t q[3];
             for (int k = 0; k < 3; k++) {
@@ -104,7 +125,14 @@ inline void build_numbering(const frog_model &m, Layout &out)
             }
             key[p - b] = { spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2), p };
         }
-        std::sort(key.begin(), key.end());                 // ties broken by the old index
+        for (int pass = 0; pass < 3; pass++) {
+            uint32_t count[1025] = { 0 };
+            const int sh = 10 * pass;
+            for (uint32_t n = 0; n < n_pts; n++) count[((key[n].first >> sh) & 1023u) + 1]++;
+            for (int c = 0; c < 1024; c++) count[c + 1] += count[c];
+            for (uint32_t n = 0; n < n_pts; n++) tmp[count[(key[n].first >> sh) & 1023u]++] = key[n];
+            key.swap(tmp);
+        }
         for (uint32_t n = 0; n < e - b; n++) {
             out.old_of_new[b + n] = key[n].second;
             out.new_of_old[key[n].second] = b + n;
@@ -116,7 +144,12 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
 {
     const uint32_t nI = m.n_images;
     const uint32_t *poff = m.point_offset;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (std::getenv("FROG_TIMING")) std::printf("[timing] build_layout, %s : %gs\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count());
+    };
     build_numbering(m, out);
+    lap("numbering");
     const std::vector<uint32_t> &new_of_old = out.new_of_old, &old_of_new = out.old_of_new;
     const uint32_t *new_of_old_base = poff;      // internal numbering keeps every image's index range
     const uint32_t p0 = poff[ib], p1 = poff[ie];
@@ -137,6 +170,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
         out.ref_link[l] = new_of_old[poff[im] + pt];
     }
     if (bad) { err = "link references a point outside its image"; return FROG_E_INVALID; }
+    lap("+ reference-order links renumbered");
     out.img_link_begin.assign(nI + 1, 0);
     for (uint32_t i = 0; i <= nI; i++) {
         uint32_t c = std::min(std::max(i, ib), ie);
@@ -186,6 +220,7 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
             for (uint64_t l = m.row_ptr[o]; l < m.row_ptr[o + 1]; l++) tl.group_cnt[group_of[m.link_image[l]]]++;
         }
     }
+    lap("+ records counted");
     uint64_t rec_total = 0;
     for (long long t = 0; t < nT; t++) {
         Tile &tl = out.tiles[t];
@@ -198,7 +233,8 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
         rec_total += off;
         if (rec_total >= 0xFFFFFFFFull) { err = "more than 2^32-1 link records in one context"; return FROG_E_INVALID; }
     }
-    if (rec_total == 0) rec_total = REC_CHUNK;               // the sweep's clamped prefetch needs one readable chunk
+    const bool no_records = rec_total == 0;
+    if (no_records) rec_total = REC_CHUNK;                   // the sweep's clamped prefetch needs one readable chunk
 
     // record format: narrow when (own point, partner image in its group, partner point in its image) fit 32 bits
     {
@@ -216,8 +252,9 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
     const uint32_t img_bits = out.format.img_bits;
 
     // partner-major records, stable counting sort per tile
-    if (narrow) out.recs32.assign(rec_total, 0u);
-    else out.recs.assign(rec_total, LinkRec{ 0u, 0u });
+    // (every slot is written below, padding included -- except the one readable chunk of a context without records)
+    if (narrow) { out.recs32.resize(rec_total); if (no_records) std::fill(out.recs32.begin(), out.recs32.end(), 0u); }
+    else { out.recs.resize(rec_total); if (no_records) std::fill(out.recs.begin(), out.recs.end(), LinkRec{ 0u, 0u }); }
     #pragma omp parallel num_threads(host_threads())
     {
         std::vector<uint32_t> cnt(nI + 1);
@@ -258,10 +295,16 @@ inline int build_layout(const frog_model &m, uint32_t ib, uint32_t ie, bool forc
                         out.recs[phys] = src[k];
                     }
                 }
+                const uint32_t padded = (tl.group_cnt[g] + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK;      // null records to the chunk's end
+                for (uint32_t k = tl.group_cnt[g]; k < padded; k++) {
+                    const size_t phys = at + (k / REC_CHUNK) * REC_CHUNK + (k % 64u) * 2u + (k % REC_CHUNK) / 64u;
+                    if (narrow) out.recs32[phys] = 0u; else out.recs[phys] = LinkRec{ 0u, 0u };
+                }
             }
         }
     }
 
+    lap("+ records placed");
     return FROG_OK;
 }
 

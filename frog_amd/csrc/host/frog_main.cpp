@@ -29,6 +29,8 @@ using std::endl;
 int main(int argc, char *argv[])
 {
     auto start = std::chrono::system_clock::now();
+    if (std::getenv("FROG_TIMING"))              // with the caller's own clock around the process: what loading and leaving cost
+        cout << "[timing] main entered at " << std::fixed << std::chrono::duration<double>(start.time_since_epoch()).count() << std::defaultfloat << endl;
     ImageGroup group;
 
     if (argc >= 2 && strcmp(argv[1], "--synth") == 0) {
@@ -167,5 +169,7 @@ int main(int argc, char *argv[])
     auto end = std::chrono::system_clock::now();
     cout << "Iteration loops : " << group.loopIterations << " iterations in " << group.loopSeconds << "s" << endl;
     cout << "Total time : " << std::chrono::duration<float>(end - start).count() << "s" << endl;
+    if (std::getenv("FROG_TIMING"))
+        cout << "[timing] main returns at " << std::fixed << std::chrono::duration<double>(end.time_since_epoch()).count() << std::defaultfloat << endl;
     return 0;
 }

@@ -3,6 +3,7 @@
 // (registration/imageGroup.cxx:31-157) step for step; stdout wording follows the
 // reference because the DESK UI greps it (js/groupwiseDeformableRegistration.js:522-545).
 
+#include "../common/usable_cpus.h"
 #include "image_group.h"
 #include "json_out.h"
 #include "pairs_store.h"
@@ -146,6 +147,7 @@ void ImageGroup::createShardedContexts()
     o.guarantee_diffeomorphism = guaranteeDiffeomorphism; o.max_displacement_ratio = maxDisplacementRatio;
     o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize; o.stats_max_iterations = statsMaxIterations; o.stats_epsilon = statsEpsilon;
     o.reference_order = exact;
+    o.selections_in_background = 1;             // a whole run: the ahead-of-time draws beside the first iterations
     frog_model m;
     frog_pairs_model(pairs, &m);
     std::vector<int> devices(nGpus);
@@ -418,6 +420,7 @@ void ImageGroup::createContext()
     o.max_displacement_ratio = maxDisplacementRatio;
     o.max_levels_hint = deformableLevels; o.stats_max_size = statsMaxSize;
     o.reference_order = exact;
+    o.selections_in_background = 1;             // a whole run: the ahead-of-time draws beside the first iterations
     o.stats_max_iterations = statsMaxIterations;
     o.stats_epsilon = statsEpsilon;
     o.n_fixed_images = numberOfFixedImages;
@@ -492,7 +495,13 @@ void ImageGroup::run()
     }
     if (numberOfFixedImages) readAndApplyFixedImagesTransforms();       // :34
     { const auto t_ctx = clk::now(); createContext();                   // :36 setupStats
-      if (std::getenv("FROG_TIMING")) cout << "[timing] frog_create : " << std::chrono::duration<double>(clk::now() - t_ctx).count() << "s" << endl; }
+      if (std::getenv("FROG_TIMING")) {
+          cout << "[timing] frog_create : " << std::chrono::duration<double>(clk::now() - t_ctx).count() << "s" << endl;
+          double part[3] = { 0, 0, 0 };
+          if (frog_create_seconds(ctx, part, nullptr) == FROG_OK)
+              cout << "[timing] frog_create, layout build : " << part[0] << "s" << endl << "[timing] frog_create, allocations + uploads : " << part[1] << "s" << endl
+                   << "[timing] frog_create, selections queued : " << part[2] << "s" << endl;
+      } }
     check(frog_linear_init(ctx, linearInitializationAnchor), "frog_linear_init");   // :37
     check(frog_transform_points(ctx, 0), "frog_transform_points");      // :38
 
@@ -648,7 +657,7 @@ void ImageGroup::saveErrorMaps()
     int failed = 0;
     // binning (frog_get_error_map works on the host copies frog_residual_sums left: read-only from here), compression and file
     // output on all host threads -- the binning of 100 images one after the other was half of this function's 0.17 s
-    #pragma omp parallel for schedule(dynamic, 1)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(frog::host_threads())
     for (int image = numberOfFixedImages; image < (int)n; image++) {
         const frog_grid_info &info = infos[image];
         maps[image].resize((size_t)4 * info.dims[0] * info.dims[1] * info.dims[2]);
@@ -991,7 +1000,7 @@ void ImageGroup::saveTransforms()
         }
     }
     int failed = 0;
-    #pragma omp parallel for schedule(dynamic, 1)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(frog::host_threads())
     for (int image = numberOfFixedImages; image < (int)n; image++) {
         const Fetched &f = all[image];
         frogjson::Value transforms = frogjson::Value::array();

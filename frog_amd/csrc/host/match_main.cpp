@@ -5,6 +5,7 @@
 // Same flags (-n -sp -np -nt -d -d2 -zmin -zmax -o -p -anat -sym -targ), same input files, same
 // pairs.bin, plus -transformPrefix (positions for the -anat test).  -all is upstream's matchAll, quirk included (include/frog_match.h).
 // A directory is read in sorted name order (upstream: the file system's order).
+#include "../common/usable_cpus.h"
 #include "frog_host.h"
 #include "frog_match.h"
 
@@ -103,7 +104,7 @@ int main(int argc, char *argv[])
     if (nb == 0) { std::cerr << "no keypoint file" << endl; return 1; }
     std::vector<frog_keypoint_file *> allPoints(nb, nullptr);
     bool bad = false;
-    #pragma omp parallel for schedule(dynamic)
+    #pragma omp parallel for schedule(dynamic) num_threads(frog::host_threads())
     for (int it = 0; it < nb; ++it) {                                       // :509-556
         int status = 0;
         frog_keypoint_file *points = frog_keypoints_read(filenames[it].c_str(), &status);

