@@ -730,6 +730,7 @@ void frog_destroy(frog_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
+    if (ctx->layout_reaper.joinable()) ctx->layout_reaper.join();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 #ifdef FROG_W1_COUNT
@@ -873,6 +874,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         }                                                                                            \
     } while (0)
 
+    auto create_lap = [&](const char *what) {
+        if (getenv("FROG_TIMING")) std::printf("[timing] frog_create device part, %s : %gs\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_layout).count());
+    };
     CREATE_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     {
@@ -916,6 +920,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(c->pos2.upload(hp2, s));
         CREATE_CHECK(hipStreamSynchronize(s));
     }
+    create_lap("+ points uploaded"); 
     CREATE_CHECK(c->d_poff.upload(c->poff, s));
     CREATE_CHECK(c->point_sums.alloc(c->P));
     CREATE_CHECK(hipMemsetAsync(c->point_sums.p, 0, c->point_sums.bytes(), s));
@@ -927,10 +932,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         CREATE_CHECK(c->new_of_old.upload(own, s));
         CREATE_CHECK(hipStreamSynchronize(s));
     }
+    create_lap("+ reference-order links uploaded");
     CREATE_CHECK(c->tiles.upload(lay.tiles, s));
     if (lay.format.narrow) { CREATE_CHECK(c->recs32.upload(lay.recs32, s)); }
     else { CREATE_CHECK(c->recs.upload(lay.recs, s)); }
     CREATE_CHECK(c->img_tile_ptr.upload(lay.img_tile_ptr, s));
+    create_lap("+ records queued");
     {
         // Fused deformable sweep (k_links.hip.h FUSED): block b works on tile order[b], and b % 8 -- the XCD the block lands on
         // under round-robin dispatch -- is the tile's eighth of its image along the Morton curve, so that an XCD's L2 sees the
@@ -1084,6 +1091,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     stats_publish_kernel<<<dim3(div_up(c->nI, 64), 2), 64, 0, s>>>(c->em.p, c->emd.p, c->emf.p, c->nI, c->opt.inlier_threshold, c->fast_theta(), c->cut_now.p, 1);
     CREATE_CHECK(hipGetLastError());
     CREATE_CHECK(hipStreamSynchronize(s));      // host staging vectors die here
+    create_lap("+ everything else allocated, uploads done");
     if (!getenv("FROG_LATTICE_LAZY")) {
         // the lattice buffers of level 0 (with their head-room) for the box of the model as it is: close enough to what
         // the first frog_deformable_setup will ask for that it finds them allocated
@@ -1142,6 +1150,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             c->retired_used = 0;
         }
     }
+    create_lap("+ lattices allocated");
     {
         // Resolve the kernels of the deformable stage now: the runtime creates a kernel's function object at its first
         // launch, which cost the first deformable step of a run 0.1-0.15 ms of host time with the GPU idle (rocprofv3
@@ -1161,12 +1170,14 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
             (const void *)stats_publish_kernel, (const void *)cull_allow_validate_kernel, (const void *)cull_count_kernel,
             (const void *)sweep_kernel<SWEEP_LINEAR, true, false, true, false>, (const void *)sweep_kernel<SWEEP_LINEAR, true, false, false, false>,
         };
+
         for (const void *k : kernels) { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, k); }
         (void)hipGetLastError();
     }
     scratch_warm_kernel<<<1, 64, 0, s>>>(c->stray.p, 0);
     (void)hipGetLastError();
     (void)hipStreamSynchronize(s);
+    create_lap("+ kernels resolved, stream idle");
     const auto t_resident = std::chrono::steady_clock::now();
     c->create_s[1] = std::chrono::duration<double>(t_resident - t_layout).count();
     // selections of the first sel_ring - 1 refreshes, ahead of time -- and awaited: a context leaves frog_create with an idle
@@ -1176,6 +1187,10 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!c->opt.selections_in_background && hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
     c->create_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_resident).count();
     c->create_selections = c->sel_ring > 0 ? c->sel_ring - 1 : 0;
+    // every upload has completed (the stream was synchronised above): the host copy of the layout is dead.  Unmapping its 0.8 GB
+    // takes the calling thread 0.07 s; a thread of its own does it while the caller goes on (joined in frog_destroy).
+    try { c->layout_reaper = std::thread([dead = std::move(lay)]() mutable { Layout gone = std::move(dead); (void)gone; }); }
+    catch (...) { /* no thread to be had: `lay` dies here as before */ }
 #undef CREATE_CHECK
     *out = c;
     return FROG_OK;

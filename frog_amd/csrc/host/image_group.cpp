@@ -983,25 +983,14 @@ void ImageGroup::saveTransforms()
     std::filesystem::create_directory(transformSubdirectory.c_str());
     const uint32_t n = frog_num_images(ctx);
     const int nGrids = frog_num_grids(ctx);
-    // first everything comes back from the device (one thread, the context's stream), then the files are formatted,
-    // compressed and written image by image on all host threads: gzip of 700 sidecars is what this function costs
-    // (1.76 s on one thread for 100 images x 7 lattices)
+    // One thread brings an image's matrix and lattices back from the device (the context's stream) and hands them over as a task;
+    // the other host threads format, compress and write while it fetches the next image: gzip of 700 sidecars is what this
+    // function costs (1.76 s on one thread for 100 images x 7 lattices; fetching everything first, then writing: 0.056 + 0.11 s)
     struct Fetched { double m[16]; std::vector<frog_grid_info> info; std::vector<std::vector<float>> coeffs; };
     std::vector<Fetched> all(n);
-    for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :1464
-        Fetched &f = all[image];
-        frog_ctx *owner = ctxOf(image);
-        check(frog_get_linear(owner, image, f.m), "frog_get_linear");
-        f.info.resize(nGrids); f.coeffs.resize(nGrids);
-        for (int k = 0; k < nGrids; k++) {
-            check(frog_get_grid(owner, image, k, &f.info[k], nullptr, 0), "frog_get_grid");
-            f.coeffs[k].resize((size_t)3 * f.info[k].dims[0] * f.info[k].dims[1] * f.info[k].dims[2]);
-            check(frog_get_grid(owner, image, k, &f.info[k], f.coeffs[k].data(), f.coeffs[k].size()), "frog_get_grid");
-        }
-    }
-    int failed = 0;
-    #pragma omp parallel for schedule(dynamic, 1) num_threads(frog::host_threads())
-    for (int image = numberOfFixedImages; image < (int)n; image++) {
+    int failed = 0, fetch_rc = FROG_OK;
+    const char *fetch_what = "";
+    auto write_image = [&](int image) {
         const Fetched &f = all[image];
         frogjson::Value transforms = frogjson::Value::array();
         {
@@ -1051,7 +1040,28 @@ void ImageGroup::saveTransforms()
         fs.open(file.str(), std::fstream::out | std::fstream::trunc);
         fs << root.serialize();
         fs.close();
+    };
+    #pragma omp parallel num_threads(frog::host_threads())
+    #pragma omp single
+    for (uint32_t image = numberOfFixedImages; image < n; image++) {               // :1464
+        Fetched &f = all[image];
+        frog_ctx *owner = ctxOf(image);
+        if ((fetch_rc = frog_get_linear(owner, image, f.m)) != FROG_OK) { fetch_what = "frog_get_linear"; break; }
+        f.info.resize(nGrids); f.coeffs.resize(nGrids);
+        for (int k = 0; k < nGrids && fetch_rc == FROG_OK; k++) {
+            fetch_rc = frog_get_grid(owner, image, k, &f.info[k], nullptr, 0);
+            if (fetch_rc != FROG_OK) break;
+            f.coeffs[k].resize((size_t)3 * f.info[k].dims[0] * f.info[k].dims[1] * f.info[k].dims[2]);
+            fetch_rc = frog_get_grid(owner, image, k, &f.info[k], f.coeffs[k].data(), f.coeffs[k].size());
+        }
+        if (fetch_rc != FROG_OK) { fetch_what = "frog_get_grid"; break; }
+        #pragma omp task firstprivate(image)
+        {
+            write_image((int)image);
+            std::vector<std::vector<float>>().swap(all[image].coeffs);              // the lattices of 500 images need not stay
+        }
     }
+    check(fetch_rc, fetch_what);
     if (failed) check(FROG_E_IO, "frog_nifti_write");
 }
 
