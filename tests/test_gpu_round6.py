@@ -178,3 +178,24 @@ def test_scatter_quad_form_equals_the_point_by_point_form_bit_for_bit(tmp_path):
     assert sorted(a.files) == sorted(b.files) and len(a.files) >= 6
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+# ---- (6) the ahead-of-time selections beside the first iterations (frog_options::selections_in_background) ------------------------
+
+def test_selections_in_background_change_nothing(monkeypatch):
+    """bin/frog creates its context with selections_in_background = 1: frog_create queues the reservoir selections of the first
+    refreshes on the side stream and returns without waiting; a refresh waits for its own selection's event.  The same schedule
+    with and without: coordinates, matrices, mixtures and every lattice bit for bit (13 refreshes over three levels)."""
+    pairs = Pairs.synthetic(12, 4000, 1500, seed=5)
+    out = []
+    for flag in (0, 1):
+        s = T.Side(pairs, selections_in_background=flag)
+        grids = T.lockstep([s], 30, 3, 30, lambda *a, **k: None)
+        out.append((grids, s.xyz2().copy(), s.matrices().copy(), np.stack([s.g.em(i) for i in range(pairs.n_images)]),
+                    [np.stack([s.grid(i, k)[1] for i in range(pairs.n_images)]) for k in range(s.num_grids())]))
+    a, b = out
+    assert a[0] == b[0]
+    for u, v in zip(a[1:4], b[1:4]):
+        assert np.array_equal(u, v)
+    for u, v in zip(a[4], b[4]):
+        assert np.array_equal(u, v)
