@@ -310,6 +310,7 @@ HOST_SYMBOLS = {
     "frog_pairs_num_points": (C.c_uint64, [C.c_void_p]),
     "frog_pairs_num_images": (C.c_uint32, [C.c_void_p]),
     "frog_pairs_num_blocks": (C.c_uint32, [C.c_void_p]),
+    "frog_host_threads": (C.c_int, []),
     "frog_pairs_block": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                    C.POINTER(C.c_uint32), C.POINTER(c_u32_p), C.POINTER(c_u32_p)]),
     "frog_pairs_from_arrays": (C.c_void_p, [C.c_uint32, c_u32_p, c_float_p, c_float_p, C.c_uint32,

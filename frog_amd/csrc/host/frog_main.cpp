@@ -106,7 +106,11 @@ int main(int argc, char *argv[])
     // readPairs, instead of inside frog_create behind it.  -dev is looked up ahead of the flag loop for this alone.
     int warmDevice = 0;
     for (int i = 2; i + 1 < argc; i++) if (strcmp(argv[i], "-dev") == 0) warmDevice = atoi(argv[i + 1]);
-    std::thread warm([warmDevice] { (void)frog_device_warm(warmDevice); });
+    // (readPairs and the flag loop leave through exit(1) on bad input: the thread is joined by an exit handler then, before the
+    // runtime's own static objects go -- leaving it in the middle of the runtime's start-up ended in malloc's abort now and then)
+    static std::thread warm;
+    warm = std::thread([warmDevice] { (void)frog_device_warm(warmDevice); });
+    std::atexit([] { if (warm.joinable()) warm.join(); });
 
     cout << "Reading : " << argv[1] << endl;
     group.readPairs(argv[1]);
@@ -164,7 +168,7 @@ int main(int argc, char *argv[])
         argumentsIndex += increment;
     }
 
-    warm.join();
+    if (warm.joinable()) warm.join();
     group.run();
     auto end = std::chrono::system_clock::now();
     cout << "Iteration loops : " << group.loopIterations << " iterations in " << group.loopSeconds << "s" << endl;

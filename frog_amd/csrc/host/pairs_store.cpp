@@ -292,6 +292,8 @@ int frog_pairs_write(const frog_pairs *p, const char *path)
 
 void frog_pairs_free(frog_pairs *p) { delete p; }
 
+int frog_host_threads(void) { return frog::host_threads(); }
+
 void frog_pairs_model(const frog_pairs *p, frog_model *out)
 {
     out->n_images = p->n_images;

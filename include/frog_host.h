@@ -61,6 +61,12 @@ frog_pairs *frog_pairs_from_arrays(uint32_t n_images, const uint32_t *point_offs
                                    const uint16_t *block_image2, const uint64_t *block_ptr,
                                    const uint32_t *p1, const uint32_t *p2);
 
+/* Host threads this library's parallel loops start (readPairs' CSR, error maps, transforms/): what OpenMP offers
+ * (OMP_NUM_THREADS, -nt), capped by the CPUs the process may use -- affinity mask and cgroup CPU quota -- and by 64.  The
+ * reference asks omp_get_num_procs() (frog.cxx -nt default); on a host that shows 256 hardware threads to a container
+ * with a 16-CPU quota that starts 256 threads which are throttled together. */
+int frog_host_threads(void);
+
 /* ---- synthetic groups (the reference ships no data) -- */
 typedef struct frog_synth_params {
     uint32_t n_images;

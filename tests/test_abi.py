@@ -97,3 +97,17 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle" not in text.replace("(no CPU engine", ""), os.path.join(base, f)
+
+
+def test_host_threads_follow_the_usable_cpus(monkeypatch):
+    """The C++ rule (csrc/common/usable_cpus.h) and the Python one (_abi.usable_cpus) read the same affinity mask and cgroup
+    files: same answer, within the machine's CPU count, and OMP_NUM_THREADS still wins when it asks for fewer."""
+    import os, subprocess, sys
+    from frog_amd import _abi
+    n = _abi.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    code = "import sys; sys.path.insert(0, %r); from frog_amd import _abi; print(_abi.host_lib().frog_host_threads())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}
+    assert int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout) == min(n, 64)
+    env["OMP_NUM_THREADS"] = "1"
+    assert int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout) == 1
