@@ -8,7 +8,6 @@
 #include <cstring>
 #include <string>
 #include <memory>
-#include <thread>
 #include <vector>
 
 #include "../../../include/frog_hip.h"
@@ -363,7 +362,6 @@ struct frog_ctx {
     bool ref_order = false;
     double create_s[3] = { 0, 0, 0 };   // frog_create: host layout build, allocations + uploads + first kernels, reservoir selections replayed ahead
     int create_selections = 0;
-    std::thread layout_reaper;          // frog_create: gives the host copy of the link layout (0.8 GB for the benchmark group) back beside the first iterations
     bool two_collectives = false;   // frog_comm_mode: the energy sums ride on the all-reduce of the proposal sums, the oversize count on the coordinate gather
     bool finish_deformable = false; // ... and they decide a deformable step (frog_step_finish commits or rejects it)
     bool speculated = false;        // frog_step_speculate has exchanged the lattices' roles ahead of the decision

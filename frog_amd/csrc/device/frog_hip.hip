@@ -564,7 +564,8 @@ static int ref_point_sums(frog_ctx *ctx, bool with_energy)
 // second dimension; the kernels bound-check blockIdx.y * gridDim.x + blockIdx.x against the group count.
 static inline dim3 rc_grid(uint32_t n_groups)
 {
-    const uint32_t gx = std::min(std::max(1u, n_groups), 1u << 22);
+    static const uint32_t max_x = getenv("FROG_RC_GRID_X") ? (uint32_t)std::max(1, atoi(getenv("FROG_RC_GRID_X"))) : 1u << 22;      // (test hook: the fold on small groups)
+    const uint32_t gx = std::min(std::max(1u, n_groups), max_x);
     return dim3(gx, div_up(std::max(1u, n_groups), gx));
 }
 
@@ -730,7 +731,6 @@ void frog_destroy(frog_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->helper) { frog_destroy(ctx->helper); ctx->helper = nullptr; }
-    if (ctx->layout_reaper.joinable()) ctx->layout_reaper.join();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 #ifdef FROG_W1_COUNT
@@ -1122,8 +1122,27 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
                 GridGeom gh{};
                 frog_grid_info ih{};
                 size_t free_b = 0, total_b = 0;
-                if (make_geometry(c, finest, mn, mx, gh, ih) == FROG_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                    gh.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)gh.n_cp * 5 / 4);
+                // The box the finest level will see is the REGISTERED group's, not the model's: frog_linear_init moves every image's
+                // anchor (the centre of its box, by default) onto the images' mean anchor, so the union of the images' boxes centred
+                // on one point is what is left of, say, +-100 mm of translation between them.  Estimated here from the per-image
+                // boxes; the union of the boxes where they lie (mn, mx) overstated cfg 5's finest lattice 3.8 times (4.4e6 control
+                // points against 0.92e6), `need` came to 320 GB of 293 and nothing was reserved: the set-up of level 4 then paid three
+                // hipMalloc of 7.4 GB inside the loops -- 17 ms on one box, 730-1 230 ms on another (round 6; FROG_SETUP_TRACE=1).
+                double rmn[3], rmx[3];
+                for (int k = 0; k < 3; k++) {
+                    double centre = 0, half = 0;
+                    uint32_t n_img = 0;
+                    for (uint32_t i = 0; i < c->nI; i++) {
+                        if (c->poff[i + 1] == c->poff[i]) continue;
+                        const double lo = c->h_img_bbox[(size_t)i * 6 + k], hi = c->h_img_bbox[(size_t)i * 6 + 3 + k];
+                        centre += 0.5 * (lo + hi); half = std::max(half, 0.5 * (hi - lo)); n_img++;
+                    }
+                    centre /= std::max(1u, n_img);
+                    rmn[k] = std::max(mn[k], centre - half); rmx[k] = std::min(mx[k], centre + half);
+                    if (!(rmn[k] < rmx[k])) { rmn[k] = mn[k]; rmx[k] = mx[k]; }
+                }
+                if (make_geometry(c, finest, rmn, rmx, gh, ih) == FROG_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    gh.n_cp = (int)std::min<size_t>(0x7FFFFFFF, (size_t)gh.n_cp * 3 / 2);       // the linear stage rescales the images; another anchor
                     const size_t nO = c->n_owned(), nPts = c->own_pt_end - c->own_pt_begin;
                     const size_t blocks = scatter_max_blocks((uint32_t)std::min<size_t>(0xFFFFFFFFu, nO * (size_t)gh.n_bricks), (uint32_t)nPts, c->scatter_chunk);
                     const size_t E = (size_t)gh.brick + 3;
@@ -1131,17 +1150,23 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
                     for (int l = 0; l <= finest; l++) {
                         GridGeom gl{};
                         frog_grid_info il{};
-                        if (make_geometry(c, l, mn, mx, gl, il) == FROG_OK) {
+                        if (make_geometry(c, l, rmn, rmx, gl, il) == FROG_OK) {
                             arena_h += 3 * ((nO * (size_t)gl.n_cp * 5 / 4 + 63) / 64 * 64);
                             // a sparse lattice retires with its bit maps and shared values (retire_current_grid): room for them too
                             if (gl.sparse) arena_h += 3 * (((nO * (size_t)gl.mask_words + 3) / 4 + (size_t)gl.n_cp) * 5 / 4 + 128);
                         }
                     }
-                    const size_t need = (3 * nO * (size_t)gh.n_cp + blocks * E * E * E + arena_h) * sizeof(float4)
-                                        + 3 * nO * (size_t)gh.n_bricks * (size_t)(gh.brick * gh.brick * gh.brick) * sizeof(uint32_t);
-                    if (need < free_b / 2) {
+                    // first the buffers of the level itself, then -- if that still leaves half of the free memory -- the arena
+                    const size_t need_level = (3 * nO * (size_t)gh.n_cp + blocks * E * E * E) * sizeof(float4)
+                                              + 3 * nO * (size_t)gh.n_bricks * (size_t)(gh.brick * gh.brick * gh.brick) * sizeof(uint32_t);
+                    const size_t need = need_level + arena_h * sizeof(float4);
+                    if (getenv("FROG_SETUP_TRACE"))
+                        std::fprintf(stderr, "[create] finest level %d: %d control points x %zu images (with head-room): %.2f GB for the level, %.2f GB with the arena, "
+                                     "%.2f GB free of %.2f: %s\n", finest, gh.n_cp, nO, need_level / 1e9, need / 1e9, free_b / 1e9, total_b / 1e9,
+                                     need < free_b / 2 ? "both reserved now" : need_level < free_b / 2 ? "the level's buffers reserved now" : "NOT reserved");
+                    if (need_level < free_b / 2) {
                         if (int rc_ = lattice_alloc(c, gh)) { (void)rc_; (void)hipGetLastError(); }
-                        arena = std::max(arena, arena_h);
+                        if (need < free_b / 2) arena = std::max(arena, arena_h);
                     }
                 }
                 (void)hipGetLastError();
@@ -1187,10 +1212,9 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!c->opt.selections_in_background && hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
     c->create_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_resident).count();
     c->create_selections = c->sel_ring > 0 ? c->sel_ring - 1 : 0;
-    // every upload has completed (the stream was synchronised above): the host copy of the layout is dead.  Unmapping its 0.8 GB
-    // takes the calling thread 0.07 s; a thread of its own does it while the caller goes on (joined in frog_destroy).
-    try { c->layout_reaper = std::thread([dead = std::move(lay)]() mutable { Layout gone = std::move(dead); (void)gone; }); }
-    catch (...) { /* no thread to be had: `lay` dies here as before */ }
+    // (The host copy of the layout -- 0.8 GB for the benchmark group -- dies with this scope: 0.07 s of unmapping.  Round 6 gave it
+    // to a thread of its own; the first iterations then ran beside the unmapping of memory the runtime had pinned for the uploads,
+    // and in one run of two the linear stage of a timed loop took 52 ms instead of 19.  Not kept.)
 #undef CREATE_CHECK
     *out = c;
     return FROG_OK;
@@ -1733,6 +1757,9 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     const size_t max_blocks = std::max<size_t>(1, scatter_max_blocks((uint32_t)n_bricks_total, nPts, ctx->scatter_chunk));
     const size_t E = (size_t)g.brick + 3;
     const size_t LG = std::max(g.lat_entries(), (size_t)nO * G);       // entries of one lattice in its layout (blocked: nodes padded to 16)
+    if (getenv("FROG_SETUP_TRACE"))
+        std::fprintf(stderr, "[lattice_alloc] %zu entries per lattice (capacity now %zu), %zu keys (capacity %zu), %zu blocks, mask %zu words (capacity %zu)\n",
+                     LG, ctx->coeff.cap, n_keys, ctx->key_counts.cap, max_blocks, g.sparse ? (size_t)nO * g.mask_words : (size_t)0, ctx->lat_mask.cap);
     FROG_HIP_CHECK(ctx->coeff.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->grad.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->gradf.alloc(LG, LG * reserve));
@@ -1811,10 +1838,19 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
     CTX_GUARD(ctx);
     if (level < 0 || level > 30) return fail(FROG_E_INVALID, "bad level");
     ctx->xyz2_fresh = false; ctx->res_valid = false; ctx->rc_valid = false;
+    // FROG_SETUP_TRACE=1: where the host's time in this call goes (a level's first lattice has been seen to take 0.7 s of it on
+    // some boxes and 0.016 s on others)
+    static const bool setup_trace = getenv("FROG_SETUP_TRACE") != nullptr;
+    const auto t_setup = std::chrono::steady_clock::now();
+    auto setup_lap = [&](const char *what) {
+        if (setup_trace) std::fprintf(stderr, "[setup level %d] %-28s %9.3f ms\n", level, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup).count());
+    };
     int rc = join_setup(ctx);                   // a set-up right behind a set-up
     if (rc) return rc;
+    setup_lap("joined the last set-up");
     rc = retire_current_grid(ctx);
     if (rc) return rc;
+    setup_lap("+ finished lattice retired");
 
     GridGeom g{};
     frog_grid_info info{};
@@ -1828,6 +1864,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
 
     rc = lattice_alloc(ctx, g);                 // within the head-room reserved earlier, as a rule: no hipMalloc here
     if (rc) return rc;
+    setup_lap("+ lattice buffers");
     // sizes the kernels below rely on, checked here where an error can still be returned to the caller
     const uint32_t keys_per_brick = (uint32_t)(g.brick * g.brick * g.brick);
     const size_t n_keys64 = (size_t)nO * nb * keys_per_brick;
@@ -1859,6 +1896,7 @@ int frog_deformable_setup_bounds(frog_ctx *ctx, int level, const double mins[3],
         ctx->cull_need_build = true;
         ctx->cull_check_due = true;
     }
+    setup_lap("+ kernels queued or deferred");
     GridRecord rec;
     rec.info = info;
     ctx->grids.push_back(std::move(rec));

@@ -30,6 +30,7 @@
 
 #include "ctx.h"
 #include "../common/usable_cpus.h"
+#include "../common/bulk_alloc.h"
 
 #include <algorithm>
 #include <chrono>
@@ -45,16 +46,7 @@
 
 namespace frog {
 
-// Arrays with an entry per half-link (0.4 GB each for the benchmark group) are sized once and written in full on all host
-// threads: resize() must not zero them on one (the three fills were 0.15 s of frog_create's 0.29 s of layout build).
-template <class T> struct noinit_alloc : std::allocator<T> {
-    template <class U> struct rebind { using other = noinit_alloc<U>; };
-    template <class U, class... A> void construct(U *p, A &&...a)
-    {
-        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
-    }
-};
-template <class T> using Bulk = std::vector<T, noinit_alloc<T>>;
+// Bulk<T> (common/bulk_alloc.h): the arrays with an entry per half-link -- no zero fill on resize(), huge pages.
 
 struct Layout {
     // Internal point numbering: inside every image the points are renumbered along a

@@ -8,17 +8,9 @@
 #include <vector>
 
 #include "../../../include/frog_host.h"
+#include "../common/bulk_alloc.h"
 
-// Arrays of 10^8 entries that are sized once and then written in full by all host threads: resize() without the zero fill (one
-// thread touching 0.6 GB of fresh pages was a third of build_links).
-template <class T> struct frog_noinit_alloc : std::allocator<T> {
-    template <class U> struct rebind { using other = frog_noinit_alloc<U>; };
-    template <class U, class... A> void construct(U *p, A &&...a)
-    {
-        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
-    }
-};
-template <class T> using frog_bulk = std::vector<T, frog_noinit_alloc<T>>;
+template <class T> using frog_bulk = frog::Bulk<T>;       // common/bulk_alloc.h: no zero fill on resize(), huge pages
 
 struct frog_pairs {
     uint32_t n_images = 0;

@@ -98,6 +98,39 @@ def test_reference_order_fast_forms_equal_the_literal_forms(monkeypatch, group):
     same_trace(fast, literal)
 
 
+def test_reference_order_chain_launches_folded_into_two_grid_dimensions():
+    """rc_grid() with at most 5 workgroups in x (FROG_RC_GRID_X=5, read once per process: a child): the fill's and the chain
+    kernel's groups come from blockIdx.z / .y * gridDim.x + blockIdx.x with a bound check, as on cfg 5's finest lattice where
+    the fold is needed -- same lattices, coordinates and energies as the unfolded launch."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, os, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from frog_amd.pairs import Pairs\n"
+        "import test_gpu_reference_order as T\n"
+        "os.environ['FROG_REFERENCE_ORDER'] = '1'\n"
+        "s = T.Side(Pairs.synthetic(6, 3000, 1500, seed=7))\n"
+        "grids = T.lockstep([s], 6, 3, 8, lambda *a, **k: None)\n"
+        "np.savez(sys.argv[1], xyz2=s.xyz2(), m=s.matrices(), **{'g%%d' %% k: np.stack([s.grid(i, k)[1] for i in range(6)]) for k in range(s.num_grids())})\n"
+    ) % (os.path.dirname(here), here)
+    outs = []
+    for fold in (None, "5"):
+        env = dict(os.environ)
+        env.pop("FROG_RC_GRID_X", None)
+        if fold:
+            env["FROG_RC_GRID_X"] = fold
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "frog_rc_grid_%s_%d.npz" % (fold or "plain", os.getpid()))
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+        os.remove(out)
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 5
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_reference_order_fast_forms_equal_the_literal_forms_at_config5_size(monkeypatch):
     """The same at BASELINE.json configs[4]'s size, -li 2 -dl 5 -di 1: its finest lattice has 5.5e8 (image, control point) pairs =
     3.4e7 groups of chains, and a launch of one 256-thread workgroup per group is 8.8e9 work-items in x -- more than the 32-bit
