@@ -64,6 +64,12 @@ def schedule(k, levels=3):
     return n_lin, per
 
 
+def lattice_reallocations(lib, ctx):
+    """lattice buffers a set-up had to allocate inside the timed loops (0 = max_levels_hint's head-room held; include/frog_hip.h)"""
+    n = C.c_int()
+    return n.value if lib.frog_lattice_reallocations(ctx, C.byref(n)) == 0 else None
+
+
 def cpu_baseline(pairs, n_lin, per_level, stat_interval, repeats=3):
     """Oracle (CPU restatement, OpenMP over images like the reference) on a bounded
     sample of the same workload: `repeats` stats refreshes, linear iterations and
@@ -457,7 +463,8 @@ def run_native(args, rank, world, local_rank, transport, rdv):
         line = make_line(args, world, k, elapsed, "native (frog_run_schedule, C loop)", collectives, pairs, levels, n_lin, per_level,
                          [int(g) for g in res.grids_per_level[:levels]], res.final_E, roofline, iteration, prof, phase_k, phase_s,
                          {"generate": t_gen, "create": t_create, "create_breakdown": create_breakdown,
-                          "lattice_setups": [la.setup_host_s for la in res.lattices[:res.n_lattices]]})
+                          "lattice_setups": [la.setup_host_s for la in res.lattices[:res.n_lattices]],
+                          "lattice_reallocations_in_the_loops": lattice_reallocations(lib, ctx)})
         if args.shard_of:
             line["proxy"] = (f"rank {args.shard_of[0]} of {args.shard_of[1]} on one GPU: owns images {shards[0]}, no collective, "
                              + ("other ranks' coordinates and mixtures: those a full run of the default schedule ends with, standing still"

@@ -284,6 +284,7 @@ HIP_SYMBOLS = {
     "frog_comm_unpack_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32]),
     "frog_comm_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "frog_create_seconds": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
+    "frog_lattice_reallocations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "frog_transform_points_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32]),
     "frog_comm_unpack_slab_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]),
     "frog_step_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

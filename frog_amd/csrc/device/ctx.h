@@ -362,6 +362,8 @@ struct frog_ctx {
     bool ref_order = false;
     double create_s[3] = { 0, 0, 0 };   // frog_create: host layout build, allocations + uploads + first kernels, reservoir selections replayed ahead
     int create_selections = 0;
+    bool created = false;               // frog_create has returned: allocations of lattice buffers from here on are counted
+    int lattice_reallocs = 0;
     bool two_collectives = false;   // frog_comm_mode: the energy sums ride on the all-reduce of the proposal sums, the oversize count on the coordinate gather
     bool finish_deformable = false; // ... and they decide a deformable step (frog_step_finish commits or rejects it)
     bool speculated = false;        // frog_step_speculate has exchanged the lattices' roles ahead of the decision

@@ -1212,6 +1212,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (!c->opt.selections_in_background && hipStreamSynchronize(c->side) != hipSuccess) { (void)hipGetLastError(); }
     c->create_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_resident).count();
     c->create_selections = c->sel_ring > 0 ? c->sel_ring - 1 : 0;
+    c->created = true;
     // (The host copy of the layout -- 0.8 GB for the benchmark group -- dies with this scope: 0.07 s of unmapping.  Round 6 gave it
     // to a thread of its own; the first iterations then ran beside the unmapping of memory the runtime had pinned for the uploads,
     // and in one run of two the linear stage of a timed loop took 52 ms instead of 19.  Not kept.)
@@ -1226,6 +1227,14 @@ int frog_create_seconds(frog_ctx *ctx, double seconds3[3], int *selections_repla
     if (!seconds3) return fail(FROG_E_INVALID, "null output");
     for (int k = 0; k < 3; k++) seconds3[k] = ctx->create_s[k];
     if (selections_replayed) *selections_replayed = ctx->create_selections;
+    return FROG_OK;
+}
+
+int frog_lattice_reallocations(frog_ctx *ctx, int *count)
+{
+    CTX_GUARD(ctx);
+    if (!count) return fail(FROG_E_INVALID, "null output");
+    *count = ctx->lattice_reallocs;
     return FROG_OK;
 }
 
@@ -1760,6 +1769,7 @@ static int lattice_alloc(frog_ctx *ctx, const GridGeom &g)
     if (getenv("FROG_SETUP_TRACE"))
         std::fprintf(stderr, "[lattice_alloc] %zu entries per lattice (capacity now %zu), %zu keys (capacity %zu), %zu blocks, mask %zu words (capacity %zu)\n",
                      LG, ctx->coeff.cap, n_keys, ctx->key_counts.cap, max_blocks, g.sparse ? (size_t)nO * g.mask_words : (size_t)0, ctx->lat_mask.cap);
+    if (ctx->created && (LG > ctx->coeff.cap || LG > ctx->grad.cap || LG > ctx->gradf.cap || n_keys > ctx->key_counts.cap)) ctx->lattice_reallocs++;
     FROG_HIP_CHECK(ctx->coeff.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->grad.alloc(LG, LG * reserve));
     FROG_HIP_CHECK(ctx->gradf.alloc(LG, LG * reserve));

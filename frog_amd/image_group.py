@@ -57,6 +57,12 @@ class ImageGroup:
         self._ctx = ctx
         self.image_begin, self.image_end = b, e
 
+    def lattice_reallocations(self):
+        """lattice buffers allocated by a set-up after frog_create (0 = the head-room of max_levels_hint held)"""
+        n = C.c_int()
+        check(self._lib.frog_lattice_reallocations(self._ctx, C.byref(n)), "frog_lattice_reallocations")
+        return n.value
+
     def close(self):
         if self._ctx:
             self._lib.frog_destroy(self._ctx)

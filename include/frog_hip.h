@@ -64,6 +64,10 @@ int frog_set_stream(frog_ctx *ctx, void *hip_stream);
  * selections replayed ahead of time on the side stream (selections_replayed of them: Stats::addSample's mt19937 acceptance tests
  * depend on nothing but the call count, stats.h:58-76, so a whole run's are produced here instead of beside the sweeps). */
 int frog_create_seconds(frog_ctx *ctx, double seconds3[3], int *selections_replayed);
+/* How many times a lattice set-up (frog_deformable_setup*) had to allocate lattice buffers after frog_create -- 0 when
+ * frog_options::max_levels_hint told frog_create how fine the lattices would get and its estimate of the registered group's box
+ * held: no multi-gigabyte hipMalloc inside the caller's loops (5 to 1 500 ms each on the test boxes). */
+int frog_lattice_reallocations(frog_ctx *ctx, int *count);
 
 /* The stream the context's work is enqueued on and its device: what a caller needs to order its own collectives
  * (RCCL: include/frog_comm.h) against the library's kernels.  Either pointer may be NULL. */
