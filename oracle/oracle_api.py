@@ -79,6 +79,13 @@ def lib():
         L.frogo_chipdf.argtypes = [C.c_float]
         L.frogo_bspline_weights_n.restype = None
         L.frogo_bspline_weights_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        # as many threads as the process may use (a container's CPU quota counts: the GPU boxes show 256 hardware threads to a
+        # 16-CPU share, and 256 OpenMP threads there are throttled together)
+        try:
+            from frog_amd._abi import usable_cpus
+            L.frogo_set_threads(max(1, min(L.frogo_get_max_threads(), usable_cpus())))
+        except ImportError:
+            pass
         _lib = L
     return _lib
 
