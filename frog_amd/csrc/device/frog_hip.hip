@@ -809,12 +809,8 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         *out = moving;
         return FROG_OK;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(FROG_E_NODEVICE, "no HIP device: libfrog_hip has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(FROG_E_INVALID, "device index out of range");
-    FROG_HIP_CHECK(hipSetDevice(device));
-
+    // (the first HIP call of a process waits for the runtime to come up -- 0.05-0.2 s; bin/frog starts that on a thread of its own
+    // beside readPairs (frog_device_warm), and the host-side layout build below needs no device: the device is asked for after it)
     frog_ctx *c = new (std::nothrow) frog_ctx;
     if (!c) return fail(FROG_E_NOMEM, "out of host memory");
     c->device = device;
@@ -847,6 +843,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = build_layout(*m, c->ib, c->ie, wide_env && wide_env[0] == '1', (int)c->n_groups, lay, err);
     if (rc) { delete c; return fail(rc, err); }
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); delete c; return fail(FROG_E_NODEVICE, "no HIP device: libfrog_hip has no CPU fallback"); }
+        if (device < 0 || device >= ndev) { delete c; return fail(FROG_E_INVALID, "device index out of range"); }
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); delete c; return fail(FROG_E_HIP, "hipSetDevice failed"); }
+    }
     const auto t_layout = std::chrono::steady_clock::now();
     c->create_s[0] = std::chrono::duration<double>(t_layout - t_create0).count();
     c->L_own = lay.ref_link.size();
