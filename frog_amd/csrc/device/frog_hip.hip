@@ -891,6 +891,7 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         }
         (void)hipGetLastError();
     }
+    create_lap("stream, memory pool");
     // [0..3] energy scalars, [4..6] bounding box (6 floats), [7] sequence number of the step whose scalars a kernel wrote here
     CREATE_CHECK(hipHostMalloc((void **)&c->h_energy, 8 * sizeof(double), hipHostMallocMapped));
     std::memset(c->h_energy, 0, 8 * sizeof(double));
@@ -898,10 +899,12 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
     if (getenv("FROG_SCALARS_COPY")) c->h_energy_dev = nullptr;      // the copy + event hand-off (A/B, fallback)
     hipStream_t s = c->stream;
 
+    create_lap("+ pinned scalar block");
     // points: xyz | image id
     std::vector<float4> hp(c->P);
     c->h_img_bbox.assign((size_t)c->nI * 6, 0.0);
-    for (uint32_t i = 0; i < c->nI; i++) {
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
+    for (int64_t i = 0; i < (int64_t)c->nI; i++) {
         double mn[3] = { std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max() };
         double mx[3] = { -mn[0], -mn[1], -mn[2] };
         for (uint32_t p = c->poff[i]; p < c->poff[i + 1]; p++) {
@@ -915,10 +918,13 @@ int frog_create(const frog_model *m, const frog_options *o, int device,
         }
         for (int k = 0; k < 3; k++) { c->h_img_bbox[(size_t)i * 6 + k] = mn[k]; c->h_img_bbox[(size_t)i * 6 + 3 + k] = mx[k]; }
     }
+    create_lap("+ points renumbered on the host");
     CREATE_CHECK(c->pos.upload(hp, s));
+    create_lap("+ first upload queued");
     {
         std::vector<P3> hp2(c->P);
-        for (size_t p = 0; p < c->P; p++) hp2[p] = P3{ hp[p].x, hp[p].y, hp[p].z };
+        #pragma omp parallel for num_threads(host_threads())
+        for (int64_t p = 0; p < (int64_t)c->P; p++) hp2[p] = P3{ hp[p].x, hp[p].y, hp[p].z };
         CREATE_CHECK(c->pos2.upload(hp2, s));
         CREATE_CHECK(hipStreamSynchronize(s));
     }
