@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <thread>
 
 #include <omp.h>
@@ -31,7 +32,8 @@ int main(int argc, char *argv[])
     auto start = std::chrono::system_clock::now();
     if (std::getenv("FROG_TIMING"))              // with the caller's own clock around the process: what loading and leaving cost
         cout << "[timing] main entered at " << std::fixed << std::chrono::duration<double>(start.time_since_epoch()).count() << std::defaultfloat << endl;
-    ImageGroup group;
+    auto groupOwner = std::make_unique<ImageGroup>();      // (released by hand at the end: FROG_TIMING times it)
+    ImageGroup &group = *groupOwner;
 
     if (argc >= 2 && strcmp(argv[1], "--synth") == 0) {
         if (argc < 6) { cout << "Usage : frog --synth out.bin nImages pointsPerImage pairsPerBlock [seed]" << endl; return 1; }
@@ -175,5 +177,8 @@ int main(int argc, char *argv[])
     cout << "Total time : " << std::chrono::duration<float>(end - start).count() << "s" << endl;
     if (std::getenv("FROG_TIMING"))
         cout << "[timing] main returns at " << std::fixed << std::chrono::duration<double>(end.time_since_epoch()).count() << std::defaultfloat << endl;
+    groupOwner.reset();                      // frog_destroy (device buffers, streams) and the host copy of pairs.bin
+    if (std::getenv("FROG_TIMING"))
+        cout << "[timing] group released : " << std::chrono::duration<double>(std::chrono::system_clock::now() - end).count() << "s" << endl;
     return 0;
 }
