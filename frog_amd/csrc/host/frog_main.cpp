@@ -99,7 +99,7 @@ int main(int argc, char *argv[])
         cout << "-ngl number   : the same with n contexts on ONE device and host-staged collectives (rehearsal)" << endl;
         cout << "-q 0/1        : do not print one line per iteration. Default : " << group.quiet << endl;
         cout << "-exact 0/1    : every solver loop in the reference's own order and arithmetic (bit-equal to the CPU path's" << endl
-             << "                coefficients; about 10 times slower: 265 instead of 2 500 iterations/s on the 100-image" << endl
+             << "                coefficients; about 10 times slower: 285 instead of 2 500 iterations/s on the 100-image" << endl
              << "                benchmark group). Default : " << group.exact << endl;
         return 1;
     }

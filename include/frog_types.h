@@ -63,7 +63,7 @@ typedef struct frog_options {
                                          * chain per point in readPairs order, getInlierProbability with its f64 exp, the
                                          * scatter image by image and point by point, f64 B-spline evaluation): the mode
                                          * that meets "transform parameters within 1e-4 relative" on RAW coefficients -- it
-                                         * has the CPU restatement's bits -- at about 1/10 of the speed (265 against 2 500
+                                         * has the CPU restatement's bits -- at about 1/10 of the speed (285 against 2 500
                                          * iterations/s on the 100-image benchmark group)                 */
     int32_t selections_in_background;   /*       0      frog_create draws the reservoir selections of the first refreshes ahead of
                                          * time on a side stream (replayUpdateStats' rand() sequence, imageGroup.cxx:887-933).
