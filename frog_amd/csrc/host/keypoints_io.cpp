@@ -4,10 +4,12 @@
 // descriptor values.
 #include "frog_host.h"
 
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <vector>
 #include <zlib.h>
 
@@ -25,8 +27,26 @@ void parse_line(const char *line, std::vector<float> &vals)
     const char *p = line;
     while (*p && *p != '\n') {
         if (*p == '\r') break;
-        char *end = nullptr;
-        const float v = std::strtof(p, &end);           // std::stof(cell)
+        // std::stof(cell) = strtof.  A plain decimal number (the only thing the detector writes) goes through std::from_chars:
+        // correctly rounded like glibc's strtof, so the same float, at a fifth of the cost (1.08 M values per image: 65 of the
+        // 110 ms a 20 000-keypoint csv.gz took to read).  Anything else -- leading blanks, '+', hex, inf / nan, a value out of
+        // float's range -- keeps strtof and its answer.
+        float v = 0.f;
+        const char *end = p;
+        bool fast = false;
+        if ((*p >= '0' && *p <= '9') || *p == '-' || *p == '.') {
+            const char *q = p;
+            while (*q && *q != ',' && *q != '\n' && *q != '\r') q++;
+            const auto r = std::from_chars(p, q, v, std::chars_format::general);
+            // (strtof would read "0x1p3" as hex and "1e5x" up to the x: from_chars stops at the same places for decimals; a cell it
+            // does not consume entirely takes the slow path, which decides)
+            if (r.ec == std::errc() && r.ptr == q) { end = q; fast = true; }
+        }
+        if (!fast) {
+            char *e2 = nullptr;
+            v = std::strtof(p, &e2);
+            end = e2;
+        }
         if (end == p) break;
         vals.push_back(v);
         p = end;
@@ -82,6 +102,7 @@ frog_keypoint_file *frog_keypoints_read(const char *path, int *status)
     } else if (ends_with(p, ".gz")) {                   // :48-83
         gzFile in = gzopen(path, "rb");
         if (!in) { delete f; return fail(FROG_E_IO); }
+        (void)gzbuffer(in, 1u << 20);                   // zlib's default is 8 KiB per inflate call
         std::string line;
         char buf[65536];
         while (gzgets(in, buf, sizeof buf)) {
