@@ -8,6 +8,7 @@
 // (frog_volume_geometry): spacing from pixdim / ElementSpacing, origin from the qform offsets / Offset;
 // axes are taken as aligned with the world axes (vtkImageData has no direction matrix either).
 // Little-endian files only; one component per voxel.
+#include "../common/parallel_gzip.h"
 #include "frog_host.h"
 
 #include <algorithm>
@@ -236,6 +237,10 @@ int frog_volume_write(const char *path, const frog_volume *v)
         for (int k = 0; k < 3; k++) put(268 + 4 * k, (float)v->origin[k]);
         for (int k = 0; k < 3; k++) { put(280 + 16 * k + 4 * k, (float)v->spacing[k]); put(280 + 16 * k + 12, (float)v->origin[k]); }
         std::memcpy(h + 344, "n+1", 4);
+        // a compressed volume of some size: one gzip member deflated chunk by chunk on all host threads (common/parallel_gzip.h;
+        // level 6 as before -- a 256^3 int16 volume: 0.95 s on one thread)
+        if (has_suffix(p, ".gz") && bytes >= ((size_t)4 << 20))
+            return frog::gzip_write_parallel(path, { { h, sizeof h }, { v->data, bytes } }, 6) ? FROG_OK : FROG_E_IO;
         gzFile f = gzopen(path, has_suffix(p, ".gz") ? "wb6" : "wbT");   // "T": transparent, no compression
         if (!f) return FROG_E_IO;
         bool ok = gzwrite(f, h, sizeof h) == (int)sizeof h;

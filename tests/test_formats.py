@@ -247,6 +247,30 @@ def test_volume_files_round_trip_and_independent_readers(tmp_path, dtype):
         read_volume(tmp_path / "bad.nii")
 
 
+def test_large_volume_is_one_gzip_member_deflated_in_chunks(tmp_path):
+    """A compressed volume of 4 MiB and more is deflated chunk by chunk on all host threads (csrc/common/parallel_gzip.h) into ONE
+    gzip member: a decoder that stops at the end of the first member (zlib.decompressobj does) returns the whole payload with
+    nothing left over, the trailer's CRC-32 and length are the payload's, and both readers get the voxels back.  Sizes chosen so
+    that the last chunk is partial and the header straddles nothing in particular."""
+    import gzip
+    import struct
+    import zlib
+    from frog_amd.volume import read_volume, write_volume
+    rng = np.random.default_rng(5)
+    vol = (rng.normal(1000, 30, (61, 130, 301)) + np.arange(301)).astype(np.int16)      # 4.8 MB: five chunks, the last one short
+    write_volume(tmp_path / "big.nii.gz", vol, (0.0, 1.0, 2.0), (1.0, 1.0, 2.5))
+    blob = open(tmp_path / "big.nii.gz", "rb").read()
+    d = zlib.decompressobj(31)
+    raw = d.decompress(blob)
+    assert d.eof and d.unused_data == b"" and len(raw) == 352 + vol.nbytes
+    assert struct.unpack("<II", blob[-8:]) == (zlib.crc32(raw), len(raw) & 0xFFFFFFFF)
+    assert raw == gzip.decompress(blob)
+    assert np.array_equal(np.frombuffer(raw, np.int16, offset=352).reshape(vol.shape), vol)
+    got, o, s = read_volume(tmp_path / "big.nii.gz")
+    assert np.array_equal(got, vol) and o == (0.0, 1.0, 2.0) and s == (1.0, 1.0, 2.5)
+    assert len(blob) < 0.8 * vol.nbytes                                                  # and it did compress
+
+
 @pytest.mark.parametrize("self_block", [False, True])
 def test_link_order_on_a_larger_random_group(self_block):
     """The link table is built by one thread per image (serially when a block pairs an image with itself): in both
