@@ -40,7 +40,15 @@ using namespace frog;
 // machine's topology for its affinity interface -- 40-120 ms on a 256-CPU host, measured as "numbering" taking 0.04-0.12 s instead
 // of 0.005 -- which nothing here uses (no thread is ever bound).  Switched off when the library is loaded, before the runtime's
 // first call, unless the user has said something about KMP_AFFINITY themselves.
-__attribute__((constructor)) static void frog_openmp_defaults() { setenv("KMP_AFFINITY", "disabled", 0); }
+// And its workers spin for 200 ms after a parallel region before they go to sleep (KMP_BLOCKTIME): the regions here are set-up
+// work followed at once by a timed device loop whose host side (the caller's thread, the matcher's collectors) then shares a
+// container's CPU quota with fifteen spinning threads -- the matcher ran 5 % slower after its create had become a parallel region
+// (10 100-10 500 against 11 100-11 700 image pairs/s).  Workers sleep at once, again unless the user said otherwise.
+__attribute__((constructor)) static void frog_openmp_defaults()
+{
+    setenv("KMP_AFFINITY", "disabled", 0);
+    setenv("KMP_BLOCKTIME", "0", 0);
+}
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
