@@ -1,0 +1,84 @@
+"""Generates tests/golden/schedule_golden.npz: the CPU oracle (oracle/frog_oracle.cpp) run over BASELINE.json configs[2] at its
+FULL size (100 images x 20 000 keypoints, 1e8 half-links) through the reference's whole default schedule (-li 50 -dl 3 -di 200,
+-g 100 -gd 1 -si 10: ImageGroup::run, imageGroup.cxx:31-157).  Data only: what the run ends with and the energy it printed at
+every iteration --
+
+  E            f64[650]   the energy of every accepted iteration (measures.csv's column)
+  grids        i32[3]     lattices per level (the guard's regrids)
+  matrices     f64[100,4,4]
+  em           f32[100,3] (c1, c2, ratio) of the last refresh
+  inliers      i64[100]   countInliers' census after the run
+  dims/origin/spacing     of every lattice, creation order
+  sha_grid     one sha256 per (lattice, image) over the f32 coefficient array: equality of ALL coefficients without storing them
+  images       the images whose coefficients are stored, nodes NODE_STRIDE apart: coeff_<k> f32[len(images), ceil(G/stride), 3]
+  max_coeff    f32[n_lattices] max |c| over ALL images (the scale deviations are quoted against)
+  sha_xyz2, xyz2_sample   final coordinates: hash of all of them, every POINT_STRIDE-th point
+
+The oracle took 1 220 s for this on the build container's eight CPUs (the file records it as oracle_seconds), which is why the GPU
+suite compares against the stored run instead (tests/test_gpu_schedule_golden.py); tests/test_schedule_golden.py holds the file
+against the oracle as it is built now for the first iterations.  Usage: python tests/golden/make_schedule_golden.py [threads]"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from frog_amd import _abi                   # noqa: E402
+from frog_amd.pairs import Pairs            # noqa: E402
+from oracle import oracle_api               # noqa: E402
+
+IMAGES = list(range(0, 100, 18))            # 0, 18, ..., 90
+NODE_STRIDE = 4
+POINT_STRIDE = 100
+LI, DL, DI = 50, 3, 200
+
+
+def main():
+    if len(sys.argv) > 1:
+        oracle_api.lib().frogo_set_threads(int(sys.argv[1]))
+    pairs = Pairs.synthetic(100, 20000, 10101, seed=1)          # bench.py's workload (CONFIGS[3])
+    ref = oracle_api.OracleGroup(pairs.model, _abi.FrogOptions.default())
+    t0 = time.time()
+    E, grids = ref.run(LI, DL, DI)
+    seconds = time.time() - t0
+    print(f"oracle run: {seconds:.0f} s, {len(E)} energies, grids per level {grids}, final E {E[-1]!r}", flush=True)
+    n_img = pairs.n_images
+    out = {"E": np.asarray(E, np.float64), "grids": np.asarray(grids, np.int32),
+           "matrices": np.stack([ref.matrix(i) for i in range(n_img)]),
+           "em": np.stack([ref.em(i) for i in range(n_img)]),
+           "images": np.asarray(IMAGES, np.int32), "node_stride": np.int32(NODE_STRIDE), "point_stride": np.int32(POINT_STRIDE),
+           "schedule": np.asarray([LI, DL, DI], np.int32), "n_half_links": np.int64(pairs.n_half_links),
+           "oracle_seconds": np.float64(seconds)}
+    counts = (_abi.FrogCounts * n_img)()
+    ref.count_inliers(counts)
+    out["inliers"] = np.asarray([counts[i].inliers for i in range(n_img)], np.int64)
+    out["outliers"] = np.asarray([counts[i].outliers for i in range(n_img)], np.int64)
+    n_grids = ref.num_grids()
+    dims, origin, spacing, shas, max_coeff = [], [], [], [], []
+    for k in range(n_grids):
+        sha_k, mx, kept = [], 0.0, []
+        for i in range(n_img):
+            info, c = ref.grid(i, k, _abi.FrogGridInfo())
+            if i == 0:
+                dims.append(list(info.dims)); origin.append(list(info.origin)); spacing.append(list(info.spacing))
+            sha_k.append(hashlib.sha256(np.ascontiguousarray(c, np.float32).tobytes()).hexdigest())
+            mx = max(mx, float(np.abs(c).max()))
+            if i in IMAGES:
+                kept.append(c[::NODE_STRIDE].copy())
+        shas.append(sha_k); max_coeff.append(mx)
+        out[f"coeff_{k}"] = np.stack(kept).astype(np.float32)
+    out["dims"] = np.asarray(dims, np.int32); out["origin"] = np.asarray(origin, np.float64); out["spacing"] = np.asarray(spacing, np.float64)
+    out["sha_grid"] = np.asarray(shas); out["max_coeff"] = np.asarray(max_coeff, np.float32)
+    xyz2 = ref.xyz2()
+    out["sha_xyz2"] = np.asarray(hashlib.sha256(xyz2.tobytes()).hexdigest())
+    out["xyz2_sample"] = xyz2[::POINT_STRIDE].copy()
+    path = os.path.join(ROOT, "tests", "golden", "schedule_golden.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
