@@ -34,6 +34,7 @@ from frog_amd.pairs import Pairs
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden.npz")
+GOLDEN_CFG5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden_cfg5.npz")
 
 
 def note(name, value):
@@ -43,11 +44,14 @@ def note(name, value):
             fh.write(f"{name} {value}\n")
 
 
-def compare_with_golden(reference_order):
+def compare_with_golden(reference_order, cfg5=False):
     """Runs the schedule on the device and returns the deviations from the stored oracle run."""
-    gold = np.load(GOLDEN)
+    gold = np.load(GOLDEN_CFG5 if cfg5 else GOLDEN)
     li, dl, di = (int(v) for v in gold["schedule"])
-    pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
+    if cfg5:
+        pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
+    else:
+        pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
     assert pairs.n_half_links == int(gold["n_half_links"]), "the synthetic group is not the one the fixture was made from"
     g = ImageGroup(pairs, reference_order=int(reference_order), linearIterations=li, deformableLevels=dl, deformableIterations=di)
     E = np.asarray(g.run(), np.float64)
@@ -70,12 +74,13 @@ def compare_with_golden(reference_order):
     inl = np.asarray([counts[i].inliers for i in range(n_img)], np.int64)
     r["census_differs_by"] = int(np.sum(np.abs(inl - gold["inliers"])))
     r["inliers_golden"] = int(gold["inliers"].sum())
-    images, stride = [int(v) for v in gold["images"]], int(gold["node_stride"])
+    images = [int(v) for v in gold["images"]]
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).digest(), np.uint8)
     assert g.num_grids() == len(gold["dims"])
     r["lattices"] = []
     for k in range(g.num_grids()):
         d = {"hash_equal_images": 0, "raw": 0.0, "rms": 0.0}
-        sq, cnt = 0.0, 0
+        sq, cnt, stride = 0.0, 0, int(gold["node_stride"][k])
         for i in range(n_img):
             info, c = g.grid(i, k)
             if i == 0:
@@ -84,7 +89,7 @@ def compare_with_golden(reference_order):
                 geo, ggeo = np.asarray(list(info.origin) + list(info.spacing)), np.concatenate([gold["origin"][k], gold["spacing"][k]])
                 d["geometry_equal"] = bool(d["dims_equal"] and np.array_equal(geo, ggeo))
                 d["geometry_rel"] = float(np.max(np.abs(geo - ggeo) / np.abs(ggeo)))
-            d["hash_equal_images"] += int(hashlib.sha256(np.ascontiguousarray(c, np.float32).tobytes()).hexdigest() == str(gold["sha_grid"][k][i]))
+            d["hash_equal_images"] += int(np.array_equal(sha(c), gold["sha_grid"][k][i]))
             if i in images:
                 dev = np.abs(c[::stride].astype(np.float64) - gold[f"coeff_{k}"][images.index(i)])
                 d["raw"] = max(d["raw"], float(dev.max()))
@@ -93,7 +98,8 @@ def compare_with_golden(reference_order):
         d["raw"] /= scale; d["rms"] = (sq / cnt) ** 0.5 / scale; d["max_coeff"] = scale
         r["lattices"].append(d)
     xyz2 = g.points()[1]
-    r["xyz2_hash_equal"] = hashlib.sha256(xyz2.tobytes()).hexdigest() == str(gold["sha_xyz2"])
+    r["xyz2_hash_equal"] = bool(np.array_equal(sha(xyz2), gold["sha_xyz2"]))
+    r["n_images"] = n_img
     s = gold["xyz2_sample"].astype(np.float64)
     dev = np.abs(xyz2[::int(gold["point_stride"])].astype(np.float64) - s)
     r["xyz2_mm"] = float(dev.max()); r["xyz2_rel"] = float(dev.max() / np.abs(s).max())
@@ -112,7 +118,7 @@ def test_exact_mode_equals_the_oracle_run_at_full_size_over_the_whole_schedule()
     report("schedule_golden_exact", r)
     assert r["grids"] == r["grids_golden"] and r["n_E"] == r["n_E_golden"], r
     assert r["E_equal"] == r["n_E"] and r["matrices_equal"] and r["em_rel"] == 0.0 and r["census_differs_by"] == 0, r
-    assert all(d["geometry_equal"] and d["hash_equal_images"] == 100 for d in r["lattices"]), r
+    assert all(d["geometry_equal"] and d["hash_equal_images"] == r["n_images"] for d in r["lattices"]), r
     assert r["xyz2_hash_equal"], r
 
 

@@ -21,10 +21,9 @@ def test_fixture_is_self_consistent():
     assert np.array_equal(g["E"], g["E"].astype(np.float32).astype(np.float64))      # measures are printed from a float
     n_lat = int(g["grids"].sum())
     assert len(g["grids"]) == dl and g["dims"].shape == (n_lat, 3) and g["origin"].shape == (n_lat, 3) and g["spacing"].shape == (n_lat, 3)
-    assert g["sha_grid"].shape == (n_lat, 100) and g["matrices"].shape == (100, 4, 4) and g["em"].shape == (100, 3)
-    stride = int(g["node_stride"])
+    assert g["sha_grid"].shape == (n_lat, 100, 32) and g["matrices"].shape == (100, 4, 4) and g["em"].shape == (100, 3)
     for k in range(n_lat):
-        nodes = int(np.prod(g["dims"][k]))
+        nodes, stride = int(np.prod(g["dims"][k])), int(g["node_stride"][k])
         c = g[f"coeff_{k}"]
         assert c.shape == (len(g["images"]), (nodes + stride - 1) // stride, 3) and c.dtype == np.float32
         assert float(np.abs(c).max()) <= float(g["max_coeff"][k])
