@@ -142,9 +142,36 @@ PRODUCT_BARS = {"E": 5e-7, "matrices": 2e-7, "em": 4e-6, "census": 1e-6, "geomet
                 "rms": 3e-4, "xyz2": 1e-6}
 
 
-if __name__ == "__main__":                      # python tests/test_gpu_schedule_golden.py: the numbers as JSON
+def test_exact_mode_equals_the_oracle_run_at_config5_size():
+    """BASELINE.json configs[4] (500 images, 4.6e8 half-links, five levels, the finest lattices sparse and in blocks of 16 nodes:
+    DESIGN.md 8 rows 34, 36) over 20 + 5 x 40 iterations: the oracle's run (tests/golden/schedule_golden_cfg5.npz)."""
+    r = compare_with_golden(True, cfg5=True)
+    report("schedule_golden_cfg5_exact", r)
+    assert r["grids"] == r["grids_golden"] and r["n_E"] == r["n_E_golden"], r
+    assert r["E_equal"] == r["n_E"] and r["matrices_equal"] and r["em_rel"] == 0.0 and r["census_differs_by"] == 0, r
+    assert all(d["geometry_equal"] and d["hash_equal_images"] == r["n_images"] for d in r["lattices"]), r
+    assert r["xyz2_hash_equal"], r
+
+
+def test_product_path_against_the_oracle_run_at_config5_size():
+    r = compare_with_golden(False, cfg5=True)
+    report("schedule_golden_cfg5_product", r)
+    assert r["grids"] == r["grids_golden"] and r["n_E"] == r["n_E_golden"], r
+    assert all(d["dims_equal"] and d["geometry_rel"] <= PRODUCT_BARS_CFG5["geometry"] for d in r["lattices"]), r
+    assert r["E_rel"] <= PRODUCT_BARS_CFG5["E"], r
+    assert r["matrices_rel"] <= PRODUCT_BARS_CFG5["matrices"] and r["em_rel"] <= PRODUCT_BARS_CFG5["em"], r
+    assert r["census_differs_by"] <= PRODUCT_BARS_CFG5["census"] * r["inliers_golden"], r
+    assert max(d["raw"] for d in r["lattices"]) <= PRODUCT_BARS_CFG5["raw"], r
+    assert max(d["rms"] for d in r["lattices"]) <= PRODUCT_BARS_CFG5["rms"], r
+    assert r["xyz2_rel"] <= PRODUCT_BARS_CFG5["xyz2"], r
+
+
+PRODUCT_BARS_CFG5 = {"E": 5e-7, "matrices": 5e-7, "em": 1e-5, "census": 1e-6, "geometry": 1e-6, "raw": 1e-2, "rms": 1e-3, "xyz2": 1e-5}
+
+
+if __name__ == "__main__":                      # python tests/test_gpu_schedule_golden.py [--config5]: the numbers as JSON
     import json
-    import sys
-    out = {"exact": compare_with_golden(True), "product": compare_with_golden(False)}
+    cfg5 = "--config5" in sys.argv[1:]
+    out = {"exact": compare_with_golden(True, cfg5), "product": compare_with_golden(False, cfg5)}
     json.dump(out, sys.stdout, indent=1)
     print()
