@@ -5,23 +5,27 @@ file's first energies to the bit (the first refresh and three linear iterations:
 import os
 
 import numpy as np
+import pytest
 
 from frog_amd import _abi
 from frog_amd.pairs import Pairs
 from oracle.oracle_api import OracleGroup
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden.npz")
+GOLDEN_CFG5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden_cfg5.npz")
 
 
-def test_fixture_is_self_consistent():
-    g = np.load(GOLDEN)
+@pytest.mark.parametrize("path, n_img, schedule", [(GOLDEN, 100, (50, 3, 200)),         # imageGroup.h:52-82, the reference's defaults
+                                                   (GOLDEN_CFG5, 500, (20, 5, 40))])
+def test_fixture_is_self_consistent(path, n_img, schedule):
+    g = np.load(path)
     li, dl, di = (int(v) for v in g["schedule"])
-    assert (li, dl, di) == (50, 3, 200)                                   # imageGroup.h:52-82, the reference's defaults
+    assert (li, dl, di) == schedule
     assert len(g["E"]) == li + dl * di and np.all(np.isfinite(g["E"])) and np.all(g["E"] > 0)
     assert np.array_equal(g["E"], g["E"].astype(np.float32).astype(np.float64))      # measures are printed from a float
     n_lat = int(g["grids"].sum())
     assert len(g["grids"]) == dl and g["dims"].shape == (n_lat, 3) and g["origin"].shape == (n_lat, 3) and g["spacing"].shape == (n_lat, 3)
-    assert g["sha_grid"].shape == (n_lat, 100, 32) and g["matrices"].shape == (100, 4, 4) and g["em"].shape == (100, 3)
+    assert g["sha_grid"].shape == (n_lat, n_img, 32) and g["matrices"].shape == (n_img, 4, 4) and g["em"].shape == (n_img, 3)
     for k in range(n_lat):
         nodes, stride = int(np.prod(g["dims"][k])), int(g["node_stride"][k])
         c = g[f"coeff_{k}"]
@@ -34,7 +38,7 @@ def test_fixture_is_self_consistent():
     m = g["matrices"]
     off = m[:, :3, :3] * (1 - np.eye(3))
     assert np.all(off == 0) and np.all(m[:, 3] == [0, 0, 0, 1])
-    assert g["inliers"].shape == (100,) and int(g["inliers"].sum() + g["outliers"].sum()) == int(g["n_half_links"])
+    assert g["inliers"].shape == (n_img,) and int(g["inliers"].sum() + g["outliers"].sum()) == int(g["n_half_links"])
 
 
 def test_the_oracle_built_here_prints_the_fixtures_first_energies():
