@@ -18,8 +18,9 @@ every iteration --
 The oracle took 1 220 s for this on the build container's eight CPUs (the file records it as oracle_seconds), which is why the GPU
 suite compares against the stored run instead (tests/test_gpu_schedule_golden.py); tests/test_schedule_golden.py holds the file
 against the oracle as it is built now for the first iterations.  With --config5: BASELINE.json configs[4] (500 images, 4.6e8
-half-links, five levels) over 20 + 5 x 40 iterations into schedule_golden_cfg5.npz.
-Usage: python tests/golden/make_schedule_golden.py [--config5] [threads]"""
+half-links, five levels) over 20 + 5 x 40 iterations into schedule_golden_cfg5.npz (2 500 s, 35 GB); with --config2: configs[1]
+(20 images, linear only, 50 iterations) into schedule_golden_cfg2.npz (seconds).
+Usage: python tests/golden/make_schedule_golden.py [--config5 | --config2] [threads]"""
 import hashlib
 import os
 import sys
@@ -34,7 +35,13 @@ from frog_amd.pairs import Pairs            # noqa: E402
 from oracle import oracle_api               # noqa: E402
 
 CFG5 = "--config5" in sys.argv[1:]
-if CFG5:
+CFG2 = "--config2" in sys.argv[1:]
+if CFG2:
+    # BASELINE.json configs[1]: 20 images, 2 M pairs, linear only (-dl 0): the reference's own CPU-runnable case
+    IMAGES, NODES_KEPT, NODE_STRIDE, POINT_STRIDE = [], None, 1, 20
+    LI, DL, DI = 50, 0, 0
+    NAME = "schedule_golden_cfg2.npz"
+elif CFG5:
     # BASELINE.json configs[4]: 500 images, ~60 partner images each, five levels; the schedule of scripts/parity_reference_order.py
     # --config5 (20 + 5 x 40: the default 50 + 5 x 200 would keep the oracle busy for four hours)
     IMAGES = list(range(0, 500, 71))
@@ -52,10 +59,12 @@ else:
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--config5"]
+    args = [a for a in sys.argv[1:] if a not in ("--config5", "--config2")]
     if args:
         oracle_api.lib().frogo_set_threads(int(args[0]))
-    if CFG5:
+    if CFG2:
+        pairs = Pairs.synthetic(20, 20000, 10526, seed=1)       # bench.py --config 2
+    elif CFG5:
         pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)     # bench.py --config 5
     else:
         pairs = Pairs.synthetic(100, 20000, 10101, seed=1)      # bench.py's workload (CONFIGS[3])
@@ -93,6 +102,8 @@ def main():
     out["dims"] = np.asarray(dims, np.int32); out["origin"] = np.asarray(origin, np.float64); out["spacing"] = np.asarray(spacing, np.float64)
     out["node_stride"] = np.asarray(strides, np.int32)
     out["sha_grid"] = np.frombuffer(b"".join(b"".join(row) for row in shas), np.uint8).reshape(n_grids, n_img, 32)
+    if n_grids == 0:
+        out["dims"] = np.zeros((0, 3), np.int32); out["origin"] = np.zeros((0, 3)); out["spacing"] = np.zeros((0, 3))
     out["max_coeff"] = np.asarray(max_coeff, np.float32)
     xyz2 = ref.xyz2()
     out["sha_xyz2"] = np.frombuffer(hashlib.sha256(xyz2.tobytes()).digest(), np.uint8)

@@ -40,6 +40,7 @@ from frog_amd.pairs import Pairs
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden.npz")
 GOLDEN_CFG5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden_cfg5.npz")
+GOLDEN_CFG2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden_cfg2.npz")
 
 
 def note(name, value):
@@ -49,11 +50,13 @@ def note(name, value):
             fh.write(f"{name} {value}\n")
 
 
-def compare_with_golden(reference_order, cfg5=False):
+def compare_with_golden(reference_order, cfg5=False, cfg2=False):
     """Runs the schedule on the device and returns the deviations from the stored oracle run."""
-    gold = np.load(GOLDEN_CFG5 if cfg5 else GOLDEN)
+    gold = np.load(GOLDEN_CFG2 if cfg2 else GOLDEN_CFG5 if cfg5 else GOLDEN)
     li, dl, di = (int(v) for v in gold["schedule"])
-    if cfg5:
+    if cfg2:
+        pairs = Pairs.synthetic(20, 20000, 10526, seed=1)
+    elif cfg5:
         pairs = Pairs.synthetic(500, 20000, 16667, seed=1, partners_per_image=60)
     else:
         pairs = Pairs.synthetic(100, 20000, 10101, seed=1)
@@ -174,12 +177,25 @@ def test_product_path_against_the_oracle_run_at_config5_size():
 # first run (profiles/r06_schedule_golden_cfg5.json): E 1.2e-7, matrices 1.4e-7, mixtures 7.9e-7, census equal (3.08e8 inliers), lattice
 # geometry 1.8e-8, raw coefficients of the stored nodes <= 2.9e-4 of the largest (first level-4 lattice; <= 3.5e-5 on the ten others),
 # rms <= 5.9e-6, final coordinates 4.4e-4 mm (7.2e-7); bars x 3-5
+def test_both_modes_against_the_oracle_run_of_config2():
+    """BASELINE.json configs[1] (20 images, 2 M pairs, linear only: the reference's own CPU-runnable case), all 50 iterations:
+    `-exact 1` equal to the bit, the product path within the linear stage's bars (tests/test_gpu_fullsize.py: 1e-6)."""
+    r = compare_with_golden(True, cfg2=True)
+    report("schedule_golden_cfg2_exact", r)
+    assert r["n_E"] == r["n_E_golden"] == 50 and r["E_equal"] == 50 and r["matrices_equal"] and r["em_rel"] == 0.0, r
+    assert r["census_differs_by"] == 0 and r["xyz2_hash_equal"], r
+    r = compare_with_golden(False, cfg2=True)
+    report("schedule_golden_cfg2_product", r)
+    assert r["n_E"] == 50 and r["E_rel"] <= 1e-6 and r["matrices_rel"] <= 1e-6 and r["em_rel"] <= 1e-5 and r["xyz2_rel"] <= 1e-6, r
+    assert r["census_differs_by"] <= 1e-6 * r["inliers_golden"], r
+
+
 PRODUCT_BARS_CFG5 = {"E": 5e-7, "matrices": 5e-7, "em": 4e-6, "census": 1e-6, "geometry": 1e-6, "raw": 1.5e-3, "rms": 3e-5, "xyz2": 4e-6}
 
 
 if __name__ == "__main__":                      # python tests/test_gpu_schedule_golden.py [--config5]: the numbers as JSON
     import json
-    cfg5 = "--config5" in sys.argv[1:]
-    out = {"exact": compare_with_golden(True, cfg5), "product": compare_with_golden(False, cfg5)}
+    cfg5, cfg2 = "--config5" in sys.argv[1:], "--config2" in sys.argv[1:]
+    out = {"exact": compare_with_golden(True, cfg5, cfg2), "product": compare_with_golden(False, cfg5, cfg2)}
     json.dump(out, sys.stdout, indent=1)
     print()

@@ -16,7 +16,8 @@ GOLDEN_CFG5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
 
 
 @pytest.mark.parametrize("path, n_img, schedule", [(GOLDEN, 100, (50, 3, 200)),         # imageGroup.h:52-82, the reference's defaults
-                                                   (GOLDEN_CFG5, 500, (20, 5, 40))])
+                                                   (GOLDEN_CFG5, 500, (20, 5, 40)),
+                                                   (os.path.join(os.path.dirname(GOLDEN), "schedule_golden_cfg2.npz"), 20, (50, 0, 0))])
 def test_fixture_is_self_consistent(path, n_img, schedule):
     g = np.load(path)
     li, dl, di = (int(v) for v in g["schedule"])
