@@ -766,12 +766,14 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
     // time to spare.
     extern __shared__ float4 tile4[];
     const int lane = threadIdx.x;
+    // the block's entry is asked for together with the count (the table has room for the whole grid, frog_hip.hip lattice_alloc:
+    // an entry past the count is stale, never out of bounds): one round trip less at the head of every block
+    const ScatterBlock blk = blocks[blockIdx.x];
     if (blockIdx.x >= *n_blocks) {              // the grid is an upper bound of the block count
         if (snap && lane == 0) disp_part[blockIdx.x] = 0u;
         return;
     }
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
-    const ScatterBlock blk = blocks[blockIdx.x];
     // the points' indices and positions run one batch ahead of the arithmetic (one wavefront per block: nothing else hides
     // the memory round trip); loads unconditional, from an index clamped into the block.  The positions come from pos_b, the
     // copy in perm's order the set-up made: coalesced and independent of the index load (they were 16-byte gathers behind
@@ -780,21 +782,39 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
     uint32_t p_cur = perm[min(blk.begin + lane, s_last)];
     uint32_t p_nxt = perm[min(blk.begin + 64 + lane, s_last)];
     float4 v_cur = pos_b[min(blk.begin + lane, s_last)];
-    const int E = g.brick + 3, n_tile = E * E * E;
+    // bricks of 4^3 cells (the launch site checks): E and the tile's 343 entries are compile-time constants, so that the six
+    // entries a lane stages are six loads IN FLIGHT TOGETHER.  With E = g.brick + 3 read at run time the loop below compiled to
+    // one load, s_waitcnt vmcnt(0), ds_write_b128 per trip (seen in the ISA): six dependent memory round trips in a row at the
+    // head of every block, and level 2 has 25 000 blocks of one and a quarter batches each.
+    constexpr int E = 7, n_tile = E * E * E, TRIPS = (n_tile + 63) / 64;
     const uint32_t img = blk.key / g.n_bricks;
     uint32_t bidx = blk.key - img * g.n_bricks;
     const int bx = bidx % g.nbricks[0]; bidx /= g.nbricks[0];
     const int by = bidx % g.nbricks[1];
     const int bz = bidx / g.nbricks[1];
-    const int cp0[3] = { bx * g.brick, by * g.brick, bz * g.brick };
+    const int cp0[3] = { bx * 4, by * 4, bz * 4 };
     const int dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
-    for (int k = lane; k < n_tile; k += 64) {
-        const int tx = k % E, ty = (k / E) % E, tz = k / (E * E);
-        const int x = cp0[0] + tx, y = cp0[1] + ty, z = cp0[2] + tz;
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
-        if (x < dx && y < dy && z < dz) c = coeff[lat(g, img, (uint32_t)x + (uint32_t)dx * ((uint32_t)y + (uint32_t)dy * (uint32_t)z))];
-        c.w = 0.f;                                      // the pad the f32 form sums along with x, y, z (fma4)
-        tile4[tx + K11_SY * ty + K11_SZ * tz] = c;
+    {
+        float4 staged[TRIPS];
+        bool inside[TRIPS];
+        #pragma unroll
+        for (int t = 0; t < TRIPS; t++) {
+            const int k = lane + 64 * t;
+            const int tz = k / (E * E), ty = (k - tz * E * E) / E, tx = k - tz * E * E - ty * E;
+            const int x = cp0[0] + tx, y = cp0[1] + ty, z = cp0[2] + tz;
+            inside[t] = k < n_tile && x < dx && y < dy && z < dz;
+            // unconditional, from node 0 for the entries outside (a branch around the load would bring the waits back)
+            const uint32_t node = inside[t] ? (uint32_t)x + (uint32_t)dx * ((uint32_t)y + (uint32_t)dy * (uint32_t)z) : 0u;
+            staged[t] = coeff[lat(g, img, node)];
+        }
+        #pragma unroll
+        for (int t = 0; t < TRIPS; t++) {
+            const int k = lane + 64 * t;
+            const int tz = k / (E * E), ty = (k - tz * E * E) / E, tx = k - tz * E * E - ty * E;
+            float4 c = inside[t] ? staged[t] : make_float4(0.f, 0.f, 0.f, 0.f);      // BorderModeZero: nodes outside the lattice count as 0
+            c.w = 0.f;                                  // the pad the f32 form sums along with x, y, z (fma4)
+            if (k < n_tile) tile4[tx + K11_SY * ty + K11_SZ * tz] = c;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1051,13 +1071,15 @@ __global__ __launch_bounds__(64) void scatter_kernel(const float4 *pos_b, const 
     const unsigned long long trace_t0 = wall_clock64();
     unsigned tr_load = 0, tr_p1 = 0, tr_p2 = 0;
 #endif
-    // the grid is an upper bound (the block table is built on the device and its length never visits the host)
+    // the grid is an upper bound (the block table is built on the device and its length never visits the host); the block's
+    // entry is asked for together with the count -- the table has room for the whole grid, an entry past the count is stale,
+    // never out of bounds -- which takes one round trip off the chain count -> entry -> index -> sums at the head of every block
+    const ScatterBlock blk = blocks[bid];
     if (bid >= *n_blocks) return;
     // the brick's (B+3)^3 control points: sized at launch ((B+3)^3 * 16 bytes), so that bricks of 4^3 cells
     // take 5.4 KB instead of the 21 KB of the largest brick
     extern __shared__ float4 tile[];
     __shared__ ScatterScratch sc;
-    const ScatterBlock blk = blocks[bid];
     const int lane = threadIdx.x;
     const int E = g.brick + 3;                  // control points per brick edge
     const int n_tile = E * E * E;
