@@ -1383,12 +1383,17 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
             const GeomDev gd = to_dev(ctx->geom);
             const size_t lds = (size_t)K11_TILE_ENTRIES * sizeof(float4);      // brick == 4 (checked above): the strided 7^3 tile
             auto kernel = ctx->k11_f64 ? transform_bspline_tile_kernel<double> : transform_bspline_tile_kernel<float>;
-            kernel<<<ctx->n_scatter_blocks, 64, lds, ctx->stream>>>(
-                ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p, ctx->perm.p, reinterpret_cast<const ScatterBlock *>(ctx->scatter_blocks.p),
+            // FROG_K11_BY_XCD=1 / 0 forces / forbids the brick-order walk (k_grid.hip.h); default: on lattices with many small blocks
+            static const int by_xcd_env = getenv("FROG_K11_BY_XCD") ? atoi(getenv("FROG_K11_BY_XCD")) : -1;
+            const bool by_xcd = by_xcd_env >= 0 ? by_xcd_env != 0 : ctx->n_scatter_blocks >= 16384u;
+            const uint32_t grid = by_xcd ? ((ctx->n_scatter_blocks + 7u) & ~7u) : ctx->n_scatter_blocks;     // the walk's grid: a multiple of 8
+            kernel<<<grid, 64, lds, ctx->stream>>>(
+                ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p, ctx->perm.p,
+                reinterpret_cast<const ScatterBlock *>(by_xcd ? ctx->scatter_blocks_tmp.p : ctx->scatter_blocks.p),
                 ctx->brick_slot_ptr.p + (size_t)ctx->n_owned() * gd.n_bricks, gd, apply,
                 with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                 after_step ? ctx->grad.p : nullptr, ctx->energy.p, ctx->opt.guarantee_diffeomorphism,
-                ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer);
+                ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer, by_xcd ? ctx->n_scatter_blocks : 0u);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
             auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : (ctx->geom.brick == 8 ? transform_bspline_kernel<float, 2> : transform_bspline_kernel<float>);

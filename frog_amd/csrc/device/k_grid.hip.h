@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void transform_bspline_tile_kernel(float4 *pos,
                                                                     const P3 *snap, uint32_t *disp_part,
                                                                     const float4 *proposal, const double *energy, int guarantee,
                                                                     const float *disp_allow, uint32_t *cull_state,
-                                                                    double *host_scalars, double seq, double *trailer);
+                                                                    double *host_scalars, double seq, double *trailer, uint32_t by_xcd);
 
 // Zeroes up to ZERO_MAX device buffers in ONE launch (a lattice set-up clears six: every hipMemsetAsync is a launch
 // of its own with a few microseconds of idle stream in front of it).  A block clears ZERO_BLOCK_BYTES of one buffer with
@@ -756,7 +756,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
                                    const P3 *snap, uint32_t *disp_part,
                                    const float4 *proposal, const double *energy, int guarantee,
                                    const float *disp_allow, uint32_t *cull_state,
-                                   double *host_scalars, double seq, double *trailer)
+                                   double *host_scalars, double seq, double *trailer, uint32_t by_xcd)
 {
     publish_step_scalars(energy, host_scalars, seq);
     write_slab_trailer(energy, trailer);
@@ -766,11 +766,30 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
     // time to spare.
     extern __shared__ float4 tile4[];
     const int lane = threadIdx.x;
+    uint32_t bid = blockIdx.x;
+    if (by_xcd) {
+        // by_xcd = the table's capacity (0: off).  `blocks` is the table in BRICK order (image-major, bricks x-fastest: what
+        // block_fill_kernel leaves) and the grid the capacity rounded up to a multiple of 8: workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 is the XCD, and XCD x takes the x-th
+        // eighth of the live entries in table order -- the wavefronts resident on an XCD at any time stage tiles of neighbouring
+        // bricks of ONE image (a 7^3 tile shares three of its seven planes with each neighbour's), so the tiles' loads hit that
+        // XCD's L2 instead of missing it (every XCD saw bricks of every image: 30 MB of coefficients through 4 MB of L2, 70 %
+        // misses by the counters).  Entries past the count are zeroed by the workgroups that have no brick.
+        const uint32_t n_live = *n_blocks, per = (n_live + 7u) / 8u;
+        const uint32_t x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        if (r < per) {
+            bid = x * per + r;
+        } else {
+            const uint32_t target = 8u * per + (r - per) * 8u + x;
+            if (snap && lane == 0 && target < by_xcd) disp_part[target] = 0u;
+            return;
+        }
+        if (bid >= by_xcd) return;
+    }
     // the block's entry is asked for together with the count (the table has room for the whole grid, frog_hip.hip lattice_alloc:
     // an entry past the count is stale, never out of bounds): one round trip less at the head of every block
-    const ScatterBlock blk = blocks[blockIdx.x];
-    if (blockIdx.x >= *n_blocks) {              // the grid is an upper bound of the block count
-        if (snap && lane == 0) disp_part[blockIdx.x] = 0u;
+    const ScatterBlock blk = blocks[bid];
+    if (bid >= *n_blocks) {                     // the grid is an upper bound of the block count
+        if (snap && lane == 0) disp_part[bid] = 0u;
         return;
     }
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
@@ -917,7 +936,7 @@ void transform_bspline_tile_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, c
         #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
         if (lane == 0) {
-            disp_part[blockIdx.x] = dmax;
+            disp_part[bid] = dmax;
             if (!(__uint_as_float(dmax) <= *disp_allow)) atomicOr(cull_state, 1u);      // see transform_bspline_kernel
         }
     }
