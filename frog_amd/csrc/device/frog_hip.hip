@@ -1397,12 +1397,17 @@ static int launch_transform(frog_ctx *ctx, P3 *out, int apply, bool after_step =
             if (with_disp) ctx->disp_n = ctx->disp_own_n = ctx->n_scatter_blocks;
         } else {
             auto kernel = ctx->k11_f64 ? transform_bspline_kernel<double> : (ctx->geom.brick == 8 ? transform_bspline_kernel<float, 2> : transform_bspline_kernel<float>);
-            kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
+            // FROG_K11_POINT_BY_XCD=1 / 0 forces / forbids the XCD-aware order of the blocks (k_grid.hip.h); default: from 8 192 blocks
+            static const int pt_xcd_env = getenv("FROG_K11_POINT_BY_XCD") ? atoi(getenv("FROG_K11_POINT_BY_XCD")) : -1;
+            const uint32_t nb = div_up(n, 256);
+            const bool pt_xcd = pt_xcd_env >= 0 ? pt_xcd_env != 0 : nb >= 8192u;
+            kernel<<<pt_xcd ? ((nb + 7u) & ~7u) : nb, 256, 0, ctx->stream>>>(ctx->pos.p, ctx->pos_b.p, out, ctx->coeff.p,
                                                                              ctx->perm.p, n, ctx->ib, to_dev(ctx->geom), apply,
                                                                              with_disp ? ctx->pos2_snap.p : nullptr, ctx->disp_part.p,
                                                                              after_step ? ctx->grad.p : nullptr, ctx->energy.p,
                                                                              ctx->opt.guarantee_diffeomorphism,
-                                                                             ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer);
+                                                                             ctx->disp_allow.p, ctx->cull_state.p, host_scalars, scalar_seq, trailer,
+                                                                             pt_xcd ? nb : 0u);
             if (with_disp) ctx->disp_n = ctx->disp_own_n = div_up(n, 256);
         }
         trailer = nullptr;

@@ -188,14 +188,23 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
                                                                 const P3 *snap, uint32_t *disp_part,
                                                                 const float4 *proposal, const double *energy, int guarantee,
                                                                 const float *disp_allow, uint32_t *cull_state,
-                                                                double *host_scalars, double seq, double *trailer)
+                                                                double *host_scalars, double seq, double *trailer, uint32_t by_xcd)
 {
     publish_step_scalars(energy, host_scalars, seq);
     write_slab_trailer(energy, trailer);
     if (proposal && !(guarantee && energy[2] > 0.0)) coeff = proposal;
+    // by_xcd = the number of 256-point blocks (0: off; the grid is then that number rounded up to a multiple of 8): XCD x =
+    // blockIdx % 8 works through the x-th eighth of the points in their (image, brick, cell) order, so that the blocks resident on an
+    // XCD are neighbouring bricks of a few images and their stencils meet in that XCD's L2 (section 8 row 42 of DESIGN.md)
+    uint32_t vb = blockIdx.x;
+    if (by_xcd) {
+        const uint32_t per = (by_xcd + 7u) / 8u;
+        vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (vb >= by_xcd) return;
+    }
     // every lane computes (the tail of the last block on the last point again, without storing): the displacement
     // reduction at the end is wave-wide
-    const uint32_t s_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s_raw = vb * blockDim.x + threadIdx.x;
     const bool valid = s_raw < n_points;
     const uint32_t s = valid ? s_raw : n_points - 1;
     const uint32_t p = perm[s];
@@ -308,7 +317,7 @@ void transform_bspline_kernel(float4 *pos, const float4 *pos_b, P3 *pos2, const 
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t mb = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
-            disp_part[blockIdx.x] = mb;
+            disp_part[vb] = mb;
             // beyond what the culling list allows (k_cull.hip.h cull_allow_kernel; NaN compares false): the next sweep
             // walks every record and the host rebuilds the list.  Hardly ever taken: no contention.
             if (!(__uint_as_float(mb) <= *disp_allow)) atomicOr(cull_state, 1u);
