@@ -185,6 +185,27 @@ def test_blocked_and_sparse_lattices_give_the_same_files(tmp_path, flags, forms)
     _same_files(plain, other, pairs.n_images)
 
 
+@pytest.mark.parametrize("flags", [(), ("-ngl", "3"), ("-gm", "0.004")])
+def test_xcd_order_of_the_transform_blocks_changes_no_bit(tmp_path, flags):
+    """The B-spline transform deals its blocks to the XCDs by image on fine lattices (the tiled form walks
+    the block table in brick order, an eighth per XCD, from 16 384 blocks; the thread-per-point form its 256-point blocks, from
+    8 192).  A block computes what it computed before, only elsewhere and at another time: both orders forced on a group that would
+    never choose them, in both forms of the transform, against both forbidden -- identical measures.csv and transforms, for one
+    context, three sharded contexts and a run whose guard rejects steps (the per-block displacement maxima of the culling list are
+    written under the new block numbers)."""
+    from test_gpu_round5 import _frog, _same_files
+    pairs = Pairs.synthetic(9, 3000, 1200, seed=4)
+    runs = {"tiled_plain": {"FROG_K11_TILED": "1", "FROG_K11_BY_XCD": "0"}, "tiled_xcd": {"FROG_K11_TILED": "1", "FROG_K11_BY_XCD": "1"},
+            "point_plain": {"FROG_K11_POINTWISE": "1", "FROG_K11_POINT_BY_XCD": "0"}, "point_xcd": {"FROG_K11_POINTWISE": "1", "FROG_K11_POINT_BY_XCD": "1"}}
+    for name, env in runs.items():
+        d = tmp_path / name
+        d.mkdir()
+        pairs.write(d / "pairs.bin")
+        _frog(d, *flags, env_extra=env)
+    for name in ("tiled_xcd", "point_plain", "point_xcd"):
+        _same_files(tmp_path / "tiled_plain", tmp_path / name, pairs.n_images)
+
+
 # ---- (5) the scatter's hand-scheduled DPP statement against the plain form (ADVICE r5) ---------------------------------------------
 
 def test_scatter_quad_form_equals_the_point_by_point_form_bit_for_bit(tmp_path):
